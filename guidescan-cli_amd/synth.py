@@ -1,0 +1,123 @@
+"""Seeded synthetic genomes and guide sets.
+
+No genome ships with either box and there is no network, so every input is
+generated here from a fixed numpy PCG64 seed; the same image runs on both boxes,
+so bytes agree.  Formats follow the reference: a genome is the FASTA-order
+concatenation of upper-cased chromosome sequences with no separators
+(src/genomics/seq_io.cxx:57-63); the reverse text is its reverse complement with
+non-ACGT bytes unchanged (src/genomics/sequences.cxx:14-46).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SACCER3_LENGTHS = [230218, 813184, 316620, 1531933, 576874, 270161, 1090940, 562643,
+                   439888, 745751, 666816, 1078177, 924431, 784333, 1091291, 948066]
+CHR1_LENGTH = 248956422
+GRCH38_LENGTHS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979,
+                  159345973, 145138636, 138394717, 133797422, 135086622, 133275309,
+                  114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+                  58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+
+_COMP = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgt", b"TGCAtgca"):
+    _COMP[_a] = _b
+
+
+def reverse_complement_bytes(text: np.ndarray) -> np.ndarray:
+    """sequences.cxx:14-46 applied to a whole text (seq_io.cxx:65-72)."""
+    return _COMP[text[::-1]]
+
+
+def make_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), n_blocks=True):
+    """Return (text uint8[sum(lengths)], names, lengths).
+
+    i.i.d. bases; when n_blocks, each chromosome longer than 100 kb gets 10 kb
+    telomeric N runs and one centromeric N block of ~1.2 % of its length
+    (SURVEY.md section 8d, C2/C3)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    total = int(sum(lengths))
+    cum = np.cumsum(np.asarray(probs, dtype=np.float64))
+    text = np.empty(total, dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    chunk = 1 << 24
+    for s in range(0, total, chunk):
+        e = min(total, s + chunk)
+        u = rng.random(e - s)
+        text[s:e] = lut[np.minimum(np.searchsorted(cum, u, side="right"), 3)]
+    off = 0
+    for ln in lengths:
+        if n_blocks and ln > 100_000:
+            tel = 10_000
+            text[off:off + tel] = ord("N")
+            text[off + ln - tel:off + ln] = ord("N")
+            cen = max(1000, int(ln * 0.012))
+            c0 = off + ln // 3
+            text[c0:c0 + cen] = ord("N")
+        off += ln
+    names = [f"chr{i + 1}" for i in range(len(lengths))]
+    return text, names, [int(x) for x in lengths]
+
+
+def sample_guides(text: np.ndarray, n: int, seed=7, L=20, pam=b"NGG", minus_fraction=0.5):
+    """Sample on-target guides: + strand sites whose next 3 bases match `pam`
+    (N = any of ACGT) and - strand sites (reverse complement), protospacer ACGT only.
+    Returns (seqs uint8[n,L], pams uint8[n,P] = the pattern, positions, strands)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P = len(pam)
+    total = text.shape[0]
+    seqs = np.empty((n, L), dtype=np.uint8)
+    strands = np.empty(n, dtype=np.uint8)
+    positions = np.empty(n, dtype=np.int64)
+    got = 0
+    acgt = np.zeros(256, dtype=bool)
+    acgt[list(b"ACGT")] = True
+    pam_arr = np.frombuffer(pam, dtype=np.uint8)
+    while got < n:
+        cand = rng.integers(0, total - (L + P), size=max(4096, (n - got) * 24))
+        minus = rng.random(cand.shape[0]) < minus_fraction
+        for is_minus in (False, True):
+            c = cand[minus == is_minus]
+            if c.size == 0:
+                continue
+            win = text[c[:, None] + np.arange(L + P)[None, :]]
+            if is_minus:
+                win = _COMP[win[:, ::-1]]
+            ok = acgt[win].all(axis=1)
+            for j in range(P):
+                if pam_arr[j] != ord("N"):
+                    ok &= win[:, L + j] == pam_arr[j]
+            sel = np.nonzero(ok)[0]
+            take = min(sel.size, n - got)
+            if take == 0:
+                continue
+            sel = sel[:take]
+            seqs[got:got + take] = win[sel, :L]
+            strands[got:got + take] = ord("-") if is_minus else ord("+")
+            positions[got:got + take] = c[sel]
+            got += take
+            if got >= n:
+                break
+    pams = np.tile(pam_arr, (n, 1))
+    return seqs, pams, positions, strands
+
+
+def write_fasta(path, text: np.ndarray, names, lengths, width=60, lowercase_chr=None):
+    with open(path, "wb") as f:
+        off = 0
+        for i, (nm, ln) in enumerate(zip(names, lengths)):
+            f.write(b">" + nm.encode() + b" synthetic\n")
+            seq = text[off:off + ln].tobytes()
+            if lowercase_chr is not None and i == lowercase_chr:
+                seq = seq.lower()
+            for s in range(0, ln, width):
+                f.write(seq[s:s + width] + b"\n")
+            off += ln
+
+
+def write_kmers_csv(path, ids, seqs, pams, chroms, positions, senses):
+    """kmers file: src/genomics/kmer.cxx:12-18 header and columns."""
+    with open(path, "w") as f:
+        f.write("id,sequence,pam,chromosome,position,sense\n")
+        for i in range(len(ids)):
+            f.write(f"{ids[i]},{seqs[i]},{pams[i]},{chroms[i]},{positions[i]},{senses[i]}\n")

@@ -1,0 +1,60 @@
+"""Oracle vs the survey-build reference outputs on the toy genome (CPU only).
+
+tests/golden/toy/ref_*.{csv,sam} were written by the guidescan binary the survey
+phase built (tools/make_survey_goldens.py explains their status).  Byte-for-byte
+equality of CSV and SAM text (-n 1 order) exercises every restated rule at once:
+search, set order/dedupe, locate, coordinates, boundary sentinel, CFD, of:H."""
+import pytest
+
+import oracle_lib as ol
+
+RUNS = {
+    "m0_csv": dict(m=0), "m1_csv": dict(m=1), "m2_csv": dict(m=2), "m3_csv": dict(m=3),
+    "m4_csv": dict(m=4),
+    "m3_sam": dict(m=3, fmt="sam"),
+    "m2_sam_succinct": dict(m=2, fmt="sam", complete=False),
+    "m3_csv_succinct": dict(m=3, complete=False),
+    "m3_csv_nag": dict(m=3, alt=("NAG",)),
+    "m3_sam_nag": dict(m=3, alt=("NAG",), fmt="sam"),
+    "m3_csv_max2": dict(m=3, maxo=2),
+    "m3_sam_max2": dict(m=3, maxo=2, fmt="sam"),
+    "m2_csv_t1": dict(m=2, thr=1),
+    "m2_csv_start": dict(m=2, start=True),
+}
+
+
+@pytest.fixture(scope="module")
+def oidx(toy):
+    ix = ol.OracleIndex(toy["text"])
+    yield ix
+    ix.close()
+
+
+def oracle_text(toy, oidx, m=3, fmt="csv", complete=True, alt=(), maxo=-1, thr=-1, start=False):
+    opts = ol.make_opts(mismatches=m, start=start, alt_pams=alt, max_off_targets=maxo,
+                        complete=complete, threshold=thr)
+    out = []
+    for k in toy["kmers"]:
+        hits, ctr, raw = oidx.enumerate(k.sequence, k.pam, opts)
+        if hits is None:
+            continue
+        out.append(ol.text_lines(fmt, toy["names"], toy["lengths"], k.id, k.sequence, k.pam,
+                                 k.positive, opts, raw))
+        ol.lib().gso_free(raw[0])
+    return "".join(out)
+
+
+def strip_header(text, fmt):
+    lines = text.split("\n")
+    if fmt == "csv":
+        return "\n".join(lines[1:])
+    return "\n".join(l for l in lines if not l.startswith("@"))
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_oracle_matches_survey_reference_output(toy, oidx, name):
+    cfg = RUNS[name]
+    fmt = cfg.get("fmt", "csv")
+    ref = (toy["dir"] / f"ref_{name}.{fmt}").read_text()
+    got = oracle_text(toy, oidx, **cfg)
+    assert got == strip_header(ref, fmt)

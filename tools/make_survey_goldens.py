@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/toy/* inputs and (when available) reference outputs.
+
+Inputs (FASTA, kmers CSV, .gs) are produced from a fixed seed by this script.
+
+Expected outputs come from the guidescan binary that the SURVEY phase built in
+this container (cmake build of /root/reference with the
+`download` TU stubbed; found at /tmp/gs_ref/build/bin/guidescan).  That build
+CANNOT be reproduced by this repo's own recipe (oracle/Makefile may not run cmake
+or provide generated headers), so these files are labelled
+"survey-build reference outputs": supplementary evidence for the restated parts
+of the oracle, not an oracle/_ref artefact.  If the binary is absent the script
+only regenerates the inputs and leaves committed outputs untouched.
+"""
+import os
+import subprocess
+import sys
+from importlib import import_module
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+synth = import_module("guidescan-cli_amd.synth")
+OUT = ROOT / "tests" / "golden" / "toy"
+REFBIN = Path(os.environ.get("GS_SURVEY_REF_BIN", "/tmp/gs_ref/build/bin/guidescan"))
+
+RUNS = {
+    # name: extra enumerate args
+    "m0_csv": ["-m", "0"],
+    "m1_csv": ["-m", "1"],
+    "m2_csv": ["-m", "2"],
+    "m3_csv": ["-m", "3"],
+    "m4_csv": ["-m", "4"],
+    "m3_sam": ["-m", "3", "--format", "sam"],
+    "m2_sam_succinct": ["-m", "2", "--format", "sam", "--mode", "succinct"],
+    "m3_csv_succinct": ["-m", "3", "--mode", "succinct"],
+    "m3_csv_nag": ["-m", "3", "-a", "NAG"],
+    "m3_sam_nag": ["-m", "3", "-a", "NAG", "--format", "sam"],
+    "m3_csv_max2": ["-m", "3", "--max-off-targets", "2"],
+    "m3_sam_max2": ["-m", "3", "--max-off-targets", "2", "--format", "sam"],
+    "m2_csv_t1": ["-m", "2", "-t", "1"],
+    "m2_csv_start": ["-m", "2", "--start"],
+}
+
+
+def rc(s: bytes) -> bytes:
+    return synth.reverse_complement_bytes(np.frombuffer(s, dtype=np.uint8)).tobytes()
+
+
+def build_inputs():
+    rng = np.random.Generator(np.random.PCG64(20251003))
+    lengths = [30000, 20000, 8000]
+    text, _, _ = synth.make_genome(lengths, seed=11, probs=(0.3, 0.2, 0.2, 0.3), n_blocks=False)
+    text = text.copy()
+    names = ["chrA", "chrB", "chrC"]
+    # N run + isolated N in chrA
+    text[5000:5500] = ord("N")
+    text[12345] = ord("N")
+    # a literal N right where a PAM's N would sit: site at 14000 (+ strand): 20-mer + "NGG"
+    site = text[14000:14020].tobytes()
+    text[14020:14023] = np.frombuffer(b"NGG", dtype=np.uint8)
+    # planted repeat family: a 23-mer (20-mer + AGG) copied with 0..4 substitutions, both strands
+    fam = text[2000:2020].tobytes() + b"AGG"
+    text[2000:2023] = np.frombuffer(fam, dtype=np.uint8)
+    spots = [(7000, 0, False), (9000, 1, False), (16000, 2, True), (21000 + 30000 - 30000, 3, False),
+             (33000, 2, False), (41000, 1, True), (52000, 3, True), (54000, 4, False), (25000, 0, True)]
+    for pos, nmut, minus in spots:
+        s = bytearray(fam)
+        idx = rng.choice(20, size=nmut, replace=False)
+        for i in idx:
+            s[i] = rng.choice([c for c in b"ACGT" if c != s[i]])
+        b = bytes(s)
+        if minus:
+            b = rc(b)
+        text[pos:pos + 23] = np.frombuffer(b, dtype=np.uint8)
+    # same 20-mer with CGG and TGG PAMs (canonical order check: key is the complement string)
+    text[27000:27023] = np.frombuffer(fam[:20] + b"CGG", dtype=np.uint8)
+    text[28000:28023] = np.frombuffer(fam[:20] + b"TGG", dtype=np.uint8)
+    # alt-PAM site (NAG)
+    text[28500:28523] = np.frombuffer(fam[:20] + b"CAG", dtype=np.uint8)
+    # boundary straddler: guide = last 20 nt of chrA, chrB starts with TGG
+    text[30000:30003] = np.frombuffer(b"TGG", dtype=np.uint8)
+    strad = text[29980:30000].tobytes()
+    # - strand straddler at chrB/chrC boundary: revcomp site spanning 49990..50013
+    # a site at the very start of the genome on the - strand: CCN + revcomp(guide) at 0  (-0 quirk)
+    g0 = text[3:23].tobytes()
+    text[0:3] = np.frombuffer(b"CCA", dtype=np.uint8)
+    zero_guide = rc(g0)
+    # site at the very end of the genome on + strand
+    text[-3:] = np.frombuffer(b"AGG", dtype=np.uint8)
+    end_guide = text[-23:-3].tobytes()
+
+    OUT.mkdir(parents=True, exist_ok=True)
+    synth.write_fasta(OUT / "toy.fa", text, names, lengths, width=70, lowercase_chr=1)
+    (OUT / "toy.gs").write_text("".join(f"{n}\n{l}\n" for n, l in zip(names, lengths)))
+
+    seqs, pams, positions, strands = synth.sample_guides(text, 40, seed=5)
+    rows = []
+    for i in range(40):
+        rows.append((f"g{i}", seqs[i].tobytes().decode(), "NGG", "chrA", int(positions[i]) + 1,
+                     chr(strands[i])))
+    specials = [
+        ("fam", fam[:20].decode(), "NGG", "+"),
+        ("litN", site.decode(), "NGG", "+"),
+        ("strad", strad.decode(), "NGG", "+"),
+        ("zero", zero_guide.decode(), "NGG", "-"),
+        ("end", end_guide.decode(), "NGG", "+"),
+        ("absent", "ACGTACGTACGTACGTACGT", "NGG", "+"),
+        ("nopam", fam[:20].decode(), "", "+"),
+        ("polyA", "A" * 20, "NGG", "-"),
+    ]
+    for nm, s, p, sense in specials:
+        rows.append((nm, s, p, "chrA", 1, sense))
+    synth.write_kmers_csv(OUT / "kmers.csv", [r[0] for r in rows], [r[1] for r in rows],
+                          [r[2] for r in rows], [r[3] for r in rows], [r[4] for r in rows],
+                          [r[5] for r in rows])
+    return text
+
+
+def run_reference():
+    if not REFBIN.exists():
+        print(f"{REFBIN} absent: inputs regenerated only")
+        return
+    import shutil
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=str(ROOT / "tests")) as td:
+        td = Path(td)
+        shutil.copy(OUT / "toy.fa", td / "toy.fa")
+        shutil.copy(OUT / "kmers.csv", td / "kmers.csv")
+        subprocess.run([str(REFBIN), "index", "--index", str(td / "toy.idx"), str(td / "toy.fa")],
+                       check=True, timeout=600, stdout=subprocess.DEVNULL)
+        gs = (td / "toy.idx.gs").read_text()
+        assert gs == (OUT / "toy.gs").read_text(), "genome structure mismatch"
+        for f in ("toy.idx.forward", "toy.idx.reverse"):
+            shutil.copy(td / f, OUT / f)
+        for name, args in RUNS.items():
+            ext = "sam" if "sam" in name else "csv"
+            outp = td / f"{name}.{ext}"
+            subprocess.run([str(REFBIN), "enumerate", str(td / "toy.idx"), "-f", str(td / "kmers.csv"),
+                            "-o", str(outp), "-n", "1"] + args, check=True, timeout=600,
+                           stdout=subprocess.DEVNULL)
+            shutil.copy(outp, OUT / f"ref_{name}.{ext}")
+            print("wrote", f"ref_{name}.{ext}", outp.stat().st_size, "bytes")
+
+
+if __name__ == "__main__":
+    build_inputs()
+    run_reference()
