@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- guides/sec of off-target enumeration on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (prepare -> search on both strand indexes ->
+canonical order -> locate) over one batch of synthetic NGG 20-mer guides that is
+already resident in HBM; the CSR hit lists are left in HBM.  Index construction is
+outside the timed region (the reference's own timer also starts after index load,
+src/guidescan.cxx:239).
+
+    python bench.py --gpus N --steps K --warmup W [--workload chr1|hg38|saccer3]
+
+N>1: launched by torch.distributed.run, one rank per GPU; the index is replicated
+into every GPU's HBM and each rank enumerates its own shard of the guide batch
+(no data-path collective; weak scaling: per-GPU batch fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from importlib import import_module
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+WORKLOADS = {
+    # name: (chromosome lengths, guides per step per GPU, base probabilities)
+    "saccer3": ("SACCER3_LENGTHS", 1000, (0.31, 0.19, 0.19, 0.31)),
+    "chr1": ("CHR1", 100_000, (0.29, 0.21, 0.21, 0.29)),
+    "hg38": ("GRCH38_LENGTHS", 1_000_000, (0.29, 0.21, 0.21, 0.29)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("GS_BENCH_WORKLOAD", "chr1"))
+    ap.add_argument("--mismatches", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0, help="guides per step per GPU (0 = workload default)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="guides timed on the CPU oracle (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the enumerate path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    api = import_module("guidescan-cli_amd.api")
+    synth = import_module("guidescan-cli_amd.synth")
+
+    lens_name, batch, probs = WORKLOADS[args.workload]
+    lengths = [synth.CHR1_LENGTH] if lens_name == "CHR1" else getattr(synth, lens_name)
+    if args.batch:
+        batch = args.batch
+    m = args.mismatches
+    t0 = time.time()
+    text, names, lengths = synth.make_genome(lengths, seed=1, probs=probs)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    gidx = api.GenomeIndex.build(text, device=local_rank)
+    torch.cuda.synchronize()
+    t_index = time.time() - t0
+
+    nb = args.steps + args.warmup
+    # every step and every rank gets its own guides (seeded): shard r of the global batch
+    seqs, pams, _, _ = synth.sample_guides(text, batch * nb, seed=1000 + rank)
+    d_seqs = torch.from_numpy(seqs).cuda()
+    d_pams = torch.from_numpy(pams).cuda()
+    L, P = seqs.shape[1], pams.shape[1]
+
+    def step(i):
+        s = d_seqs[i * batch:(i + 1) * batch]
+        p = d_pams[i * batch:(i + 1) * batch]
+        return gidx.enumerate_device(s.data_ptr(), batch, L, p.data_ptr(), P, mismatches=m)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    n_ext = n_hits = 0
+    ms_search = ms_total = 0.0
+    for i in range(args.warmup, nb):
+        _, _, st = step(i)
+        n_ext += st["n_ext"]
+        n_hits += st["n_hits"]
+        ms_search += st["ms_search"]
+        ms_total += st["ms_total"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    K = args.steps
+    guides_total = batch * K * world
+    value = guides_total / elapsed
+
+    # roofline of the dominant kernel (k_search): algorithmic bytes = 128 B per extended
+    # node (two 64-byte Occ blocks), per launch, over the kernel's
+    # HIP-event duration measured inside the library on the launch stream.
+    alg_bytes_per_launch = 128.0 * n_ext / K
+    search_s = (ms_search / K) / 1e3
+    achieved = alg_bytes_per_launch / search_s / 1e9 if search_s > 0 else 0.0
+    out = {
+        "metric": "guides/sec off-target enum, <=3 mismatches",
+        "value": value,
+        "unit": "guides/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}-sized synthetic genome ({sum(lengths)} bp, "
+                               f"{len(lengths)} chr, fwd+rev index in HBM), {batch} NGG 20-mers per GPU "
+                               f"per step, <={m} mismatches",
+                   "guides_per_step_per_gpu": batch, "mismatches": m,
+                   "parallelism": f"replicated index, guide batch sharded x{world}"},
+        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes_per_launch": alg_bytes_per_launch,
+                     "avg_launch_ms": ms_search / K},
+        "detail": {"n_ext_per_guide": n_ext / (batch * K), "hits_per_guide": n_hits / (batch * K),
+                   "device_ms_total_per_step": ms_total / K, "index_build_s": t_index,
+                   "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes},
+    }
+
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        out["cpu_baseline"] = cpu_baseline(text, gidx, seqs, pams, m, args.cpu_sample)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    gidx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(text, gidx, seqs, pams, m, sample):
+    """The CPU oracle (oracle/gs_oracle.c, a port of the reference's algorithm) timed on this
+    host's cores on a bounded sample of the same guides.  The oracle only serves as the
+    reported baseline here, never as the measured path."""
+    import oracle_lib as ol
+    cores = os.cpu_count() or 1
+    if sample < 0:
+        sample = max(cores * 8, 64)
+    sample = min(sample, seqs.shape[0])
+    sa_f = gidx.suffix_array(0)
+    sa_r = gidx.suffix_array(1)
+    oidx = ol.OracleIndex(text, sa_fwd=sa_f, sa_rev=sa_r)
+    del sa_f, sa_r
+    opts = ol.make_opts(mismatches=m)
+    t0 = time.perf_counter()
+    tot, counts, ctr = oidx.enumerate_batch(seqs[:sample], pams[:sample], opts, nthreads=cores)
+    dt = time.perf_counter() - t0
+    oidx.close()
+    return {"value": sample / dt, "unit": "guides/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample} guides of rank 0's batch, {cores} threads (guide i -> thread i mod n "
+                      f"as src/guidescan.cxx:229-231), {dt:.1f} s",
+            "n_ext_per_guide": ctr.n_ext / sample, "rank_bwt_per_guide": ctr.n_rank / sample}
+
+
+if __name__ == "__main__":
+    main()

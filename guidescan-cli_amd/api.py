@@ -1,0 +1,223 @@
+"""ctypes binding of libgsamd.so (include/guidescan_amd.h) plus the thin host layer
+that mirrors the reference's per-guide pipeline interface
+(include/genomics/process.hpp:35-158) over the batch C-ABI.
+
+The product path is the HIP library only: there is no CPU fallback.  Importing
+this module without the built library raises; calling it without a GPU returns
+GS_ERR_DEVICE from the library, surfaced as GsError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "libgsamd.so"
+
+GS_FLAG_PAM_AT_START = 1
+
+
+class GsError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"gs_status {status}: {msg}")
+        self.status = status
+
+
+class GsHit(C.Structure):
+    _fields_ = [("pos", C.c_int64), ("key", C.c_uint64)]
+
+
+HIT_DTYPE = np.dtype([("pos", "<i8"), ("key", "<u8")])
+
+
+class GsResultView(C.Structure):
+    _fields_ = [("n_guides", C.c_uint64), ("n_hits", C.c_uint64),
+                ("guide_offsets", C.POINTER(C.c_uint64)), ("hits", C.POINTER(GsHit)),
+                ("n_ext", C.c_uint64), ("n_matches", C.c_uint64),
+                ("ms_search", C.c_float), ("ms_total", C.c_float)]
+
+
+def build_library():
+    subprocess.run(["make", "-s", "-C", str(PKG / "csrc")], check=True, timeout=3600)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(f"{LIB_PATH} is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is mandatory; there is no CPU fallback)")
+    L = C.CDLL(str(LIB_PATH))
+    vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+    L.gs_index_build.restype = i32
+    L.gs_index_build.argtypes = [vp, u64, i32, C.POINTER(vp)]
+    L.gs_index_build_with_sa.restype = i32
+    L.gs_index_build_with_sa.argtypes = [vp, u64, vp, vp, i32, C.POINTER(vp)]
+    L.gs_index_open_sdsl.restype = i32
+    L.gs_index_open_sdsl.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.gs_index_close.argtypes = [vp]
+    L.gs_index_genome_length.restype = u64
+    L.gs_index_genome_length.argtypes = [vp]
+    L.gs_index_device_bytes.restype = u64
+    L.gs_index_device_bytes.argtypes = [vp]
+    L.gs_enumerate.restype = i32
+    L.gs_enumerate.argtypes = [vp, vp, u64, u32, vp, u32, C.c_char_p, u32, u32, u32, C.POINTER(vp)]
+    L.gs_enumerate_device.restype = i32
+    L.gs_enumerate_device.argtypes = [vp, vp, u64, u32, vp, u32, C.c_char_p, u32, u32, u32, vp,
+                                      C.POINTER(vp), C.POINTER(vp), C.POINTER(GsResultView)]
+    L.gs_result_get.restype = i32
+    L.gs_result_get.argtypes = [vp, C.POINTER(GsResultView)]
+    L.gs_result_free.argtypes = [vp]
+    L.gs_decode_sequence.restype = i32
+    L.gs_decode_sequence.argtypes = [C.c_char_p, u32, u32, u32, u64, C.c_char_p]
+    L.gs_rank_bwt4.restype = i32
+    L.gs_rank_bwt4.argtypes = [vp, i32, vp, u64, vp]
+    L.gs_resolve.restype = i32
+    L.gs_resolve.argtypes = [vp, i32, vp, u64, vp]
+    L.gs_index_meta.restype = i32
+    L.gs_index_meta.argtypes = [vp, i32, vp, C.POINTER(u64)]
+    L.gs_index_copy_sa.restype = i32
+    L.gs_index_copy_sa.argtypes = [vp, i32, vp]
+    L.gs_calculate_cfd.restype = C.c_float
+    L.gs_calculate_cfd.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.gs_status_string.restype = C.c_char_p
+    L.gs_status_string.argtypes = [i32]
+    L.gs_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs_index_close",
+           "gs_index_genome_length", "gs_index_device_bytes", "gs_enumerate", "gs_enumerate_device",
+           "gs_result_get", "gs_result_free", "gs_decode_sequence", "gs_rank_bwt4", "gs_resolve",
+           "gs_index_meta", "gs_index_copy_sa", "gs_calculate_cfd", "gs_status_string", "gs_version"]
+
+
+def _check(rc):
+    if rc != 0:
+        raise GsError(rc, lib().gs_status_string(rc).decode())
+
+
+def decode_sequence(guide: str, P: int, key: int, flags: int = 0) -> str:
+    buf = C.create_string_buffer(len(guide) + P + 1)
+    _check(lib().gs_decode_sequence(guide.encode(), len(guide), P, flags, key, buf))
+    return buf.value.decode()
+
+
+class GenomeIndex:
+    """Both strand indexes of one genome in one GPU's HBM.  Mirrors the pair of
+    genome_index objects of src/guidescan.cxx:210-211."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+
+    @classmethod
+    def build(cls, text: np.ndarray, device: int = 0, sa_fwd=None, sa_rev=None):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        h = C.c_void_p()
+        if sa_fwd is not None:
+            sa_fwd = np.ascontiguousarray(sa_fwd, dtype=np.uint32)
+            sa_rev = np.ascontiguousarray(sa_rev, dtype=np.uint32)
+            _check(lib().gs_index_build_with_sa(text.ctypes.data, text.shape[0], sa_fwd.ctypes.data,
+                                                sa_rev.ctypes.data, device, C.byref(h)))
+        else:
+            _check(lib().gs_index_build(text.ctypes.data, text.shape[0], device, C.byref(h)))
+        return cls(h, device)
+
+    def close(self):
+        if self._h:
+            lib().gs_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def genome_length(self):
+        return int(lib().gs_index_genome_length(self._h))
+
+    @property
+    def device_bytes(self):
+        return int(lib().gs_index_device_bytes(self._h))
+
+    def meta(self, strand=0):
+        c = (C.c_uint64 * 5)()
+        n = C.c_uint64()
+        _check(lib().gs_index_meta(self._h, strand, c, C.byref(n)))
+        return list(c), int(n.value)
+
+    def rank_bwt4(self, rows, strand=0):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.empty((rows.shape[0], 4), dtype=np.uint64)
+        _check(lib().gs_rank_bwt4(self._h, strand, rows.ctypes.data, rows.shape[0], out.ctypes.data))
+        return out
+
+    def resolve(self, rows, strand=0):
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        out = np.empty(rows.shape[0], dtype=np.uint64)
+        _check(lib().gs_resolve(self._h, strand, rows.ctypes.data, rows.shape[0], out.ctypes.data))
+        return out
+
+    def suffix_array(self, strand=0):
+        _, n = self.meta(strand)
+        out = np.empty(n, dtype=np.uint32)
+        _check(lib().gs_index_copy_sa(self._h, strand, out.ctypes.data))
+        return out
+
+    def enumerate(self, seqs: np.ndarray, pams: np.ndarray, mismatches=3, alt_pams=(), start=False):
+        """seqs uint8[n,L], pams uint8[n,P] -> (offsets uint64[n+1], hits HIT_DTYPE[], stats dict).
+        Hits of guide i are hits[offsets[i]:offsets[i+1]] in the reference's canonical order."""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        n, L = seqs.shape
+        pams = np.ascontiguousarray(pams, dtype=np.uint8)
+        P = pams.shape[1] if pams.ndim == 2 else 0
+        pams = pams.reshape(n, P)
+        alt = b"".join(p.encode() for p in alt_pams)
+        for p in alt_pams:
+            if len(p) != P:
+                raise ValueError("alt PAM length differs from the guides' PAM length")
+        r = C.c_void_p()
+        flags = GS_FLAG_PAM_AT_START if start else 0
+        _check(lib().gs_enumerate(self._h, seqs.ctypes.data, n, L, pams.ctypes.data if P else None, P,
+                                  alt if alt_pams else None, len(alt_pams), mismatches, flags,
+                                  C.byref(r)))
+        try:
+            v = GsResultView()
+            _check(lib().gs_result_get(r, C.byref(v)))
+            offsets = np.ctypeslib.as_array(v.guide_offsets, shape=(n + 1,)).copy()
+            if v.n_hits:
+                raw = C.string_at(C.cast(v.hits, C.c_void_p), int(v.n_hits) * 16)
+                hits = np.frombuffer(raw, dtype=HIT_DTYPE).copy()
+            else:
+                hits = np.empty(0, dtype=HIT_DTYPE)
+            stats = dict(n_ext=int(v.n_ext), n_matches=int(v.n_matches), n_hits=int(v.n_hits),
+                         ms_search=float(v.ms_search), ms_total=float(v.ms_total))
+        finally:
+            lib().gs_result_free(r)
+        return offsets, hits, stats
+
+    def enumerate_device(self, d_guides_ptr, n, L, d_pams_ptr, P, mismatches=3, alt_pams=(),
+                         start=False, stream=None):
+        """Device-resident variant (what bench.py times): pointers are raw device addresses.
+        Returns (d_offsets_ptr, d_hits_ptr, stats)."""
+        alt = b"".join(p.encode() for p in alt_pams)
+        flags = GS_FLAG_PAM_AT_START if start else 0
+        d_off, d_hits = C.c_void_p(), C.c_void_p()
+        v = GsResultView()
+        _check(lib().gs_enumerate_device(self._h, d_guides_ptr, n, L, d_pams_ptr, P,
+                                         alt if alt_pams else None, len(alt_pams), mismatches, flags,
+                                         stream, C.byref(d_off), C.byref(d_hits), C.byref(v)))
+        stats = dict(n_ext=int(v.n_ext), n_matches=int(v.n_matches), n_hits=int(v.n_hits),
+                     ms_search=float(v.ms_search), ms_total=float(v.ms_total))
+        return d_off.value, d_hits.value, stats

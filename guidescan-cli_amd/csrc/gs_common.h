@@ -1,0 +1,83 @@
+/* gs_common.h -- internal declarations shared by the translation units of libgsamd.so */
+#ifndef GS_COMMON_H
+#define GS_COMMON_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "guidescan_amd.h"
+
+/* ---- device-resident FM-index of one strand ---------
+ * Occ block = 64 bytes covering 128 BWT rows:
+ *   uint32 cnt[4]   occurrences of A,C,G,T in BWT[0, 128*b)
+ *   uint64 lo[2]    bit j of word w: low  bit of the 2-bit code of row 128*b+64*w+j
+ *   uint64 hi[2]    high bit of the code (A=0 C=1 G=2 T=3)
+ *   uint64 ex[2]    1 = row holds a non-ACGT symbol ('\0' sentinel, N, IUPAC) or padding
+ * One aligned 64-byte read answers Occ(c, i) for all four bases exactly, including
+ * rows whose BWT symbol is not a base (no side table on the fast path). */
+#define GS_BLOCK_ROWS 128u
+#define GS_BLOCK_SHIFT 7u
+
+struct gs_strand_dev {
+  const uint4 *blocks;       /* (n >> 7) + 1 blocks of 4 x uint4 */
+  const uint32_t *sa;        /* full suffix array, n entries */
+  const uint32_t *run_start; /* first row of each maximal run of 'N' in the BWT */
+  const uint32_t *run_cum;   /* run_cum[r] = number of N rows in runs < r ; nruns+1 entries */
+  uint32_t n;                /* rows = text length + 1 */
+  uint32_t nruns;
+  uint32_t C[4]; /* first row of the A, C, G, T ranges */
+  uint32_t CN;   /* first row of the N range (undefined when has_n == 0) */
+  uint32_t has_n;
+};
+
+struct gs_strand {
+  gs_strand_dev d{};
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr;
+  uint64_t n = 0;
+  uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
+  uint64_t bytes = 0;
+};
+
+struct gs_buffer {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct gs_index {
+  int device = 0;
+  uint64_t genome_length = 0;
+  gs_strand strand[2];
+  /* per-handle workspace, grown on demand, reused across calls */
+  gs_buffer w_guides, w_slots, w_counts, w_nmatch, w_nhits, w_offsets, w_hits, w_misc, w_blocksums,
+      w_grec;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+#define GS_HIP(expr)                                                              \
+  do {                                                                            \
+    hipError_t e__ = (expr);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      gs_set_error(std::string(#expr) + ": " + hipGetErrorString(e__));           \
+      return GS_ERR_DEVICE;                                                       \
+    }                                                                             \
+  } while (0)
+
+void gs_set_error(const std::string &s);
+gs_status gs_reserve(gs_buffer &b, size_t bytes);
+
+/* GPU suffix array: d_text (n bytes incl. sentinel) -> d_sa (n uint32) */
+gs_status gs_device_suffix_array(const uint8_t *d_text, uint64_t n, uint32_t *d_sa, hipStream_t st);
+/* build the device layout of one strand from device-resident text and SA */
+gs_status gs_strand_from_device(const uint8_t *d_text, uint32_t *d_sa_owned, uint64_t n,
+                                gs_strand *out, hipStream_t st);
+void gs_strand_free(gs_strand *s);
+
+/* SDSL importer (gs_sdsl_import.cpp): reads <path> into BWT bytes + SA samples */
+gs_status gs_sdsl_read(const char *path, std::vector<uint8_t> &bwt, std::vector<uint64_t> &sa_samples,
+                       uint64_t C256[257]);
+
+#endif

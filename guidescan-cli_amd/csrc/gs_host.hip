@@ -1,0 +1,157 @@
+/*
+ * gs_host.hip -- host-side half of the C-ABI: the host-pointer enumerate wrapper, hit
+ * decoding, CFD, status strings.  No kernels here.
+ */
+#include "gs_common.h"
+#include "cfd_table.h"
+
+#include <cctype>
+#include <cstring>
+#include <mutex>
+
+static thread_local std::string g_last_error;
+void gs_set_error(const std::string &s) { g_last_error = s; }
+
+extern "C" const char *gs_status_string(gs_status s) {
+  switch (s) {
+    case GS_OK: return "ok";
+    case GS_ERR_ARG: return "bad argument";
+    case GS_ERR_DEVICE: return g_last_error.empty() ? "device error" : g_last_error.c_str();
+    case GS_ERR_UNSUPPORTED:
+      return g_last_error.empty() ? "unsupported input" : g_last_error.c_str();
+    case GS_ERR_NOMEM: return "out of memory";
+    case GS_ERR_IO: return g_last_error.empty() ? "i/o error" : g_last_error.c_str();
+    case GS_ERR_FORMAT: return g_last_error.empty() ? "malformed index file" : g_last_error.c_str();
+  }
+  return "unknown";
+}
+extern "C" const char *gs_version(void) { return "guidescan-amd 0.1 (gfx950)"; }
+
+struct gs_result {
+  std::vector<uint64_t> offsets;
+  std::vector<gs_hit> hits;
+  gs_result_view view{};
+};
+
+extern "C" gs_status gs_enumerate(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
+                                  const char *guide_pams, uint32_t P, const char *alt_pams,
+                                  uint32_t n_alt, uint32_t mismatches, uint32_t flags,
+                                  gs_result **out) {
+  if (!ix || !out || (n && !guides) || (n && P && !guide_pams)) return GS_ERR_ARG;
+  GS_HIP(hipSetDevice(ix->device));
+  gs_status rc = gs_reserve(ix->w_guides, n * (size_t)(L + P) + 16);
+  if (rc != GS_OK) return rc;
+  char *d_g = (char *)ix->w_guides.p;
+  char *d_p = d_g + n * (size_t)L;
+  if (n) {
+    GS_HIP(hipMemcpy(d_g, guides, n * (size_t)L, hipMemcpyHostToDevice));
+    if (P) GS_HIP(hipMemcpy(d_p, guide_pams, n * (size_t)P, hipMemcpyHostToDevice));
+  }
+  const void *d_off = nullptr, *d_hits = nullptr;
+  gs_result *r = new gs_result();
+  rc = gs_enumerate_device(ix, d_g, n, L, d_p, P, alt_pams, n_alt, mismatches, flags, nullptr, &d_off,
+                           &d_hits, &r->view);
+  if (rc != GS_OK) {
+    delete r;
+    return rc;
+  }
+  r->offsets.resize(n + 1);
+  r->hits.resize(r->view.n_hits);
+  GS_HIP(hipMemcpy(r->offsets.data(), d_off, 8 * (n + 1), hipMemcpyDeviceToHost));
+  if (r->view.n_hits)
+    GS_HIP(hipMemcpy(r->hits.data(), d_hits, sizeof(gs_hit) * r->view.n_hits, hipMemcpyDeviceToHost));
+  r->view.n_guides = n;
+  r->view.guide_offsets = r->offsets.data();
+  r->view.hits = r->hits.data();
+  *out = r;
+  return GS_OK;
+}
+
+extern "C" gs_status gs_result_get(const gs_result *r, gs_result_view *view) {
+  if (!r || !view) return GS_ERR_ARG;
+  *view = r->view;
+  return GS_OK;
+}
+extern "C" void gs_result_free(gs_result *r) { delete r; }
+
+static char comp(char c) {
+  switch (c) {
+    case 'A': return 'T';
+    case 'T': return 'A';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'a': return 't';
+    case 't': return 'a';
+    case 'c': return 'g';
+    case 'g': return 'c';
+    default: return c;
+  }
+}
+
+extern "C" gs_status gs_decode_sequence(const char *guide, uint32_t L, uint32_t P, uint32_t flags,
+                                        uint64_t key, char *out) {
+  if (!guide || !out || L < 1 || 2 * L + 3 * P > 52) return GS_ERR_ARG;
+  const uint64_t path = (key >> 8) & ((1ull << 52) - 1);
+  const bool start = flags & GS_FLAG_PAM_AT_START;
+  static const char B[4] = {'A', 'C', 'G', 'T'};
+  for (uint32_t t = 0; t < L; t++) {
+    /* query char consumed at step t (process.hpp:63, index.hpp:218) */
+    const char qc = start ? guide[L - 1 - t] : comp(guide[t]);
+    const uint32_t code = (uint32_t)(path >> (50 - 2 * t)) & 3u;
+    if (code == 0) {
+      out[t] = qc;
+    } else {
+      /* code-1 = rank among the three bases other than qc, in A<C<G<T order */
+      int q = qc == 'A' ? 0 : qc == 'C' ? 1 : qc == 'G' ? 2 : qc == 'T' ? 3 : -1;
+      if (q < 0) return GS_ERR_ARG;
+      int a = (int)code - 1;
+      if (a >= q) a++;
+      out[t] = (char)tolower(B[a]); /* index.hpp:243 */
+    }
+  }
+  static const char PB[5] = {'A', 'C', 'G', 'N', 'T'};
+  for (uint32_t u = 0; u < P; u++) {
+    const uint32_t code = (uint32_t)(path >> (49 - 2 * L - 3 * u)) & 7u;
+    if (code > 4) return GS_ERR_ARG;
+    out[L + u] = PB[code];
+  }
+  out[L + P] = 0;
+  return GS_OK;
+}
+
+static int bidx(char c) {
+  switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return -1;
+  }
+}
+/* include/genomics/printer.hpp:98-113 with the std::map tables flattened (immutable,
+ * so the reference's operator[] data race, SURVEY 5.2, cannot happen here) */
+extern "C" float gs_calculate_cfd(const char *sgrna, const char *seq, const char *pam) {
+  if (!sgrna || !seq || !pam) return 1.0f;
+  if (strlen(sgrna) != 20 || strlen(pam) != 3) return 1.0f;
+  float cfd = 1.0f;
+  for (int i = 0; i < 20; i++) {
+    const char g = sgrna[i], t = seq[i];
+    if (g != t) {
+      const int r = bidx(g); /* T is looked up as U: same slot */
+      const int d = bidx((char)toupper(comp(t)));
+      const double sc = (r >= 0 && d >= 0) ? gs_cfd_mm[(r * 4 + d) * 20 + i] : 0.0;
+      cfd = (float)((double)cfd * sc);
+    }
+  }
+  const int b1 = bidx(pam[1]), b2 = bidx(pam[2]);
+  const double ps = (b1 >= 0 && b2 >= 0) ? gs_cfd_pam[b1 * 4 + b2] : 0.0;
+  return (float)((double)cfd * ps);
+}
+
+extern "C" gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out) {
+  (void)prefix;
+  (void)device;
+  (void)out;
+  gs_set_error("SDSL index import is not built yet (DESIGN.md section 9, next rows)");
+  return GS_ERR_UNSUPPORTED;
+}

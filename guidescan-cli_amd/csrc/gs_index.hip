@@ -1,0 +1,474 @@
+/*
+ * gs_index.hip -- builds the device-resident FM-index layout.
+ *
+ * Replaces `guidescan index` (src/guidescan.cxx:109-179: sdsl::construct = divsufsort
+ * SA -> BWT -> wt_huff -> 1-in-64 SA samples) with a GPU builder: suffix array by
+ * prefix doubling over rocPRIM radix sorts, then BWT -> 64-byte Occ blocks + the full
+ * uint32 suffix array kept in HBM (288 GB makes the reference's sampling unnecessary).
+ * Offline step, not on the enumerate hot path; rocPRIM is used for the plain sorts/scans.
+ */
+#include "gs_common.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+/* BWT symbol class of a text byte: 0..3 = A,C,G,T ; 4 = N ; 5 = anything else (incl. '\0') */
+__device__ __forceinline__ uint32_t sym_class(uint8_t c) {
+  switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    case 'N': return 4;
+    default: return 5;
+  }
+}
+__device__ __forceinline__ uint8_t bwt_at(const uint8_t *text, const uint32_t *sa, uint64_t n,
+                                          uint64_t row) {
+  const uint32_t s = sa[row];
+  return s ? text[s - 1] : text[n - 1];
+}
+
+/* one thread per 32-row word: builds lo/hi/ex words and per-word A,C,G,T counts */
+__global__ void k_build_words(const uint8_t *text, const uint32_t *sa, uint64_t n, uint64_t nwords,
+                              uint4 *blocks, uint32_t *wcount /* [4][nwords] */) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= nwords) return;
+  uint32_t lo = 0, hi = 0, ex = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const uint64_t base = w * 32;
+  for (uint32_t j = 0; j < 32; j++) {
+    const uint64_t row = base + j;
+    uint32_t cls = 5;
+    if (row < n) cls = sym_class(bwt_at(text, sa, n, row));
+    if (cls < 4) {
+      lo |= (cls & 1u) << j;
+      hi |= (cls >> 1) << j;
+      c0 += cls == 0;
+      c1 += cls == 1;
+      c2 += cls == 2;
+      c3 += cls == 3;
+    } else {
+      ex |= 1u << j;
+    }
+  }
+  /* block = 4 x uint4: [cnt][lo x4][hi x4][ex x4]; word w%4 of block w/4 */
+  uint32_t *b = (uint32_t *)(blocks + (w >> 2) * 4);
+  const uint32_t k = (uint32_t)(w & 3);
+  b[4 + k] = lo;
+  b[8 + k] = hi;
+  b[12 + k] = ex;
+  wcount[0 * nwords + w] = c0;
+  wcount[1 * nwords + w] = c1;
+  wcount[2 * nwords + w] = c2;
+  wcount[3 * nwords + w] = c3;
+}
+/* after an exclusive scan of wcount: header of block b = scanned value at word 4b */
+__global__ void k_write_headers(uint4 *blocks, const uint32_t *wscan, uint64_t nwords,
+                                uint64_t nblocks) {
+  const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  uint4 h;
+  h.x = wscan[0 * nwords + 4 * b];
+  h.y = wscan[1 * nwords + 4 * b];
+  h.z = wscan[2 * nwords + 4 * b];
+  h.w = wscan[3 * nwords + 4 * b];
+  blocks[4 * b] = h;
+}
+__global__ void k_histogram(const uint8_t *text, uint64_t n, unsigned long long *hist) {
+  __shared__ unsigned int s[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) s[i] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    atomicAdd(&s[text[i]], 1u);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 256; i += blockDim.x)
+    if (s[i]) atomicAdd(&hist[i], (unsigned long long)s[i]);
+}
+/* boundaries of maximal runs of 'N' in the BWT: starts and (exclusive) ends */
+__global__ void k_n_runs(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t *starts,
+                         uint32_t *ends, uint32_t *counters, uint32_t cap) {
+  const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const bool cur = bwt_at(text, sa, n, row) == 'N';
+  const bool prev = row > 0 && bwt_at(text, sa, n, row - 1) == 'N';
+  if (cur && !prev) {
+    const uint32_t k = atomicAdd(&counters[0], 1u);
+    if (k < cap) starts[k] = (uint32_t)row;
+  }
+  if (!cur && prev) {
+    const uint32_t k = atomicAdd(&counters[1], 1u);
+    if (k < cap) ends[k] = (uint32_t)row;
+  }
+  if (cur && row == n - 1) {
+    const uint32_t k = atomicAdd(&counters[1], 1u);
+    if (k < cap) ends[k] = (uint32_t)n;
+  }
+}
+__global__ void k_revcomp(const uint8_t *in, uint8_t *out, uint64_t len) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  uint8_t c = in[len - 1 - i];
+  switch (c) { /* src/genomics/sequences.cxx:14-26 */
+    case 'A': c = 'T'; break;
+    case 'T': c = 'A'; break;
+    case 'C': c = 'G'; break;
+    case 'G': c = 'C'; break;
+    case 'a': c = 't'; break;
+    case 't': c = 'a'; break;
+    case 'c': c = 'g'; break;
+    case 'g': c = 'c'; break;
+    default: break;
+  }
+  out[i] = c;
+}
+
+static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+void gs_strand_free(gs_strand *s) {
+  if (s->blocks) hipFree(s->blocks);
+  if (s->sa) hipFree(s->sa);
+  if (s->run_start) hipFree(s->run_start);
+  if (s->run_cum) hipFree(s->run_cum);
+  *s = gs_strand();
+}
+
+gs_status gs_strand_from_device(const uint8_t *d_text, uint32_t *d_sa_owned, uint64_t n,
+                                gs_strand *out, hipStream_t st) {
+  if (n < 2 || n >= (1ull << 32) - 256) {
+    gs_set_error("text length must be in [1, 2^32-258]");
+    return GS_ERR_UNSUPPORTED;
+  }
+  const uint64_t nblocks = (n >> GS_BLOCK_SHIFT) + 1;
+  const uint64_t nwords = nblocks * 4;
+  uint4 *blocks = nullptr;
+  uint32_t *wcount = nullptr, *wscan = nullptr;
+  unsigned long long *d_hist = nullptr;
+  GS_HIP(hipMalloc(&blocks, nblocks * 64));
+  GS_HIP(hipMalloc(&wcount, nwords * 16));
+  GS_HIP(hipMalloc(&wscan, nwords * 16));
+  GS_HIP(hipMalloc(&d_hist, 256 * 8));
+  GS_HIP(hipMemsetAsync(d_hist, 0, 256 * 8, st));
+  hipLaunchKernelGGL(k_build_words, dim3(nblk(nwords, 256)), dim3(256), 0, st, d_text, d_sa_owned, n,
+                     nwords, blocks, wcount);
+  {
+    size_t tmp_bytes = 0;
+    GS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, wcount, wscan, 0u, nwords,
+                                   rocprim::plus<uint32_t>(), st));
+    void *tmp = nullptr;
+    GS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    for (int c = 0; c < 4; c++)
+      GS_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, wcount + c * nwords, wscan + c * nwords, 0u,
+                                     nwords, rocprim::plus<uint32_t>(), st));
+    GS_HIP(hipStreamSynchronize(st));
+    hipFree(tmp);
+  }
+  hipLaunchKernelGGL(k_write_headers, dim3(nblk(nblocks, 256)), dim3(256), 0, st, blocks, wscan,
+                     nwords, nblocks);
+  hipLaunchKernelGGL(k_histogram, dim3(1024), dim3(256), 0, st, d_text, n, d_hist);
+  unsigned long long hist[256];
+  GS_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  hipFree(wcount);
+  hipFree(wscan);
+  hipFree(d_hist);
+
+  /* byte_alphabet semantics: C[c] = number of text symbols smaller than c
+   * (sdsl/lib/csa_alphabet_strategy.cpp:25-55) */
+  uint64_t Cc[257];
+  uint64_t acc = 0;
+  for (int c = 0; c < 256; c++) {
+    Cc[c] = acc;
+    acc += hist[c];
+  }
+  Cc[256] = acc;
+  const char bases[5] = {'A', 'C', 'G', 'T', 'N'};
+  for (int k = 0; k < 5; k++) out->C_acgtn[k] = hist[(uint8_t)bases[k]] ? Cc[(uint8_t)bases[k]] : 0;
+
+  /* runs of N in the BWT */
+  uint32_t *d_cnt = nullptr, *d_starts = nullptr, *d_ends = nullptr;
+  uint32_t cap = 1u << 20;
+  std::vector<uint32_t> starts, ends;
+  for (;;) {
+    GS_HIP(hipMalloc(&d_cnt, 8));
+    GS_HIP(hipMalloc(&d_starts, 4ull * cap));
+    GS_HIP(hipMalloc(&d_ends, 4ull * cap));
+    GS_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
+    hipLaunchKernelGGL(k_n_runs, dim3(nblk(n, 256)), dim3(256), 0, st, d_text, d_sa_owned, n, d_starts,
+                       d_ends, d_cnt, cap);
+    uint32_t hc[2];
+    GS_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (hc[0] <= cap && hc[1] <= cap) {
+      starts.resize(hc[0]);
+      ends.resize(hc[1]);
+      if (hc[0]) GS_HIP(hipMemcpy(starts.data(), d_starts, 4ull * hc[0], hipMemcpyDeviceToHost));
+      if (hc[1]) GS_HIP(hipMemcpy(ends.data(), d_ends, 4ull * hc[1], hipMemcpyDeviceToHost));
+      hipFree(d_cnt);
+      hipFree(d_starts);
+      hipFree(d_ends);
+      break;
+    }
+    cap = std::max(hc[0], hc[1]);
+    hipFree(d_cnt);
+    hipFree(d_starts);
+    hipFree(d_ends);
+  }
+  if (starts.size() != ends.size()) {
+    gs_set_error("internal: N run boundaries do not pair up");
+    return GS_ERR_DEVICE;
+  }
+  std::sort(starts.begin(), starts.end());
+  std::sort(ends.begin(), ends.end());
+  std::vector<uint32_t> cum(starts.size() + 1, 0);
+  for (size_t r = 0; r < starts.size(); r++) cum[r + 1] = cum[r] + (ends[r] - starts[r]);
+
+  out->blocks = blocks;
+  out->sa = d_sa_owned;
+  out->n = n;
+  out->bytes = nblocks * 64 + n * 4;
+  if (!starts.empty()) {
+    GS_HIP(hipMalloc(&out->run_start, 4 * starts.size()));
+    GS_HIP(hipMalloc(&out->run_cum, 4 * cum.size()));
+    GS_HIP(hipMemcpy(out->run_start, starts.data(), 4 * starts.size(), hipMemcpyHostToDevice));
+    GS_HIP(hipMemcpy(out->run_cum, cum.data(), 4 * cum.size(), hipMemcpyHostToDevice));
+  }
+  gs_strand_dev &d = out->d;
+  d.blocks = blocks;
+  d.sa = d_sa_owned;
+  d.run_start = (const uint32_t *)out->run_start;
+  d.run_cum = (const uint32_t *)out->run_cum;
+  d.n = (uint32_t)n;
+  d.nruns = (uint32_t)starts.size();
+  for (int k = 0; k < 4; k++) d.C[k] = (uint32_t)Cc[(uint8_t)bases[k]];
+  d.CN = (uint32_t)Cc[(uint8_t)'N'];
+  d.has_n = hist[(uint8_t)'N'] ? 1u : 0u;
+  return GS_OK;
+}
+
+/* ---------------- GPU suffix array: prefix doubling ------------------------- */
+struct sa_flag_op {
+  /* max-scan of group starts */
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
+};
+
+__global__ void k_sa_init_keys(const uint8_t *text, uint64_t n, const uint8_t *dense /*256*/,
+                               uint32_t bits, uint32_t k0, uint64_t *keys, uint32_t *idx) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t key = 0;
+  for (uint32_t j = 0; j < k0; j++) {
+    const uint64_t p = i + j;
+    const uint64_t c = p < n ? dense[text[p]] : 0; /* past the sentinel: pad with the smallest */
+    key = (key << bits) | c;
+  }
+  keys[i] = key;
+  idx[i] = (uint32_t)i;
+}
+/* head[i] = i if key[i] != key[i-1] else 0 */
+__global__ void k_sa_heads(const uint64_t *keys, uint64_t n, uint32_t *head) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  head[i] = (i == 0 || keys[i] != keys[i - 1]) ? (uint32_t)i : 0u;
+}
+__global__ void k_sa_scatter_rank(const uint32_t *sa, const uint32_t *grp, uint64_t n, uint32_t *rank) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rank[sa[i]] = grp[i];
+}
+__global__ void k_sa_pair_keys(const uint32_t *sa, const uint32_t *rank, uint64_t n, uint64_t h,
+                               uint32_t nbits, uint64_t *keys) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t s = sa[i];
+  const uint64_t r1 = rank[s];
+  const uint64_t r2 = (s + h < n) ? (uint64_t)rank[s + h] : 0ull;
+  keys[i] = (r1 << nbits) | r2;
+}
+__global__ void k_sa_count_heads(const uint32_t *head, uint64_t n, unsigned long long *cnt) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool h = i < n && (i == 0 || head[i] != 0);
+  const uint64_t b = __ballot(h);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(cnt, (unsigned long long)__popcll(b));
+}
+
+gs_status gs_device_suffix_array(const uint8_t *d_text, uint64_t n, uint32_t *d_sa, hipStream_t st) {
+  /* dense alphabet */
+  unsigned long long *d_hist = nullptr;
+  GS_HIP(hipMalloc(&d_hist, 256 * 8 + 8));
+  GS_HIP(hipMemsetAsync(d_hist, 0, 256 * 8 + 8, st));
+  hipLaunchKernelGGL(k_histogram, dim3(1024), dim3(256), 0, st, d_text, n, d_hist);
+  unsigned long long hist[256];
+  GS_HIP(hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  uint8_t dense[256];
+  uint32_t sigma = 0;
+  for (int c = 0; c < 256; c++) dense[c] = hist[c] ? (uint8_t)sigma++ : 0;
+  uint32_t bits = 1;
+  while ((1u << bits) < sigma) bits++;
+  const uint32_t k0 = 64 / bits;
+  uint32_t nbits = 1;
+  while ((1ull << nbits) < n) nbits++;
+
+  uint8_t *d_dense = nullptr;
+  uint64_t *keys_a = nullptr, *keys_b = nullptr;
+  uint32_t *idx_a = nullptr, *rank = nullptr, *head = nullptr;
+  unsigned long long *d_cnt = d_hist + 256;
+  GS_HIP(hipMalloc(&d_dense, 256));
+  GS_HIP(hipMemcpy(d_dense, dense, 256, hipMemcpyHostToDevice));
+  GS_HIP(hipMalloc(&keys_a, 8 * n));
+  GS_HIP(hipMalloc(&keys_b, 8 * n));
+  GS_HIP(hipMalloc(&idx_a, 4 * n));
+  GS_HIP(hipMalloc(&rank, 4 * n));
+  GS_HIP(hipMalloc(&head, 4 * n));
+  const unsigned g = nblk(n, 256);
+  hipLaunchKernelGGL(k_sa_init_keys, dim3(g), dim3(256), 0, st, d_text, n, d_dense, bits, k0, keys_a,
+                     idx_a);
+  size_t sort_bytes = 0, scan_bytes = 0;
+  GS_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a, keys_b, idx_a, d_sa, n, 0, 64, st));
+  GS_HIP(rocprim::inclusive_scan(nullptr, scan_bytes, head, head, n, sa_flag_op(), st));
+  void *tmp = nullptr;
+  const size_t tmp_bytes = std::max(sort_bytes, scan_bytes);
+  GS_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  size_t sb = tmp_bytes;
+  GS_HIP(rocprim::radix_sort_pairs(tmp, sb, keys_a, keys_b, idx_a, d_sa, n, 0, bits * k0, st));
+  gs_status rc = GS_OK;
+  for (uint64_t h = k0;; h *= 2) {
+    /* keys_b sorted, d_sa = suffixes in that order */
+    hipLaunchKernelGGL(k_sa_heads, dim3(g), dim3(256), 0, st, keys_b, n, head);
+    GS_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
+    hipLaunchKernelGGL(k_sa_count_heads, dim3(g), dim3(256), 0, st, head, n, d_cnt);
+    unsigned long long groups = 0;
+    GS_HIP(hipMemcpyAsync(&groups, d_cnt, 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (groups == n) break; /* every suffix has a distinct rank: sorted */
+    if (h >= n) {
+      gs_set_error("internal: suffix array doubling did not converge");
+      rc = GS_ERR_DEVICE;
+      break;
+    }
+    sb = tmp_bytes;
+    GS_HIP(rocprim::inclusive_scan(tmp, sb, head, head, n, sa_flag_op(), st));
+    hipLaunchKernelGGL(k_sa_scatter_rank, dim3(g), dim3(256), 0, st, d_sa, head, n, rank);
+    hipLaunchKernelGGL(k_sa_pair_keys, dim3(g), dim3(256), 0, st, d_sa, rank, n, h, nbits, keys_a);
+    GS_HIP(hipMemcpyAsync(idx_a, d_sa, 4 * n, hipMemcpyDeviceToDevice, st));
+    sb = tmp_bytes;
+    GS_HIP(rocprim::radix_sort_pairs(tmp, sb, keys_a, keys_b, idx_a, d_sa, n, 0, 2 * nbits, st));
+  }
+  GS_HIP(hipStreamSynchronize(st));
+  hipFree(tmp);
+  hipFree(d_dense);
+  hipFree(keys_a);
+  hipFree(keys_b);
+  hipFree(idx_a);
+  hipFree(rank);
+  hipFree(head);
+  hipFree(d_hist);
+  return rc;
+}
+
+/* ---------------- C-ABI: index lifecycle -------------------------------------- */
+static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t *sa_fwd,
+                              const uint32_t *sa_rev, int device, gs_index **out) {
+  if (!text || !out || len < 1) return GS_ERR_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    gs_set_error("no such HIP device");
+    return GS_ERR_DEVICE;
+  }
+  GS_HIP(hipSetDevice(device));
+  const uint64_t n = len + 1;
+  gs_index *ix = new gs_index();
+  ix->device = device;
+  ix->genome_length = len;
+  hipStream_t st = nullptr;
+  uint8_t *d_fwd = nullptr, *d_rev = nullptr;
+  GS_HIP(hipMalloc(&d_fwd, n));
+  GS_HIP(hipMalloc(&d_rev, n));
+  GS_HIP(hipMemcpy(d_fwd, text, len, hipMemcpyHostToDevice));
+  GS_HIP(hipMemset(d_fwd + len, 0, 1)); /* sentinel: sdsl/include/sdsl/construct.hpp:133-135 */
+  hipLaunchKernelGGL(k_revcomp, dim3(nblk(len, 256)), dim3(256), 0, st, d_fwd, d_rev, len);
+  GS_HIP(hipMemset(d_rev + len, 0, 1));
+  gs_status rc = GS_OK;
+  for (int s = 0; s < 2 && rc == GS_OK; s++) {
+    uint32_t *d_sa = nullptr;
+    GS_HIP(hipMalloc(&d_sa, 4 * n));
+    const uint32_t *given = s == 0 ? sa_fwd : sa_rev;
+    const uint8_t *d_t = s == 0 ? d_fwd : d_rev;
+    if (given) {
+      GS_HIP(hipMemcpy(d_sa, given, 4 * n, hipMemcpyHostToDevice));
+    } else {
+      rc = gs_device_suffix_array(d_t, n, d_sa, st);
+    }
+    if (rc == GS_OK) rc = gs_strand_from_device(d_t, d_sa, n, &ix->strand[s], st);
+    if (rc != GS_OK) hipFree(d_sa);
+  }
+  hipFree(d_fwd);
+  hipFree(d_rev);
+  if (rc != GS_OK) {
+    gs_index_close(ix);
+    return rc;
+  }
+  *out = ix;
+  return GS_OK;
+}
+
+extern "C" gs_status gs_index_build(const uint8_t *text, uint64_t len, int device, gs_index **out) {
+  return build_common(text, len, nullptr, nullptr, device, out);
+}
+extern "C" gs_status gs_index_build_with_sa(const uint8_t *text, uint64_t len, const uint32_t *sa_fwd,
+                                            const uint32_t *sa_rev, int device, gs_index **out) {
+  if (!sa_fwd || !sa_rev) return GS_ERR_ARG;
+  return build_common(text, len, sa_fwd, sa_rev, device, out);
+}
+
+extern "C" void gs_index_close(gs_index *ix) {
+  if (!ix) return;
+  hipSetDevice(ix->device);
+  gs_strand_free(&ix->strand[0]);
+  gs_strand_free(&ix->strand[1]);
+  gs_buffer *bufs[] = {&ix->w_guides, &ix->w_slots, &ix->w_counts, &ix->w_nmatch, &ix->w_nhits,
+                       &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec};
+  for (gs_buffer *b : bufs)
+    if (b->p) hipFree(b->p);
+  for (int i = 0; i < 4; i++)
+    if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
+  delete ix;
+}
+extern "C" uint64_t gs_index_genome_length(const gs_index *ix) { return ix ? ix->genome_length : 0; }
+extern "C" uint64_t gs_index_device_bytes(const gs_index *ix) {
+  return ix ? ix->strand[0].bytes + ix->strand[1].bytes : 0;
+}
+extern "C" gs_status gs_index_meta(const gs_index *ix, int strand, uint64_t C_acgtn[5],
+                                   uint64_t *size) {
+  if (!ix || strand < 0 || strand > 1) return GS_ERR_ARG;
+  if (C_acgtn)
+    for (int k = 0; k < 5; k++) C_acgtn[k] = ix->strand[strand].C_acgtn[k];
+  if (size) *size = ix->strand[strand].n;
+  return GS_OK;
+}
+extern "C" gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out) {
+  if (!ix || strand < 0 || strand > 1 || !out) return GS_ERR_ARG;
+  GS_HIP(hipSetDevice(ix->device));
+  GS_HIP(hipMemcpy(out, ix->strand[strand].sa, 4 * ix->strand[strand].n, hipMemcpyDeviceToHost));
+  return GS_OK;
+}
+
+gs_status gs_reserve(gs_buffer &b, size_t bytes) {
+  if (b.cap >= bytes && b.p) return GS_OK;
+  if (b.p) hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4 + 256;
+  if (hipMalloc(&b.p, want) != hipSuccess) {
+    if (hipMalloc(&b.p, bytes) != hipSuccess) {
+      gs_set_error("out of device memory");
+      return GS_ERR_NOMEM;
+    }
+    want = bytes;
+  }
+  b.cap = want;
+  return GS_OK;
+}

@@ -1,0 +1,764 @@
+/*
+ * gs_search.hip -- the enumerate hot path as hand-written CDNA4 (gfx950) kernels.
+ *
+ * Pipeline per batch (all on one stream, device resident):
+ *   k_prepare   ASCII guides/PAMs -> packed query records        (process.hpp:51-63)
+ *   k_search    one wavefront per (guide, strand): bounded-Hamming backward search,
+ *               DFS stack of SA intervals in LDS, ballot/prefix compaction of live
+ *               branches                                          (index.hpp:182-248, 125-170)
+ *   k_order     per guide: canonical order + dedupe of matches   (process.hpp:21-23,
+ *                                                                  structures.hpp:40-42)
+ *   k_scan*     hits-per-guide -> CSR offsets
+ *   k_locate    SA gather + coordinate rule                       (process.hpp:100-115,
+ *                                                                  csa_wt.hpp:333-346)
+ * No MFMA: integer rank/popcount work bound by random 64-byte HBM reads.
+ */
+#include "gs_common.h"
+
+#define WAVE 64
+#define SEARCH_WAVES 4 /* waves per workgroup */
+#define STACK_ENTRIES 512 /* 16-byte nodes per wave: 8 KiB of LDS per wave */
+#define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
+
+/* node meta (64 bit):  [63:59] t  [58:56] k  [55] -  [54] fan  [53:52] pam id  [51:0] path */
+#define META_T(m) ((uint32_t)((m) >> 59))
+#define META_K(m) ((uint32_t)(((m) >> 56) & 7))
+#define META_FAN(m) ((uint32_t)(((m) >> 54) & 1))
+#define META_PAM(m) ((uint32_t)(((m) >> 52) & 3))
+#define PATH_MASK ((1ull << 52) - 1)
+
+struct gs_guide_rec {
+  uint64_t q;      /* 2-bit codes of the query in consumption order: step t at bits [2t+1:2t] */
+  uint32_t pam[4]; /* per PAM pattern: 3-bit codes in consumption order (0-3 ACGT, 4 = N wildcard) */
+  uint32_t npams;
+  uint32_t valid;
+};
+
+struct gs_search_args {
+  gs_strand_dev sd[2];
+  const gs_guide_rec *guides;
+  uint4 *slots;          /* [n_items][cap] match records {key_lo, key_hi, sp, ep} */
+  uint32_t *counts;      /* [n_items] matches found (may exceed cap -> overflow) */
+  uint32_t *work;        /* work-queue head */
+  unsigned long long *stats; /* [0] n_ext, [1] overflow items */
+  uint32_t n_items, L, P, m, cap;
+};
+
+/* ---- Occ for all four bases from one 64-byte block ------------------------ */
+__device__ __forceinline__ void occ4(const uint4 *__restrict__ blocks, uint32_t i, uint32_t &oA,
+                                     uint32_t &oC, uint32_t &oG, uint32_t &oT) {
+  const uint4 *p = blocks + ((size_t)(i >> GS_BLOCK_SHIFT) << 2);
+  const uint4 cnt = p[0];
+  const uint4 lo = p[1];
+  const uint4 hi = p[2];
+  const uint4 ex = p[3];
+  const uint32_t r = i & (GS_BLOCK_ROWS - 1);
+  /* 32-bit prefix masks for the four words of the 128-row block */
+  const uint32_t m0 = r >= 32 ? 0xffffffffu : ((1u << r) - 1u);
+  const uint32_t m1 = r >= 64 ? 0xffffffffu : (r > 32 ? ((1u << (r - 32)) - 1u) : 0u);
+  const uint32_t m2 = r >= 96 ? 0xffffffffu : (r > 64 ? ((1u << (r - 64)) - 1u) : 0u);
+  const uint32_t m3 = r > 96 ? ((1u << (r - 96)) - 1u) : 0u;
+  const uint32_t v0 = ~ex.x & m0, v1 = ~ex.y & m1, v2 = ~ex.z & m2, v3 = ~ex.w & m3;
+  oA = cnt.x + __popc(~lo.x & ~hi.x & v0) + __popc(~lo.y & ~hi.y & v1) +
+       __popc(~lo.z & ~hi.z & v2) + __popc(~lo.w & ~hi.w & v3);
+  oC = cnt.y + __popc(lo.x & ~hi.x & v0) + __popc(lo.y & ~hi.y & v1) +
+       __popc(lo.z & ~hi.z & v2) + __popc(lo.w & ~hi.w & v3);
+  oG = cnt.z + __popc(~lo.x & hi.x & v0) + __popc(~lo.y & hi.y & v1) +
+       __popc(~lo.z & hi.z & v2) + __popc(~lo.w & hi.w & v3);
+  oT = cnt.w + __popc(lo.x & hi.x & v0) + __popc(lo.y & hi.y & v1) + __popc(lo.z & hi.z & v2) +
+       __popc(lo.w & hi.w & v3);
+}
+
+/* number of BWT rows < i holding a literal 'N' (only the PAM's N can ask: index.hpp:139-149) */
+__device__ __forceinline__ uint32_t occ_n(const gs_strand_dev &sd, uint32_t i) {
+  uint32_t lo = 0, hi = sd.nruns; /* last run with start < i */
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (sd.run_start[mid] < i)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo == 0) return 0;
+  uint32_t r = lo - 1;
+  uint32_t len = sd.run_cum[r + 1] - sd.run_cum[r];
+  uint32_t d = i - sd.run_start[r];
+  return sd.run_cum[r] + (d < len ? d : len);
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t ballot) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
+                                   __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+}
+
+/* ---- search: one wavefront per (guide, strand) ---------------------------- */
+__global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a) {
+  __shared__ uint4 s_stack[SEARCH_WAVES][STACK_ENTRIES];
+  const uint32_t wave = threadIdx.x / WAVE;
+  const uint32_t lane = lane_id();
+  uint4 *stk = s_stack[wave];
+  unsigned long long n_ext = 0, n_ovf = 0;
+  const uint32_t T_end = a.L + a.P;
+  const uint32_t reserve = (MAX_FANOUT - 1) * (T_end + 2);
+
+  for (;;) {
+    uint32_t item = 0;
+    if (lane == 0) item = atomicAdd(a.work, 1u);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= a.n_items) break; /* exit condition every wave reaches */
+    const uint32_t strand = item & 1u;
+    const gs_guide_rec gr = a.guides[item >> 1];
+    if (!gr.valid) {
+      if (lane == 0) a.counts[item] = 0;
+      continue;
+    }
+    const gs_strand_dev &sd = a.sd[strand];
+    const uint4 *__restrict__ blocks = sd.blocks;
+    const uint32_t npams = a.P ? gr.npams : 1u;
+    uint4 *out = a.slots + (size_t)item * a.cap;
+    uint32_t n_match = 0;
+
+    /* root: whole SA range, nothing consumed (index.hpp:388-391) */
+    uint32_t size = 1;
+    if (lane == 0) {
+      uint64_t meta0 = (a.L == 0 && a.P > 0 && npams > 1) ? (1ull << 54) : 0ull;
+      stk[0] = make_uint4(0u, sd.n - 1u, (uint32_t)meta0, (uint32_t)(meta0 >> 32));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    while (size > 0) {
+      /* pop up to 64 nodes, but never more than the stack can take children for.  `reserve`
+       * keeps room for a single-node DFS of depth T_end, so w >= 1 always makes progress and
+       * size never exceeds STACK_ENTRIES. */
+      uint32_t w = size < WAVE ? size : WAVE;
+      const uint32_t limit = STACK_ENTRIES - reserve;
+      const uint32_t room = size < limit ? (limit - size) / (MAX_FANOUT - 1) : 0u;
+      if (w > room) w = room ? room : 1u;
+      const bool active = lane < w;
+      uint4 nd = make_uint4(0, 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (active) nd = stk[size - 1 - lane];
+      size -= w;
+
+      const uint32_t sp = nd.x, ep = nd.y;
+      const uint64_t meta = ((uint64_t)nd.w << 32) | nd.z;
+      const uint32_t t = META_T(meta), k = META_K(meta);
+      const bool fan = META_FAN(meta) != 0;
+      const uint32_t pamid = META_PAM(meta);
+      const uint64_t path = meta & PATH_MASK;
+      const bool ext = active && !fan;
+      n_ext += __popcll(__ballot(ext));
+
+      /* Occ at both interval ends: two independent 64-byte reads per lane */
+      uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+      if (ext) {
+        occ4(blocks, sp, a0, a1, a2, a3);
+        occ4(blocks, ep + 1u, b0, b1, b2, b3);
+      }
+
+      /* which symbols may be tried, and what they cost */
+      const bool inpam = t >= a.L;
+      uint32_t qc = 0, allow = 0, pc = 0;
+      if (!inpam) {
+        qc = (uint32_t)(gr.q >> (2u * t)) & 3u;
+        allow = (k < a.m) ? 0xFu : (1u << qc); /* index.hpp:230 */
+      } else {
+        const uint32_t pw = pamid == 0 ? gr.pam[0] : pamid == 1 ? gr.pam[1] : pamid == 2 ? gr.pam[2] : gr.pam[3];
+        pc = (pw >> (3u * (t - a.L))) & 7u;
+        allow = pc < 4u ? (1u << pc) : 0xFu; /* 'N' tries A,T,C,G at cost 0: index.hpp:151-169 */
+      }
+      const uint32_t t2 = t + 1u;
+      const bool term = (t2 == T_end);
+      const bool needfan = (t2 == a.L) && (a.P > 0) && (npams > 1u);
+      const uint32_t sh_g = 50u - 2u * t;                 /* guide step: 2-bit code */
+      const uint32_t sh_p = inpam ? 49u - 2u * a.L - 3u * (t - a.L) : 0u; /* PAM step: 3-bit code */
+
+#pragma unroll
+      for (uint32_t c = 0; c < MAX_FANOUT; ++c) {
+        bool live = false;
+        uint32_t csp = 0, cep = 0;
+        uint64_t cmeta = 0;
+        bool cterm = false;
+        if (c < 4u) {
+          if (fan) {
+            /* PAM fan-out: one copy of the finished 20-mer node per PAM pattern (index.hpp:212-214) */
+            live = active && c < npams;
+            csp = sp;
+            cep = ep;
+            cmeta = (meta & ~((1ull << 54) | (3ull << 52))) | ((uint64_t)c << 52);
+            cterm = false;
+          } else {
+            const uint32_t oa = c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3;
+            const uint32_t ob = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
+            live = ext && ((allow >> c) & 1u) && ob > oa; /* occ_within > 0 */
+            csp = sd.C[c] + oa;
+            cep = sd.C[c] + ob - 1u;
+            uint64_t p2;
+            uint32_t k2 = k;
+            if (!inpam) {
+              const uint32_t code = (c == qc) ? 0u : 1u + c - (c > qc ? 1u : 0u);
+              p2 = path | ((uint64_t)code << sh_g);
+              k2 += (c != qc);
+            } else {
+              const uint32_t code = c < 3u ? c : 4u; /* A=0 C=1 G=2 (N=3) T=4 */
+              p2 = path | ((uint64_t)code << sh_p);
+            }
+            cmeta = ((uint64_t)t2 << 59) | ((uint64_t)k2 << 56) | ((uint64_t)pamid << 52) | p2 |
+                    (needfan ? (1ull << 54) : 0ull);
+            cterm = term;
+          }
+        } else {
+          /* literal 'N' of the genome under a PAM 'N' (index.hpp:139-149); rare */
+          if (sd.has_n && sd.nruns) {
+            const bool want = ext && inpam && pc == 4u;
+            if (__ballot(want)) {
+              if (want) {
+                const uint32_t na = occ_n(sd, sp), nb = occ_n(sd, ep + 1u);
+                live = nb > na;
+                csp = sd.CN + na;
+                cep = sd.CN + nb - 1u;
+                cmeta = ((uint64_t)t2 << 59) | ((uint64_t)k << 56) | ((uint64_t)pamid << 52) | path |
+                        (3ull << sh_p);
+                cterm = term;
+              }
+            }
+          }
+        }
+        const bool push = live && !cterm;
+        const bool emit = live && cterm;
+        const uint64_t pb = __ballot(push);
+        if (pb) {
+          if (push) stk[size + lanes_below(pb)] = make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+          size += __popcll(pb);
+        }
+        const uint64_t eb = __ballot(emit);
+        if (eb) {
+          if (emit) {
+            const uint32_t idx = n_match + lanes_below(eb);
+            if (idx < a.cap) {
+              const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
+                                   ((cmeta & PATH_MASK) << 8);
+              out[idx] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
+            }
+          }
+          n_match += __popcll(eb);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (lane == 0) a.counts[item] = n_match;
+    if (n_match > a.cap) n_ovf++;
+  }
+  if (lane == 0) {
+    if (n_ext) atomicAdd(&a.stats[0], n_ext);
+    if (n_ovf) atomicAdd(&a.stats[1], n_ovf);
+  }
+}
+
+/* ---- prepare: ASCII -> packed records (process.hpp:51-63) ------------------ */
+__device__ __forceinline__ int base_code(uint8_t c) {
+  switch (c) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return -1;
+  }
+}
+
+struct gs_prep_args {
+  const uint8_t *guides;     /* n*L */
+  const uint8_t *guide_pams; /* n*P */
+  uint8_t alt[4][8];         /* alt PAM patterns (ASCII) */
+  gs_guide_rec *out;
+  uint32_t *n_invalid;
+  uint32_t n, L, P, n_alt, start;
+};
+
+__global__ void k_prepare(gs_prep_args a) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.n) return;
+  gs_guide_rec r;
+  r.q = 0;
+  r.valid = 1;
+  r.npams = 0;
+  for (int j = 0; j < 4; j++) r.pam[j] = 0;
+  const uint8_t *s = a.guides + (size_t)g * a.L;
+  /* query = reverse_complement(sequence) consumed right to left == complement of the guide left
+   * to right (process.hpp:63, index.hpp:218); with --start the guide itself right to left */
+  for (uint32_t t = 0; t < a.L; t++) {
+    int c = a.start ? base_code(s[a.L - 1 - t]) : base_code(s[t]);
+    if (c < 0) {
+      r.valid = 0;
+      c = 0;
+    }
+    if (!a.start) c = 3 - c; /* complement in A,C,G,T = 0..3 */
+    r.q |= (uint64_t)c << (2 * t);
+  }
+  if (a.P > 0) {
+    const uint8_t *own = a.guide_pams + (size_t)g * a.P;
+    /* pams = alt_pams ++ [k.pam] (process.hpp:51-56) */
+    const uint32_t np = a.n_alt + 1;
+    for (uint32_t j = 0; j < np; j++) {
+      const uint8_t *p = j < a.n_alt ? a.alt[j] : own;
+      uint32_t code = 0;
+      for (uint32_t u = 0; u < a.P; u++) {
+        uint8_t ch = a.start ? p[a.P - 1 - u] : p[u];
+        int c;
+        if (ch == 'N') {
+          c = 4;
+        } else {
+          c = base_code(ch);
+          if (c < 0) {
+            r.valid = 0;
+            c = 0;
+          } else if (!a.start) {
+            c = 3 - c;
+          }
+        }
+        code |= (uint32_t)c << (3 * u);
+      }
+      r.pam[j] = code;
+    }
+    r.npams = np;
+  } else {
+    r.npams = 1;
+  }
+  if (!r.valid) atomicAdd(a.n_invalid, 1u);
+  a.out[g] = r;
+}
+
+/* ---- order: per guide canonical order + dedupe ----------------------------- */
+struct gs_order_args {
+  uint4 *slots;           /* in: [n][2][cap] raw ; out: [n][2*cap] ordered unique {key_lo,key_hi,sp,cnt} */
+  const uint32_t *counts; /* [2n] */
+  uint32_t *nmatch;       /* [n] */
+  uint32_t *nhits;        /* [n] */
+  unsigned long long *stats; /* [2] total matches */
+  uint32_t n, cap;
+};
+
+/* one wavefront per guide; dynamic LDS: 2*cap uint4 (records) + 2*cap uint4 (sorted) */
+__global__ __launch_bounds__(WAVE) void k_order(gs_order_args a) {
+  extern __shared__ uint4 s_mem[];
+  const uint32_t g = blockIdx.x;
+  const uint32_t lane = lane_id();
+  if (g >= a.n) return;
+  const uint32_t cap = a.cap;
+  uint32_t c0 = a.counts[2 * g], c1 = a.counts[2 * g + 1];
+  if (c0 > cap) c0 = cap;
+  if (c1 > cap) c1 = cap;
+  const uint32_t M = c0 + c1;
+  uint4 *rec = s_mem;
+  uint4 *srt = s_mem + 2 * cap;
+  uint4 *base = a.slots + (size_t)g * 2 * cap;
+  for (uint32_t i = lane; i < M; i += WAVE) rec[i] = i < c0 ? base[i] : base[cap + (i - c0)];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  /* rank sort: ascending (key, original index) */
+  for (uint32_t i = lane; i < M; i += WAVE) {
+    const uint4 me = rec[i];
+    const uint64_t key = ((uint64_t)me.y << 32) | me.x;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < M; j++) {
+      const uint4 o = rec[j];
+      const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
+      rank += (ok < key) || (ok == key && j < i);
+    }
+    srt[rank] = me;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  /* dedupe equal sequences (std::set keeps the first), compact, count hits */
+  uint32_t n_out = 0, hits = 0;
+  for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
+    const uint32_t i = i0 + lane;
+    bool keep = false;
+    uint4 me = make_uint4(0, 0, 0, 0);
+    if (i < M) {
+      me = srt[i];
+      keep = true;
+      if (i > 0) {
+        const uint4 pv = srt[i - 1];
+        keep = !(pv.x == me.x && pv.y == me.y);
+      }
+    }
+    const uint64_t kb = __ballot(keep);
+    const uint32_t cnt = keep ? (me.w - me.z + 1u) : 0u;
+    if (keep) base[n_out + lanes_below(kb)] = make_uint4(me.x, me.y, me.z, cnt);
+    n_out += __popcll(kb);
+    /* wave sum of cnt */
+    uint32_t s = cnt;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    hits += s;
+  }
+  if (lane == 0) {
+    a.nmatch[g] = n_out;
+    a.nhits[g] = hits;
+    if (n_out) atomicAdd(&a.stats[2], (unsigned long long)n_out);
+  }
+}
+
+/* ---- exclusive scan of nhits (uint32) into uint64 offsets ------------------- */
+#define SCAN_BLOCK 1024
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_partial(const uint32_t *in, uint64_t *blocksum,
+                                                             uint32_t n) {
+  __shared__ unsigned long long s[SCAN_BLOCK / WAVE];
+  const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  unsigned long long v = i < n ? in[i] : 0;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane_id() == 0) s[threadIdx.x / WAVE] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int j = 0; j < SCAN_BLOCK / WAVE; j++) t += s[j];
+    blocksum[blockIdx.x] = t;
+  }
+}
+/* single block: exclusive scan of the block sums in place, total to blocksum[nb] */
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_blocksums(uint64_t *blocksum, uint32_t nb) {
+  __shared__ unsigned long long s[SCAN_BLOCK];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nb; b0 += SCAN_BLOCK) {
+    const uint32_t i = b0 + threadIdx.x;
+    const unsigned long long v = i < nb ? blocksum[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t o = 1; o < SCAN_BLOCK; o <<= 1) {
+      unsigned long long add = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+      __syncthreads();
+      s[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nb) blocksum[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += s[SCAN_BLOCK - 1];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blocksum[nb] = carry;
+}
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(const uint32_t *in, const uint64_t *blocksum,
+                                                           uint64_t *out, uint32_t n, uint32_t nb) {
+  __shared__ unsigned long long s[SCAN_BLOCK];
+  const uint32_t i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const unsigned long long v = i < n ? in[i] : 0;
+  s[threadIdx.x] = v;
+  __syncthreads();
+  for (uint32_t o = 1; o < SCAN_BLOCK; o <<= 1) {
+    unsigned long long add = threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+    __syncthreads();
+    s[threadIdx.x] += add;
+    __syncthreads();
+  }
+  if (i < n) out[i] = blocksum[blockIdx.x] + s[threadIdx.x] - v;
+  if (i == 0) out[n] = blocksum[nb];
+}
+
+/* ---- locate: SA gather + coordinate rule ----------------------------------- */
+struct gs_locate_args {
+  gs_strand_dev sd[2];
+  const uint4 *matches; /* [n][2*cap] ordered unique */
+  const uint32_t *nmatch;
+  const uint64_t *offsets;
+  gs_hit *hits;
+  uint64_t genome_length;
+  uint32_t n, cap;
+};
+
+/* one wavefront per guide; dynamic LDS: (2*cap + 1) uint32 exclusive prefix of match sizes */
+__global__ __launch_bounds__(WAVE) void k_locate(gs_locate_args a) {
+  extern __shared__ uint32_t s_pre[];
+  const uint32_t g = blockIdx.x;
+  const uint32_t lane = lane_id();
+  if (g >= a.n) return;
+  const uint32_t M = a.nmatch[g];
+  if (M == 0) return;
+  const uint4 *mt = a.matches + (size_t)g * 2 * a.cap;
+  uint32_t run = 0;
+  for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
+    const uint32_t i = i0 + lane;
+    const uint32_t c = i < M ? mt[i].w : 0;
+    uint32_t inc = c; /* inclusive wave scan */
+    for (int o = 1; o < WAVE; o <<= 1) {
+      const uint32_t up = __shfl_up(inc, o);
+      if ((int)lane >= o) inc += up;
+    }
+    if (i < M) s_pre[i] = run + inc - c;
+    run += __shfl(inc, WAVE - 1);
+  }
+  if (lane == 0) s_pre[M] = run;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t H = run;
+  gs_hit *out = a.hits + a.offsets[g];
+  for (uint32_t h = lane; h < H; h += WAVE) {
+    /* last match j with s_pre[j] <= h */
+    uint32_t lo = 0, hi = M;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_pre[mid] <= h)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const uint4 m = mt[lo];
+    const uint64_t key = ((uint64_t)m.y << 32) | m.x;
+    const uint32_t strand = (uint32_t)(key >> 60) & 1u;
+    const uint32_t row = m.z + (h - s_pre[lo]);
+    const uint64_t sa = a.sd[strand].sa[row];
+    gs_hit o;
+    /* process.hpp:104 / :111 */
+    o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
+    o.key = key;
+    out[h] = o;
+  }
+}
+
+/* ---- unit kernels ----------------------------------------------------------- */
+__global__ void k_rank4(gs_strand_dev sd, const uint64_t *rows, uint64_t n, uint64_t *out) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t a, c, g, t;
+  occ4(sd.blocks, (uint32_t)rows[j], a, c, g, t);
+  out[4 * j + 0] = a;
+  out[4 * j + 1] = c;
+  out[4 * j + 2] = g;
+  out[4 * j + 3] = t;
+}
+__global__ void k_resolve(gs_strand_dev sd, const uint64_t *rows, uint64_t n, uint64_t *out) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  out[j] = sd.sa[rows[j]];
+}
+
+/* ---- host side of the pipeline ---------------------------------------------- */
+static uint32_t default_cap(uint32_t m, uint64_t n_rows) {
+  /* expected matches per (guide, strand) on a repeat-free genome is ~ n_rows/4^(L) * sum C(L,k)3^k;
+   * start small and let the overflow retry grow it */
+  (void)n_rows;
+  if (m <= 3) return 64;
+  if (m == 4) return 256;
+  if (m == 5) return 1024;
+  return 2048;
+}
+
+static int g_num_cus(int device) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return 256;
+  return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+}
+
+extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,
+                                         const void *d_guide_pams, uint32_t P, const char *alt_pams,
+                                         uint32_t n_alt, uint32_t mismatches, uint32_t flags,
+                                         void *stream, const void **d_offsets, const void **d_hits,
+                                         gs_result_view *stats) {
+  if (!ix || (!d_guides && n) || (P && !d_guide_pams && n) || (n_alt && !alt_pams))
+    return GS_ERR_ARG;
+  if (n >= (1ull << 31)) return GS_ERR_ARG;
+  if (L < 1 || L > 31 || P > 8 || 2 * L + 3 * P > 52 || mismatches > 7 || n_alt > 3) {
+    gs_set_error("device path supports 1<=L<=31, P<=8, 2L+3P<=52, mismatches<=7, <=3 alt PAMs");
+    return GS_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  GS_HIP(hipSetDevice(ix->device));
+  for (int i = 0; i < 4; i++)
+    if (!ix->ev[i]) GS_HIP(hipEventCreate(&ix->ev[i]));
+
+  const uint32_t n32 = (uint32_t)n;
+  uint32_t cap = default_cap(mismatches, ix->strand[0].n);
+  gs_status rc;
+  /* misc: [0..15] uint64 stats ; then work counter / invalid counter */
+  if ((rc = gs_reserve(ix->w_misc, 256)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_grec, sizeof(gs_guide_rec) * (n + 1))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_counts, sizeof(uint32_t) * (2 * n + 2))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_nmatch, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_nhits, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_offsets, sizeof(uint64_t) * (n + 2))) != GS_OK) return rc;
+  const uint32_t nb = (n32 + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  if ((rc = gs_reserve(ix->w_blocksums, sizeof(uint64_t) * (nb + 2))) != GS_OK) return rc;
+
+  unsigned long long *d_stats = (unsigned long long *)ix->w_misc.p;
+  uint32_t *d_work = (uint32_t *)((char *)ix->w_misc.p + 128);
+  uint32_t *d_invalid = d_work + 1;
+
+  GS_HIP(hipEventRecord(ix->ev[0], st));
+  GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 256, st));
+  if (n == 0) {
+    GS_HIP(hipMemsetAsync(ix->w_offsets.p, 0, sizeof(uint64_t), st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (d_offsets) *d_offsets = ix->w_offsets.p;
+    if (d_hits) *d_hits = ix->w_hits.p;
+    if (stats) {
+      memset(stats, 0, sizeof(*stats));
+    }
+    return GS_OK;
+  }
+  {
+    gs_prep_args pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.guides = (const uint8_t *)d_guides;
+    pa.guide_pams = (const uint8_t *)d_guide_pams;
+    for (uint32_t j = 0; j < n_alt; j++)
+      for (uint32_t u = 0; u < P; u++) pa.alt[j][u] = (uint8_t)alt_pams[j * P + u];
+    pa.out = (gs_guide_rec *)ix->w_grec.p;
+    pa.n_invalid = d_invalid;
+    pa.n = n32;
+    pa.L = L;
+    pa.P = P;
+    pa.n_alt = P ? n_alt : 0; /* empty guide PAM drops the alt PAMs: process.hpp:52-53 */
+    pa.start = (flags & GS_FLAG_PAM_AT_START) ? 1 : 0;
+    hipLaunchKernelGGL(k_prepare, dim3((n32 + 255) / 256), dim3(256), 0, st, pa);
+  }
+  uint32_t h_invalid = 0;
+  GS_HIP(hipMemcpyAsync(&h_invalid, d_invalid, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  if (h_invalid) {
+    gs_set_error("guide or PAM contains a symbol outside A,C,G,T (PAM: +N): not implemented on the device path");
+    return GS_ERR_UNSUPPORTED;
+  }
+
+  const int cus = g_num_cus(ix->device);
+  float ms_search = 0.f;
+  for (;;) {
+    if (cap > 2048) {
+      gs_set_error("more than 2048 distinct matches for one (guide, strand): not implemented");
+      return GS_ERR_UNSUPPORTED;
+    }
+    if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
+    GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 256, st));
+    gs_search_args sa;
+    sa.sd[0] = ix->strand[0].d;
+    sa.sd[1] = ix->strand[1].d;
+    sa.guides = (const gs_guide_rec *)ix->w_grec.p;
+    sa.slots = (uint4 *)ix->w_slots.p;
+    sa.counts = (uint32_t *)ix->w_counts.p;
+    sa.work = d_work;
+    sa.stats = d_stats;
+    sa.n_items = 2 * n32;
+    sa.L = L;
+    sa.P = P;
+    sa.m = mismatches;
+    sa.cap = cap;
+    /* persistent waves pulling (guide, strand) items: 5 workgroups of 4 waves per CU
+     * (LDS: 32 KiB per workgroup) */
+    uint32_t grid = (uint32_t)cus * 5u;
+    const uint32_t need = (2 * n32 + SEARCH_WAVES - 1) / SEARCH_WAVES;
+    if (grid > need) grid = need;
+    GS_HIP(hipEventRecord(ix->ev[1], st));
+    hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 0, st, sa);
+    GS_HIP(hipEventRecord(ix->ev[2], st));
+    unsigned long long h_stats[2] = {0, 0};
+    GS_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    GS_HIP(hipGetLastError());
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]);
+    ms_search += ms;
+    if (stats) stats->n_ext = h_stats[0];
+    if (h_stats[1] == 0) break;
+    /* some (guide, strand) found more matches than its slots hold: redo with room */
+    cap = cap >= 1024 ? cap * 2 : cap * 4;
+  }
+
+  {
+    gs_order_args oa;
+    oa.slots = (uint4 *)ix->w_slots.p;
+    oa.counts = (const uint32_t *)ix->w_counts.p;
+    oa.nmatch = (uint32_t *)ix->w_nmatch.p;
+    oa.nhits = (uint32_t *)ix->w_nhits.p;
+    oa.stats = d_stats;
+    oa.n = n32;
+    oa.cap = cap;
+    const size_t lds = sizeof(uint4) * 4 * (size_t)cap;
+    if (lds > 64 * 1024)
+      GS_HIP(hipFuncSetAttribute((const void *)k_order, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    hipLaunchKernelGGL(k_order, dim3(n32), dim3(WAVE), lds, st, oa);
+  }
+  hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_BLOCK), 0, st,
+                     (const uint32_t *)ix->w_nhits.p, (uint64_t *)ix->w_blocksums.p, n32);
+  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st,
+                     (uint64_t *)ix->w_blocksums.p, nb);
+  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st,
+                     (const uint32_t *)ix->w_nhits.p, (const uint64_t *)ix->w_blocksums.p,
+                     (uint64_t *)ix->w_offsets.p, n32, nb);
+  uint64_t total = 0;
+  GS_HIP(hipMemcpyAsync(&total, (uint64_t *)ix->w_offsets.p + n, 8, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  if ((rc = gs_reserve(ix->w_hits, sizeof(gs_hit) * (total + 1))) != GS_OK) return rc;
+  {
+    gs_locate_args la;
+    la.sd[0] = ix->strand[0].d;
+    la.sd[1] = ix->strand[1].d;
+    la.matches = (const uint4 *)ix->w_slots.p;
+    la.nmatch = (const uint32_t *)ix->w_nmatch.p;
+    la.offsets = (const uint64_t *)ix->w_offsets.p;
+    la.hits = (gs_hit *)ix->w_hits.p;
+    la.genome_length = ix->genome_length;
+    la.n = n32;
+    la.cap = cap;
+    const size_t lds = sizeof(uint32_t) * (2 * (size_t)cap + 1);
+    hipLaunchKernelGGL(k_locate, dim3(n32), dim3(WAVE), lds, st, la);
+  }
+  GS_HIP(hipEventRecord(ix->ev[3], st));
+  unsigned long long h_stats3[3] = {0, 0, 0};
+  GS_HIP(hipMemcpyAsync(h_stats3, d_stats, sizeof(h_stats3), hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  GS_HIP(hipGetLastError());
+  if (d_offsets) *d_offsets = ix->w_offsets.p;
+  if (d_hits) *d_hits = ix->w_hits.p;
+  if (stats) {
+    stats->n_guides = n;
+    stats->n_hits = total;
+    stats->guide_offsets = nullptr;
+    stats->hits = nullptr;
+    stats->n_matches = h_stats3[2];
+    stats->ms_search = ms_search;
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, ix->ev[0], ix->ev[3]);
+    stats->ms_total = ms;
+  }
+  return GS_OK;
+}
+
+extern "C" gs_status gs_rank_bwt4(gs_index *ix, int strand, const uint64_t *rows, uint64_t n,
+                                  uint64_t *out) {
+  if (!ix || strand < 0 || strand > 1 || (n && (!rows || !out))) return GS_ERR_ARG;
+  for (uint64_t j = 0; j < n; j++)
+    if (rows[j] > ix->strand[strand].n) return GS_ERR_ARG;
+  GS_HIP(hipSetDevice(ix->device));
+  uint64_t *d_rows = nullptr, *d_out = nullptr;
+  if (n == 0) return GS_OK;
+  GS_HIP(hipMalloc(&d_rows, 8 * n));
+  GS_HIP(hipMalloc(&d_out, 32 * n));
+  GS_HIP(hipMemcpy(d_rows, rows, 8 * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_rank4, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, ix->strand[strand].d,
+                     d_rows, n, d_out);
+  GS_HIP(hipMemcpy(out, d_out, 32 * n, hipMemcpyDeviceToHost));
+  hipFree(d_rows);
+  hipFree(d_out);
+  return GS_OK;
+}
+
+extern "C" gs_status gs_resolve(gs_index *ix, int strand, const uint64_t *rows, uint64_t n,
+                                uint64_t *out) {
+  if (!ix || strand < 0 || strand > 1 || (n && (!rows || !out))) return GS_ERR_ARG;
+  for (uint64_t j = 0; j < n; j++)
+    if (rows[j] >= ix->strand[strand].n) return GS_ERR_ARG;
+  GS_HIP(hipSetDevice(ix->device));
+  uint64_t *d_rows = nullptr, *d_out = nullptr;
+  if (n == 0) return GS_OK;
+  GS_HIP(hipMalloc(&d_rows, 8 * n));
+  GS_HIP(hipMalloc(&d_out, 8 * n));
+  GS_HIP(hipMemcpy(d_rows, rows, 8 * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_resolve, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0,
+                     ix->strand[strand].d, d_rows, n, d_out);
+  GS_HIP(hipMemcpy(out, d_out, 8 * n, hipMemcpyDeviceToHost));
+  hipFree(d_rows);
+  hipFree(d_out);
+  return GS_OK;
+}

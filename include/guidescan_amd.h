@@ -1,0 +1,161 @@
+/*
+ * guidescan_amd.h -- C-ABI of the MI355X-native off-target enumerator.
+ *
+ * This is the drop-in boundary for guidescan's enumerate hot path.  The
+ * reference has no FFI: the seam is a C++ template call from the per-guide
+ * pipeline into the FM-index.  Each entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * tree).  Plain pointers and sizes only; no C++ or torch types; every function
+ * returns a gs_status and never throws.
+ *
+ * Batch-oriented by design: the reference calls inexact_search once per guide
+ * per strand from N std::threads (src/guidescan.cxx:240-247); a GPU needs the
+ * whole batch, so gs_enumerate takes n guides and returns CSR hit lists in the
+ * reference's canonical per-guide order (include/genomics/process.hpp:100-115).
+ */
+#ifndef GUIDESCAN_AMD_H
+#define GUIDESCAN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GS_OK = 0,
+  GS_ERR_ARG = 1,         /* bad argument (NULL, sizes out of range) */
+  GS_ERR_DEVICE = 2,      /* HIP runtime error / no usable device */
+  GS_ERR_UNSUPPORTED = 3, /* input outside what the device path implements */
+  GS_ERR_NOMEM = 4,
+  GS_ERR_IO = 5,
+  GS_ERR_FORMAT = 6 /* malformed index file */
+} gs_status;
+
+/* Opaque handle: both strand indexes of one genome resident in one GPU's HBM.
+ * Replaces the two `genome_index<wt_huff<>,64,8192>` objects built in
+ * src/guidescan.cxx:198-211 (include/genomics/index.hpp:23-123).  Immutable after
+ * creation; one in-flight enumerate per handle. */
+typedef struct gs_index gs_index;
+
+/* One off-target hit, 16 bytes.
+ *   pos : signed absolute coordinate exactly as process.hpp:104,111 computes it
+ *         (forward-index hit: -SA[row]; reverse-index hit: L-(SA[row]+1)).
+ *   key : canonical sort key that also encodes the whole `match` struct
+ *         (include/genomics/structures.hpp:33-43):
+ *           bits 63..61  match.mismatches
+ *           bit  60      0 = found in the forward index, 1 = reverse index
+ *           bits 59..8   match.sequence as per-position codes, position 0 first:
+ *                        guide positions (2 bits): 0 = equals the query base
+ *                          (upper case), 1..3 = mismatch, the matched base's rank
+ *                          among the three other bases in A<C<G<T order (lower case);
+ *                        PAM positions (3 bits): A=0 C=1 G=2 N=3 T=4 (upper case).
+ *           bits 7..0    zero
+ *         Ascending key == the reference's order of (distance, index, std::set<match>
+ *         ordered by sequence string) because 'A'<'C'<'G'<'N'<'T'<'a'<'c'<'g'<'t'.
+ * gs_decode_sequence() rebuilds match.sequence from (guide, key). */
+typedef struct {
+  int64_t pos;
+  uint64_t key;
+} gs_hit;
+
+#define GS_KEY_MISMATCHES(key) ((uint32_t)((key) >> 61))
+#define GS_KEY_INDEX(key) ((uint32_t)(((key) >> 60) & 1))
+
+/* flags for gs_enumerate */
+#define GS_FLAG_PAM_AT_START 1u /* --start, process.hpp:63,84-87 */
+
+typedef struct {
+  uint64_t n_guides;
+  uint64_t n_hits;
+  const uint64_t *guide_offsets; /* n_guides+1 entries, host memory owned by the result */
+  const gs_hit *hits;            /* n_hits entries, host memory owned by the result */
+  /* work counters of SURVEY.md section 8d (properties of the input): */
+  uint64_t n_ext;     /* search-tree nodes extended (a3 calls with position>=0 + a4 calls with begin!=end) */
+  uint64_t n_matches; /* distinct (index, match.sequence) intervals */
+  /* device timing of the last call, milliseconds (HIP events on the call's stream) */
+  float ms_search;  /* search kernel only */
+  float ms_total;   /* prepare + search + order + locate, device side */
+} gs_result_view;
+
+typedef struct gs_result gs_result;
+
+/* ---- index lifecycle ------------------------------------------------------ */
+
+/* Build both strand indexes from the forward genome text (the reference's
+ * <fasta>.forward.dna bytes: upper-cased, concatenated, no separators,
+ * src/genomics/seq_io.cxx:57-63) and upload them to `device`.
+ * Replaces `guidescan index` = sdsl::construct x2 (src/guidescan.cxx:109-179)
+ * followed by sdsl::load_from_file x2 (src/guidescan.cxx:198-208).
+ * The suffix arrays are built on the GPU. */
+gs_status gs_index_build(const uint8_t *text, uint64_t len, int device, gs_index **out);
+
+/* Same, with caller-supplied suffix arrays of text+'\0' and of
+ * reverse_complement(text)+'\0' (len+1 uint32 entries each). */
+gs_status gs_index_build_with_sa(const uint8_t *text, uint64_t len, const uint32_t *sa_fwd,
+                                 const uint32_t *sa_rev, int device, gs_index **out);
+
+/* Import the reference's on-disk index: <prefix>.forward, <prefix>.reverse
+ * (sdsl::csa_wt<wt_huff<>,64,8192>::serialize, sdsl/include/sdsl/csa_wt.hpp:372-382).
+ * Replaces sdsl::load_from_file (src/guidescan.cxx:198-208). */
+gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out);
+
+void gs_index_close(gs_index *ix);
+uint64_t gs_index_genome_length(const gs_index *ix); /* sum of chromosome lengths (no sentinel) */
+uint64_t gs_index_device_bytes(const gs_index *ix);
+
+/* ---- the hot path ---------------------------------------------------------- */
+
+/* Enumerate all off-targets of n guides.
+ *   guides     : n*L ASCII bytes (kmer.sequence), no terminators
+ *   guide_pams : n*P ASCII bytes (kmer.pam), P may be 0
+ *   alt_pams   : n_alt*P ASCII bytes (-a/--alt-pam), searched before the guide's own PAM
+ * Replaces, per guide, process.hpp:51-115: query/PAM preparation, the two
+ * genome_index::inexact_search calls (index.hpp:377-398 -> 182-248 -> 125-170),
+ * the std::set<match> ordering (process.hpp:21-23) and the resolve() expansion
+ * (index.hpp:53-55 -> csa_wt.hpp:333-346).  Bulge budgets are 0 (index.hpp:388-391).
+ * Host pointers in, host result out (device work and copies inside). */
+gs_status gs_enumerate(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
+                       const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,
+                       uint32_t mismatches, uint32_t flags, gs_result **out);
+
+/* Same with the guide/PAM arrays already resident in this device's HBM and the
+ * result left in HBM: *d_offsets (n+1 uint64) and *d_hits (gs_hit[]) point into
+ * buffers owned by the index handle, valid until the next call on it.
+ * `stream` is a hipStream_t (NULL = default stream).  This is what bench.py times. */
+gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,
+                              const void *d_guide_pams, uint32_t P, const char *alt_pams,
+                              uint32_t n_alt, uint32_t mismatches, uint32_t flags, void *stream,
+                              const void **d_offsets, const void **d_hits, gs_result_view *stats);
+
+gs_status gs_result_get(const gs_result *r, gs_result_view *view);
+void gs_result_free(gs_result *r);
+
+/* Rebuild match.sequence (index.hpp:226,243-244; lower case = mismatch) from the
+ * hit key.  `guide`/`L`, `P`, `flags` as passed to gs_enumerate.  out needs L+P+1 bytes. */
+gs_status gs_decode_sequence(const char *guide, uint32_t L, uint32_t P, uint32_t flags,
+                             uint64_t key, char *out);
+
+/* ---- unit-level entry points (parity tests of SURVEY section 8a rows a6-a8) ---- */
+
+/* Occ(c, i) for c in A,C,G,T at each rows[j] in [0, n]: out[4*j + {0,1,2,3}].
+ * Replaces csa_wt::rank_bwt (sdsl/include/sdsl/csa_wt.hpp:270-273). strand 0 = forward index. */
+gs_status gs_rank_bwt4(gs_index *ix, int strand, const uint64_t *rows, uint64_t n, uint64_t *out);
+/* SA[rows[j]].  Replaces genome_index::resolve (index.hpp:53-55). */
+gs_status gs_resolve(gs_index *ix, int strand, const uint64_t *rows, uint64_t n, uint64_t *out);
+/* csa.C[csa.char2comp[c]] for c in "ACGT" then 'N' (0 when absent), and csa.size(). */
+gs_status gs_index_meta(const gs_index *ix, int strand, uint64_t C_acgtn[5], uint64_t *size);
+/* copy the device-resident suffix array back (n = size entries) */
+gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out);
+
+/* CFD score of one hit (include/genomics/printer.hpp:98-113), float semantics preserved. */
+float gs_calculate_cfd(const char *sgrna, const char *match_sequence, const char *pam);
+
+const char *gs_status_string(gs_status s);
+const char *gs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GUIDESCAN_AMD_H */
