@@ -288,10 +288,18 @@ __global__ void k_sa_pair_keys(const uint32_t *sa, const uint32_t *rank, uint64_
   keys[i] = (r1 << nbits) | r2;
 }
 __global__ void k_sa_count_heads(const uint32_t *head, uint64_t n, unsigned long long *cnt) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool h = i < n && (i == 0 || head[i] != 0);
-  const uint64_t b = __ballot(h);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(cnt, (unsigned long long)__popcll(b));
+  /* grid-stride count of group heads; one atomic per workgroup */
+  __shared__ unsigned int s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  unsigned int local = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    local += (i == 0 || head[i] != 0);
+  for (int o = 32; o > 0; o >>= 1) local += __shfl_xor(local, o);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(&s_sum, local);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_sum) atomicAdd(cnt, (unsigned long long)s_sum);
 }
 
 gs_status gs_device_suffix_array(const uint8_t *d_text, uint64_t n, uint32_t *d_sa, hipStream_t st) {
@@ -339,7 +347,7 @@ gs_status gs_device_suffix_array(const uint8_t *d_text, uint64_t n, uint32_t *d_
     /* keys_b sorted, d_sa = suffixes in that order */
     hipLaunchKernelGGL(k_sa_heads, dim3(g), dim3(256), 0, st, keys_b, n, head);
     GS_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
-    hipLaunchKernelGGL(k_sa_count_heads, dim3(g), dim3(256), 0, st, head, n, d_cnt);
+    hipLaunchKernelGGL(k_sa_count_heads, dim3(g < 2048 ? g : 2048), dim3(256), 0, st, head, n, d_cnt);
     unsigned long long groups = 0;
     GS_HIP(hipMemcpyAsync(&groups, d_cnt, 8, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
