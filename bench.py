@@ -41,9 +41,9 @@ WORKLOADS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("GS_BENCH_WORKLOAD", "chr1"))
+    ap.add_argument("--workload", default=os.environ.get("GS_BENCH_WORKLOAD", "hg38"))
     ap.add_argument("--mismatches", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="guides per step per GPU (0 = workload default)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="guides timed on the CPU oracle (0 = skip)")
@@ -170,12 +170,9 @@ def cpu_baseline(text, gidx, seqs, pams, m, sample):
     import oracle_lib as ol
     cores = os.cpu_count() or 1
     if sample < 0:
-        sample = max(cores * 8, 64)
+        sample = max(cores * 32, 256)
     sample = min(sample, seqs.shape[0])
-    sa_f = gidx.suffix_array(0)
-    sa_r = gidx.suffix_array(1)
-    oidx = ol.OracleIndex(text, sa_fwd=sa_f, sa_rev=sa_r)
-    del sa_f, sa_r
+    oidx = ol.OracleIndex(text, sa_provider=lambda s: gidx.suffix_array(s), nthreads=cores)
     opts = ol.make_opts(mismatches=m)
     t0 = time.perf_counter()
     tot, counts, ctr = oidx.enumerate_batch(seqs[:sample], pams[:sample], opts, nthreads=cores)

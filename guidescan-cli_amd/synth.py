@@ -60,9 +60,11 @@ def make_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), n_blocks=True):
 
 
 def sample_guides(text: np.ndarray, n: int, seed=7, L=20, pam=b"NGG", minus_fraction=0.5):
-    """Sample on-target guides: + strand sites whose next 3 bases match `pam`
+    """Sample on-target guides: + strand sites whose next P bases match `pam`
     (N = any of ACGT) and - strand sites (reverse complement), protospacer ACGT only.
-    Returns (seqs uint8[n,L], pams uint8[n,P] = the pattern, positions, strands)."""
+    Returns (seqs uint8[n,L], pams uint8[n,P] = the pattern, positions, strands).
+    Candidates are drawn in bounded chunks and pre-filtered on the fixed PAM bases, so
+    millions of guides on a 3 Gbp text stay cheap."""
     rng = np.random.Generator(np.random.PCG64(seed))
     P = len(pam)
     total = text.shape[0]
@@ -73,31 +75,34 @@ def sample_guides(text: np.ndarray, n: int, seed=7, L=20, pam=b"NGG", minus_frac
     acgt = np.zeros(256, dtype=bool)
     acgt[list(b"ACGT")] = True
     pam_arr = np.frombuffer(pam, dtype=np.uint8)
+    ar = np.arange(L + P)[None, :]
     while got < n:
-        cand = rng.integers(0, total - (L + P), size=max(4096, (n - got) * 24))
-        minus = rng.random(cand.shape[0]) < minus_fraction
-        for is_minus in (False, True):
-            c = cand[minus == is_minus]
-            if c.size == 0:
+        m = int(min(max(65536, (n - got) * 32), 8_000_000))
+        cand = rng.integers(0, total - (L + P), size=m)
+        minus = rng.random(m) < minus_fraction
+        ok = np.ones(m, dtype=bool)
+        for j in range(P):
+            if pam_arr[j] == ord("N"):
                 continue
-            win = text[c[:, None] + np.arange(L + P)[None, :]]
-            if is_minus:
-                win = _COMP[win[:, ::-1]]
-            ok = acgt[win].all(axis=1)
-            for j in range(P):
-                if pam_arr[j] != ord("N"):
-                    ok &= win[:, L + j] == pam_arr[j]
-            sel = np.nonzero(ok)[0]
-            take = min(sel.size, n - got)
-            if take == 0:
-                continue
-            sel = sel[:take]
-            seqs[got:got + take] = win[sel, :L]
-            strands[got:got + take] = ord("-") if is_minus else ord("+")
-            positions[got:got + take] = c[sel]
-            got += take
-            if got >= n:
-                break
+            # + strand: PAM base j sits at c+L+j ; - strand: its complement at c+P-1-j
+            at = np.where(minus, cand + (P - 1 - j), cand + L + j)
+            want = np.where(minus, _COMP[pam_arr[j]], pam_arr[j])
+            ok &= text[at] == want
+        idx = np.nonzero(ok)[0]
+        if idx.size == 0:
+            continue
+        c = cand[idx]
+        mi = minus[idx]
+        win = text[c[:, None] + ar]
+        win[mi] = _COMP[win[mi][:, ::-1]]
+        good = acgt[win].all(axis=1)
+        sel = np.nonzero(good)[0]
+        take = min(sel.size, n - got)
+        sel = sel[:take]
+        seqs[got:got + take] = win[sel, :L]
+        strands[got:got + take] = np.where(mi[sel], ord("-"), ord("+"))
+        positions[got:got + take] = c[sel]
+        got += take
     pams = np.tile(pam_arr, (n, 1))
     return seqs, pams, positions, strands
 

@@ -95,25 +95,78 @@ static void build_sa(const uint8_t *t, uint64_t n, uint32_t *sa) {
   free(rank);
 }
 
-gso_index *gso_index_build(const uint8_t *text, uint64_t len, const uint32_t *sa_opt) {
+/* parallel helpers for large inputs (cpu_baseline at hg38 size): chunked over threads */
+typedef struct {
+  gso_index *ix;
+  const uint8_t *t;
+  const uint32_t *sa;
+  uint64_t lo, hi; /* row range, multiple of 64 at lo */
+  uint64_t cnt[256];
+  uint32_t base[256];
+  int phase;
+} bjob_t;
+
+static void *build_worker(void *arg) {
+  bjob_t *j = arg;
+  gso_index *ix = j->ix;
+  if (j->phase == 0) {
+    memset(j->cnt, 0, sizeof j->cnt);
+    for (uint64_t i = j->lo; i < j->hi; i++) {
+      uint8_t c = j->sa[i] ? j->t[j->sa[i] - 1] : j->t[ix->n - 1];
+      ix->bwt[i] = c;
+      j->cnt[c]++;
+    }
+  } else {
+    uint32_t run[256];
+    memcpy(run, j->base, sizeof run);
+    for (uint64_t i = j->lo; i < j->hi; i++) {
+      if (i % 64 == 0)
+        for (int c = 0; c < 256; c++)
+          if (ix->present[c]) ix->ck[(i / 64) * ix->sigma + ix->sym_idx[c]] = run[c];
+      run[ix->bwt[i]]++;
+    }
+    if (j->hi == ix->n && ix->n % 64 == 0)
+      for (int c = 0; c < 256; c++)
+        if (ix->present[c]) ix->ck[(ix->n / 64) * ix->sigma + ix->sym_idx[c]] = run[c];
+  }
+  return NULL;
+}
+
+static gso_index *index_build_impl(const uint8_t *text, uint64_t len, const uint32_t *sa_opt,
+                                   int keep_sa, int nthreads) {
   gso_index *ix = calloc(1, sizeof(*ix));
   uint64_t n = len + 1;
   ix->n = n;
   uint8_t *t = malloc(n);
   memcpy(t, text, len);
   t[len] = 0; /* construct.hpp:133-135 appends the 0 sentinel */
-  uint32_t *sa = malloc(sizeof(uint32_t) * n);
-  if (sa_opt)
-    memcpy(sa, sa_opt, sizeof(uint32_t) * n);
-  else
-    build_sa(t, n, sa);
-  ix->sa_full = sa;
-  ix->bwt = malloc(n);
-  uint64_t cnt[256] = {0};
-  for (uint64_t i = 0; i < n; i++) {
-    ix->bwt[i] = sa[i] ? t[sa[i] - 1] : t[n - 1];
-    cnt[t[i]]++;
+  uint32_t *sa_own = NULL;
+  const uint32_t *sa = sa_opt;
+  if (!sa_opt) {
+    sa_own = malloc(sizeof(uint32_t) * n);
+    build_sa(t, n, sa_own);
+    sa = sa_own;
   }
+  ix->bwt = malloc(n);
+  if (nthreads < 1) nthreads = 1;
+  if (n < 1000000) nthreads = 1;
+  bjob_t *jobs = calloc(nthreads, sizeof(bjob_t));
+  pthread_t *th = malloc(sizeof(pthread_t) * nthreads);
+  uint64_t chunk = ((n / nthreads) / 64 + 1) * 64;
+  for (int k = 0; k < nthreads; k++) {
+    jobs[k].ix = ix;
+    jobs[k].t = t;
+    jobs[k].sa = sa;
+    jobs[k].lo = (uint64_t)k * chunk < n ? (uint64_t)k * chunk : n;
+    jobs[k].hi = (uint64_t)(k + 1) * chunk < n ? (uint64_t)(k + 1) * chunk : n;
+    if (k == nthreads - 1) jobs[k].hi = n;
+    jobs[k].phase = 0;
+  }
+  for (int k = 0; k < nthreads; k++) pthread_create(&th[k], NULL, build_worker, &jobs[k]);
+  for (int k = 0; k < nthreads; k++) pthread_join(th[k], NULL);
+  uint64_t cnt[256] = {0};
+  for (int k = 0; k < nthreads; k++)
+    for (int c = 0; c < 256; c++) cnt[c] += jobs[k].cnt[c]; /* BWT is a permutation of the text */
   /* byte_alphabet: sdsl/lib/csa_alphabet_strategy.cpp:25-55 */
   uint64_t acc = 0;
   for (int c = 0; c < 256; c++) {
@@ -126,20 +179,38 @@ gso_index *gso_index_build(const uint8_t *text, uint64_t len, const uint32_t *sa
   uint64_t nb = n / 64 + 1;
   ix->ck = calloc(nb * ix->sigma, sizeof(uint32_t));
   uint32_t run[256] = {0};
-  for (uint64_t i = 0; i < n; i++) {
-    if (i % 64 == 0)
-      for (int c = 0; c < 256; c++)
-        if (ix->present[c]) ix->ck[(i / 64) * ix->sigma + ix->sym_idx[c]] = run[c];
-    run[ix->bwt[i]]++;
+  for (int k = 0; k < nthreads; k++) {
+    memcpy(jobs[k].base, run, sizeof run);
+    for (int c = 0; c < 256; c++) run[c] += (uint32_t)jobs[k].cnt[c];
+    jobs[k].phase = 1;
   }
-  if (n % 64 == 0)
-    for (int c = 0; c < 256; c++)
-      if (ix->present[c]) ix->ck[(n / 64) * ix->sigma + ix->sym_idx[c]] = run[c];
+  for (int k = 0; k < nthreads; k++) pthread_create(&th[k], NULL, build_worker, &jobs[k]);
+  for (int k = 0; k < nthreads; k++) pthread_join(th[k], NULL);
+  free(jobs);
+  free(th);
   uint64_t ns = (n + SA_DENS - 1) / SA_DENS;
   ix->sa_sample = malloc(sizeof(uint32_t) * ns);
   for (uint64_t i = 0; i < ns; i++) ix->sa_sample[i] = sa[i * SA_DENS];
+  if (keep_sa) {
+    if (sa_own) {
+      ix->sa_full = sa_own;
+      sa_own = NULL;
+    } else {
+      ix->sa_full = malloc(sizeof(uint32_t) * n);
+      memcpy(ix->sa_full, sa, sizeof(uint32_t) * n);
+    }
+  }
+  free(sa_own);
   free(t);
   return ix;
+}
+
+gso_index *gso_index_build(const uint8_t *text, uint64_t len, const uint32_t *sa_opt) {
+  return index_build_impl(text, len, sa_opt, 1, 1);
+}
+/* large inputs: borrow the caller's suffix array (not kept), build with nthreads */
+gso_index *gso_index_build_borrow(const uint8_t *text, uint64_t len, const uint32_t *sa, int nthreads) {
+  return index_build_impl(text, len, sa, 0, nthreads);
 }
 
 void gso_index_free(gso_index *ix) {
@@ -152,7 +223,9 @@ void gso_index_free(gso_index *ix) {
 }
 uint64_t gso_size(const gso_index *ix) { return ix->n; }
 uint8_t gso_bwt(const gso_index *ix, uint64_t row) { return ix->bwt[row]; }
-void gso_copy_sa(const gso_index *ix, uint32_t *out) { memcpy(out, ix->sa_full, 4 * ix->n); }
+void gso_copy_sa(const gso_index *ix, uint32_t *out) {
+  if (ix->sa_full) memcpy(out, ix->sa_full, 4 * ix->n);
+}
 
 /* csa_wt.hpp:270-273 -> wt_pc.hpp:360-384: number of c in BWT[0,i); a symbol that
  * is not in the text ranks 0 (wt_pc.hpp:363-365). */

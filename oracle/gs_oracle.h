@@ -30,6 +30,8 @@ typedef struct gso_index gso_index;
  * does, sdsl/include/sdsl/construct.hpp:133-135).  sa_opt: optional suffix array
  * of the len+1 suffixes (uint32), or NULL to build one here. */
 gso_index *gso_index_build(const uint8_t *text, uint64_t len, const uint32_t *sa_opt);
+/* large inputs: sa is borrowed (not kept, gso_copy_sa unavailable), built with nthreads */
+gso_index *gso_index_build_borrow(const uint8_t *text, uint64_t len, const uint32_t *sa, int nthreads);
 void gso_index_free(gso_index *);
 uint64_t gso_size(const gso_index *);                            /* csa.size() = len+1 */
 uint64_t gso_rank_bwt(const gso_index *, uint64_t i, uint8_t c); /* csa_wt.hpp:270-273 */

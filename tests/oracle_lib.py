@@ -47,6 +47,8 @@ def lib():
         L = C.CDLL(str(so))
         L.gso_index_build.restype = C.c_void_p
         L.gso_index_build.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
+        L.gso_index_build_borrow.restype = C.c_void_p
+        L.gso_index_build_borrow.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.gso_index_free.argtypes = [C.c_void_p]
         L.gso_size.restype = C.c_uint64
         L.gso_size.argtypes = [C.c_void_p]
@@ -137,13 +139,23 @@ def make_opts(mismatches=3, start=False, alt_pams=(), max_off_targets=-1, comple
 class OracleIndex:
     """forward + reverse FM-index of a genome text (uint8 array without sentinel)."""
 
-    def __init__(self, text: np.ndarray, sa_fwd=None, sa_rev=None):
+    def __init__(self, text: np.ndarray, sa_fwd=None, sa_rev=None, sa_provider=None, nthreads=1):
+        """sa_provider(strand) -> uint32 suffix array: large-input mode, the array is borrowed
+        for the build of that strand only and then dropped (bounded host memory)."""
         from importlib import import_module
         synth = import_module("guidescan-cli_amd.synth")
         L = lib()
         self.text = np.ascontiguousarray(text, dtype=np.uint8)
         self.rtext = np.ascontiguousarray(synth.reverse_complement_bytes(self.text))
         self.length = int(self.text.shape[0])
+        if sa_provider is not None:
+            sa = sa_provider(0)
+            self.fwd = L.gso_index_build_borrow(self.text.ctypes.data, self.length, sa.ctypes.data, nthreads)
+            del sa
+            sa = sa_provider(1)
+            self.rev = L.gso_index_build_borrow(self.rtext.ctypes.data, self.length, sa.ctypes.data, nthreads)
+            del sa
+            return
         pf = sa_fwd.ctypes.data if sa_fwd is not None else None
         pr = sa_rev.ctypes.data if sa_rev is not None else None
         self.fwd = L.gso_index_build(self.text.ctypes.data, self.length, pf)

@@ -1,0 +1,68 @@
+"""N>1 path on CPU: world_size-2 gloo.  The sharding/gather layer is exercised with the
+oracle standing in as the per-rank enumerate function AND as the unsharded checker
+(the HIP library cannot run here).  CPU only."""
+import os
+import sys
+from importlib import import_module
+
+import numpy as np
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_lib as ol
+
+parallel = import_module("guidescan-cli_amd.parallel")
+synth = import_module("guidescan-cli_amd.synth")
+api = import_module("guidescan-cli_amd.api")
+
+
+def oracle_enumerate_fn(text):
+    oidx = ol.OracleIndex(text)
+    opts = ol.make_opts(mismatches=2)
+
+    def fn(seqs, pams, **kw):
+        offsets = [0]
+        recs = []
+        for i in range(seqs.shape[0]):
+            hits, ctr, raw = oidx.enumerate(seqs[i].tobytes().decode(), pams[i].tobytes().decode(), opts)
+            ol.lib().gso_free(raw[0])
+            for pos, mm, idx, seq, row in hits:
+                recs.append((pos, (mm << 61) | (idx << 60)))
+            offsets.append(len(recs))
+        return (np.asarray(offsets, dtype=np.uint64), np.array(recs, dtype=api.HIT_DTYPE).reshape(-1),
+                dict(n=seqs.shape[0]))
+    return fn
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    text, _, _ = synth.make_genome([150_000], seed=6)
+    seqs, pams, _, _ = synth.sample_guides(text, 23, seed=2)   # odd count: uneven shards
+    fn = oracle_enumerate_fn(text)
+    off, hits, stats = parallel.enumerate_sharded(fn, seqs, pams, dist=dist)
+    b = parallel.shard_bounds(23, world)
+    assert stats["n"] == b[rank + 1] - b[rank]
+    el = parallel.timed_steps(lambda i: None, 2, 1, lambda: None, dist=dist)
+    assert el >= 0
+    if rank == 0:
+        full_off, full_hits, _ = fn(seqs, pams)
+        assert np.array_equal(off, full_off)
+        assert np.array_equal(hits, full_hits)
+        open(out, "w").write("ok %d" % len(full_hits))
+    else:
+        assert off is None
+    dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    assert parallel.shard_bounds(10, 4) == [0, 3, 6, 8, 10]
+    assert parallel.shard_bounds(2, 4) == [0, 1, 2, 2, 2]
+    assert parallel.shard_bounds(0, 2) == [0, 0, 0]
+
+
+def test_world2_gloo_sharded_equals_unsharded(tmp_path):
+    out = tmp_path / "r0.txt"
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(out)), nprocs=2, join=True)
+    assert out.read_text().startswith("ok")
