@@ -107,16 +107,21 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
     if (lane == 0) item = atomicAdd(a.work, 1u);
     item = __builtin_amdgcn_readfirstlane(item);
     if (item >= a.n_items) break; /* exit condition every wave reaches */
-    const uint32_t strand = item & 1u;
-    const gs_guide_rec gr = a.guides[item >> 1];
+    /* all forward-index items first, then all reverse-index items: at any moment the waves
+     * touch one strand's Occ array, which halves the hot footprint (TLB reach) */
+    const uint32_t n_guides = a.n_items >> 1;
+    const uint32_t strand = item >= n_guides ? 1u : 0u;
+    const uint32_t guide = item - strand * n_guides;
+    const uint32_t slot = 2u * guide + strand;
+    const gs_guide_rec gr = a.guides[guide];
     if (!gr.valid) {
-      if (lane == 0) a.counts[item] = 0;
+      if (lane == 0) a.counts[slot] = 0;
       continue;
     }
     const gs_strand_dev &sd = a.sd[strand];
     const uint4 *__restrict__ blocks = sd.blocks;
     const uint32_t npams = a.P ? gr.npams : 1u;
-    uint4 *out = a.slots + (size_t)item * a.cap;
+    uint4 *out = a.slots + (size_t)slot * a.cap;
     uint32_t n_match = 0;
 
     /* root: whole SA range, nothing consumed (index.hpp:388-391) */
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    if (lane == 0) a.counts[item] = n_match;
+    if (lane == 0) a.counts[slot] = n_match;
     if (n_match > a.cap) n_ovf++;
   }
   if (lane == 0) {
