@@ -18,6 +18,7 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libgsamd.so"
 
 GS_FLAG_PAM_AT_START = 1
+GS_FLAG_FAITHFUL_WALK = 2
 
 
 class GsError(RuntimeError):
@@ -175,7 +176,8 @@ class GenomeIndex:
         _check(lib().gs_index_copy_sa(self._h, strand, out.ctypes.data))
         return out
 
-    def enumerate(self, seqs: np.ndarray, pams: np.ndarray, mismatches=3, alt_pams=(), start=False):
+    def enumerate(self, seqs: np.ndarray, pams: np.ndarray, mismatches=3, alt_pams=(), start=False,
+                  faithful=False):
         """seqs uint8[n,L], pams uint8[n,P] -> (offsets uint64[n+1], hits HIT_DTYPE[], stats dict).
         Hits of guide i are hits[offsets[i]:offsets[i+1]] in the reference's canonical order."""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
@@ -188,7 +190,7 @@ class GenomeIndex:
             if len(p) != P:
                 raise ValueError("alt PAM length differs from the guides' PAM length")
         r = C.c_void_p()
-        flags = GS_FLAG_PAM_AT_START if start else 0
+        flags = (GS_FLAG_PAM_AT_START if start else 0) | (GS_FLAG_FAITHFUL_WALK if faithful else 0)
         _check(lib().gs_enumerate(self._h, seqs.ctypes.data, n, L, pams.ctypes.data if P else None, P,
                                   alt if alt_pams else None, len(alt_pams), mismatches, flags,
                                   C.byref(r)))
@@ -208,11 +210,11 @@ class GenomeIndex:
         return offsets, hits, stats
 
     def enumerate_device(self, d_guides_ptr, n, L, d_pams_ptr, P, mismatches=3, alt_pams=(),
-                         start=False, stream=None):
+                         start=False, stream=None, faithful=False):
         """Device-resident variant (what bench.py times): pointers are raw device addresses.
         Returns (d_offsets_ptr, d_hits_ptr, stats)."""
         alt = b"".join(p.encode() for p in alt_pams)
-        flags = GS_FLAG_PAM_AT_START if start else 0
+        flags = (GS_FLAG_PAM_AT_START if start else 0) | (GS_FLAG_FAITHFUL_WALK if faithful else 0)
         d_off, d_hits = C.c_void_p(), C.c_void_p()
         v = GsResultView()
         _check(lib().gs_enumerate_device(self._h, d_guides_ptr, n, L, d_pams_ptr, P,

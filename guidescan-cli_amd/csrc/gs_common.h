@@ -32,11 +32,15 @@ struct gs_strand_dev {
   uint32_t C[4]; /* first row of the A, C, G, T ranges */
   uint32_t CN;   /* first row of the N range (undefined when has_n == 0) */
   uint32_t has_n;
+  /* prefix interval table: entry {sp, end} of every k-mer, indexed by
+   * the k-mer with its FIRST text symbol in the LOWEST bits, so the 16 two-symbol left
+   * extensions of a (k-2)-mer share one aligned 128-byte line.  end==0: k-mer absent. */
+  const uint2 *ptab;
 };
 
 struct gs_strand {
   gs_strand_dev d{};
-  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr;
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr;
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;
@@ -55,6 +59,12 @@ struct gs_index {
   gs_buffer w_guides, w_slots, w_counts, w_nmatch, w_nhits, w_offsets, w_hits, w_misc, w_blocksums,
       w_grec;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  /* prefix-table seeding plan: position masks of every mismatch combination over the first
+   * pt_k-2 query symbols, grouped by mismatch count j (gs_index.hip: build_seed_plan) */
+  uint32_t pt_k = 0;
+  void *d_combo = nullptr;         /* uint32 masks, all j concatenated */
+  uint32_t combo_off[10] = {0};    /* start of the masks with j mismatches */
+  uint32_t combo_cnt[10] = {0};    /* C(pt_k-2, j) */
 };
 
 #define GS_HIP(expr)                                                              \

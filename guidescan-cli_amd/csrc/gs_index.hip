@@ -12,6 +12,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 /* BWT symbol class of a text byte: 0..3 = A,C,G,T ; 4 = N ; 5 = anything else (incl. '\0') */
@@ -132,6 +133,7 @@ void gs_strand_free(gs_strand *s) {
   if (s->sa) hipFree(s->sa);
   if (s->run_start) hipFree(s->run_start);
   if (s->run_cum) hipFree(s->run_cum);
+  if (s->ptab) hipFree(s->ptab);
   *s = gs_strand();
 }
 
@@ -377,6 +379,84 @@ gs_status gs_device_suffix_array(const uint8_t *d_text, uint64_t n, uint32_t *d_
   return rc;
 }
 
+/* ---------------- prefix interval table ---------------------------------------- */
+__device__ __forceinline__ bool kmer_code(const uint8_t *text, uint64_t n, uint64_t p, uint32_t k,
+                                          uint32_t &code) {
+  if (p + k > n - 1) return false; /* would run into the sentinel */
+  uint32_t c = 0;
+  for (uint32_t i = 0; i < k; i++) {
+    const uint32_t cls = sym_class(text[p + i]);
+    if (cls > 3) return false;
+    c |= cls << (2 * i); /* first text symbol of the k-mer in the lowest bits */
+  }
+  code = c;
+  return true;
+}
+__global__ void k_ptab_build(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t k,
+                             uint2 *tab) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  uint32_t c = 0, cp = 0, cn = 0;
+  if (!kmer_code(text, n, sa[r], k, c)) return;
+  const bool vp = r > 0 && kmer_code(text, n, sa[r - 1], k, cp);
+  const bool vn = r + 1 < n && kmer_code(text, n, sa[r + 1], k, cn);
+  if (!vp || cp != c) tab[c].x = (uint32_t)r;       /* first row of the k-mer's interval */
+  if (!vn || cn != c) tab[c].y = (uint32_t)(r + 1); /* one past its last row */
+}
+
+static uint32_t choose_prefix_k(uint64_t n) {
+  if (const char *e = getenv("GS_PREFIX_K")) return (uint32_t)atoi(e);
+  /* deepest level at which k-mers still average ~8+ rows; capped so the table stays <= 2 GiB */
+  uint32_t k = 0;
+  uint64_t v = n / 8;
+  while (v >= 4) {
+    v >>= 2;
+    k++;
+  }
+  if (k > 14) k = 14;
+  if (k < 4) k = 0;
+  return k;
+}
+
+static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hipStream_t st) {
+  if (!k) return GS_OK;
+  const size_t bytes = sizeof(uint2) << (2 * k);
+  uint2 *tab = nullptr;
+  GS_HIP(hipMalloc(&tab, bytes));
+  GS_HIP(hipMemsetAsync(tab, 0, bytes, st));
+  hipLaunchKernelGGL(k_ptab_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
+                     (const uint32_t *)s->sa, s->n, k, tab);
+  GS_HIP(hipStreamSynchronize(st));
+  s->ptab = tab;
+  s->d.ptab = tab;
+  s->bytes += bytes;
+  return GS_OK;
+}
+
+/* all position masks with j bits over kp positions, j = 0..min(kp,7), in a fixed order */
+static gs_status build_seed_plan(gs_index *ix, uint32_t k) {
+  ix->pt_k = k;
+  if (!k) return GS_OK;
+  const uint32_t kp = k - 2;
+  std::vector<uint32_t> masks(16, 0u); /* [0..7] offsets, [8..15] counts, then the masks */
+  for (uint32_t j = 0; j <= 7; j++) {
+    masks[j] = (uint32_t)masks.size();
+    uint32_t cnt = 0;
+    if (j <= kp)
+      for (uint32_t m = 0; m < (1u << kp); m++)
+        if ((uint32_t)__builtin_popcount(m) == j) {
+          masks.push_back(m);
+          cnt++;
+        }
+    masks[8 + j] = cnt;
+    ix->combo_off[j] = masks[j];
+    ix->combo_cnt[j] = cnt;
+  }
+  GS_HIP(hipMalloc(&ix->d_combo, 4 * masks.size()));
+  GS_HIP(hipMemcpy(ix->d_combo, masks.data(), 4 * masks.size(), hipMemcpyHostToDevice));
+  return GS_OK;
+}
+
 /* ---------------- C-ABI: index lifecycle -------------------------------------- */
 static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t *sa_fwd,
                               const uint32_t *sa_rev, int device, gs_index **out) {
@@ -400,6 +480,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
   hipLaunchKernelGGL(k_revcomp, dim3(nblk(len, 256)), dim3(256), 0, st, d_fwd, d_rev, len);
   GS_HIP(hipMemset(d_rev + len, 0, 1));
   gs_status rc = GS_OK;
+  const uint32_t pk = choose_prefix_k(n);
   for (int s = 0; s < 2 && rc == GS_OK; s++) {
     uint32_t *d_sa = nullptr;
     GS_HIP(hipMalloc(&d_sa, 4 * n));
@@ -412,7 +493,9 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
     }
     if (rc == GS_OK) rc = gs_strand_from_device(d_t, d_sa, n, &ix->strand[s], st);
     if (rc != GS_OK) hipFree(d_sa);
+    if (rc == GS_OK) rc = build_ptab(d_t, &ix->strand[s], pk, st);
   }
+  if (rc == GS_OK) rc = build_seed_plan(ix, pk);
   hipFree(d_fwd);
   hipFree(d_rev);
   if (rc != GS_OK) {
@@ -443,6 +526,7 @@ extern "C" void gs_index_close(gs_index *ix) {
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)
     if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
+  if (ix->d_combo) hipFree(ix->d_combo);
   delete ix;
 }
 extern "C" uint64_t gs_index_genome_length(const gs_index *ix) { return ix ? ix->genome_length : 0; }

@@ -17,7 +17,9 @@
 
 #define WAVE 64
 #define SEARCH_WAVES 4 /* waves per workgroup */
-#define STACK_ENTRIES 512 /* 16-byte nodes per wave: 8 KiB of LDS per wave */
+#ifndef STACK_ENTRIES
+#define STACK_ENTRIES 320 /* 16-byte nodes per wave: 5 KiB of LDS per wave -> 32 waves per CU */
+#endif
 #define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
 
 /* node meta (64 bit):  [63:59] t  [58:56] k  [55] -  [54] fan  [53:52] pam id  [51:0] path */
@@ -42,23 +44,33 @@ struct gs_search_args {
   uint32_t *work;        /* work-queue head */
   unsigned long long *stats; /* [0] n_ext, [1] overflow items */
   uint32_t n_items, L, P, m, cap;
+  /* prefix-table seeding (pt_k = 0: walk from the root) */
+  /* seeding plan in device memory: [0..7] offset of the masks with j bits, [8..15] their
+   * count C(pt_k-2, j), then the position masks over the first pt_k-2 steps */
+  const uint32_t *combo;
+  uint32_t pt_k; /* table depth k; seeds are the depth-k nodes */
+  uint32_t jmax; /* min(m, pt_k-2, 7) */
 };
 
-/* ---- Occ for all four bases from one 64-byte block ------------------------ */
-__device__ __forceinline__ void occ4(const uint4 *__restrict__ blocks, uint32_t i, uint32_t &oA,
-                                     uint32_t &oC, uint32_t &oG, uint32_t &oT) {
-  const uint4 *p = blocks + ((size_t)(i >> GS_BLOCK_SHIFT) << 2);
+#define SEED_LOW 128 /* refill the stacks from the prefix table when they hold this few nodes */
+
+/* prefix mask of r_j = clamp(r - 32*j, 0, 32) low bits, r in [0,128] */
+__device__ __forceinline__ uint32_t word_mask(uint32_t r, uint32_t j) {
+  int rj = (int)r - (int)(32u * j);
+  rj = rj < 0 ? 0 : rj > 32 ? 32 : rj; /* v_med3_i32 */
+  return (uint32_t)((0xFFFFFFFFull << rj) >> 32);
+}
+
+/* ---- Occ for all four bases: rows [128*blk, 128*blk + r) of one 64-byte block, r in [0,128] */
+__device__ __forceinline__ void occ4(const uint4 *__restrict__ blocks, uint32_t blk, uint32_t r,
+                                     uint32_t &oA, uint32_t &oC, uint32_t &oG, uint32_t &oT) {
+  const uint4 *p = blocks + ((size_t)blk << 2);
   const uint4 cnt = p[0];
   const uint4 lo = p[1];
   const uint4 hi = p[2];
   const uint4 ex = p[3];
-  const uint32_t r = i & (GS_BLOCK_ROWS - 1);
-  /* 32-bit prefix masks for the four words of the 128-row block */
-  const uint32_t m0 = r >= 32 ? 0xffffffffu : ((1u << r) - 1u);
-  const uint32_t m1 = r >= 64 ? 0xffffffffu : (r > 32 ? ((1u << (r - 32)) - 1u) : 0u);
-  const uint32_t m2 = r >= 96 ? 0xffffffffu : (r > 64 ? ((1u << (r - 64)) - 1u) : 0u);
-  const uint32_t m3 = r > 96 ? ((1u << (r - 96)) - 1u) : 0u;
-  const uint32_t v0 = ~ex.x & m0, v1 = ~ex.y & m1, v2 = ~ex.z & m2, v3 = ~ex.w & m3;
+  const uint32_t v0 = ~ex.x & word_mask(r, 0), v1 = ~ex.y & word_mask(r, 1),
+                 v2 = ~ex.z & word_mask(r, 2), v3 = ~ex.w & word_mask(r, 3);
   oA = cnt.x + __popc(~lo.x & ~hi.x & v0) + __popc(~lo.y & ~hi.y & v1) +
        __popc(~lo.z & ~hi.z & v2) + __popc(~lo.w & ~hi.w & v3);
   oC = cnt.y + __popc(lo.x & ~hi.x & v0) + __popc(lo.y & ~hi.y & v1) +
@@ -67,6 +79,22 @@ __device__ __forceinline__ void occ4(const uint4 *__restrict__ blocks, uint32_t 
        __popc(~lo.z & hi.z & v2) + __popc(~lo.w & hi.w & v3);
   oT = cnt.w + __popc(lo.x & hi.x & v0) + __popc(lo.y & hi.y & v1) + __popc(lo.z & hi.z & v2) +
        __popc(lo.w & hi.w & v3);
+}
+/* ---- Occ for ONE base c (the common case: mismatch budget spent, or a fixed PAM base) */
+__device__ __forceinline__ uint32_t occ1(const uint4 *__restrict__ blocks, uint32_t blk, uint32_t r,
+                                         uint32_t c) {
+  const uint4 *p = blocks + ((size_t)blk << 2);
+  const uint4 cnt = p[0];
+  const uint4 lo = p[1];
+  const uint4 hi = p[2];
+  const uint4 ex = p[3];
+  const uint32_t base = c == 0 ? cnt.x : c == 1 ? cnt.y : c == 2 ? cnt.z : cnt.w;
+  const uint32_t fl = (c & 1u) ? 0u : 0xFFFFFFFFu; /* flip planes so that "matches c" == 1&1 */
+  const uint32_t fh = (c & 2u) ? 0u : 0xFFFFFFFFu;
+  return base + __popc((lo.x ^ fl) & (hi.x ^ fh) & ~ex.x & word_mask(r, 0)) +
+         __popc((lo.y ^ fl) & (hi.y ^ fh) & ~ex.y & word_mask(r, 1)) +
+         __popc((lo.z ^ fl) & (hi.z ^ fh) & ~ex.z & word_mask(r, 2)) +
+         __popc((lo.w ^ fl) & (hi.w ^ fh) & ~ex.w & word_mask(r, 3));
 }
 
 /* number of BWT rows < i holding a literal 'N' (only the PAM's N can ask: index.hpp:139-149) */
@@ -92,15 +120,22 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot) {
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
-/* ---- search: one wavefront per (guide, strand) ---------------------------- */
+/* ---- search: one wavefront per (guide, strand) ----------------------------
+ * Two LDS stacks per wave share one 8 KiB array: X (grows up) holds "single-symbol" nodes -
+ * mismatch budget spent (index.hpp:230 returns before the substitution loop) or a fixed PAM
+ * base - which need Occ of one base and have at most one child; G (grows down) holds nodes
+ * that still branch (k < m), PAM 'N' wildcards and PAM fan-out nodes.  ~89 % of all nodes are
+ * X nodes, and an X iteration costs ~1/4 of the instructions of a G one. */
 __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a) {
   __shared__ uint4 s_stack[SEARCH_WAVES][STACK_ENTRIES];
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t lane = lane_id();
   uint4 *stk = s_stack[wave];
   unsigned long long n_ext = 0, n_ovf = 0;
-  const uint32_t T_end = a.L + a.P;
+  const uint32_t L = a.L, P = a.P, m = a.m;
+  const uint32_t T_end = L + P;
   const uint32_t reserve = (MAX_FANOUT - 1) * (T_end + 2);
+  const uint32_t limit = STACK_ENTRIES - reserve;
 
   for (;;) {
     uint32_t item = 0;
@@ -113,38 +148,214 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
     const uint32_t strand = item >= n_guides ? 1u : 0u;
     const uint32_t guide = item - strand * n_guides;
     const uint32_t slot = 2u * guide + strand;
-    const gs_guide_rec gr = a.guides[guide];
-    if (!gr.valid) {
+    /* the guide record is wave-uniform: keep every field in scalar registers */
+    const uint32_t *gp = (const uint32_t *)(a.guides + guide);
+    const uint32_t gw0 = __builtin_amdgcn_readfirstlane(gp[0]);
+    const uint32_t gw1 = __builtin_amdgcn_readfirstlane(gp[1]);
+    const uint64_t gr_q = ((uint64_t)gw1 << 32) | gw0;
+    const uint32_t gr_pam0 = __builtin_amdgcn_readfirstlane(gp[2]);
+    const uint32_t gr_pam1 = __builtin_amdgcn_readfirstlane(gp[3]);
+    const uint32_t gr_pam2 = __builtin_amdgcn_readfirstlane(gp[4]);
+    const uint32_t gr_pam3 = __builtin_amdgcn_readfirstlane(gp[5]);
+    const uint32_t gr_npams = __builtin_amdgcn_readfirstlane(gp[6]);
+    const uint32_t gr_valid = __builtin_amdgcn_readfirstlane(gp[7]);
+    if (!gr_valid) {
       if (lane == 0) a.counts[slot] = 0;
       continue;
     }
     const gs_strand_dev &sd = a.sd[strand];
     const uint4 *__restrict__ blocks = sd.blocks;
-    const uint32_t npams = a.P ? gr.npams : 1u;
+    const uint32_t npams = P ? gr_npams : 1u;
+    const bool fanning = P > 0 && npams > 1u; /* a finished 20-mer fans out per PAM pattern */
     uint4 *out = a.slots + (size_t)slot * a.cap;
     uint32_t n_match = 0;
+    uint32_t xs = 0, gs = 0; /* sizes of the X and G stacks */
 
-    /* root: whole SA range, nothing consumed (index.hpp:388-391) */
-    uint32_t size = 1;
-    if (lane == 0) {
-      uint64_t meta0 = (a.L == 0 && a.P > 0 && npams > 1) ? (1ull << 54) : 0ull;
-      stk[0] = make_uint4(0u, sd.n - 1u, (uint32_t)meta0, (uint32_t)(meta0 >> 32));
+    /* is a node at step t2 with k2 mismatches (PAM pattern pamid) a single-symbol node? */
+    auto is_single = [&](uint32_t t2, uint32_t k2, uint32_t pamid) __attribute__((always_inline)) -> bool {
+      if (t2 < L) return k2 == m;
+      if (t2 == L && fanning) return false;
+      const uint32_t pw =
+          pamid == 0 ? gr_pam0 : pamid == 1 ? gr_pam1 : pamid == 2 ? gr_pam2 : gr_pam3;
+      return ((pw >> (3u * (t2 - L))) & 7u) < 4u;
+    };
+    /* route a live child: emit (terminal), push on X or on G */
+    auto route = [&](bool live, bool term, bool single, uint32_t csp, uint32_t cep,
+                     uint64_t cmeta) __attribute__((always_inline)) {
+      const bool px = live && !term && single;
+      const bool pg = live && !term && !single;
+      const bool em = live && term;
+      const uint64_t bx = __ballot(px);
+      if (bx) {
+        if (px) stk[xs + lanes_below(bx)] = make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+        xs += __popcll(bx);
+      }
+      const uint64_t bg = __ballot(pg);
+      if (bg) {
+        if (pg)
+          stk[STACK_ENTRIES - 1u - (gs + lanes_below(bg))] =
+              make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+        gs += __popcll(bg);
+      }
+      const uint64_t be = __ballot(em);
+      if (be) {
+        if (em) {
+          const uint32_t idx = n_match + lanes_below(be);
+          if (idx < a.cap) {
+            const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
+                                 ((cmeta & PATH_MASK) << 8);
+            out[idx] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
+          }
+        }
+        n_match += __popcll(be);
+      }
+    };
+
+    /* seeding state (all wave-uniform): mismatch count j of the prefix variants being
+     * enumerated, substitution index sub in [0,3^j), position in the (combination, entry) space */
+    uint32_t sj = 0, ssub = 0, spos = 0, spow = 1;
+    const bool seeding = a.pt_k != 0;
+    bool seeds_left = seeding;
+    uint32_t pidx0 = 0; /* table index of the exact k-prefix of the query */
+    if (seeding) {
+      for (uint32_t t = 0; t < a.pt_k; ++t)
+        pidx0 |= ((uint32_t)(gr_q >> (2u * t)) & 3u) << (2u * (a.pt_k - 1u - t));
+    } else {
+      /* root: whole SA range, nothing consumed (index.hpp:388-391) */
+      if (is_single(0, 0, 0)) {
+        xs = 1;
+        if (lane == 0) stk[0] = make_uint4(0u, sd.n - 1u, 0u, 0u);
+      } else {
+        gs = 1;
+        if (lane == 0) stk[STACK_ENTRIES - 1u] = make_uint4(0u, sd.n - 1u, 0u, 0u);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-    while (size > 0) {
-      /* pop up to 64 nodes, but never more than the stack can take children for.  `reserve`
-       * keeps room for a single-node DFS of depth T_end, so w >= 1 always makes progress and
-       * size never exceeds STACK_ENTRIES. */
-      uint32_t w = size < WAVE ? size : WAVE;
-      const uint32_t limit = STACK_ENTRIES - reserve;
-      const uint32_t room = size < limit ? (limit - size) / (MAX_FANOUT - 1) : 0u;
-      if (w > room) w = room ? room : 1u;
+    for (;;) {
+      const uint32_t total = xs + gs;
+      if (seeds_left && total <= SEED_LOW) {
+        /* ---- seed depth-k nodes from the prefix interval table -------------------------
+         * The top of the search tree is input independent and full down to depth ~log4(n):
+         * instead of walking it, enumerate every variant of the first k-2 query symbols with
+         * j <= m substitutions and, one table entry per lane, the two-symbol extensions the
+         * remaining budget allows.  Same node set at depth k as the walk (index.hpp:182-248). */
+        const uint32_t k = a.pt_k, kp = k - 2u;
+        const uint32_t bud = m - sj;
+        const uint32_t E = bud >= 2u ? 16u : bud == 1u ? 7u : 1u;
+        const uint32_t span = a.combo[8u + sj] * E;
+        const uint32_t l = spos + lane;
+        const bool act = l < span;
+        const uint32_t ci = E == 16u ? l >> 4 : E == 7u ? l / 7u : l;
+        const uint32_t u = l - ci * E;
+        uint32_t mask = act ? a.combo[a.combo[sj] + ci] : 0u;
+        uint32_t pidx = pidx0;
+        uint64_t path = 0;
+        uint32_t sub = ssub;
+        for (uint32_t i = 0; i < sj; ++i) { /* sj substitutions at the set bits of mask */
+          const uint32_t d = sub % 3u;     /* scalar */
+          sub /= 3u;
+          const uint32_t t = mask ? (uint32_t)__builtin_ctz(mask) : 0u;
+          mask &= mask - 1u;
+          const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+          const uint32_t sym = (qc + 1u + d) & 3u;               /* one of the three other bases */
+          const uint32_t code = 1u + sym - (sym > qc ? 1u : 0u); /* its rank among them, A<C<G<T */
+          pidx ^= (qc ^ sym) << (2u * (k - 1u - t));
+          path |= (uint64_t)code << (50u - 2u * t);
+        }
+        const uint32_t q2 = (uint32_t)(gr_q >> (2u * kp)) & 3u;        /* query symbol of step k-2 */
+        const uint32_t q1 = (uint32_t)(gr_q >> (2u * (kp + 1u))) & 3u; /* and of step k-1 */
+        uint32_t s2 = q2, s1 = q1;
+        if (E == 16u) {
+          s2 = u >> 2;
+          s1 = u & 3u;
+        } else if (E == 7u) {
+          if (u >= 1u && u <= 3u) s2 = (q2 + u) & 3u;
+          if (u >= 4u) s1 = (q1 + u - 3u) & 3u;
+        }
+        const uint32_t mm = (s2 != q2) + (s1 != q1);
+        pidx ^= ((q2 ^ s2) << 2) | (q1 ^ s1);
+        uint2 ent = make_uint2(0u, 0u);
+        if (act) ent = sd.ptab[pidx];
+        const bool live = act && ent.y != 0u;
+        const uint32_t c2 = s2 == q2 ? 0u : 1u + s2 - (s2 > q2 ? 1u : 0u);
+        const uint32_t c1 = s1 == q1 ? 0u : 1u + s1 - (s1 > q1 ? 1u : 0u);
+        const uint32_t kk = sj + mm;
+        const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path |
+                               ((uint64_t)c2 << (50u - 2u * kp)) |
+                               ((uint64_t)c1 << (50u - 2u * (kp + 1u)));
+        route(live, false, kk == m, ent.x, ent.y - 1u, cmeta); /* k < L: never terminal */
+        /* advance the (j, sub, pos) cursor */
+        spos += WAVE;
+        if (spos >= span) {
+          spos = 0;
+          if (++ssub >= spow) {
+            ssub = 0;
+            do {
+              ++sj;
+              spow *= 3u;
+            } while (sj <= a.jmax && a.combo[8u + sj] == 0u);
+            if (sj > a.jmax) seeds_left = false;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        continue;
+      }
+      if (total == 0) break;
+      const uint32_t room = total < limit ? limit - total : 0u;
+
+      if (xs > 0 && (xs >= WAVE || gs == 0 || room < (MAX_FANOUT - 1) * WAVE)) {
+        /* ---- X iteration: one symbol, at most one child, stack cannot grow ------------ */
+        const uint32_t w = xs < WAVE ? xs : WAVE;
+        const bool active = lane < w;
+        uint4 nd = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (active) nd = stk[xs - 1u - lane];
+        xs -= w;
+        n_ext += w;
+        const uint32_t sp = nd.x, ep = nd.y;
+        const uint64_t meta = ((uint64_t)nd.w << 32) | nd.z;
+        const uint32_t t = META_T(meta), k = META_K(meta), pamid = META_PAM(meta);
+        uint64_t path = meta & PATH_MASK;
+        uint32_t c;
+        if (t < L) {
+          c = (uint32_t)(gr_q >> (2u * t)) & 3u; /* exact child keeps code 0 (upper case) */
+        } else {
+          const uint32_t pw =
+              pamid == 0 ? gr_pam0 : pamid == 1 ? gr_pam1 : pamid == 2 ? gr_pam2 : gr_pam3;
+          c = (pw >> (3u * (t - L))) & 3u; /* fixed PAM base (code < 4 by construction) */
+          path |= (uint64_t)(c < 3u ? c : 4u) << (49u - 2u * L - 3u * (t - L));
+        }
+        uint32_t oa = 0, ob = 0;
+        if (active) {
+          /* Occ(c, sp) and Occ(c, ep+1): rows before sp in sp's block, rows up to and including
+           * ep in ep's block - the same 64-byte line whenever the interval does not straddle */
+          oa = occ1(blocks, sp >> GS_BLOCK_SHIFT, sp & (GS_BLOCK_ROWS - 1u), c);
+          ob = occ1(blocks, ep >> GS_BLOCK_SHIFT, (ep & (GS_BLOCK_ROWS - 1u)) + 1u, c);
+        }
+        const uint32_t Cc = c == 0 ? sd.C[0] : c == 1 ? sd.C[1] : c == 2 ? sd.C[2] : sd.C[3];
+        const uint32_t t2 = t + 1u;
+        const uint64_t cmeta =
+            ((uint64_t)t2 << 59) | ((uint64_t)k << 56) | ((uint64_t)pamid << 52) | path |
+            ((t2 == L && fanning) ? (1ull << 54) : 0ull);
+        route(active && ob > oa, t2 == T_end, is_single(t2, k, pamid), Cc + oa, Cc + ob - 1u, cmeta);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        continue;
+      }
+
+      /* ---- G iteration: up to four substitution children, PAM wildcard, PAM fan-out ------ */
+      uint32_t w = gs < WAVE ? gs : WAVE;
+      {
+        /* never pop more than the stacks can take children for; w >= 1 keeps a plain DFS
+         * going, whose depth (T_end) is covered by `reserve` */
+        const uint32_t fit = room / (MAX_FANOUT - 1);
+        if (w > fit) w = fit ? fit : 1u;
+      }
       const bool active = lane < w;
       uint4 nd = make_uint4(0, 0, 0, 0);
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (active) nd = stk[size - 1 - lane];
-      size -= w;
+      if (active) nd = stk[STACK_ENTRIES - gs + lane];
+      gs -= w;
 
       const uint32_t sp = nd.x, ep = nd.y;
       const uint64_t meta = ((uint64_t)nd.w << 32) | nd.z;
@@ -155,36 +366,35 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
       const bool ext = active && !fan;
       n_ext += __popcll(__ballot(ext));
 
-      /* Occ at both interval ends: two independent 64-byte reads per lane */
       uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0;
       if (ext) {
-        occ4(blocks, sp, a0, a1, a2, a3);
-        occ4(blocks, ep + 1u, b0, b1, b2, b3);
+        occ4(blocks, sp >> GS_BLOCK_SHIFT, sp & (GS_BLOCK_ROWS - 1u), a0, a1, a2, a3);
+        occ4(blocks, ep >> GS_BLOCK_SHIFT, (ep & (GS_BLOCK_ROWS - 1u)) + 1u, b0, b1, b2, b3);
       }
 
       /* which symbols may be tried, and what they cost */
-      const bool inpam = t >= a.L;
+      const bool inpam = t >= L;
       uint32_t qc = 0, allow = 0, pc = 0;
       if (!inpam) {
-        qc = (uint32_t)(gr.q >> (2u * t)) & 3u;
-        allow = (k < a.m) ? 0xFu : (1u << qc); /* index.hpp:230 */
+        qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+        allow = (k < m) ? 0xFu : (1u << qc); /* index.hpp:230 */
       } else {
-        const uint32_t pw = pamid == 0 ? gr.pam[0] : pamid == 1 ? gr.pam[1] : pamid == 2 ? gr.pam[2] : gr.pam[3];
-        pc = (pw >> (3u * (t - a.L))) & 7u;
+        const uint32_t pw =
+            pamid == 0 ? gr_pam0 : pamid == 1 ? gr_pam1 : pamid == 2 ? gr_pam2 : gr_pam3;
+        pc = (pw >> (3u * (t - L))) & 7u;
         allow = pc < 4u ? (1u << pc) : 0xFu; /* 'N' tries A,T,C,G at cost 0: index.hpp:151-169 */
       }
       const uint32_t t2 = t + 1u;
       const bool term = (t2 == T_end);
-      const bool needfan = (t2 == a.L) && (a.P > 0) && (npams > 1u);
-      const uint32_t sh_g = 50u - 2u * t;                 /* guide step: 2-bit code */
-      const uint32_t sh_p = inpam ? 49u - 2u * a.L - 3u * (t - a.L) : 0u; /* PAM step: 3-bit code */
+      const bool needfan = (t2 == L) && fanning;
+      const uint32_t sh_g = 50u - 2u * t;                                    /* guide step: 2-bit code */
+      const uint32_t sh_p = inpam ? 49u - 2u * L - 3u * (t - L) : 0u; /* PAM step: 3-bit code */
 
 #pragma unroll
       for (uint32_t c = 0; c < MAX_FANOUT; ++c) {
-        bool live = false;
+        bool live = false, cterm = false, single = false;
         uint32_t csp = 0, cep = 0;
         uint64_t cmeta = 0;
-        bool cterm = false;
         if (c < 4u) {
           if (fan) {
             /* PAM fan-out: one copy of the finished 20-mer node per PAM pattern (index.hpp:212-214) */
@@ -192,7 +402,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
             csp = sp;
             cep = ep;
             cmeta = (meta & ~((1ull << 54) | (3ull << 52))) | ((uint64_t)c << 52);
-            cterm = false;
+            const uint32_t pw0 = c == 0 ? gr_pam0 : c == 1 ? gr_pam1 : c == 2 ? gr_pam2 : gr_pam3;
+            single = (pw0 & 7u) < 4u;
           } else {
             const uint32_t oa = c == 0 ? a0 : c == 1 ? a1 : c == 2 ? a2 : a3;
             const uint32_t ob = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
@@ -212,6 +423,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
             cmeta = ((uint64_t)t2 << 59) | ((uint64_t)k2 << 56) | ((uint64_t)pamid << 52) | p2 |
                     (needfan ? (1ull << 54) : 0ull);
             cterm = term;
+            single = is_single(t2, k2, pamid);
           }
         } else {
           /* literal 'N' of the genome under a PAM 'N' (index.hpp:139-149); rare */
@@ -226,29 +438,12 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
                 cmeta = ((uint64_t)t2 << 59) | ((uint64_t)k << 56) | ((uint64_t)pamid << 52) | path |
                         (3ull << sh_p);
                 cterm = term;
+                single = is_single(t2, k, pamid);
               }
             }
           }
         }
-        const bool push = live && !cterm;
-        const bool emit = live && cterm;
-        const uint64_t pb = __ballot(push);
-        if (pb) {
-          if (push) stk[size + lanes_below(pb)] = make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
-          size += __popcll(pb);
-        }
-        const uint64_t eb = __ballot(emit);
-        if (eb) {
-          if (emit) {
-            const uint32_t idx = n_match + lanes_below(eb);
-            if (idx < a.cap) {
-              const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
-                                   ((cmeta & PATH_MASK) << 8);
-              out[idx] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
-            }
-          }
-          n_match += __popcll(eb);
-        }
+        route(live, cterm, single, csp, cep, cmeta);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
@@ -527,7 +722,8 @@ __global__ void k_rank4(gs_strand_dev sd, const uint64_t *rows, uint64_t n, uint
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   uint32_t a, c, g, t;
-  occ4(sd.blocks, (uint32_t)rows[j], a, c, g, t);
+  const uint32_t i = (uint32_t)rows[j];
+  occ4(sd.blocks, i >> GS_BLOCK_SHIFT, i & (GS_BLOCK_ROWS - 1u), a, c, g, t);
   out[4 * j + 0] = a;
   out[4 * j + 1] = c;
   out[4 * j + 2] = g;
@@ -648,9 +844,21 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.P = P;
     sa.m = mismatches;
     sa.cap = cap;
-    /* persistent waves pulling (guide, strand) items: 5 workgroups of 4 waves per CU
-     * (LDS: 32 KiB per workgroup) */
-    uint32_t grid = (uint32_t)cus * 5u;
+    sa.combo = (const uint32_t *)ix->d_combo;
+    sa.pt_k = 0;
+    sa.jmax = 0;
+    if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
+      /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
+       * substitutions x the two-symbol extensions the remaining budget allows */
+      sa.pt_k = ix->pt_k;
+      const uint32_t kp = ix->pt_k - 2;
+      uint32_t jmax = mismatches < kp ? mismatches : kp;
+      if (jmax > 7) jmax = 7;
+      sa.jmax = jmax;
+    }
+    /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
+     * their LDS stacks allow (8 at 20 KiB each = 32 waves per CU) */
+    uint32_t grid = (uint32_t)cus * (160u * 1024u / (STACK_ENTRIES * 16u * SEARCH_WAVES));
     const uint32_t need = (2 * n32 + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
     GS_HIP(hipEventRecord(ix->ev[1], st));

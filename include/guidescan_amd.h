@@ -65,6 +65,10 @@ typedef struct {
 
 /* flags for gs_enumerate */
 #define GS_FLAG_PAM_AT_START 1u /* --start, process.hpp:63,84-87 */
+/* Walk the whole search tree from the root exactly as the reference does (no prefix-table
+ * shortcut).  Same hits; n_ext then equals the reference traversal's node count.  Without it
+ * n_ext counts only the extensions actually executed below the table depth. */
+#define GS_FLAG_FAITHFUL_WALK 2u
 
 typedef struct {
   uint64_t n_guides;
@@ -72,7 +76,8 @@ typedef struct {
   const uint64_t *guide_offsets; /* n_guides+1 entries, host memory owned by the result */
   const gs_hit *hits;            /* n_hits entries, host memory owned by the result */
   /* work counters of SURVEY.md section 8d (properties of the input): */
-  uint64_t n_ext;     /* search-tree nodes extended (a3 calls with position>=0 + a4 calls with begin!=end) */
+  uint64_t n_ext;     /* search-tree nodes extended (a3 calls with position>=0 + a4 calls with begin!=end);
+                         exact only under GS_FLAG_FAITHFUL_WALK, see there */
   uint64_t n_matches; /* distinct (index, match.sequence) intervals */
   /* device timing of the last call, milliseconds (HIP events on the call's stream) */
   float ms_search;  /* search kernel only */

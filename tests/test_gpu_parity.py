@@ -89,17 +89,19 @@ def test_toy_hit_sets_bit_exact(toy_gpu, cfg):
             continue
         seqs = np.array([list(k.sequence.encode()) for k in group], dtype=np.uint8)
         pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8).reshape(len(group), P)
-        offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt if P else (),
-                                              start=start)
         opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
-        n_ext = 0
-        for i, k in enumerate(group):
-            exp, ctr = oracle_hits_as_records(oidx, k.sequence, k.pam, opts, P, start)
-            got = gpu_hits_as_records(offsets, hits, i, k.sequence, P, start)
-            assert got == exp, (k.id, cfg)
-            n_ext += ctr.n_ext
-        assert stats["n_ext"] == n_ext
-        assert stats["n_hits"] == offsets[-1]
+        expected = [oracle_hits_as_records(oidx, k.sequence, k.pam, opts, P, start) for k in group]
+        for faithful in (True, False):   # reference-order walk, then the prefix-table shortcut
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt if P else (),
+                                                  start=start, faithful=faithful)
+            for i, k in enumerate(group):
+                got = gpu_hits_as_records(offsets, hits, i, k.sequence, P, start)
+                assert got == expected[i][0], (k.id, cfg, faithful)
+            if faithful:
+                assert stats["n_ext"] == sum(e[1].n_ext for e in expected)
+            else:
+                assert stats["n_ext"] <= sum(e[1].n_ext for e in expected)
+            assert stats["n_hits"] == offsets[-1]
 
 
 def test_unsupported_symbols_fail_loudly(toy_gpu):
@@ -126,17 +128,18 @@ def test_medium_genome_random_guides_bit_exact():
         assert np.array_equal(gidx.suffix_array(0), oidx.sa("fwd"))
         assert np.array_equal(gidx.suffix_array(1), oidx.sa("rev"))
         seqs, pams, pos, strands = synth.sample_guides(text, 300, seed=9)
-        offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3)
         opts = ol.make_opts(mismatches=3)
-        n_ext = 0
-        for i in range(seqs.shape[0]):
-            g = seqs[i].tobytes().decode()
-            exp, ctr = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
-            got = gpu_hits_as_records(offsets, hits, i, g, 3)
-            assert got == exp, i
-            assert len(got) >= 1  # the sampled site itself
-            n_ext += ctr.n_ext
-        assert stats["n_ext"] == n_ext
+        expected = [oracle_hits_as_records(oidx, seqs[i].tobytes().decode(), "NGG", opts, 3)
+                    for i in range(seqs.shape[0])]
+        for faithful in (True, False):
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
+            for i in range(seqs.shape[0]):
+                g = seqs[i].tobytes().decode()
+                got = gpu_hits_as_records(offsets, hits, i, g, 3)
+                assert got == expected[i][0], (i, faithful)
+                assert len(got) >= 1  # the sampled site itself
+            if faithful:
+                assert stats["n_ext"] == sum(e[1].n_ext for e in expected)
     finally:
         gidx.close()
         oidx.close()
