@@ -41,6 +41,20 @@ class GsResultView(C.Structure):
                 ("ms_search", C.c_float), ("ms_total", C.c_float)]
 
 
+class GsGenomeStructure(C.Structure):
+    _fields_ = [("chr_names", C.POINTER(C.c_char_p)), ("chr_lengths", C.POINTER(C.c_uint64)),
+                ("n_chr", C.c_uint32)]
+
+
+class GsKmer(C.Structure):
+    _fields_ = [("id", C.c_char_p), ("sequence", C.c_char_p), ("pam", C.c_char_p),
+                ("sense_positive", C.c_int)]
+
+
+GS_TEXT_SAM = 0x100
+GS_TEXT_COMPLETE = 0x200
+
+
 def build_library():
     subprocess.run(["make", "-s", "-C", str(PKG / "csrc")], check=True, timeout=3600)
 
@@ -88,6 +102,13 @@ def lib():
     L.gs_index_copy_sa.argtypes = [vp, i32, vp]
     L.gs_calculate_cfd.restype = C.c_float
     L.gs_calculate_cfd.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.gs_format_guide.restype = i32
+    L.gs_format_guide.argtypes = [C.POINTER(GsGenomeStructure), C.POINTER(GsKmer), vp, u64, u32, u32,
+                                  C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.gs_format_header.restype = i32
+    L.gs_format_header.argtypes = [C.POINTER(GsGenomeStructure), u32, C.POINTER(vp),
+                                   C.POINTER(C.c_size_t)]
+    L.gs_free.argtypes = [vp]
     L.gs_status_string.restype = C.c_char_p
     L.gs_status_string.argtypes = [i32]
     L.gs_version.restype = C.c_char_p
@@ -98,12 +119,45 @@ def lib():
 EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs_index_close",
            "gs_index_genome_length", "gs_index_device_bytes", "gs_enumerate", "gs_enumerate_device",
            "gs_result_get", "gs_result_free", "gs_decode_sequence", "gs_rank_bwt4", "gs_resolve",
-           "gs_index_meta", "gs_index_copy_sa", "gs_calculate_cfd", "gs_status_string", "gs_version"]
+           "gs_index_meta", "gs_index_copy_sa", "gs_calculate_cfd", "gs_status_string", "gs_version",
+           "gs_format_guide", "gs_format_header", "gs_free"]
 
 
 def _check(rc):
     if rc != 0:
         raise GsError(rc, lib().gs_status_string(rc).decode())
+
+
+def make_genome_structure(names, lengths):
+    arr_n = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    arr_l = (C.c_uint64 * len(lengths))(*lengths)
+    g = GsGenomeStructure(arr_n, arr_l, len(names))
+    g._keep = (arr_n, arr_l)
+    return g
+
+
+def format_header(gs, sam=False, complete=True) -> str:
+    out, n = C.c_void_p(), C.c_size_t()
+    flags = (GS_TEXT_SAM if sam else 0) | (GS_TEXT_COMPLETE if complete else 0)
+    _check(lib().gs_format_header(C.byref(gs), flags, C.byref(out), C.byref(n)))
+    s = C.string_at(out, n.value).decode()
+    lib().gs_free(out)
+    return s
+
+
+def format_guide(gs, gid, sequence, pam, sense_positive, hits, mismatches, sam=False, complete=True,
+                 start=False, max_off_targets=-1) -> str:
+    """hits: numpy HIT_DTYPE array of this guide (canonical order, as gs_enumerate returns)"""
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    k = GsKmer(gid.encode(), sequence.encode(), pam.encode(), int(sense_positive))
+    out, n = C.c_void_p(), C.c_size_t()
+    flags = ((GS_TEXT_SAM if sam else 0) | (GS_TEXT_COMPLETE if complete else 0) |
+             (GS_FLAG_PAM_AT_START if start else 0))
+    _check(lib().gs_format_guide(C.byref(gs), C.byref(k), hits.ctypes.data, hits.shape[0], mismatches,
+                                 flags, max_off_targets, C.byref(out), C.byref(n)))
+    s = C.string_at(out, n.value).decode()
+    lib().gs_free(out)
+    return s
 
 
 def decode_sequence(guide: str, P: int, key: int, flags: int = 0) -> str:

@@ -1,0 +1,282 @@
+/*
+ * gs_text.hip -- host-side text encoders for the hit lists the device returns: the step right
+ * after the hot path.  Byte-exact restatement of the reference's
+ * CSV and SAM database formats (include/genomics/printer.hpp:173-360) and of
+ * resolve_absolute (src/genomics/structures.cxx:7-52).  Host code only; no kernels.
+ */
+#include "gs_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#ifndef GS_GUIDESCAN_VERSION
+#define GS_GUIDESCAN_VERSION "2.0.0" /* the database format version this writer is compatible with */
+#endif
+
+namespace {
+
+char comp(char c) { /* src/genomics/sequences.cxx:14-26 */
+  switch (c) {
+    case 'A': return 'T';
+    case 'T': return 'A';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'a': return 't';
+    case 't': return 'a';
+    case 'c': return 'g';
+    case 'g': return 'c';
+    default: return c;
+  }
+}
+std::string complement(const std::string &s) {
+  std::string o(s);
+  for (auto &c : o) c = comp(c);
+  return o;
+}
+std::string reverse_complement(const std::string &s) {
+  std::string o(s.rbegin(), s.rend());
+  for (auto &c : o) c = comp(c);
+  return o;
+}
+
+/* src/genomics/structures.cxx:7-52.  Returns chromosome index or -1 for the sentinel. */
+int resolve_absolute(const gs_genome_structure *gs, int64_t abs, size_t seq_len, size_t pam_len,
+                     int64_t *start, char *strand) {
+  char st = '+';
+  if (abs < 0) {
+    abs = -abs;
+    st = '-';
+  }
+  int c = -1;
+  for (uint32_t i = 0; i < gs->n_chr; i++) {
+    if (abs <= (int64_t)(gs->chr_lengths[i] - 1)) {
+      c = (int)i;
+      break;
+    }
+    abs -= (int64_t)gs->chr_lengths[i];
+  }
+  if (c < 0) return -1;
+  int64_t s, e;
+  if (st == '+') { /* abs = 0-based inclusive end of the site */
+    e = abs + 1;
+    s = e - (int64_t)seq_len - (int64_t)pam_len + 1;
+  } else { /* abs = 0-based start of the site */
+    s = abs + 1;
+    e = s + (int64_t)seq_len + (int64_t)pam_len - 1;
+  }
+  if (s < 0 || e > (int64_t)gs->chr_lengths[c]) return -1; /* :46-48, note s<0 not s<1 */
+  *start = s;
+  *strand = st;
+  return c;
+}
+
+void hex_le(std::string &out, uint64_t v) { /* printer.hpp:18-79 */
+  static const char *hx = "0123456789abcdef";
+  for (int i = 0; i < 8; i++) {
+    const unsigned b = (unsigned)(v & 0xff);
+    v >>= 8;
+    out += hx[b >> 4];
+    out += hx[b & 15];
+  }
+}
+std::string f2s(float f) { /* std::to_string(float) */
+  char t[64];
+  snprintf(t, sizeof t, "%f", (double)f);
+  return t;
+}
+
+struct decoded_hit {
+  int64_t pos;
+  uint32_t mismatches;
+  std::string sequence;       /* match.sequence */
+  std::string match_sequence; /* complement(match.sequence), printer.hpp:232,264 */
+  std::string pam;            /* printer.hpp:139-143 */
+};
+
+}  // namespace
+
+extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kmer *k,
+                                     const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
+                                     uint32_t flags, int64_t max_off_targets, char **out_text,
+                                     size_t *out_len) {
+  if (!gs || !k || !k->id || !k->sequence || !k->pam || (n_hits && !hits) || !out_text)
+    return GS_ERR_ARG;
+  const bool start = flags & GS_FLAG_PAM_AT_START;
+  const bool sam = flags & GS_TEXT_SAM;
+  const bool complete = flags & GS_TEXT_COMPLETE;
+  const std::string seq(k->sequence), pam(k->pam);
+  const uint32_t L = (uint32_t)seq.size(), P = (uint32_t)pam.size();
+  const std::string sequence = start ? pam + seq : seq + pam;
+
+  /* split by distance; hits arrive in canonical order (distance ascending) */
+  std::vector<std::vector<decoded_hit>> off(mismatches + 1);
+  std::vector<char> buf(L + P + 1);
+  for (uint64_t h = 0; h < n_hits; h++) {
+    const uint32_t d = GS_KEY_MISMATCHES(hits[h].key);
+    if (d > mismatches) return GS_ERR_ARG;
+    gs_status rc = gs_decode_sequence(k->sequence, L, P, flags & GS_FLAG_PAM_AT_START, hits[h].key,
+                                      buf.data());
+    if (rc != GS_OK) return rc;
+    decoded_hit dh;
+    dh.pos = hits[h].pos;
+    dh.mismatches = d;
+    dh.sequence = buf.data();
+    dh.match_sequence = complement(dh.sequence);
+    dh.pam = dh.match_sequence.size() < 20 ? std::string() : dh.match_sequence.substr(20, 3);
+    off[d].push_back(std::move(dh));
+  }
+
+  std::string out;
+  if (!sam) {
+    /* printer.hpp:245-300 */
+    float cfd_sum = 0.0f;
+    bool perfect = false, none = true;
+    std::vector<std::string> lines;
+    for (uint32_t d = 0; d <= mismatches; d++) {
+      for (int64_t i = 0; i < (int64_t)off[d].size(); i++) {
+        none = false;
+        if (max_off_targets != -1 && i >= max_off_targets) break; /* raw index, :259 */
+        const decoded_hit &h = off[d][(size_t)i];
+        if (h.mismatches == 0 && h.pam.size() == 3 && h.pam.compare(1, 2, "GG") == 0) perfect = true;
+        int64_t s;
+        char st;
+        const int c = resolve_absolute(gs, h.pos, L, P, &s, &st);
+        if (c < 0) continue; /* boundary sentinel: no row, no CFD (:280-283) */
+        std::string line(k->id);
+        line += ',';
+        line += sequence;
+        line += ',';
+        line += gs->chr_names[c];
+        line += ',';
+        line += std::to_string(s);
+        line += ',';
+        line += st;
+        line += ',';
+        line += std::to_string(h.mismatches);
+        if (complete) {
+          line += ',';
+          line += h.match_sequence;
+          line += ",0,0"; /* rna_bulges, dna_bulges */
+        }
+        lines.push_back(std::move(line));
+        cfd_sum += gs_calculate_cfd(k->sequence, h.match_sequence.c_str(), h.pam.c_str());
+      }
+    }
+    if (none) { /* :189-199 */
+      out += k->id;
+      out += ',';
+      out += sequence;
+      out += ",NA,NA,NA,0";
+      if (complete) out += ",NA,NA,NA";
+      out += ",1.0\n";
+    } else {
+      float specificity = 0.0f;
+      if (!perfect) cfd_sum += 1;
+      if (cfd_sum > 0) specificity = 1 / cfd_sum;
+      const std::string sp = f2s(specificity);
+      for (const auto &l : lines) {
+        out += l;
+        out += ',';
+        out += sp;
+        out += '\n';
+      }
+    }
+  } else {
+    /* off_target_fields printer.hpp:115-170 */
+    int64_t delim = 0;
+    for (uint32_t i = 0; i < gs->n_chr; i++) delim += (int64_t)gs->chr_lengths[i];
+    delim = -(delim + 1);
+    std::string hex;
+    float cfd_sum = 0.0f;
+    bool perfect = false;
+    for (uint32_t d = 0; d <= mismatches; d++) {
+      int64_t n_off = 0;
+      for (const decoded_hit &h : off[d]) {
+        if (max_off_targets != -1 && n_off >= max_off_targets) break; /* kept hits, :129 */
+        if (h.mismatches == 0 && h.pam.size() == 3 && h.pam.compare(1, 2, "GG") == 0) perfect = true;
+        int64_t s;
+        char st;
+        if (resolve_absolute(gs, h.pos, L, P, &s, &st) < 0) continue;
+        hex_le(hex, (uint64_t)h.pos);
+        cfd_sum += gs_calculate_cfd(k->sequence, h.match_sequence.c_str(), h.pam.c_str());
+        n_off++;
+      }
+      hex_le(hex, (uint64_t)d);
+      hex_le(hex, (uint64_t)delim);
+    }
+    float specificity = 0.0f;
+    if (!perfect) cfd_sum += 1;
+    if (cfd_sum > 0) specificity = 1 / cfd_sum;
+    /* one line per distance-0 hit, printer.hpp:314-357 */
+    for (const decoded_hit &h : off[0]) {
+      int64_t s = 0;
+      char st = 0;
+      const int c = resolve_absolute(gs, h.pos, L, P, &s, &st);
+      out += k->id;
+      out += '\t';
+      out += k->sense_positive ? "0" : "16";
+      out += '\t';
+      if (c >= 0) out += gs->chr_names[c]; /* no sentinel check in the reference: empty RNAME */
+      out += '\t';
+      out += std::to_string(c >= 0 ? s : 0);
+      out += "\t100\t";
+      out += std::to_string(sequence.size());
+      out += "M\t*\t0\t0\t";
+      out += k->sense_positive ? sequence : reverse_complement(sequence);
+      out += "\t*";
+      for (uint32_t d = 0; d <= mismatches; d++) {
+        out += "\tk";
+        out += std::to_string(d);
+        out += ":i:";
+        out += std::to_string(off[d].size());
+      }
+      if (complete) {
+        out += "\tof:H:";
+        out += hex;
+      }
+      out += "\tsp:f:";
+      out += f2s(specificity);
+      out += '\n';
+    }
+  }
+  char *p = (char *)malloc(out.size() + 1);
+  if (!p) return GS_ERR_NOMEM;
+  memcpy(p, out.data(), out.size());
+  p[out.size()] = 0;
+  *out_text = p;
+  if (out_len) *out_len = out.size();
+  return GS_OK;
+}
+
+extern "C" gs_status gs_format_header(const gs_genome_structure *gs, uint32_t flags, char **out_text,
+                                      size_t *out_len) {
+  if (!gs || !out_text) return GS_ERR_ARG;
+  std::string out;
+  if (flags & GS_TEXT_SAM) { /* printer.hpp:173-179 */
+    out += "@HD\tVN:1.0\tSO:unknown\n";
+    out += "@PG\tID:Guidescan\tVN:" GS_GUIDESCAN_VERSION "\n";
+    for (uint32_t i = 0; i < gs->n_chr; i++) {
+      out += "@SQ\tSN:";
+      out += gs->chr_names[i];
+      out += "\tLN:";
+      out += std::to_string(gs->chr_lengths[i]);
+      out += '\n';
+    }
+  } else { /* printer.hpp:181-187 */
+    out += "id,sequence,match_chrm,match_position,match_strand,match_distance";
+    if (flags & GS_TEXT_COMPLETE) out += ",match_sequence,rna_bulges,dna_bulges";
+    out += ",specificity\n";
+  }
+  char *p = (char *)malloc(out.size() + 1);
+  if (!p) return GS_ERR_NOMEM;
+  memcpy(p, out.data(), out.size());
+  p[out.size()] = 0;
+  *out_text = p;
+  if (out_len) *out_len = out.size();
+  return GS_OK;
+}
+
+extern "C" void gs_free(void *p) { free(p); }

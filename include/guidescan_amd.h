@@ -154,6 +154,38 @@ gs_status gs_index_meta(const gs_index *ix, int strand, uint64_t C_acgtn[5], uin
 /* copy the device-resident suffix array back (n = size entries) */
 gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out);
 
+/* ---- text encoders: the step right after the path (host side) ---------------------------- */
+
+typedef struct {
+  const char *const *chr_names; /* genome_structure, include/genomics/structures.hpp:45 */
+  const uint64_t *chr_lengths;
+  uint32_t n_chr;
+} gs_genome_structure;
+
+typedef struct { /* the kmer fields the printers use, include/genomics/structures.hpp:10-17 */
+  const char *id;
+  const char *sequence;
+  const char *pam;
+  int sense_positive; /* kmers file `sense` column == "+" */
+} gs_kmer;
+
+#define GS_TEXT_SAM 0x100u      /* --format sam (default csv) */
+#define GS_TEXT_COMPLETE 0x200u /* --mode complete */
+
+/* The database lines of one guide from its hit list (as returned by gs_enumerate, canonical
+ * order).  Byte-exact replacement of get_csv_lines / get_sam_lines
+ * (include/genomics/printer.hpp:245-300, 302-360) including resolve_absolute
+ * (src/genomics/structures.cxx:7-52), CFD and specificity.  `mismatches` and
+ * GS_FLAG_PAM_AT_START as passed to gs_enumerate; max_off_targets = -1 for none.
+ * *out_text is malloc'ed (NUL terminated); release with gs_free. */
+gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kmer *k, const gs_hit *hits,
+                          uint64_t n_hits, uint32_t mismatches, uint32_t flags,
+                          int64_t max_off_targets, char **out_text, size_t *out_len);
+/* write_sam_header / write_csv_header (include/genomics/printer.hpp:173-187) */
+gs_status gs_format_header(const gs_genome_structure *gs, uint32_t flags, char **out_text,
+                           size_t *out_len);
+void gs_free(void *p);
+
 /* CFD score of one hit (include/genomics/printer.hpp:98-113), float semantics preserved. */
 float gs_calculate_cfd(const char *sgrna, const char *match_sequence, const char *pam);
 

@@ -117,3 +117,40 @@ def test_product_does_not_import_oracle():
     for p in list(pkg.rglob("*.py")) + list(pkg.rglob("*.hip")) + list(pkg.rglob("*.h")) + list(pkg.rglob("Makefile")):
         txt = p.read_text()
         assert "gs_oracle" not in txt and "oracle_lib" not in txt and "libgs_ref" not in txt, p
+
+
+# ---- text encoders (host side, no GPU): product printers vs the survey-build goldens ---------
+TEXT_RUNS = {
+    "m0_csv": dict(m=0), "m1_csv": dict(m=1), "m2_csv": dict(m=2), "m3_csv": dict(m=3),
+    "m4_csv": dict(m=4), "m3_sam": dict(m=3, sam=True),
+    "m2_sam_succinct": dict(m=2, sam=True, complete=False),
+    "m3_csv_succinct": dict(m=3, complete=False),
+    "m3_csv_nag": dict(m=3, alt=("NAG",)), "m3_sam_nag": dict(m=3, alt=("NAG",), sam=True),
+    "m3_csv_max2": dict(m=3, maxo=2), "m3_sam_max2": dict(m=3, maxo=2, sam=True),
+    "m2_csv_start": dict(m=2, start=True),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TEXT_RUNS))
+def test_product_printers_reproduce_reference_files(toy, name):
+    """gs_format_header + gs_format_guide fed with hits in the C-ABI's own record format
+    (built here from oracle matches) give the reference's output file byte for byte"""
+    cfg = TEXT_RUNS[name]
+    m, sam, complete = cfg["m"], cfg.get("sam", False), cfg.get("complete", True)
+    start, alt, maxo = cfg.get("start", False), cfg.get("alt", ()), cfg.get("maxo", -1)
+    gs = api.make_genome_structure(toy["names"], toy["lengths"])
+    oidx = ol.OracleIndex(toy["text"])
+    opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
+    out = [api.format_header(gs, sam=sam, complete=complete)]
+    try:
+        for k in toy["kmers"]:
+            hits, ctr, raw = oidx.enumerate(k.sequence, k.pam, opts)
+            ol.lib().gso_free(raw[0])
+            rec = np.array([(pos, encode_key(k.sequence, seq, mm, idx, len(k.pam), start))
+                            for pos, mm, idx, seq, row in hits], dtype=api.HIT_DTYPE).reshape(-1)
+            out.append(api.format_guide(gs, k.id, k.sequence, k.pam, k.positive, rec, m, sam=sam,
+                                        complete=complete, start=start, max_off_targets=maxo))
+    finally:
+        oidx.close()
+    ext = "sam" if sam else "csv"
+    assert "".join(out) == (toy["dir"] / f"ref_{name}.{ext}").read_text()

@@ -1,0 +1,48 @@
+"""End to end through the C++ host that keeps the reference's command line: `guidescan index` +
+`guidescan enumerate` on the toy genome must write the reference's output files byte for byte
+(tests/golden/toy/ref_*, -n 1 order).  GPU only."""
+import subprocess
+
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+CLI = ol.ROOT / "guidescan-cli_amd" / "bin" / "guidescan"
+
+RUNS = {
+    "m0_csv": ["-m", "0"], "m1_csv": ["-m", "1"], "m2_csv": ["-m", "2"], "m3_csv": ["-m", "3"],
+    "m4_csv": ["-m", "4"],
+    "m3_sam": ["-m", "3", "--format", "sam"],
+    "m2_sam_succinct": ["-m", "2", "--format", "sam", "--mode", "succinct"],
+    "m3_csv_succinct": ["-m", "3", "--mode", "succinct"],
+    "m3_csv_nag": ["-m", "3", "-a", "NAG"],
+    "m3_sam_nag": ["-m", "3", "-a", "NAG", "--format", "sam"],
+    "m3_csv_max2": ["-m", "3", "--max-off-targets", "2"],
+    "m3_sam_max2": ["-m", "3", "--max-off-targets", "2", "--format", "sam"],
+    "m2_csv_start": ["-m", "2", "--start"],
+}
+
+
+@pytest.fixture(scope="module")
+def indexed(toy, tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    subprocess.run([str(CLI), "index", "--index", str(d / "toy"), str(toy["dir"] / "toy.fa")], check=True,
+                   timeout=120)
+    assert (d / "toy.gs").read_text() == (toy["dir"] / "toy.gs").read_text()
+    return d
+
+
+@pytest.mark.parametrize("name", sorted(RUNS))
+def test_cli_output_is_byte_identical(toy, indexed, name):
+    ext = "sam" if "sam" in name else "csv"
+    out = indexed / f"{name}.{ext}"
+    subprocess.run([str(CLI), "enumerate", str(indexed / "toy"), "-f", str(toy["dir"] / "kmers.csv"),
+                    "-o", str(out), "-n", "1"] + RUNS[name], check=True, timeout=300)
+    assert out.read_bytes() == (toy["dir"] / f"ref_{name}.{ext}").read_bytes()
+
+
+def test_cli_rejects_unbuilt_modes(toy, indexed):
+    r = subprocess.run([str(CLI), "enumerate", str(indexed / "toy"), "-f", str(toy["dir"] / "kmers.csv"),
+                        "-o", str(indexed / "x.csv"), "--rna-bulges", "1"], timeout=60)
+    assert r.returncode == 1
