@@ -112,8 +112,10 @@ def main():
     t0 = time.perf_counter()
     n_ext = n_hits = 0
     ms_search = ms_total = 0.0
+    per_step_ms = []
     for i in range(args.warmup, nb):
         _, _, st = step(i)
+        per_step_ms.append(round(st["ms_search"], 1))
         n_ext += st["n_ext"]
         n_hits += st["n_hits"]
         ms_search += st["ms_search"]
@@ -160,6 +162,7 @@ def main():
         "detail": {"n_ext_per_guide": n_ext_ref_per_guide, "n_ext_sample": ns,
                    "executed_ext_per_guide": n_ext / (batch * K), "hits_per_guide": n_hits / (batch * K),
                    "prefix_table_k": os.environ.get("GS_PREFIX_K", "auto"),
+                   "k_search_ms_per_step": per_step_ms,
                    "device_ms_total_per_step": ms_total / K, "index_build_s": t_index,
                    "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes},
     }

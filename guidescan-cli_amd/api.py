@@ -77,6 +77,8 @@ def lib():
     L.gs_index_build_with_sa.argtypes = [vp, u64, vp, vp, i32, C.POINTER(vp)]
     L.gs_index_open_sdsl.restype = i32
     L.gs_index_open_sdsl.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
+    L.gs_sdsl_extract_text.restype = i32
+    L.gs_sdsl_extract_text.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
     L.gs_index_close.argtypes = [vp]
     L.gs_index_genome_length.restype = u64
     L.gs_index_genome_length.argtypes = [vp]
@@ -120,7 +122,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_index_genome_length", "gs_index_device_bytes", "gs_enumerate", "gs_enumerate_device",
            "gs_result_get", "gs_result_free", "gs_decode_sequence", "gs_rank_bwt4", "gs_resolve",
            "gs_index_meta", "gs_index_copy_sa", "gs_calculate_cfd", "gs_status_string", "gs_version",
-           "gs_format_guide", "gs_format_header", "gs_free"]
+           "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text"]
 
 
 def _check(rc):
@@ -160,6 +162,15 @@ def format_guide(gs, gid, sequence, pam, sense_positive, hits, mismatches, sam=F
     return s
 
 
+def sdsl_extract_text(index_file) -> np.ndarray:
+    """genome text held in a reference `.forward` / `.reverse` index file"""
+    out, n = C.c_void_p(), C.c_uint64()
+    _check(lib().gs_sdsl_extract_text(str(index_file).encode(), C.byref(out), C.byref(n)))
+    t = np.frombuffer(C.string_at(out, n.value), dtype=np.uint8).copy()
+    lib().gs_free(out)
+    return t
+
+
 def decode_sequence(guide: str, P: int, key: int, flags: int = 0) -> str:
     buf = C.create_string_buffer(len(guide) + P + 1)
     _check(lib().gs_decode_sequence(guide.encode(), len(guide), P, flags, key, buf))
@@ -185,6 +196,13 @@ class GenomeIndex:
                                                 sa_rev.ctypes.data, device, C.byref(h)))
         else:
             _check(lib().gs_index_build(text.ctypes.data, text.shape[0], device, C.byref(h)))
+        return cls(h, device)
+
+    @classmethod
+    def open_sdsl(cls, prefix, device: int = 0):
+        """import the reference's <prefix>.forward index file (sdsl::load_from_file replacement)"""
+        h = C.c_void_p()
+        _check(lib().gs_index_open_sdsl(str(prefix).encode(), device, C.byref(h)))
         return cls(h, device)
 
     def close(self):

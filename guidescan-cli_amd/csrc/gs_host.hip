@@ -148,10 +148,3 @@ extern "C" float gs_calculate_cfd(const char *sgrna, const char *seq, const char
   return (float)((double)cfd * ps);
 }
 
-extern "C" gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out) {
-  (void)prefix;
-  (void)device;
-  (void)out;
-  gs_set_error("SDSL index import is not built yet (DESIGN.md section 9, next rows)");
-  return GS_ERR_UNSUPPORTED;
-}

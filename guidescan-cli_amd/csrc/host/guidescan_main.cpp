@@ -234,14 +234,22 @@ int do_enumerate(int argc, char **argv) {
     std::cerr << "error: No genome structure file " << prefix << ".gs\n";
     return 1;
   }
-  std::ifstream dna_in(prefix + ".dna", std::ios::binary | std::ios::ate);
-  if (!dna_in) {
-    std::cerr << "error: No sequence file " << prefix << ".dna (run `guidescan index`)\n";
-    return 1;
+  /* PREFIX.dna (this tool's `index`) or, for indices made by the reference, PREFIX.forward */
+  std::string text;
+  bool from_sdsl = false;
+  {
+    std::ifstream dna_in(prefix + ".dna", std::ios::binary | std::ios::ate);
+    if (dna_in) {
+      text.resize((size_t)dna_in.tellg());
+      dna_in.seekg(0);
+      dna_in.read(&text[0], (std::streamsize)text.size());
+    } else if (std::ifstream(prefix + ".forward")) {
+      from_sdsl = true;
+    } else {
+      std::cerr << "error: neither " << prefix << ".dna nor " << prefix << ".forward exists\n";
+      return 1;
+    }
   }
-  std::string text((size_t)dna_in.tellg(), '\0');
-  dna_in.seekg(0);
-  dna_in.read(&text[0], (std::streamsize)text.size());
 
   std::vector<kmer_row> kmers;
   std::string err;
@@ -253,7 +261,8 @@ int do_enumerate(int argc, char **argv) {
 
   auto t0 = std::chrono::steady_clock::now();
   gs_index *ix = nullptr;
-  gs_status rc = gs_index_build((const uint8_t *)text.data(), text.size(), device, &ix);
+  gs_status rc = from_sdsl ? gs_index_open_sdsl(prefix.c_str(), device, &ix)
+                           : gs_index_build((const uint8_t *)text.data(), text.size(), device, &ix);
   if (rc != GS_OK) {
     std::cerr << "error: " << gs_status_string(rc) << "\n";
     return 1;

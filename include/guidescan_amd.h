@@ -105,6 +105,9 @@ gs_status gs_index_build_with_sa(const uint8_t *text, uint64_t len, const uint32
  * (sdsl::csa_wt<wt_huff<>,64,8192>::serialize, sdsl/include/sdsl/csa_wt.hpp:372-382).
  * Replaces sdsl::load_from_file (src/guidescan.cxx:198-208). */
 gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out);
+/* The genome text stored in one reference index file (BWT inverted on the host); what
+ * gs_index_open_sdsl feeds to the GPU builder.  *text is malloc'ed: release with gs_free. */
+gs_status gs_sdsl_extract_text(const char *index_file, uint8_t **text, uint64_t *len);
 
 void gs_index_close(gs_index *ix);
 uint64_t gs_index_genome_length(const gs_index *ix); /* sum of chromosome lengths (no sentinel) */

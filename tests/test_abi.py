@@ -154,3 +154,20 @@ def test_product_printers_reproduce_reference_files(toy, name):
         oidx.close()
     ext = "sam" if sam else "csv"
     assert "".join(out) == (toy["dir"] / f"ref_{name}.{ext}").read_text()
+
+
+def test_sdsl_importer_recovers_the_genome_text(toy):
+    """the reference's on-disk index files (written by the survey build) -> genome text"""
+    synth = import_module("guidescan-cli_amd.synth")
+    fwd = api.sdsl_extract_text(toy["dir"] / "toy.idx.forward")
+    assert fwd.tobytes() == toy["text"].tobytes()
+    rev = api.sdsl_extract_text(toy["dir"] / "toy.idx.reverse")
+    assert rev.tobytes() == synth.reverse_complement_bytes(toy["text"]).tobytes()
+
+
+def test_sdsl_importer_rejects_garbage(tmp_path):
+    p = tmp_path / "bad.forward"
+    p.write_bytes(b"\x01" * 1000)
+    with pytest.raises(api.GsError) as e:
+        api.sdsl_extract_text(p)
+    assert e.value.status in (5, 6)

@@ -46,3 +46,15 @@ def test_cli_rejects_unbuilt_modes(toy, indexed):
     r = subprocess.run([str(CLI), "enumerate", str(indexed / "toy"), "-f", str(toy["dir"] / "kmers.csv"),
                         "-o", str(indexed / "x.csv"), "--rna-bulges", "1"], timeout=60)
     assert r.returncode == 1
+
+
+def test_cli_reads_reference_index_files(toy, tmp_path):
+    """an index made by the reference itself (toy.idx.forward + .gs) works as is"""
+    import shutil
+    for f in ("toy.idx.forward", "toy.idx.reverse"):
+        shutil.copy(toy["dir"] / f, tmp_path / f)
+    shutil.copy(toy["dir"] / "toy.gs", tmp_path / "toy.idx.gs")
+    out = tmp_path / "o.csv"
+    subprocess.run([str(CLI), "enumerate", str(tmp_path / "toy.idx"), "-f", str(toy["dir"] / "kmers.csv"),
+                    "-o", str(out), "-m", "3"], check=True, timeout=300)
+    assert out.read_bytes() == (toy["dir"] / "ref_m3_csv.csv").read_bytes()
