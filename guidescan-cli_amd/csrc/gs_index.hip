@@ -521,7 +521,9 @@ extern "C" void gs_index_close(gs_index *ix) {
   gs_strand_free(&ix->strand[0]);
   gs_strand_free(&ix->strand[1]);
   gs_buffer *bufs[] = {&ix->w_guides, &ix->w_slots, &ix->w_counts, &ix->w_nmatch, &ix->w_nhits,
-                       &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec};
+                       &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec,
+                       &ix->w_ovf_list, &ix->w_grec2, &ix->w_slots2, &ix->w_counts2, &ix->w_nmatch2,
+                       &ix->w_nhits2};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)

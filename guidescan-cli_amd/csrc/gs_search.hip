@@ -547,8 +547,15 @@ __global__ __launch_bounds__(WAVE) void k_order(gs_order_args a) {
   if (g >= a.n) return;
   const uint32_t cap = a.cap;
   uint32_t c0 = a.counts[2 * g], c1 = a.counts[2 * g + 1];
-  if (c0 > cap) c0 = cap;
-  if (c1 > cap) c1 = cap;
+  if (c0 > cap || c1 > cap) {
+    /* more matches than slots: this guide is redone with larger slots (host side); the
+     * redo's totals are patched in before the scan */
+    if (lane == 0) {
+      a.nmatch[g] = 0;
+      a.nhits[g] = 0;
+    }
+    return;
+  }
   const uint32_t M = c0 + c1;
   uint4 *rec = s_mem;
   uint4 *srt = s_mem + 2 * cap;
@@ -663,6 +670,7 @@ struct gs_locate_args {
   const uint4 *matches; /* [n][2*cap] ordered unique */
   const uint32_t *nmatch;
   const uint64_t *offsets;
+  const uint32_t *gmap; /* optional: offsets index of guide g is gmap[g] (redo batch) */
   gs_hit *hits;
   uint64_t genome_length;
   uint32_t n, cap;
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(WAVE) void k_locate(gs_locate_args a) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const uint32_t H = run;
-  gs_hit *out = a.hits + a.offsets[g];
+  gs_hit *out = a.hits + a.offsets[a.gmap ? a.gmap[g] : g];
   for (uint32_t h = lane; h < H; h += WAVE) {
     /* last match j with s_pre[j] <= h */
     uint32_t lo = 0, hi = M;
@@ -733,6 +741,24 @@ __global__ void k_resolve(gs_strand_dev sd, const uint64_t *rows, uint64_t n, ui
   const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   out[j] = sd.sa[rows[j]];
+}
+
+/* ---- selective redo of guides whose matches overflowed their slots -------------------- */
+__global__ void k_collect_overflow(const uint32_t *counts, uint32_t n, uint32_t cap, uint32_t *list,
+                                   uint32_t *n_list) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  if (counts[2 * g] > cap || counts[2 * g + 1] > cap) list[atomicAdd(n_list, 1u)] = g;
+}
+__global__ void k_gather_guides(const gs_guide_rec *in, const uint32_t *list, uint32_t n_o,
+                                gs_guide_rec *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_o) out[i] = in[list[i]];
+}
+__global__ void k_patch_overflow(const uint32_t *list, uint32_t n_o, const uint32_t *nhits2,
+                                 uint32_t *nhits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_o) nhits[list[i]] = nhits2[i];
 }
 
 /* ---- host side of the pipeline ---------------------------------------------- */
@@ -824,26 +850,25 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
 
   const int cus = g_num_cus(ix->device);
   float ms_search = 0.f;
-  for (;;) {
-    if (cap > 2048) {
-      gs_set_error("more than 2048 distinct matches for one (guide, strand): not implemented");
-      return GS_ERR_UNSUPPORTED;
-    }
-    if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
-    GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 256, st));
+  uint32_t *d_nlist = d_work + 2;
+
+  auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
+                        uint32_t cap_, unsigned long long h_stats[2]) -> gs_status {
+    GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 16, st)); /* n_ext, overflow items */
+    GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
     gs_search_args sa;
     sa.sd[0] = ix->strand[0].d;
     sa.sd[1] = ix->strand[1].d;
-    sa.guides = (const gs_guide_rec *)ix->w_grec.p;
-    sa.slots = (uint4 *)ix->w_slots.p;
-    sa.counts = (uint32_t *)ix->w_counts.p;
+    sa.guides = guides;
+    sa.slots = slots;
+    sa.counts = counts;
     sa.work = d_work;
     sa.stats = d_stats;
-    sa.n_items = 2 * n32;
+    sa.n_items = 2 * ng;
     sa.L = L;
     sa.P = P;
     sa.m = mismatches;
-    sa.cap = cap;
+    sa.cap = cap_;
     sa.combo = (const uint32_t *)ix->d_combo;
     sa.pt_k = 0;
     sa.jmax = 0;
@@ -859,39 +884,102 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
      * their LDS stacks allow (8 at 20 KiB each = 32 waves per CU) */
     uint32_t grid = (uint32_t)cus * (160u * 1024u / (STACK_ENTRIES * 16u * SEARCH_WAVES));
-    const uint32_t need = (2 * n32 + SEARCH_WAVES - 1) / SEARCH_WAVES;
+    const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
     GS_HIP(hipEventRecord(ix->ev[1], st));
     hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 0, st, sa);
     GS_HIP(hipEventRecord(ix->ev[2], st));
-    unsigned long long h_stats[2] = {0, 0};
-    GS_HIP(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, st));
+    GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
     float ms = 0.f;
     hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]);
     ms_search += ms;
-    if (stats) stats->n_ext = h_stats[0];
-    if (h_stats[1] == 0) break;
-    /* some (guide, strand) found more matches than its slots hold: redo with room */
-    cap = cap >= 1024 ? cap * 2 : cap * 4;
-  }
-
-  {
+    return GS_OK;
+  };
+  auto run_order = [&](uint4 *slots, const uint32_t *counts, uint32_t *nmatch, uint32_t *nhits,
+                       uint32_t ng, uint32_t cap_) -> gs_status {
     gs_order_args oa;
-    oa.slots = (uint4 *)ix->w_slots.p;
-    oa.counts = (const uint32_t *)ix->w_counts.p;
-    oa.nmatch = (uint32_t *)ix->w_nmatch.p;
-    oa.nhits = (uint32_t *)ix->w_nhits.p;
+    oa.slots = slots;
+    oa.counts = counts;
+    oa.nmatch = nmatch;
+    oa.nhits = nhits;
     oa.stats = d_stats;
-    oa.n = n32;
-    oa.cap = cap;
-    const size_t lds = sizeof(uint4) * 4 * (size_t)cap;
+    oa.n = ng;
+    oa.cap = cap_;
+    const size_t lds = sizeof(uint4) * 4 * (size_t)cap_;
     if (lds > 64 * 1024)
       GS_HIP(hipFuncSetAttribute((const void *)k_order, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-    hipLaunchKernelGGL(k_order, dim3(n32), dim3(WAVE), lds, st, oa);
+    hipLaunchKernelGGL(k_order, dim3(ng), dim3(WAVE), lds, st, oa);
+    return GS_OK;
+  };
+  auto run_locate = [&](const uint4 *matches, const uint32_t *nmatch, const uint32_t *gmap, uint32_t ng,
+                        uint32_t cap_) {
+    gs_locate_args la;
+    la.sd[0] = ix->strand[0].d;
+    la.sd[1] = ix->strand[1].d;
+    la.matches = matches;
+    la.nmatch = nmatch;
+    la.offsets = (const uint64_t *)ix->w_offsets.p;
+    la.gmap = gmap;
+    la.hits = (gs_hit *)ix->w_hits.p;
+    la.genome_length = ix->genome_length;
+    la.n = ng;
+    la.cap = cap_;
+    const size_t lds = sizeof(uint32_t) * (2 * (size_t)cap_ + 1);
+    hipLaunchKernelGGL(k_locate, dim3(ng), dim3(WAVE), lds, st, la);
+  };
+
+  /* ---- main pass ---- */
+  if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
+  unsigned long long h_stats[2] = {0, 0};
+  if ((rc = run_search((const gs_guide_rec *)ix->w_grec.p, n32, (uint4 *)ix->w_slots.p,
+                       (uint32_t *)ix->w_counts.p, cap, h_stats)) != GS_OK)
+    return rc;
+  if (stats) stats->n_ext = h_stats[0];
+  GS_HIP(hipMemsetAsync(d_stats + 2, 0, 8, st)); /* match counter */
+  if ((rc = run_order((uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_counts.p,
+                      (uint32_t *)ix->w_nmatch.p, (uint32_t *)ix->w_nhits.p, n32, cap)) != GS_OK)
+    return rc;
+
+  /* ---- redo only the guides whose matches did not fit their slots ---- */
+  uint32_t n_o = 0, cap2 = cap;
+  if (h_stats[1] != 0) {
+    if ((rc = gs_reserve(ix->w_ovf_list, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
+    GS_HIP(hipMemsetAsync(d_nlist, 0, 4, st));
+    hipLaunchKernelGGL(k_collect_overflow, dim3((n32 + 255) / 256), dim3(256), 0, st,
+                       (const uint32_t *)ix->w_counts.p, n32, cap, (uint32_t *)ix->w_ovf_list.p, d_nlist);
+    GS_HIP(hipMemcpyAsync(&n_o, d_nlist, 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if ((rc = gs_reserve(ix->w_grec2, sizeof(gs_guide_rec) * (size_t)n_o)) != GS_OK) return rc;
+    if ((rc = gs_reserve(ix->w_counts2, sizeof(uint32_t) * 2 * (size_t)n_o)) != GS_OK) return rc;
+    if ((rc = gs_reserve(ix->w_nmatch2, sizeof(uint32_t) * (size_t)n_o)) != GS_OK) return rc;
+    if ((rc = gs_reserve(ix->w_nhits2, sizeof(uint32_t) * (size_t)n_o)) != GS_OK) return rc;
+    hipLaunchKernelGGL(k_gather_guides, dim3((n_o + 255) / 256), dim3(256), 0, st,
+                       (const gs_guide_rec *)ix->w_grec.p, (const uint32_t *)ix->w_ovf_list.p, n_o,
+                       (gs_guide_rec *)ix->w_grec2.p);
+    for (;;) {
+      cap2 = cap2 >= 1024 ? cap2 * 2 : cap2 * 4;
+      if (cap2 > 2048) {
+        gs_set_error("more than 2048 distinct matches for one (guide, strand): not implemented");
+        return GS_ERR_UNSUPPORTED;
+      }
+      if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (size_t)cap2 * 2 * n_o)) != GS_OK) return rc;
+      unsigned long long h2[2] = {0, 0};
+      if ((rc = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
+                           (uint32_t *)ix->w_counts2.p, cap2, h2)) != GS_OK)
+        return rc;
+      if (h2[1] == 0) break;
+    }
+    if ((rc = run_order((uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_counts2.p,
+                        (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2)) != GS_OK)
+      return rc;
+    hipLaunchKernelGGL(k_patch_overflow, dim3((n_o + 255) / 256), dim3(256), 0, st,
+                       (const uint32_t *)ix->w_ovf_list.p, n_o, (const uint32_t *)ix->w_nhits2.p,
+                       (uint32_t *)ix->w_nhits.p);
   }
+
   hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_BLOCK), 0, st,
                      (const uint32_t *)ix->w_nhits.p, (uint64_t *)ix->w_blocksums.p, n32);
   hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st,
@@ -903,20 +991,10 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   GS_HIP(hipMemcpyAsync(&total, (uint64_t *)ix->w_offsets.p + n, 8, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   if ((rc = gs_reserve(ix->w_hits, sizeof(gs_hit) * (total + 1))) != GS_OK) return rc;
-  {
-    gs_locate_args la;
-    la.sd[0] = ix->strand[0].d;
-    la.sd[1] = ix->strand[1].d;
-    la.matches = (const uint4 *)ix->w_slots.p;
-    la.nmatch = (const uint32_t *)ix->w_nmatch.p;
-    la.offsets = (const uint64_t *)ix->w_offsets.p;
-    la.hits = (gs_hit *)ix->w_hits.p;
-    la.genome_length = ix->genome_length;
-    la.n = n32;
-    la.cap = cap;
-    const size_t lds = sizeof(uint32_t) * (2 * (size_t)cap + 1);
-    hipLaunchKernelGGL(k_locate, dim3(n32), dim3(WAVE), lds, st, la);
-  }
+  run_locate((const uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_nmatch.p, nullptr, n32, cap);
+  if (n_o)
+    run_locate((const uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_nmatch2.p,
+               (const uint32_t *)ix->w_ovf_list.p, n_o, cap2);
   GS_HIP(hipEventRecord(ix->ev[3], st));
   unsigned long long h_stats3[3] = {0, 0, 0};
   GS_HIP(hipMemcpyAsync(h_stats3, d_stats, sizeof(h_stats3), hipMemcpyDeviceToHost, st));

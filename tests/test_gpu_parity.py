@@ -161,13 +161,23 @@ def test_match_slot_overflow_retry():
     oidx = ol.OracleIndex(text)
     gidx = api.GenomeIndex.build(text, device=0)
     try:
-        seqs = np.array([list(site)], dtype=np.uint8)
-        pams = np.array([list(b"NGG")], dtype=np.uint8)
-        offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3)
-        exp, ctr = oracle_hits_as_records(oidx, site.tobytes().decode(), "NGG", ol.make_opts(3), 3)
-        got = gpu_hits_as_records(offsets, hits, 0, site.tobytes().decode(), 3)
-        assert got == exp
-        assert stats["n_matches"] > 64
+        # the overflowing guide sits between ordinary ones: only it is redone, and its hits
+        # must land at its own CSR position
+        others, _, _, _ = synth.sample_guides(text, 6, seed=4)
+        seqs = np.concatenate([others[:3], np.array([list(site)], dtype=np.uint8), others[3:],
+                               np.array([list(site)], dtype=np.uint8)])
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
+        for faithful in (False, True):
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
+            n_matches = 0
+            for i in range(seqs.shape[0]):
+                g = seqs[i].tobytes().decode()
+                exp, ctr = oracle_hits_as_records(oidx, g, "NGG", ol.make_opts(3), 3)
+                got = gpu_hits_as_records(offsets, hits, i, g, 3)
+                assert got == exp, (i, faithful)
+                n_matches += len(set((e[2], e[3]) for e in exp))
+            assert stats["n_matches"] == n_matches
+            assert stats["n_matches"] > 2 * 64
     finally:
         gidx.close()
         oidx.close()
