@@ -34,13 +34,19 @@ struct gs_strand_dev {
   uint32_t has_n;
   /* prefix interval table: entry {sp, end} of every k-mer, indexed by
    * the k-mer with its FIRST text symbol in the LOWEST bits, so the 16 two-symbol left
-   * extensions of a (k-2)-mer share one aligned 128-byte line.  end==0: k-mer absent. */
+   * extensions of a (k-2)-mer share one aligned 128-byte line.  Entry = {sp, cnt | flag<<31}:
+   * cnt==0: k-mer absent; flag: some row of the interval has a non-ACGT symbol (or the text
+   * start) within the 16 symbols preceding its suffix, so it must take the Occ walk. */
   const uint2 *ptab;
+  /* preceding context: ctx[r] = the 16 text symbols before suffix SA[r],
+   * nearest first, 2 bits each (A,C,G,T = 0..3).  Lets a small interval at depth k be resolved
+   * against the rest of the pattern with one 4-byte read per row instead of an Occ walk. */
+  const uint32_t *ctx;
 };
 
 struct gs_strand {
   gs_strand_dev d{};
-  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr;
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr;
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;

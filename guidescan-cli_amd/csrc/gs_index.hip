@@ -134,6 +134,7 @@ void gs_strand_free(gs_strand *s) {
   if (s->run_start) hipFree(s->run_start);
   if (s->run_cum) hipFree(s->run_cum);
   if (s->ptab) hipFree(s->ptab);
+  if (s->ctx) hipFree(s->ctx);
   *s = gs_strand();
 }
 
@@ -418,17 +419,61 @@ static uint32_t choose_prefix_k(uint64_t n) {
   return k;
 }
 
+/* end -> count */
+__global__ void k_ptab_finish(uint2 *tab, uint64_t entries) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= entries) return;
+  uint2 e = tab[i];
+  e.y = e.y ? e.y - e.x : 0u;
+  tab[i] = e;
+}
+/* ctx[r] = 16 symbols preceding suffix SA[r] (nearest first); rows whose window holds a
+ * non-ACGT symbol or runs off the text start flag their k-mer's table entry */
+__global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t k,
+                            uint32_t *ctx, uint2 *tab) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t p = sa[r];
+  uint32_t w = 0;
+  bool exc = false;
+  for (uint32_t j = 1; j <= 16; j++) {
+    uint32_t cls = 5;
+    if (p >= j) cls = sym_class(text[p - j]);
+    if (cls > 3) {
+      exc = true;
+      cls = 0;
+    }
+    w |= cls << (2 * (j - 1));
+  }
+  ctx[r] = w;
+  if (exc && tab) {
+    uint32_t c;
+    if (kmer_code(text, n, p, k, c)) atomicOr(&tab[c].y, 0x80000000u);
+  }
+}
+
 static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hipStream_t st) {
   if (!k) return GS_OK;
-  const size_t bytes = sizeof(uint2) << (2 * k);
+  const uint64_t entries = 1ull << (2 * k);
+  const size_t bytes = sizeof(uint2) * entries;
   uint2 *tab = nullptr;
   GS_HIP(hipMalloc(&tab, bytes));
   GS_HIP(hipMemsetAsync(tab, 0, bytes, st));
   hipLaunchKernelGGL(k_ptab_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
                      (const uint32_t *)s->sa, s->n, k, tab);
+  hipLaunchKernelGGL(k_ptab_finish, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, entries);
+  uint32_t *ctx = nullptr;
+  if (!getenv("GS_NO_CTX")) {
+    GS_HIP(hipMalloc(&ctx, 4 * s->n));
+    hipLaunchKernelGGL(k_ctx_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
+                       (const uint32_t *)s->sa, s->n, k, ctx, tab);
+    s->bytes += 4 * s->n;
+  }
   GS_HIP(hipStreamSynchronize(st));
   s->ptab = tab;
   s->d.ptab = tab;
+  s->ctx = ctx;
+  s->d.ctx = ctx;
   s->bytes += bytes;
   return GS_OK;
 }

@@ -50,7 +50,11 @@ struct gs_search_args {
   const uint32_t *combo;
   uint32_t pt_k; /* table depth k; seeds are the depth-k nodes */
   uint32_t jmax; /* min(m, pt_k-2, 7) */
+  /* context verification: L+P-pt_k (<= 16) symbols remain after the table depth; 0 = disabled */
+  uint32_t v_rem;
 };
+
+#define VERIFY_MAX 32u /* intervals up to this many rows are resolved row by row from ctx[] */
 
 #define SEED_LOW 128 /* refill the stacks from the prefix table when they hold this few nodes */
 
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
       return ((pw >> (3u * (t2 - L))) & 7u) < 4u;
     };
     /* route a live child: emit (terminal), push on X or on G */
-    auto route = [&](bool live, bool term, bool single, uint32_t csp, uint32_t cep,
-                     uint64_t cmeta) __attribute__((always_inline)) {
+    auto route = [&](bool live, bool term, bool single, uint32_t csp, uint32_t cep, uint64_t cmeta,
+                     uint32_t vflag = 0u) __attribute__((always_inline)) {
       const bool px = live && !term && single;
       const bool pg = live && !term && !single;
       const bool em = live && term;
@@ -202,8 +206,10 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         if (em) {
           const uint32_t idx = n_match + lanes_below(be);
           if (idx < a.cap) {
+            /* bit 0: the record is a single row at the table depth whose text position still
+             * has to move left by v_rem symbols (k_locate) */
             const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
-                                 ((cmeta & PATH_MASK) << 8);
+                                 ((cmeta & PATH_MASK) << 8) | vflag;
             out[idx] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
           }
         }
@@ -277,14 +283,68 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         pidx ^= ((q2 ^ s2) << 2) | (q1 ^ s1);
         uint2 ent = make_uint2(0u, 0u);
         if (act) ent = sd.ptab[pidx];
-        const bool live = act && ent.y != 0u;
+        const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
+        const bool live = act && ecnt != 0u;
         const uint32_t c2 = s2 == q2 ? 0u : 1u + s2 - (s2 > q2 ? 1u : 0u);
         const uint32_t c1 = s1 == q1 ? 0u : 1u + s1 - (s1 > q1 ? 1u : 0u);
         const uint32_t kk = sj + mm;
         const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path |
                                ((uint64_t)c2 << (50u - 2u * kp)) |
                                ((uint64_t)c1 << (50u - 2u * (kp + 1u)));
-        route(live, false, kk == m, ent.x, ent.y - 1u, cmeta); /* k < L: never terminal */
+        /* small, exception-free intervals are resolved right here against ctx[]; the rest
+         * continue as ordinary nodes (k < L: never terminal) */
+        const bool ver = live && a.v_rem != 0u && (ent.y >> 31) == 0u && ecnt <= VERIFY_MAX;
+        route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
+        if (__ballot(ver)) {
+          /* The v_rem symbols left of each suffix are in ctx[row], nearest first, i.e. in
+           * consumption order: compare the remaining guide symbols under the remaining
+           * budget, then each PAM pattern exactly ('N' = any base).  Hits are the rows
+           * themselves; their text position is SA[row] - v_rem (k_locate). */
+          const uint32_t g = L - k; /* guide symbols left */
+          const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
+          const uint32_t qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
+          for (uint32_t base = 0; __ballot(ver && base < ecnt); base += 8u) {
+            /* eight independent 4-byte reads in flight per lane before any is looked at */
+            uint32_t wv[8];
+#pragma unroll
+            for (uint32_t jj = 0; jj < 8u; ++jj) {
+              wv[jj] = 0u;
+              if (ver && base + jj < ecnt) wv[jj] = sd.ctx[ent.x + base + jj];
+            }
+#pragma unroll
+            for (uint32_t jj = 0; jj < 8u; ++jj) {
+              const bool on = ver && base + jj < ecnt;
+              const uint32_t row = ent.x + base + jj;
+              const uint32_t w = wv[jj];
+              const uint32_t x = (w ^ qrem) & gmask;
+              const uint32_t mmv = __popc((x | (x >> 1)) & 0x55555555u);
+              const bool gok = on && kk + mmv <= m;
+              if (!__ballot(gok)) continue;
+              for (uint32_t pj = 0; pj < npams; ++pj) {
+                const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+                bool ok = gok;
+                uint64_t ppath = 0;
+                for (uint32_t u = 0; u < P; ++u) {
+                  const uint32_t pc = (pw >> (3u * u)) & 7u;
+                  const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+                  ok = ok && (pc == 4u || pc == tb);
+                  ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+                }
+                if (!__ballot(ok)) continue;
+                uint64_t gpath = 0;
+                for (uint32_t v = 0; v < g; ++v) {
+                  const uint32_t qc = (qrem >> (2u * v)) & 3u;
+                  const uint32_t tb = (w >> (2u * v)) & 3u;
+                  const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+                  gpath |= (uint64_t)code << (50u - 2u * (k + v));
+                }
+                const uint64_t mmeta =
+                    ((uint64_t)(kk + mmv) << 56) | (cmeta & PATH_MASK) | gpath | ppath;
+                route(ok, true, false, row, row, mmeta, 1u);
+              }
+            }
+          }
+        }
         /* advance the (j, sub, pos) cursor */
         spos += WAVE;
         if (spos >= span) {
@@ -571,7 +631,7 @@ __global__ __launch_bounds__(WAVE) void k_order(gs_order_args a) {
     for (uint32_t j = 0; j < M; j++) {
       const uint4 o = rec[j];
       const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
-      rank += (ok < key) || (ok == key && j < i);
+      rank += (ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < i)));
     }
     srt[rank] = me;
   }
@@ -588,7 +648,7 @@ __global__ __launch_bounds__(WAVE) void k_order(gs_order_args a) {
       keep = true;
       if (i > 0) {
         const uint4 pv = srt[i - 1];
-        keep = !(pv.x == me.x && pv.y == me.y);
+        keep = !(pv.x == me.x && pv.y == me.y && pv.z == me.z); /* same sequence, same rows */
       }
     }
     const uint64_t kb = __ballot(keep);
@@ -674,6 +734,7 @@ struct gs_locate_args {
   gs_hit *hits;
   uint64_t genome_length;
   uint32_t n, cap;
+  uint32_t v_rem; /* records with key bit 0 set sit v_rem symbols right of the site's start */
 };
 
 /* one wavefront per guide; dynamic LDS: (2*cap + 1) uint32 exclusive prefix of match sizes */
@@ -716,11 +777,11 @@ __global__ __launch_bounds__(WAVE) void k_locate(gs_locate_args a) {
     const uint64_t key = ((uint64_t)m.y << 32) | m.x;
     const uint32_t strand = (uint32_t)(key >> 60) & 1u;
     const uint32_t row = m.z + (h - s_pre[lo]);
-    const uint64_t sa = a.sd[strand].sa[row];
+    const uint64_t sa = (uint64_t)a.sd[strand].sa[row] - ((key & 1ull) ? a.v_rem : 0u);
     gs_hit o;
     /* process.hpp:104 / :111 */
     o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
-    o.key = key;
+    o.key = key & ~1ull;
     out[h] = o;
   }
 }
@@ -850,6 +911,11 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
 
   const int cus = g_num_cus(ix->device);
   float ms_search = 0.f;
+  /* context verification is possible when what remains after the table depth fits ctx[] */
+  uint32_t v_rem = 0;
+  if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK) && ix->strand[0].ctx &&
+      ix->strand[1].ctx && L + P - ix->pt_k <= 16)
+    v_rem = L + P - ix->pt_k;
   uint32_t *d_nlist = d_work + 2;
 
   auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
@@ -872,6 +938,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.combo = (const uint32_t *)ix->d_combo;
     sa.pt_k = 0;
     sa.jmax = 0;
+    sa.v_rem = 0;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
        * substitutions x the two-symbol extensions the remaining budget allows */
@@ -880,6 +947,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       uint32_t jmax = mismatches < kp ? mismatches : kp;
       if (jmax > 7) jmax = 7;
       sa.jmax = jmax;
+      sa.v_rem = v_rem;
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
      * their LDS stacks allow (8 at 20 KiB each = 32 waves per CU) */
@@ -927,6 +995,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     la.genome_length = ix->genome_length;
     la.n = ng;
     la.cap = cap_;
+    la.v_rem = v_rem;
     const size_t lds = sizeof(uint32_t) * (2 * (size_t)cap_ + 1);
     hipLaunchKernelGGL(k_locate, dim3(ng), dim3(WAVE), lds, st, la);
   };

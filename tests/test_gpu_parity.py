@@ -181,3 +181,57 @@ def test_match_slot_overflow_retry():
     finally:
         gidx.close()
         oidx.close()
+
+
+@pytest.mark.parametrize("pk", ["8", "10", "12"])
+def test_context_verification_paths_bit_exact(toy, pk, monkeypatch):
+    """force deep prefix tables so that intervals are resolved through ctx[] (the hg38-size
+    code path) on small genomes: toy (literal-N PAM, boundaries, repeats) and a 2 Mbp genome"""
+    monkeypatch.setenv("GS_PREFIX_K", pk)
+    oidx = ol.OracleIndex(toy["text"])
+    gidx = api.GenomeIndex.build(toy["text"], device=0)
+    try:
+        for cfg in (dict(m=3), dict(m=4), dict(m=2, alt=("NAG",)), dict(m=1, start=True), dict(m=0)):
+            m, alt, start = cfg["m"], cfg.get("alt", ()), cfg.get("start", False)
+            for P, group in ((3, [k for k in toy["kmers"] if k.pam]), (0, [k for k in toy["kmers"] if not k.pam])):
+                seqs = np.array([list(k.sequence.encode()) for k in group], dtype=np.uint8)
+                pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8).reshape(len(group), P)
+                opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
+                offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt if P else (),
+                                                      start=start)
+                for i, k in enumerate(group):
+                    exp, _ = oracle_hits_as_records(oidx, k.sequence, k.pam, opts, P, start)
+                    assert gpu_hits_as_records(offsets, hits, i, k.sequence, P, start) == exp, (k.id, cfg, pk)
+    finally:
+        gidx.close()
+        oidx.close()
+
+
+@pytest.mark.parametrize("pk", ["9", "11"])
+def test_context_verification_medium_genome(pk, monkeypatch):
+    monkeypatch.setenv("GS_PREFIX_K", pk)
+    text, names, lengths = synth.make_genome([900_000, 700_000, 400_000], seed=5)
+    # plant a few near-copies so that verification has multi-row intervals with hits
+    rng = np.random.default_rng(0)
+    seqs, pams, pos, strands = synth.sample_guides(text, 200, seed=9)
+    for i in range(0, 40):
+        s = np.concatenate([seqs[i], np.frombuffer(b"TGG", np.uint8)]).copy()
+        for j in rng.choice(20, size=i % 4, replace=False):
+            s[j] = rng.choice([c for c in b"ACGT" if c != s[j]])
+        at = int(rng.integers(50_000, 1_900_000))
+        text[at:at + 23] = s if i % 2 else synth.reverse_complement_bytes(s)
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        opts = ol.make_opts(mismatches=3)
+        offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3)
+        total = 0
+        for i in range(seqs.shape[0]):
+            g = seqs[i].tobytes().decode()
+            exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
+            assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, (i, pk)
+            total += len(exp)
+        assert total > 200
+    finally:
+        gidx.close()
+        oidx.close()

@@ -42,6 +42,42 @@ __global__ __launch_bounds__(256) void k_chase(const uint4* __restrict__ tab, ui
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+
+// quad-cooperative variant: 4 adjacent lanes read ONE random 64-byte block (16 B each), and every
+// lane takes part in 4 different blocks per iteration: same number of load instructions per lane
+// as k_gather<64>, but each wave-instruction touches 16 lines instead of 64.
+__global__ __launch_bounds__(256) void k_gather_quad(const uint4* __restrict__ tab, uint64_t nblocks,
+                                                     uint32_t iters, uint32_t* out) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t s = (uint64_t)(tid >> 2) * 0x9E3779B97F4A7C15ull + 777;
+  const uint32_t piece = tid & 3;
+  uint32_t acc = 0;
+  for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      const uint64_t b = (uint64_t)(((unsigned __int128)s * nblocks) >> 64);
+      uint4 v = tab[b * 4 + piece];
+      acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+static void run_quad(const uint4* tab, uint64_t bytes, int grid, uint32_t iters, uint32_t* out) {
+  const uint64_t nblocks = bytes / 64;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k_gather_quad, dim3(grid), dim3(256), 0, 0, tab, nblocks, iters, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double reads = (double)grid * 256 * iters;   // blocks = lanes*iters*4/4
+    if (rep == 1)
+      printf("quad   B= 64 table=%6.0f MiB grid=%5d iters=%4u : %8.3f ms  %7.2f Gblocks/s  %8.1f GB/s\n",
+             bytes / 1048576.0, grid, iters, ms, reads / ms / 1e6, reads * 64 / ms / 1e6);
+  }
+}
+
 template <int B>
 static void run(const uint4* tab, uint64_t bytes, int grid, uint32_t iters, uint32_t* out, bool chase) {
   const uint64_t nblocks = bytes / B;
@@ -67,7 +103,7 @@ int main(int argc, char** argv) {
   hipMalloc(&out, 64);
   hipMemset(tab, 0, max_bytes);
   hipDeviceSynchronize();
-  const uint64_t sizes[] = {64ull << 20, 200ull << 20, 900ull << 20, 1600ull << 20, 2048ull << 20, 3200ull << 20, 6400ull << 20, max_bytes};
+  const uint64_t sizes[] = {3200ull << 20, 8000ull << 20, 16000ull << 20, max_bytes};
   for (uint64_t sz : sizes) {
     if (sz > max_bytes) continue;
     for (int grid : {5120}) {
@@ -75,6 +111,7 @@ int main(int argc, char** argv) {
       run<32>(tab, sz, grid, 256, out, false);
       run<64>(tab, sz, grid, 256, out, false);
       run<128>(tab, sz, grid, 128, out, false);
+      run_quad(tab, sz, grid, 256, out);
     }
 
   }
