@@ -295,53 +295,81 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
          * continue as ordinary nodes (k < L: never terminal) */
         const bool ver = live && a.v_rem != 0u && (ent.y >> 31) == 0u && ecnt <= VERIFY_MAX;
         route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
-        if (__ballot(ver)) {
-          /* The v_rem symbols left of each suffix are in ctx[row], nearest first, i.e. in
-           * consumption order: compare the remaining guide symbols under the remaining
-           * budget, then each PAM pattern exactly ('N' = any base).  Hits are the rows
-           * themselves; their text position is SA[row] - v_rem (k_locate). */
+        /* The v_rem symbols left of each suffix are in ctx[row], nearest first, i.e. in
+         * consumption order: compare the remaining guide symbols under the remaining budget,
+         * then each PAM pattern exactly ('N' = any base).  Hits are the rows themselves; their
+         * text position is SA[row] - v_rem (k_locate).
+         * The rows of all verifying seeds of this step are flattened over the lanes (row slot s
+         * -> lane s mod 64), so consecutive lanes read consecutive ctx words: one coalesced
+         * 4-byte load per lane per 64 rows instead of one scattered load per row per lane. */
+        const uint32_t vcnt = ver ? ecnt : 0u;
+        uint32_t incl = vcnt;
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+          const uint32_t up = __shfl_up(incl, o);
+          if ((int)lane >= o) incl += up;
+        }
+        const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1);
+        if (R) {
+          const uint32_t excl = incl - vcnt;
+          /* scratch above the X stack: 64 seed descriptors + 64 owner markers (xs+gs <= 192
+           * here, so [xs, xs+80) cannot reach the G stack at the top of the 320-entry array) */
+          uint4 *scr = stk + xs;
+          uint32_t *own = (uint32_t *)(stk + xs + WAVE);
+          scr[lane] = make_uint4(ent.x, excl | (kk << 12), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
           const uint32_t g = L - k; /* guide symbols left */
           const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
           const uint32_t qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
-          for (uint32_t base = 0; __ballot(ver && base < ecnt); base += 8u) {
-            /* eight independent 4-byte reads in flight per lane before any is looked at */
-            uint32_t wv[8];
-#pragma unroll
-            for (uint32_t jj = 0; jj < 8u; ++jj) {
-              wv[jj] = 0u;
-              if (ver && base + jj < ecnt) wv[jj] = sd.ctx[ent.x + base + jj];
+          for (uint32_t base = 0; base < R; base += WAVE) {
+            /* owner seed of every row slot in [base, base+64): seeds mark their first slot (or
+             * slot 0 when they straddle the window start), then a max-scan spreads the marks */
+            own[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (vcnt) {
+              if (excl >= base && excl < base + WAVE) own[excl - base] = lane + 1u;
+              if (excl < base && excl + vcnt > base) own[0] = lane + 1u;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t ow = own[lane];
 #pragma unroll
-            for (uint32_t jj = 0; jj < 8u; ++jj) {
-              const bool on = ver && base + jj < ecnt;
-              const uint32_t row = ent.x + base + jj;
-              const uint32_t w = wv[jj];
-              const uint32_t x = (w ^ qrem) & gmask;
-              const uint32_t mmv = __popc((x | (x >> 1)) & 0x55555555u);
-              const bool gok = on && kk + mmv <= m;
-              if (!__ballot(gok)) continue;
-              for (uint32_t pj = 0; pj < npams; ++pj) {
-                const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-                bool ok = gok;
-                uint64_t ppath = 0;
-                for (uint32_t u = 0; u < P; ++u) {
-                  const uint32_t pc = (pw >> (3u * u)) & 7u;
-                  const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-                  ok = ok && (pc == 4u || pc == tb);
-                  ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
-                }
-                if (!__ballot(ok)) continue;
-                uint64_t gpath = 0;
-                for (uint32_t v = 0; v < g; ++v) {
-                  const uint32_t qc = (qrem >> (2u * v)) & 3u;
-                  const uint32_t tb = (w >> (2u * v)) & 3u;
-                  const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-                  gpath |= (uint64_t)code << (50u - 2u * (k + v));
-                }
-                const uint64_t mmeta =
-                    ((uint64_t)(kk + mmv) << 56) | (cmeta & PATH_MASK) | gpath | ppath;
-                route(ok, true, false, row, row, mmeta, 1u);
+            for (int o = 1; o < WAVE; o <<= 1) {
+              const uint32_t up = __shfl_up(ow, o);
+              if ((int)lane >= o && up > ow) ow = up;
+            }
+            const uint32_t slot = base + lane;
+            const bool on = slot < R;
+            uint4 sdesc = make_uint4(0u, 0u, 0u, 0u);
+            if (on) sdesc = scr[ow - 1u];
+            const uint32_t row = sdesc.x + (slot - (sdesc.y & 0xFFFu));
+            uint32_t w = 0;
+            if (on) w = sd.ctx[row];
+            const uint32_t skk = (sdesc.y >> 12) & 7u;
+            const uint32_t x = (w ^ qrem) & gmask;
+            const uint32_t mmv = __popc((x | (x >> 1)) & 0x55555555u);
+            const bool gok = on && skk + mmv <= m;
+            if (!__ballot(gok)) continue;
+            const uint64_t spath = (((uint64_t)sdesc.w << 32) | sdesc.z) & PATH_MASK;
+            for (uint32_t pj = 0; pj < npams; ++pj) {
+              const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+              bool ok = gok;
+              uint64_t ppath = 0;
+              for (uint32_t u = 0; u < P; ++u) {
+                const uint32_t pc = (pw >> (3u * u)) & 7u;
+                const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+                ok = ok && (pc == 4u || pc == tb);
+                ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
               }
+              if (!__ballot(ok)) continue;
+              uint64_t gpath = 0;
+              for (uint32_t v = 0; v < g; ++v) {
+                const uint32_t qc = (qrem >> (2u * v)) & 3u;
+                const uint32_t tb = (w >> (2u * v)) & 3u;
+                const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+                gpath |= (uint64_t)code << (50u - 2u * (k + v));
+              }
+              const uint64_t mmeta = ((uint64_t)(skk + mmv) << 56) | spath | gpath | ppath;
+              route(ok, true, false, row, row, mmeta, 1u);
             }
           }
         }
