@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--mismatches", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="guides per step per GPU (0 = workload default)")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="guides timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--verify", action="store_true",
+                    help="after timing, check full-size properties of the last batch (on-target found, order)")
     args = ap.parse_args()
 
     import torch
@@ -60,7 +62,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the enumerate path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
+        # one process per GPU under torch.distributed.run; backend "nccl" is RCCL on ROCm.  Used
+        # for rendezvous, the barriers around the timed region and the MAX-reduce only.
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -167,6 +171,8 @@ def main():
                    "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes},
     }
 
+    if args.verify:
+        out["verify"] = verify_last_batch(torch, gidx, d_seqs, d_pams, batch, nb - 1, L, P, m, text, seqs)
     if rank == 0 and world == 1 and args.cpu_sample != 0:
         out["cpu_baseline"] = cpu_baseline(text, gidx, seqs, pams, m, args.cpu_sample)
     if rank == 0:
@@ -174,6 +180,48 @@ def main():
     gidx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def verify_last_batch(torch, gidx, d_seqs, d_pams, batch, i, L, P, m, text, seqs):
+    """size-independent properties at the full workload size: CSR offsets monotone, keys ascending
+    within each guide, every guide (sampled from the genome) has a distance-0 hit whose 23-mer in
+    the genome equals guide+PAM.  Reads the device result back through ctypes."""
+    import ctypes as C
+    api = import_module("guidescan-cli_amd.api")
+    synth = import_module("guidescan-cli_amd.synth")
+    s = d_seqs[i * batch:(i + 1) * batch]
+    p = d_pams[i * batch:(i + 1) * batch]
+    d_off, d_hits, st = gidx.enumerate_device(s.data_ptr(), batch, L, p.data_ptr(), P, mismatches=m)
+    n_hits = st["n_hits"]
+    off = torch.empty(batch + 1, dtype=torch.int64, device="cuda")
+    hits = torch.empty((n_hits, 2), dtype=torch.int64, device="cuda")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(off.data_ptr(), d_off, 8 * (batch + 1), 3) == 0
+    assert hip.hipMemcpy(hits.data_ptr(), d_hits, 16 * n_hits, 3) == 0
+    off = off.cpu().numpy()
+    hits = hits.cpu().numpy()
+    pos, key = hits[:, 0], hits[:, 1].view(np.uint64)
+    assert off[0] == 0 and off[-1] == n_hits and np.all(np.diff(off) >= 0)
+    seg = np.repeat(np.arange(batch), np.diff(off))
+    same = seg[1:] == seg[:-1]
+    assert np.all(key[1:][same] >= key[:-1][same]), "keys not ascending within a guide"
+    d0 = (key >> np.uint64(61)) == 0
+    has0 = np.zeros(batch, dtype=bool)
+    has0[seg[d0]] = True
+    assert has0.all(), "a sampled guide has no distance-0 hit"
+    # check a sample of distance-0 hits against the genome text itself
+    idx = np.nonzero(d0)[0][:: max(1, int(d0.sum()) // 20000)]
+    Lg = text.shape[0]
+    g = seqs[i * batch:(i + 1) * batch]
+    for h in idx:
+        q = np.concatenate([g[seg[h]], np.frombuffer(b"NGG", np.uint8)])
+        if (key[h] >> np.uint64(60)) & np.uint64(1):          # reverse index: + strand, pos = end
+            w = text[pos[h] - 22:pos[h] + 1]
+        else:                                                  # forward index: - strand, pos = -start
+            w = synth.reverse_complement_bytes(text[-pos[h]:-pos[h] + 23])
+        assert np.array_equal(w[:20], q[:20]) and w[21] == ord("G") and w[22] == ord("G")
+    return {"guides": int(batch), "hits": int(n_hits), "distance0_hits_checked_vs_text": int(idx.size)}
 
 
 def cpu_baseline(text, gidx, seqs, pams, m, sample):
