@@ -312,64 +312,87 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1);
         if (R) {
           const uint32_t excl = incl - vcnt;
-          /* scratch above the X stack: 64 seed descriptors + 64 owner markers (xs+gs <= 192
-           * here, so [xs, xs+80) cannot reach the G stack at the top of the 320-entry array) */
+          /* scratch above the X stack: 64 seed descriptors + 256 owner markers = 128 entries
+           * (xs+gs <= 192 here, so [xs, xs+128) cannot reach the G stack at the top of the
+           * 320-entry array) */
           uint4 *scr = stk + xs;
-          uint32_t *own = (uint32_t *)(stk + xs + WAVE);
+          uint4 *own4 = stk + xs + WAVE;
+          uint32_t *own = (uint32_t *)own4;
           scr[lane] = make_uint4(ent.x, excl | (kk << 12), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
           const uint32_t g = L - k; /* guide symbols left */
           const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
           const uint32_t qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
-          for (uint32_t base = 0; base < R; base += WAVE) {
-            /* owner seed of every row slot in [base, base+64): seeds mark their first slot (or
-             * slot 0 when they straddle the window start), then a max-scan spreads the marks */
-            own[lane] = 0u;
+          for (uint32_t base = 0; base < R; base += 4u * WAVE) {
+            /* 256 row slots per pass, lane l takes slots base+4l .. base+4l+3 (consecutive rows
+             * of one interval as a rule).  Owner seed of a slot: seeds mark their first slot (or
+             * slot 0 when they straddle the pass start); a running max spreads the marks. */
+            own4[lane] = make_uint4(0u, 0u, 0u, 0u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             if (vcnt) {
-              if (excl >= base && excl < base + WAVE) own[excl - base] = lane + 1u;
+              if (excl >= base && excl < base + 4u * WAVE) own[excl - base] = lane + 1u;
               if (excl < base && excl + vcnt > base) own[0] = lane + 1u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint32_t ow = own[lane];
+            const uint4 mk = own4[lane];
+            uint32_t o0 = mk.x, o1 = mk.y > o0 ? mk.y : o0, o2 = mk.z > o1 ? mk.z : o1,
+                     o3 = mk.w > o2 ? mk.w : o2;
+            uint32_t run = o3; /* inclusive max-scan over lanes, then shift to exclusive */
 #pragma unroll
             for (int o = 1; o < WAVE; o <<= 1) {
-              const uint32_t up = __shfl_up(ow, o);
-              if ((int)lane >= o && up > ow) ow = up;
+              const uint32_t up = __shfl_up(run, o);
+              if ((int)lane >= o && up > run) run = up;
             }
-            const uint32_t slot = base + lane;
-            const bool on = slot < R;
-            uint4 sdesc = make_uint4(0u, 0u, 0u, 0u);
-            if (on) sdesc = scr[ow - 1u];
-            const uint32_t row = sdesc.x + (slot - (sdesc.y & 0xFFFu));
-            uint32_t w = 0;
-            if (on) w = sd.ctx[row];
-            const uint32_t skk = (sdesc.y >> 12) & 7u;
-            const uint32_t x = (w ^ qrem) & gmask;
-            const uint32_t mmv = __popc((x | (x >> 1)) & 0x55555555u);
-            const bool gok = on && skk + mmv <= m;
-            if (!__ballot(gok)) continue;
-            const uint64_t spath = (((uint64_t)sdesc.w << 32) | sdesc.z) & PATH_MASK;
-            for (uint32_t pj = 0; pj < npams; ++pj) {
-              const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-              bool ok = gok;
-              uint64_t ppath = 0;
-              for (uint32_t u = 0; u < P; ++u) {
-                const uint32_t pc = (pw >> (3u * u)) & 7u;
-                const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-                ok = ok && (pc == 4u || pc == tb);
-                ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+            uint32_t prev = __shfl_up(run, 1);
+            if (lane == 0) prev = 0u;
+            o0 = o0 > prev ? o0 : prev;
+            o1 = o1 > prev ? o1 : prev;
+            o2 = o2 > prev ? o2 : prev;
+            o3 = o3 > prev ? o3 : prev;
+            const uint32_t ow[4] = {o0, o1, o2, o3};
+            uint32_t wv[4], rowv[4], kkv[4];
+            uint4 dsc[4];
+            bool onv[4];
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4u; ++jj) { /* four independent loads in flight */
+              const uint32_t slot = base + 4u * lane + jj;
+              onv[jj] = slot < R;
+              dsc[jj] = make_uint4(0u, 0u, 0u, 0u);
+              if (onv[jj]) dsc[jj] = scr[ow[jj] - 1u];
+              rowv[jj] = dsc[jj].x + (slot - (dsc[jj].y & 0xFFFu));
+              kkv[jj] = (dsc[jj].y >> 12) & 7u;
+              wv[jj] = 0u;
+              if (onv[jj]) wv[jj] = sd.ctx[rowv[jj]];
+            }
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4u; ++jj) {
+              const uint32_t w = wv[jj];
+              const uint32_t x = (w ^ qrem) & gmask;
+              const uint32_t mmv = __popc((x | (x >> 1)) & 0x55555555u);
+              const bool gok = onv[jj] && kkv[jj] + mmv <= m;
+              if (!__ballot(gok)) continue;
+              const uint64_t spath = (((uint64_t)dsc[jj].w << 32) | dsc[jj].z) & PATH_MASK;
+              for (uint32_t pj = 0; pj < npams; ++pj) {
+                const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+                bool ok = gok;
+                uint64_t ppath = 0;
+                for (uint32_t u = 0; u < P; ++u) {
+                  const uint32_t pc = (pw >> (3u * u)) & 7u;
+                  const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+                  ok = ok && (pc == 4u || pc == tb);
+                  ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+                }
+                if (!__ballot(ok)) continue;
+                uint64_t gpath = 0;
+                for (uint32_t v = 0; v < g; ++v) {
+                  const uint32_t qc = (qrem >> (2u * v)) & 3u;
+                  const uint32_t tb = (w >> (2u * v)) & 3u;
+                  const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+                  gpath |= (uint64_t)code << (50u - 2u * (k + v));
+                }
+                const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv) << 56) | spath | gpath | ppath;
+                route(ok, true, false, rowv[jj], rowv[jj], mmeta, 1u);
               }
-              if (!__ballot(ok)) continue;
-              uint64_t gpath = 0;
-              for (uint32_t v = 0; v < g; ++v) {
-                const uint32_t qc = (qrem >> (2u * v)) & 3u;
-                const uint32_t tb = (w >> (2u * v)) & 3u;
-                const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-                gpath |= (uint64_t)code << (50u - 2u * (k + v));
-              }
-              const uint64_t mmeta = ((uint64_t)(skk + mmv) << 56) | spath | gpath | ppath;
-              route(ok, true, false, row, row, mmeta, 1u);
             }
           }
         }
