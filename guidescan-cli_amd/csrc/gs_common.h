@@ -32,12 +32,13 @@ struct gs_strand_dev {
   uint32_t C[4]; /* first row of the A, C, G, T ranges */
   uint32_t CN;   /* first row of the N range (undefined when has_n == 0) */
   uint32_t has_n;
-  /* prefix interval table: entry {sp, end} of every k-mer, indexed by
-   * the k-mer with its FIRST text symbol in the LOWEST bits, so the 16 two-symbol left
-   * extensions of a (k-2)-mer share one aligned 128-byte line.  Entry = {sp, cnt | flag<<31}:
+  /* prefix interval table: one 16-byte entry per k-mer, indexed by the
+   * k-mer with its FIRST text symbol in the LOWEST bits, so the 16 two-symbol left extensions of
+   * a (k-2)-mer are contiguous.  Entry = {sp, cnt | flag<<31, mask_lo, mask_hi}:
    * cnt==0: k-mer absent; flag: some row of the interval has a non-ACGT symbol (or the text
-   * start) within the 16 symbols preceding its suffix, so it must take the Occ walk. */
-  const uint2 *ptab;
+   * start) within the 16 symbols preceding its suffix, so it must take the Occ walk;
+   * mask bit t (t = 3 symbols, 2 bits each, nearest first): some row is preceded by triple t. */
+  const uint4 *ptab;
   /* preceding context: ctx[r] = the 16 text symbols before suffix SA[r],
    * nearest first, 2 bits each (A,C,G,T = 0..3).  Lets a small interval at depth k be resolved
    * against the rest of the pattern with one 4-byte read per row instead of an Occ walk. */

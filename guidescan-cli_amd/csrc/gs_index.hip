@@ -394,7 +394,7 @@ __device__ __forceinline__ bool kmer_code(const uint8_t *text, uint64_t n, uint6
   return true;
 }
 __global__ void k_ptab_build(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t k,
-                             uint2 *tab) {
+                             uint4 *tab) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   uint32_t c = 0, cp = 0, cn = 0;
@@ -407,7 +407,7 @@ __global__ void k_ptab_build(const uint8_t *text, const uint32_t *sa, uint64_t n
 
 static uint32_t choose_prefix_k(uint64_t n) {
   if (const char *e = getenv("GS_PREFIX_K")) return (uint32_t)atoi(e);
-  /* deepest level at which k-mers still average ~8+ rows; capped so the table stays <= 2 GiB */
+  /* deepest level at which k-mers still average ~8+ rows; capped so the table stays <= 4 GiB */
   uint32_t k = 0;
   uint64_t v = n / 8;
   while (v >= 4) {
@@ -420,17 +420,17 @@ static uint32_t choose_prefix_k(uint64_t n) {
 }
 
 /* end -> count */
-__global__ void k_ptab_finish(uint2 *tab, uint64_t entries) {
+__global__ void k_ptab_finish(uint4 *tab, uint64_t entries) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= entries) return;
-  uint2 e = tab[i];
+  uint4 e = tab[i];
   e.y = e.y ? e.y - e.x : 0u;
   tab[i] = e;
 }
 /* ctx[r] = 16 symbols preceding suffix SA[r] (nearest first); rows whose window holds a
  * non-ACGT symbol or runs off the text start flag their k-mer's table entry */
 __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t k,
-                            uint32_t *ctx, uint2 *tab) {
+                            uint32_t *ctx, uint4 *tab) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const uint64_t p = sa[r];
@@ -446,17 +446,22 @@ __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n,
     w |= cls << (2 * (j - 1));
   }
   ctx[r] = w;
-  if (exc && tab) {
+  if (tab) {
     uint32_t c;
-    if (kmer_code(text, n, p, k, c)) atomicOr(&tab[c].y, 0x80000000u);
+    if (kmer_code(text, n, p, k, c)) {
+      if (exc) atomicOr(&tab[c].y, 0x80000000u);
+      /* which 3-symbol left contexts occur in this k-mer's interval */
+      const uint32_t t = w & 63u;
+      atomicOr(t < 32u ? &tab[c].z : &tab[c].w, 1u << (t & 31u));
+    }
   }
 }
 
 static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hipStream_t st) {
   if (!k) return GS_OK;
   const uint64_t entries = 1ull << (2 * k);
-  const size_t bytes = sizeof(uint2) * entries;
-  uint2 *tab = nullptr;
+  const size_t bytes = sizeof(uint4) * entries;
+  uint4 *tab = nullptr;
   GS_HIP(hipMalloc(&tab, bytes));
   GS_HIP(hipMemsetAsync(tab, 0, bytes, st));
   hipLaunchKernelGGL(k_ptab_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,

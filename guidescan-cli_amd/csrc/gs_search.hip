@@ -223,9 +223,19 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
     const bool seeding = a.pt_k != 0;
     bool seeds_left = seeding;
     uint32_t pidx0 = 0; /* table index of the exact k-prefix of the query */
+    uint64_t allow3[3] = {0ull, 0ull, 0ull}; /* triples within 0,1,2 substitutions of the next 3 symbols */
+    const bool use_mask3 = seeding && a.pt_k + 3u <= L; /* the next three steps are guide steps */
     if (seeding) {
       for (uint32_t t = 0; t < a.pt_k; ++t)
         pidx0 |= ((uint32_t)(gr_q >> (2u * t)) & 3u) << (2u * (a.pt_k - 1u - t));
+      const uint32_t q3 = (uint32_t)(gr_q >> (2u * a.pt_k)) & 63u;
+      for (uint32_t t3 = 0; t3 < 64u; ++t3) {
+        const uint32_t x = t3 ^ q3;
+        const uint32_t d = ((x & 3u) != 0u) + (((x >> 2) & 3u) != 0u) + (((x >> 4) & 3u) != 0u);
+        if (d <= 0u) allow3[0] |= 1ull << t3;
+        if (d <= 1u) allow3[1] |= 1ull << t3;
+        if (d <= 2u) allow3[2] |= 1ull << t3;
+      }
     } else {
       /* root: whole SA range, nothing consumed (index.hpp:388-391) */
       if (is_single(0, 0, 0)) {
@@ -281,10 +291,16 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         }
         const uint32_t mm = (s2 != q2) + (s1 != q1);
         pidx ^= ((q2 ^ s2) << 2) | (q1 ^ s1);
-        uint2 ent = make_uint2(0u, 0u);
+        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
         if (act) ent = sd.ptab[pidx];
         const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
-        const bool live = act && ecnt != 0u;
+        /* context mask: drop the seed when none of the 3-symbol left contexts present in its
+         * interval is within the remaining budget of the next three query symbols */
+        const uint32_t bl = m - (sj + mm); /* budget left (>= 0 by construction) */
+        const uint64_t amask = bl == 0u ? allow3[0] : bl == 1u ? allow3[1] : bl == 2u ? allow3[2] : ~0ull;
+        const uint64_t emask = ((uint64_t)ent.w << 32) | ent.z;
+        const bool hopeless = use_mask3 && (ent.y >> 31) == 0u && (emask & amask) == 0ull;
+        const bool live = act && ecnt != 0u && !hopeless;
         const uint32_t c2 = s2 == q2 ? 0u : 1u + s2 - (s2 > q2 ? 1u : 0u);
         const uint32_t c1 = s1 == q1 ? 0u : 1u + s1 - (s1 > q1 ? 1u : 0u);
         const uint32_t kk = sj + mm;
