@@ -141,6 +141,7 @@ def main():
     alg_bytes_per_launch = 128.0 * n_ext_ref_per_guide * batch
     search_s = (ms_search / K) / 1e3
     achieved = alg_bytes_per_launch / search_s / 1e9 if search_s > 0 else 0.0
+    traffic, traffic_src = recorded_traffic(args.workload, batch, m)
     out = {
         "metric": "guides/sec off-target enum, <=3 mismatches",
         "value": value,
@@ -160,7 +161,8 @@ def main():
                    "guides_per_step_per_gpu": batch, "mismatches": m,
                    "parallelism": f"replicated index, guide batch sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg_bytes_per_launch,
                      "avg_launch_ms": ms_search / K},
         "detail": {"n_ext_per_guide": n_ext_ref_per_guide, "n_ext_sample": ns,
@@ -180,6 +182,20 @@ def main():
     gidx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def recorded_traffic(workload, batch, m):
+    """HBM-side bytes of one k_search launch (FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be
+    read from inside this process: they come from separate `rocprofv3 --pmc` passes of this same
+    command, committed under profiles/ (calibration: DESIGN.md section 6).  None when no pass
+    was recorded for this exact workload."""
+    f = ROOT / "profiles" / "traffic.json"
+    if not f.exists():
+        return None, None
+    for rec in json.loads(f.read_text()):
+        if rec["workload"] == workload and rec["batch"] == batch and rec["mismatches"] == m:
+            return rec["fetch_bytes"] + rec["write_bytes"], rec["source"]
+    return None, None
 
 
 def verify_last_batch(torch, gidx, d_seqs, d_pams, batch, i, L, P, m, text, seqs):

@@ -15,6 +15,8 @@
  */
 #include "gs_common.h"
 
+#include <rocprim/rocprim.hpp>
+
 #define WAVE 64
 #define SEARCH_WAVES 4 /* waves per workgroup */
 #ifndef STACK_ENTRIES
@@ -40,6 +42,7 @@ struct gs_search_args {
   gs_strand_dev sd[2];
   const gs_guide_rec *guides;
   uint4 *slots;          /* [n_items][cap] match records {key_lo, key_hi, sp, ep} */
+  const uint64_t *slot_off; /* optional: item s owns slots [slot_off[s], slot_off[s+1]) instead */
   uint32_t *counts;      /* [n_items] matches found (may exceed cap -> overflow) */
   uint32_t *work;        /* work-queue head */
   unsigned long long *stats; /* [0] n_ext, [1] overflow items */
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
     const uint4 *__restrict__ blocks = sd.blocks;
     const uint32_t npams = P ? gr_npams : 1u;
     const bool fanning = P > 0 && npams > 1u; /* a finished 20-mer fans out per PAM pattern */
-    uint4 *out = a.slots + (size_t)slot * a.cap;
+    uint4 *out = a.slots + (a.slot_off ? (size_t)a.slot_off[slot] : (size_t)slot * a.cap);
+    const uint32_t item_cap = a.slot_off ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : a.cap;
     uint32_t n_match = 0;
     uint32_t xs = 0, gs = 0; /* sizes of the X and G stacks */
 
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
       if (be) {
         if (em) {
           const uint32_t idx = n_match + lanes_below(be);
-          if (idx < a.cap) {
+          if (idx < item_cap) {
             /* bit 0: the record is a single row at the table depth whose text position still
              * has to move left by v_rem symbols (k_locate) */
             const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
     if (lane == 0) a.counts[slot] = n_match;
-    if (n_match > a.cap) n_ovf++;
+    if (n_match > item_cap) n_ovf++;
   }
   if (lane == 0) {
     if (n_ext) atomicAdd(&a.stats[0], n_ext);
@@ -889,6 +893,91 @@ __global__ void k_patch_overflow(const uint32_t *list, uint32_t n_o, const uint3
   if (i < n_o) nhits[list[i]] = nhits2[i];
 }
 
+/* ---- guides with more matches than an LDS sort can hold (repeat-derived guides) ---------
+ * Their records are written at exact per-item offsets, tagged with the guide, ordered by one
+ * device-wide comparator sort, made unique, and located one wavefront per record. */
+struct gs_hrec {
+  uint4 rec;  /* {key_lo, key_hi, sp, ep} */
+  uint32_t g; /* position of the guide in the redo list */
+  uint32_t pad[3];
+};
+struct gs_hrec_less {
+  __host__ __device__ bool operator()(const gs_hrec &a, const gs_hrec &b) const {
+    if (a.g != b.g) return a.g < b.g;
+    const uint64_t ka = ((uint64_t)a.rec.y << 32) | a.rec.x, kb = ((uint64_t)b.rec.y << 32) | b.rec.x;
+    if (ka != kb) return ka < kb;
+    return a.rec.z < b.rec.z;
+  }
+};
+__global__ void k_huge_tag(const uint4 *slots, const uint64_t *slot_off, uint32_t n_items, gs_hrec *out) {
+  /* one workgroup per item */
+  const uint32_t item = blockIdx.x;
+  if (item >= n_items) return;
+  const uint64_t b = slot_off[item], e = slot_off[item + 1];
+  for (uint64_t r = b + threadIdx.x; r < e; r += blockDim.x) {
+    gs_hrec h;
+    h.rec = slots[r];
+    h.g = item >> 1;
+    h.pad[0] = h.pad[1] = h.pad[2] = 0;
+    out[r] = h;
+  }
+}
+/* flag[r] = 1 when sorted record r starts a new (guide, key, sp) */
+__global__ void k_huge_flags(const gs_hrec *srt, uint64_t T, uint32_t *flag) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= T) return;
+  bool f = true;
+  if (r > 0) {
+    const gs_hrec &p = srt[r - 1], &c = srt[r];
+    f = !(p.g == c.g && p.rec.x == c.rec.x && p.rec.y == c.rec.y && p.rec.z == c.rec.z);
+  }
+  flag[r] = f ? 1u : 0u;
+}
+/* compact unique records: uq[pos] = {key, sp, cnt}, cnt64[pos] = rows, per-guide totals */
+__global__ void k_huge_compact(const gs_hrec *srt, const uint32_t *flag, const uint32_t *pos, uint64_t T,
+                               uint4 *uq, uint32_t *uq_g, unsigned long long *cnt64, uint32_t *nmatch,
+                               unsigned long long *nhits64) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= T || !flag[r]) return;
+  const gs_hrec h = srt[r];
+  const uint32_t c = h.rec.w - h.rec.z + 1u;
+  const uint32_t p = pos[r];
+  uq[p] = make_uint4(h.rec.x, h.rec.y, h.rec.z, c);
+  uq_g[p] = h.g;
+  cnt64[p] = c;
+  atomicAdd(&nmatch[h.g], 1u);
+  atomicAdd(&nhits64[h.g], (unsigned long long)c);
+}
+/* one wavefront per unique record: write its hits at the guide's CSR offset */
+struct gs_hlocate_args {
+  gs_strand_dev sd[2];
+  const uint4 *uq;
+  const uint32_t *uq_g;
+  const unsigned long long *hit_scan; /* exclusive scan of cnt over all unique records */
+  const unsigned long long *guide_first; /* hit_scan value at each guide's first record */
+  const uint32_t *list;                  /* redo list position -> guide index */
+  const uint64_t *offsets;
+  gs_hit *hits;
+  uint64_t genome_length;
+  uint32_t n_uq, v_rem;
+};
+__global__ __launch_bounds__(WAVE) void k_huge_locate(gs_hlocate_args a) {
+  const uint32_t r = blockIdx.x;
+  if (r >= a.n_uq) return;
+  const uint4 m = a.uq[r];
+  const uint32_t g = a.uq_g[r];
+  const uint64_t key = ((uint64_t)m.y << 32) | m.x;
+  const uint32_t strand = (uint32_t)(key >> 60) & 1u;
+  gs_hit *out = a.hits + a.offsets[a.list[g]] + (a.hit_scan[r] - a.guide_first[g]);
+  for (uint32_t h = lane_id(); h < m.w; h += WAVE) {
+    const uint64_t sa = (uint64_t)a.sd[strand].sa[m.z + h] - ((key & 1ull) ? a.v_rem : 0u);
+    gs_hit o;
+    o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
+    o.key = key & ~1ull;
+    out[h] = o;
+  }
+}
+
 /* ---- host side of the pipeline ---------------------------------------------- */
 static uint32_t default_cap(uint32_t m, uint64_t n_rows) {
   /* expected matches per (guide, strand) on a repeat-free genome is ~ n_rows/4^(L) * sum C(L,k)3^k;
@@ -986,7 +1075,8 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   uint32_t *d_nlist = d_work + 2;
 
   auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
-                        uint32_t cap_, unsigned long long h_stats[2]) -> gs_status {
+                        uint32_t cap_, unsigned long long h_stats[2],
+                        const uint64_t *slot_off = nullptr) -> gs_status {
     GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 16, st)); /* n_ext, overflow items */
     GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
     gs_search_args sa;
@@ -994,6 +1084,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.sd[1] = ix->strand[1].d;
     sa.guides = guides;
     sa.slots = slots;
+    sa.slot_off = slot_off;
     sa.counts = counts;
     sa.work = d_work;
     sa.stats = d_stats;
@@ -1067,6 +1158,105 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_locate, dim3(ng), dim3(WAVE), lds, st, la);
   };
 
+  /* guides whose match count exceeds what k_order can sort in LDS */
+  std::vector<uint64_t> h_slot_off;
+  uint32_t h_n_uq = 0;
+  auto huge_redo = [&](uint32_t n_o) -> gs_status {
+    std::vector<uint32_t> c2(2 * (size_t)n_o);
+    GS_HIP(hipMemcpy(c2.data(), ix->w_counts2.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost));
+    h_slot_off.assign(2 * (size_t)n_o + 1, 0);
+    for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + c2[i];
+    const uint64_t T = h_slot_off.back();
+    if (T >= (1ull << 31)) {
+      gs_set_error("more than 2^31 match records in one batch of repeat-derived guides");
+      return GS_ERR_UNSUPPORTED;
+    }
+    gs_status rc2;
+    if ((rc2 = gs_reserve(ix->w_slots2, sizeof(uint4) * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_off, 8 * h_slot_off.size())) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_a, sizeof(gs_hrec) * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_b, sizeof(gs_hrec) * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_flag, 4 * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_pos, 4 * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_uq, sizeof(uint4) * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_uqg, 4 * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_cnt, 8 * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_scan, 8 * (T + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_nh, 8 * ((size_t)n_o + 1))) != GS_OK) return rc2;
+    if ((rc2 = gs_reserve(ix->w_h_first, 8 * ((size_t)n_o + 1))) != GS_OK) return rc2;
+    GS_HIP(hipMemcpyAsync(ix->w_h_off.p, h_slot_off.data(), 8 * h_slot_off.size(), hipMemcpyHostToDevice, st));
+    unsigned long long h2[2] = {0, 0};
+    if ((rc2 = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
+                          (uint32_t *)ix->w_counts2.p, 0, h2, (const uint64_t *)ix->w_h_off.p)) != GS_OK)
+      return rc2;
+    if (h2[1] != 0) {
+      gs_set_error("internal: exact-size redo overflowed");
+      return GS_ERR_DEVICE;
+    }
+    gs_hrec *ha = (gs_hrec *)ix->w_h_a.p, *hb = (gs_hrec *)ix->w_h_b.p;
+    hipLaunchKernelGGL(k_huge_tag, dim3(2 * n_o), dim3(256), 0, st, (const uint4 *)ix->w_slots2.p,
+                       (const uint64_t *)ix->w_h_off.p, 2 * n_o, ha);
+    size_t tb = 0;
+    GS_HIP(rocprim::merge_sort(nullptr, tb, ha, hb, (size_t)T, gs_hrec_less(), st));
+    size_t tb2 = 0, tb3 = 0;
+    GS_HIP(rocprim::exclusive_scan(nullptr, tb2, (uint32_t *)ix->w_h_flag.p, (uint32_t *)ix->w_h_pos.p, 0u,
+                                   (size_t)T, rocprim::plus<uint32_t>(), st));
+    GS_HIP(rocprim::exclusive_scan(nullptr, tb3, (unsigned long long *)ix->w_h_cnt.p,
+                                   (unsigned long long *)ix->w_h_scan.p, 0ull, (size_t)T,
+                                   rocprim::plus<unsigned long long>(), st));
+    if (tb2 > tb) tb = tb2;
+    if (tb3 > tb) tb = tb3;
+    if ((rc2 = gs_reserve(ix->w_h_tmp, tb + 16)) != GS_OK) return rc2;
+    size_t tbs = tb;
+    GS_HIP(rocprim::merge_sort(ix->w_h_tmp.p, tbs, ha, hb, (size_t)T, gs_hrec_less(), st));
+    const unsigned gT = (unsigned)((T + 255) / 256);
+    hipLaunchKernelGGL(k_huge_flags, dim3(gT), dim3(256), 0, st, (const gs_hrec *)hb, T,
+                       (uint32_t *)ix->w_h_flag.p);
+    tbs = tb;
+    GS_HIP(rocprim::exclusive_scan(ix->w_h_tmp.p, tbs, (uint32_t *)ix->w_h_flag.p, (uint32_t *)ix->w_h_pos.p,
+                                   0u, (size_t)T, rocprim::plus<uint32_t>(), st));
+    GS_HIP(hipMemsetAsync(ix->w_nmatch2.p, 0, 4 * (size_t)n_o, st));
+    GS_HIP(hipMemsetAsync(ix->w_h_nh.p, 0, 8 * (size_t)n_o, st));
+    GS_HIP(hipMemsetAsync(ix->w_h_cnt.p, 0, 8 * (T + 1), st));
+    hipLaunchKernelGGL(k_huge_compact, dim3(gT), dim3(256), 0, st, (const gs_hrec *)hb,
+                       (const uint32_t *)ix->w_h_flag.p, (const uint32_t *)ix->w_h_pos.p, T,
+                       (uint4 *)ix->w_h_uq.p, (uint32_t *)ix->w_h_uqg.p, (unsigned long long *)ix->w_h_cnt.p,
+                       (uint32_t *)ix->w_nmatch2.p, (unsigned long long *)ix->w_h_nh.p);
+    std::vector<uint32_t> nm(n_o);
+    std::vector<unsigned long long> nh(n_o);
+    GS_HIP(hipMemcpyAsync(nm.data(), ix->w_nmatch2.p, 4 * (size_t)n_o, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipMemcpyAsync(nh.data(), ix->w_h_nh.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    uint64_t nuq = 0;
+    std::vector<unsigned long long> first(n_o + 1, 0);
+    std::vector<uint32_t> nh32(n_o);
+    for (uint32_t i = 0; i < n_o; i++) {
+      if (nh[i] >= (1ull << 32)) {
+        gs_set_error("more than 2^32 hits for one guide");
+        return GS_ERR_UNSUPPORTED;
+      }
+      nh32[i] = (uint32_t)nh[i];
+      first[i + 1] = first[i] + nh[i]; /* unique records are grouped by guide in list order */
+      nuq += nm[i];
+    }
+    h_n_uq = (uint32_t)nuq;
+    tbs = tb;
+    GS_HIP(rocprim::exclusive_scan(ix->w_h_tmp.p, tbs, (unsigned long long *)ix->w_h_cnt.p,
+                                   (unsigned long long *)ix->w_h_scan.p, 0ull, (size_t)nuq + 1,
+                                   rocprim::plus<unsigned long long>(), st));
+    GS_HIP(hipMemcpyAsync(ix->w_h_first.p, first.data(), 8 * (size_t)n_o, hipMemcpyHostToDevice, st));
+    GS_HIP(hipMemcpyAsync(ix->w_nhits2.p, nh32.data(), 4 * (size_t)n_o, hipMemcpyHostToDevice, st));
+    unsigned long long tot_m = nuq;
+    (void)tot_m;
+    GS_HIP(hipStreamSynchronize(st));
+    /* matches counter: these guides were skipped by the main k_order */
+    unsigned long long cur = 0;
+    GS_HIP(hipMemcpy(&cur, d_stats + 2, 8, hipMemcpyDeviceToHost));
+    cur += nuq;
+    GS_HIP(hipMemcpy(d_stats + 2, &cur, 8, hipMemcpyHostToDevice));
+    return GS_OK;
+  };
+
   /* ---- main pass ---- */
   if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
   unsigned long long h_stats[2] = {0, 0};
@@ -1095,11 +1285,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_gather_guides, dim3((n_o + 255) / 256), dim3(256), 0, st,
                        (const gs_guide_rec *)ix->w_grec.p, (const uint32_t *)ix->w_ovf_list.p, n_o,
                        (gs_guide_rec *)ix->w_grec2.p);
+    bool huge = false;
     for (;;) {
       cap2 = cap2 >= 1024 ? cap2 * 2 : cap2 * 4;
       if (cap2 > 2048) {
-        gs_set_error("more than 2048 distinct matches for one (guide, strand): not implemented");
-        return GS_ERR_UNSUPPORTED;
+        huge = true; /* counts2 of the last pass are exact: size the slots from them */
+        break;
       }
       if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (size_t)cap2 * 2 * n_o)) != GS_OK) return rc;
       unsigned long long h2[2] = {0, 0};
@@ -1108,9 +1299,13 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
         return rc;
       if (h2[1] == 0) break;
     }
-    if ((rc = run_order((uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_counts2.p,
-                        (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2)) != GS_OK)
-      return rc;
+    if (!huge) {
+      if ((rc = run_order((uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_counts2.p,
+                          (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2)) != GS_OK)
+        return rc;
+    } else {
+      if ((rc = huge_redo(n_o)) != GS_OK) return rc;
+    }
     hipLaunchKernelGGL(k_patch_overflow, dim3((n_o + 255) / 256), dim3(256), 0, st,
                        (const uint32_t *)ix->w_ovf_list.p, n_o, (const uint32_t *)ix->w_nhits2.p,
                        (uint32_t *)ix->w_nhits.p);
@@ -1128,9 +1323,25 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   GS_HIP(hipStreamSynchronize(st));
   if ((rc = gs_reserve(ix->w_hits, sizeof(gs_hit) * (total + 1))) != GS_OK) return rc;
   run_locate((const uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_nmatch.p, nullptr, n32, cap);
-  if (n_o)
+  if (n_o && !h_n_uq)
     run_locate((const uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_nmatch2.p,
                (const uint32_t *)ix->w_ovf_list.p, n_o, cap2);
+  if (n_o && h_n_uq) {
+    gs_hlocate_args ha;
+    ha.sd[0] = ix->strand[0].d;
+    ha.sd[1] = ix->strand[1].d;
+    ha.uq = (const uint4 *)ix->w_h_uq.p;
+    ha.uq_g = (const uint32_t *)ix->w_h_uqg.p;
+    ha.hit_scan = (const unsigned long long *)ix->w_h_scan.p;
+    ha.guide_first = (const unsigned long long *)ix->w_h_first.p;
+    ha.list = (const uint32_t *)ix->w_ovf_list.p;
+    ha.offsets = (const uint64_t *)ix->w_offsets.p;
+    ha.hits = (gs_hit *)ix->w_hits.p;
+    ha.genome_length = ix->genome_length;
+    ha.n_uq = h_n_uq;
+    ha.v_rem = v_rem;
+    hipLaunchKernelGGL(k_huge_locate, dim3(h_n_uq), dim3(WAVE), 0, st, ha);
+  }
   GS_HIP(hipEventRecord(ix->ev[3], st));
   unsigned long long h_stats3[3] = {0, 0, 0};
   GS_HIP(hipMemcpyAsync(h_stats3, d_stats, sizeof(h_stats3), hipMemcpyDeviceToHost, st));

@@ -224,9 +224,8 @@ int do_enumerate(int argc, char **argv) {
   }
   if (prefix.empty() || kmers_file.empty() || output.empty()) return usage();
   if ((format != "csv" && format != "sam") || (mode != "succinct" && mode != "complete")) return usage();
-  if (rna > 0 || dna > 0 || threshold > 0) {
-    std::cerr << "error: --rna-bulges/--dna-bulges/--threshold are not implemented on the device "
-                 "path yet\n";
+  if (rna > 0 || dna > 0) {
+    std::cerr << "error: --rna-bulges/--dna-bulges are not implemented on the device path yet\n";
     return 1;
   }
   genome_structure gs;
@@ -309,6 +308,23 @@ int do_enumerate(int argc, char **argv) {
         alts += a;
         n_alt++;
       }
+    /* --threshold t (process.hpp:66-76): a guide with more than one site within t mismatches
+     * (both indexes, bulges off) is dropped before the real search */
+    std::vector<char> skip(end - done, 0);
+    if (threshold > 0) {
+      gs_result *cres = nullptr;
+      rc = gs_enumerate(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P, alts.data(),
+                        n_alt, (uint32_t)threshold, sflags, &cres);
+      if (rc != GS_OK) {
+        std::cerr << "error: " << gs_status_string(rc) << "\n";
+        return 1;
+      }
+      gs_result_view cv;
+      gs_result_get(cres, &cv);
+      for (size_t g = 0; g < end - done; g++)
+        skip[g] = cv.guide_offsets[g + 1] - cv.guide_offsets[g] > 1;
+      gs_result_free(cres);
+    }
     gs_result *res = nullptr;
     rc = gs_enumerate(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P, alts.data(),
                       n_alt, (uint32_t)mismatches, sflags, &res);
@@ -319,6 +335,7 @@ int do_enumerate(int argc, char **argv) {
     gs_result_view v;
     gs_result_get(res, &v);
     for (size_t g = done; g < end; g++) {
+      if (skip[g - done]) continue;
       const kmer_row &k = kmers[g];
       gs_kmer ck{k.id.c_str(), k.sequence.c_str(), k.pam.c_str(), k.sense == "+" ? 1 : 0};
       const uint64_t b = v.guide_offsets[g - done], e = v.guide_offsets[g - done + 1];

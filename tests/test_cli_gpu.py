@@ -21,6 +21,7 @@ RUNS = {
     "m3_csv_max2": ["-m", "3", "--max-off-targets", "2"],
     "m3_sam_max2": ["-m", "3", "--max-off-targets", "2", "--format", "sam"],
     "m2_csv_start": ["-m", "2", "--start"],
+    "m2_csv_t1": ["-m", "2", "-t", "1"],
 }
 
 

@@ -294,3 +294,38 @@ def test_full_size_properties_chr1_sized():
         oidx.close()
     finally:
         gidx.close()
+
+
+def test_repeat_guide_with_thousands_of_matches():
+    """a guide whose (guide, strand) match count exceeds the LDS sort (2048): exact-size redo,
+    device-wide comparator sort, per-record locate - still bit-exact and in CSR order"""
+    rng = np.random.default_rng(7)
+    site = np.frombuffer(b"GATTACAGATTACAGATTAC", np.uint8)
+    chunks = []
+    for i in range(7000):
+        s = site.copy()
+        for j in rng.choice(20, size=int(rng.integers(0, 4)), replace=False):
+            s[j] = rng.choice([c for c in b"ACGT" if c != s[j]])
+        pam = np.frombuffer(rng.choice([b"AGG", b"CGG", b"GGG", b"TGG"]), np.uint8)
+        filler = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(30, 60)))
+        chunks += [filler, s, pam]
+    text = np.concatenate(chunks)
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        others, _, _, _ = synth.sample_guides(text, 5, seed=4)
+        seqs = np.concatenate([others[:2], np.array([list(site)], dtype=np.uint8), others[2:]])
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
+        for faithful in (False, True):
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
+            big = 0
+            for i in range(seqs.shape[0]):
+                g = seqs[i].tobytes().decode()
+                exp, ctr = oracle_hits_as_records(oidx, g, "NGG", ol.make_opts(3), 3)
+                got = gpu_hits_as_records(offsets, hits, i, g, 3)
+                assert got == exp, (i, faithful)
+                big = max(big, len(set((e[2], e[3]) for e in exp)))
+            assert big > 2048
+    finally:
+        gidx.close()
+        oidx.close()
