@@ -20,6 +20,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "guidescan_amd.h"
@@ -195,6 +196,7 @@ int do_enumerate(int argc, char **argv) {
   long long mismatches = 3, max_off = -1, threshold = -1, rna = 0, dna = 0;
   int device = 0;
   size_t batch_size = 1u << 20;
+  unsigned fmt_threads = 0;
   bool start = false;
   for (int i = 0; i < argc; i++) {
     const std::string a = argv[i];
@@ -209,7 +211,7 @@ int do_enumerate(int argc, char **argv) {
     else if (a == "-o" || a == "--output") output = need("-o");
     else if (a == "-m" || a == "--mismatches") mismatches = atoll(need("-m"));
     else if (a == "-a" || a == "--alt-pam") alt_pams.push_back(need("-a"));
-    else if (a == "-n" || a == "--threads") need("-n"); /* accepted; the search runs on the GPU */
+    else if (a == "-n" || a == "--threads") fmt_threads = (unsigned)atoi(need("-n")); /* text formatting threads; the search runs on the GPU */
     else if (a == "-t" || a == "--threshold") threshold = atoll(need("-t"));
     else if (a == "--rna-bulges") rna = atoll(need("--rna-bulges"));
     else if (a == "--dna-bulges") dna = atoll(need("--dna-bulges"));
@@ -334,19 +336,41 @@ int do_enumerate(int argc, char **argv) {
     }
     gs_result_view v;
     gs_result_get(res, &v);
-    for (size_t g = done; g < end; g++) {
-      if (skip[g - done]) continue;
-      const kmer_row &k = kmers[g];
-      gs_kmer ck{k.id.c_str(), k.sequence.c_str(), k.pam.c_str(), k.sense == "+" ? 1 : 0};
-      const uint64_t b = v.guide_offsets[g - done], e = v.guide_offsets[g - done + 1];
-      rc = gs_format_guide(&cgs, &ck, v.hits + b, e - b, (uint32_t)mismatches, tflags | sflags, max_off,
-                           &txt, &len);
-      if (rc != GS_OK) {
-        std::cerr << "error: " << gs_status_string(rc) << "\n";
+    /* format in parallel over contiguous guide ranges, write in input order (-n 1 order) */
+    unsigned nt = fmt_threads ? fmt_threads : std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > end - done) nt = (unsigned)(end - done);
+    std::vector<std::string> parts(nt);
+    std::vector<gs_status> prc(nt, GS_OK);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t++) {
+      pool.emplace_back([&, t]() {
+        const size_t lo = done + (end - done) * t / nt, hi = done + (end - done) * (t + 1) / nt;
+        char *tx = nullptr;
+        size_t tl = 0;
+        for (size_t g = lo; g < hi; g++) {
+          if (skip[g - done]) continue;
+          const kmer_row &k = kmers[g];
+          gs_kmer ck{k.id.c_str(), k.sequence.c_str(), k.pam.c_str(), k.sense == "+" ? 1 : 0};
+          const uint64_t b = v.guide_offsets[g - done], e = v.guide_offsets[g - done + 1];
+          const gs_status r = gs_format_guide(&cgs, &ck, v.hits + b, e - b, (uint32_t)mismatches,
+                                              tflags | sflags, max_off, &tx, &tl);
+          if (r != GS_OK) {
+            prc[t] = r;
+            return;
+          }
+          parts[t].append(tx, tl);
+          gs_free(tx);
+        }
+      });
+    }
+    for (auto &th : pool) th.join();
+    for (unsigned t = 0; t < nt; t++) {
+      if (prc[t] != GS_OK) {
+        std::cerr << "error: " << gs_status_string(prc[t]) << "\n";
         return 1;
       }
-      out.write(txt, (std::streamsize)len);
-      gs_free(txt);
+      out.write(parts[t].data(), (std::streamsize)parts[t].size());
     }
     gs_result_free(res);
     done = end;
