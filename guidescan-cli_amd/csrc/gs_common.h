@@ -39,6 +39,10 @@ struct gs_strand_dev {
    * start) within the 16 symbols preceding its suffix, so it must take the Occ walk;
    * mask bit t (t = 3 symbols, 2 bits each, nearest first): some row is preceded by triple t. */
   const uint4 *ptab;
+  /* rotated copies of the table: copy p (p < k-2) has the symbol of
+   * consumption step p moved to the lowest index bits, so the three substitutions at step p
+   * of an otherwise fixed k-mer are neighbours in one 64-byte line.  k-2 tables back to back. */
+  const uint4 *ptab_rot;
   /* preceding context: ctx[r] = the 16 text symbols before suffix SA[r],
    * nearest first, 2 bits each (A,C,G,T = 0..3).  Lets a small interval at depth k be resolved
    * against the rest of the pattern with one 4-byte read per row instead of an Occ walk. */
@@ -47,7 +51,7 @@ struct gs_strand_dev {
 
 struct gs_strand {
   gs_strand_dev d{};
-  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr;
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ptab_rot = nullptr;
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;

@@ -135,6 +135,7 @@ void gs_strand_free(gs_strand *s) {
   if (s->run_cum) hipFree(s->run_cum);
   if (s->ptab) hipFree(s->ptab);
   if (s->ctx) hipFree(s->ctx);
+  if (s->ptab_rot) hipFree(s->ptab_rot);
   *s = gs_strand();
 }
 
@@ -457,6 +458,16 @@ __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n,
   }
 }
 
+/* rot[p][perm_p(i)] = tab[i]: the field of consumption step p (bits 2(k-1-p)) moves to bits 1:0 */
+__global__ void k_rot_copy(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> (2 * k)) return;
+  const uint32_t sh = 2u * (k - 1u - p);
+  const uint64_t hi = i >> (sh + 2u), lo = i & ((1ull << sh) - 1ull), f = (i >> sh) & 3ull;
+  const uint64_t j = (hi << (sh + 2u)) | (lo << 2) | f;
+  rot[((uint64_t)p << (2 * k)) + j] = tab[i];
+}
+
 static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hipStream_t st) {
   if (!k) return GS_OK;
   const uint64_t entries = 1ull << (2 * k);
@@ -474,7 +485,21 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
                        (const uint32_t *)s->sa, s->n, k, ctx, tab);
     s->bytes += 4 * s->n;
   }
+  uint4 *rot = nullptr;
+  if (ctx && k >= 4 && !getenv("GS_NO_ROT")) {
+    const uint32_t kp = k - 2;
+    if (hipMalloc(&rot, bytes * kp) == hipSuccess) {
+      for (uint32_t p = 0; p < kp; p++)
+        hipLaunchKernelGGL(k_rot_copy, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, rot, k, p);
+      s->bytes += bytes * kp;
+    } else {
+      rot = nullptr; /* not enough memory: the plain table serves every class */
+      (void)hipGetLastError();
+    }
+  }
   GS_HIP(hipStreamSynchronize(st));
+  s->ptab_rot = rot;
+  s->d.ptab_rot = rot;
   s->ptab = tab;
   s->d.ptab = tab;
   s->ctx = ctx;

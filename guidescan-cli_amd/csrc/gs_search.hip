@@ -263,20 +263,27 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         const uint32_t k = a.pt_k, kp = k - 2u;
         const uint32_t bud = m - sj;
         const uint32_t E = bud >= 2u ? 16u : bud == 1u ? 7u : 1u;
-        const uint32_t span = a.combo[8u + sj] * E;
+        /* budget-0 variants with >= 1 substitution use the rotated table of their LAST
+         * substituted step: the three substitutions there sit in neighbouring lanes and in one
+         * 64-byte line, so three variants cost one request */
+        const bool rot = sd.ptab_rot != nullptr && bud == 0u && sj >= 1u;
+        const uint32_t span = a.combo[8u + sj] * (rot ? 3u : E);
         const uint32_t l = spos + lane;
         const bool act = l < span;
-        const uint32_t ci = E == 16u ? l >> 4 : E == 7u ? l / 7u : l;
-        const uint32_t u = l - ci * E;
+        const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 7u ? l / 7u : l;
+        const uint32_t u = l - ci * (rot ? 3u : E);
         uint32_t mask = act ? a.combo[a.combo[sj] + ci] : 0u;
         uint32_t pidx = pidx0;
         uint64_t path = 0;
         uint32_t sub = ssub;
+        uint32_t plast = 0;
         for (uint32_t i = 0; i < sj; ++i) { /* sj substitutions at the set bits of mask */
-          const uint32_t d = sub % 3u;     /* scalar */
+          uint32_t d = sub % 3u; /* scalar */
           sub /= 3u;
+          if (rot && i + 1u == sj) d = u; /* the last step's digit runs over the lanes */
           const uint32_t t = mask ? (uint32_t)__builtin_ctz(mask) : 0u;
           mask &= mask - 1u;
+          plast = t;
           const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
           const uint32_t sym = (qc + 1u + d) & 3u;               /* one of the three other bases */
           const uint32_t code = 1u + sym - (sym > qc ? 1u : 0u); /* its rank among them, A<C<G<T */
@@ -286,7 +293,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         const uint32_t q2 = (uint32_t)(gr_q >> (2u * kp)) & 3u;        /* query symbol of step k-2 */
         const uint32_t q1 = (uint32_t)(gr_q >> (2u * (kp + 1u))) & 3u; /* and of step k-1 */
         uint32_t s2 = q2, s1 = q1;
-        if (E == 16u) {
+        if (rot) {
+          /* exact last two symbols; u was the substitution digit */
+        } else if (E == 16u) {
           s2 = u >> 2;
           s1 = u & 3u;
         } else if (E == 7u) {
@@ -296,7 +305,16 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         const uint32_t mm = (s2 != q2) + (s1 != q1);
         pidx ^= ((q2 ^ s2) << 2) | (q1 ^ s1);
         uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-        if (act) ent = sd.ptab[pidx];
+        if (act) {
+          if (rot) {
+            const uint32_t sh = 2u * (k - 1u - plast);
+            const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
+                                  ((pidx >> sh) & 3u);
+            ent = sd.ptab_rot[((size_t)plast << (2u * k)) + ridx];
+          } else {
+            ent = sd.ptab[pidx];
+          }
+        }
         const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
         /* context mask: drop the seed when none of the 3-symbol left contexts present in its
          * interval is within the remaining budget of the next three query symbols */
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         spos += WAVE;
         if (spos >= span) {
           spos = 0;
-          if (++ssub >= spow) {
+          if (++ssub >= (rot ? spow / 3u : spow)) {
             ssub = 0;
             do {
               ++sj;
