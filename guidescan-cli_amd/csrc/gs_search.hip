@@ -51,6 +51,7 @@ struct gs_search_args {
   /* seeding plan in device memory: [0..7] offset of the masks with j bits, [8..15] their
    * count C(pt_k-2, j), then the position masks over the first pt_k-2 steps */
   const uint32_t *combo;
+  uint32_t plan_words; /* words of the plan the kernel needs (copied to LDS per workgroup) */
   uint32_t pt_k; /* table depth k; seeds are the depth-k nodes */
   uint32_t jmax; /* min(m, pt_k-2, 7) */
   /* context verification: L+P-pt_k (<= 16) symbols remain after the table depth; 0 = disabled */
@@ -135,9 +136,12 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot) {
  * X nodes, and an X iteration costs ~1/4 of the instructions of a G one. */
 __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a) {
   __shared__ uint4 s_stack[SEARCH_WAVES][STACK_ENTRIES];
+  extern __shared__ uint32_t s_plan[]; /* seeding plan: one LDS read instead of a global one */
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t lane = lane_id();
   uint4 *stk = s_stack[wave];
+  for (uint32_t i = threadIdx.x; i < a.plan_words; i += WAVE * SEARCH_WAVES) s_plan[i] = a.combo[i];
+  __syncthreads();
   unsigned long long n_ext = 0, n_ovf = 0;
   const uint32_t L = a.L, P = a.P, m = a.m;
   const uint32_t T_end = L + P;
@@ -267,12 +271,12 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
          * substituted step: the three substitutions there sit in neighbouring lanes and in one
          * 64-byte line, so three variants cost one request */
         const bool rot = sd.ptab_rot != nullptr && bud == 0u && sj >= 1u;
-        const uint32_t span = a.combo[8u + sj] * (rot ? 3u : E);
+        const uint32_t span = s_plan[8u + sj] * (rot ? 3u : E);
         const uint32_t l = spos + lane;
         const bool act = l < span;
         const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 7u ? l / 7u : l;
         const uint32_t u = l - ci * (rot ? 3u : E);
-        uint32_t mask = act ? a.combo[a.combo[sj] + ci] : 0u;
+        uint32_t mask = act ? s_plan[s_plan[sj] + ci] : 0u;
         uint32_t pidx = pidx0;
         uint64_t path = 0;
         uint32_t sub = ssub;
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
             do {
               ++sj;
               spow *= 3u;
-            } while (sj <= a.jmax && a.combo[8u + sj] == 0u);
+            } while (sj <= a.jmax && s_plan[8u + sj] == 0u);
             if (sj > a.jmax) seeds_left = false;
           }
         }
@@ -1115,6 +1119,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.pt_k = 0;
     sa.jmax = 0;
     sa.v_rem = 0;
+    sa.plan_words = 0;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
        * substitutions x the two-symbol extensions the remaining budget allows */
@@ -1124,6 +1129,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       if (jmax > 7) jmax = 7;
       sa.jmax = jmax;
       sa.v_rem = v_rem;
+      sa.plan_words = ix->combo_off[jmax] + ix->combo_cnt[jmax];
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
      * their LDS stacks allow (8 at 20 KiB each = 32 waves per CU) */
@@ -1131,7 +1137,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
     GS_HIP(hipEventRecord(ix->ev[1], st));
-    hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 0, st, sa);
+    hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 4 * (size_t)sa.plan_words, st, sa);
     GS_HIP(hipEventRecord(ix->ev[2], st));
     GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
