@@ -73,8 +73,9 @@ def test_resolve_matches_oracle(toy_gpu):
         assert got.tolist() == exp
 
 
-CASES = [dict(m=0), dict(m=1), dict(m=2), dict(m=3), dict(m=4), dict(m=3, alt=("NAG",)),
-         dict(m=2, start=True), dict(m=3, alt=("NAG", "NGA"))]
+CASES = [dict(m=0), dict(m=1), dict(m=2), dict(m=3), dict(m=4), dict(m=5), dict(m=6),
+         dict(m=3, alt=("NAG",)), dict(m=2, start=True), dict(m=3, alt=("NAG", "NGA")),
+         dict(m=5, alt=("NAG",), start=True)]
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
