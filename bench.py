@@ -143,7 +143,7 @@ def main():
     achieved = alg_bytes_per_launch / search_s / 1e9 if search_s > 0 else 0.0
     traffic, traffic_src = recorded_traffic(args.workload, batch, m)
     out = {
-        "metric": "guides/sec off-target enum, <=3 mismatches",
+        "metric": f"guides/sec off-target enum, <={m} mismatches",
         "value": value,
         "unit": "guides/s",
         "n_gpus": world,

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Generates a set of kmers for `guidescan enumerate` (same options and output as the
+reference's scripts/generate_kmers.py, without the Biopython dependency)."""
+import argparse
+import sys
+from importlib import import_module
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+kmers = import_module("guidescan-cli_amd.kmers")
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(description=__doc__)
+    ap.add_argument("fasta")
+    ap.add_argument("--pam", default="NGG")
+    ap.add_argument("--kmer-length", type=int, default=20)
+    ap.add_argument("--min-chr-length", type=int, default=0)
+    ap.add_argument("--prefix", default="")
+    ap.add_argument("--start", action="store_true")
+    a = ap.parse_args()
+    kmers.write_kmers_csv(sys.stdout, kmers.fasta_records(a.fasta), a.pam, a.kmer_length, a.start, a.prefix,
+                          a.min_chr_length)
