@@ -59,3 +59,21 @@ def test_cli_reads_reference_index_files(toy, tmp_path):
     subprocess.run([str(CLI), "enumerate", str(tmp_path / "toy.idx"), "-f", str(toy["dir"] / "kmers.csv"),
                     "-o", str(out), "-m", "3"], check=True, timeout=300)
     assert out.read_bytes() == (toy["dir"] / "ref_m3_csv.csv").read_bytes()
+
+
+@pytest.mark.parametrize("name,args", [("m1_csv", ["-m", "1"]), ("m3_csv", ["-m", "3"]),
+                                       ("m3_sam", ["-m", "3", "--format", "sam"])])
+def test_config1_cli_byte_identical_to_reference(tmp_path, name, args):
+    """BASELINE config 1 end to end: sacCer3-sized genome (regenerated from its seed), 1,000
+    guides: the CLI's output file equals the reference binary's (tests/golden/config1)"""
+    from importlib import import_module
+    synth = import_module("guidescan-cli_amd.synth")
+    gold = ol.ROOT / "tests" / "golden" / "config1"
+    text, names, lengths = synth.make_genome(synth.SACCER3_LENGTHS, seed=1, probs=(.31, .19, .19, .31))
+    text.tofile(tmp_path / "g.dna")
+    (tmp_path / "g.gs").write_text("".join(f"{a}\n{b}\n" for a, b in zip(names, lengths)))
+    ext = "sam" if "sam" in name else "csv"
+    out = tmp_path / f"o.{ext}"
+    subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(gold / "kmers.csv"), "-o", str(out)]
+                   + args, check=True, timeout=600)
+    assert out.read_bytes() == (gold / f"ref_{name}.{ext}").read_bytes()

@@ -58,3 +58,27 @@ def test_oracle_matches_survey_reference_output(toy, oidx, name):
     ref = (toy["dir"] / f"ref_{name}.{fmt}").read_text()
     got = oracle_text(toy, oidx, **cfg)
     assert got == strip_header(ref, fmt)
+
+
+def test_oracle_config1_matches_reference_files():
+    """BASELINE config 1 (sacCer3-sized synthetic genome, 1,000 guides): the oracle's CSV and SAM
+    text equals the reference binary's files (tests/golden/config1) at -m 1 and -m 3"""
+    from importlib import import_module
+    synth = import_module("guidescan-cli_amd.synth")
+    seqio = import_module("guidescan-cli_amd.seqio")
+    gold = ol.ROOT / "tests" / "golden" / "config1"
+    text, names, lengths = synth.make_genome(synth.SACCER3_LENGTHS, seed=1, probs=(.31, .19, .19, .31))
+    kmers = seqio.read_kmers(gold / "kmers.csv")
+    oidx = ol.OracleIndex(text)
+    try:
+        for name, m, fmt in (("m1_csv", 1, "csv"), ("m3_csv", 3, "csv"), ("m3_sam", 3, "sam")):
+            opts = ol.make_opts(mismatches=m)
+            out = []
+            for k in kmers:
+                hits, ctr, raw = oidx.enumerate(k.sequence, k.pam, opts)
+                out.append(ol.text_lines(fmt, names, lengths, k.id, k.sequence, k.pam, k.positive, opts, raw))
+                ol.lib().gso_free(raw[0])
+            ref = (gold / f"ref_{name}.{fmt}").read_text()
+            assert "".join(out) == strip_header(ref, fmt), name
+    finally:
+        oidx.close()
