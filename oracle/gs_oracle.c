@@ -283,7 +283,7 @@ static void revcomp_s(const char *in, char *out) {
 typedef struct {
   char sequence[48];
   uint64_t sp, ep;
-  uint32_t mismatches;
+  uint32_t mismatches, dna_bulges, rna_bulges;
 } omatch;
 
 typedef struct {
@@ -302,6 +302,8 @@ typedef struct {
   mvec *sets;    /* one per mismatch count (process.hpp:21-23); NULL when counting */
   uint64_t count; /* off_target_counter process.hpp:27-29 */
   gso_counters *ctr;
+  int max_rna, max_dna, max_bulge_size; /* bulge budgets (index.hpp:250-375) */
+  uint32_t cur_dna, cur_rna;            /* bulge counts of the match being emitted */
 } sctx;
 
 static const char SEARCH_ALPHABET[] = "ATCG"; /* index.hpp:31 */
@@ -327,6 +329,8 @@ static void emit(sctx *s, uint64_t sp, uint64_t ep, uint32_t k, const char *seq,
   m->sp = sp;
   m->ep = ep;
   m->mismatches = k;
+  m->dna_bulges = s->cur_dna;
+  m->rna_bulges = s->cur_rna;
 }
 
 /* index.hpp:125-170  basic recursion with 'N' wildcard; used for the PAM with
@@ -399,14 +403,110 @@ static void search_pam(sctx *s, long position, uint64_t sp, uint64_t ep, char *s
   }
 }
 
+/* index.hpp:12-20 */
+typedef struct {
+  uint64_t mismatches, dna_bulges, rna_bulges;
+  int state; /* 0 none, 1 dna, 2 rna */
+  uint64_t curr_bulge_size;
+} affinity;
+
+/* index.hpp:250-375  bulge-aware recursion */
+static void search_bulge(sctx *s, long position, uint64_t sp, uint64_t ep, char *seq, int seqlen,
+                         affinity aff) {
+  affinity dna_aff = aff; /* :265-273 */
+  if ((uint64_t)s->max_dna > aff.dna_bulges) {
+    if (aff.state != 1 || dna_aff.curr_bulge_size == (uint64_t)s->max_bulge_size) {
+      dna_aff.state = 1;
+      dna_aff.curr_bulge_size = 0;
+      dna_aff.dna_bulges += 1;
+    }
+  }
+  /* :275-277: `position != query.length() - 1` compares after conversion to unsigned, so
+   * position == -1 passes: a DNA bulge may sit between protospacer and PAM */
+  if (dna_aff.state == 1 && dna_aff.curr_bulge_size < (uint64_t)s->max_bulge_size &&
+      (size_t)position != (size_t)s->qlen - 1) {
+    dna_aff.curr_bulge_size += 1;
+    for (size_t i = 0; i < 4; i++) { /* :280-294 */
+      char a = SEARCH_ALPHABET[i];
+      uint64_t occ_before = rk(s, sp, a);
+      uint64_t occ_within = rk(s, ep + 1, a) - occ_before;
+      if (occ_within > 0) {
+        uint64_t spp = gso_C(s->ix, (uint8_t)a) + occ_before;
+        uint64_t epp = spp + occ_within - 1;
+        seq[seqlen] = (char)tolower(a);
+        search_bulge(s, position, spp, epp, seq, seqlen + 1, dna_aff);
+      }
+    }
+  }
+  if (position < 0) { /* :297-314 */
+    s->cur_dna = (uint32_t)aff.dna_bulges;
+    s->cur_rna = (uint32_t)aff.rna_bulges;
+    for (int p = 0; p < s->npams; p++) {
+      const char *pam = s->pams[p];
+      search_basic(s, pam, pam + s->pam_len[p], sp, ep, seq, seqlen, 0, 0, (uint32_t)aff.mismatches);
+    }
+    s->cur_dna = s->cur_rna = 0;
+    return;
+  }
+  s->ctr->n_ext++;
+  char c = s->query[position];
+  uint64_t occ_before = rk(s, sp, c);
+  uint64_t occ_within = rk(s, ep + 1, c) - occ_before;
+  if (occ_within > 0) { /* :321-331 */
+    uint64_t spp = gso_C(s->ix, (uint8_t)c) + occ_before;
+    uint64_t epp = spp + occ_within - 1;
+    affinity aff_orig = aff;
+    aff_orig.state = 0;
+    seq[seqlen] = c;
+    search_bulge(s, position - 1, spp, epp, seq, seqlen + 1, aff_orig);
+  }
+  if ((uint64_t)s->mismatches > aff.mismatches) { /* :333-356 */
+    for (size_t i = 0; i < 4; i++) {
+      if (SEARCH_ALPHABET[i] == c) continue;
+      char a = SEARCH_ALPHABET[i];
+      occ_before = rk(s, sp, a);
+      occ_within = rk(s, ep + 1, a) - occ_before;
+      if (occ_within > 0) {
+        uint64_t spp = gso_C(s->ix, (uint8_t)a) + occ_before;
+        uint64_t epp = spp + occ_within - 1;
+        affinity am = aff;
+        am.state = 0;
+        am.mismatches += 1;
+        seq[seqlen] = (char)tolower(a);
+        search_bulge(s, position - 1, spp, epp, seq, seqlen + 1, am);
+      }
+    }
+  }
+  affinity rna_aff = aff; /* :358-366 */
+  if ((uint64_t)s->max_rna > aff.rna_bulges) {
+    if (aff.state != 2 || rna_aff.curr_bulge_size == (uint64_t)s->max_bulge_size) {
+      rna_aff.state = 2;
+      rna_aff.curr_bulge_size = 0;
+      rna_aff.rna_bulges += 1;
+    }
+  }
+  if (rna_aff.state == 2 && rna_aff.curr_bulge_size < (uint64_t)s->max_bulge_size &&
+      (size_t)position != (size_t)s->qlen - 1) { /* :368-374 */
+    rna_aff.curr_bulge_size += 1;
+    seq[seqlen] = '.';
+    search_bulge(s, position - 1, sp, ep, seq, seqlen + 1, rna_aff);
+  }
+}
+
 /* index.hpp:377-398 dispatcher (bulge budgets 0 only; the bulge-aware variant
  * :250-375 is not restated: no BASELINE config uses it) */
 static void inexact_search(const gso_index *ix, const char *query, const char *const *pams,
-                           const int *pam_len, int npams, int mismatches, mvec *sets,
-                           uint64_t *count, gso_counters *ctr) {
-  sctx s = {ix, query, (int)strlen(query), pams, pam_len, npams, mismatches, sets, 0, ctr};
+                           const int *pam_len, int npams, int mismatches, int max_rna, int max_dna,
+                           int max_bulge_size, mvec *sets, uint64_t *count, gso_counters *ctr) {
+  sctx s = {ix, query, (int)strlen(query), pams, pam_len, npams, mismatches, sets, 0, ctr,
+            max_rna, max_dna, max_bulge_size, 0, 0};
   char seq[64];
-  search_pam(&s, (long)s.qlen - 1, 0, ix->n - 1, seq, 0, 0);
+  if (max_rna == 0 && max_dna == 0) { /* :388-391 performance path */
+    search_pam(&s, (long)s.qlen - 1, 0, ix->n - 1, seq, 0, 0);
+  } else {
+    affinity aff = {0, 0, 0, 0, 0}; /* :394-397 */
+    search_bulge(&s, (long)s.qlen - 1, 0, ix->n - 1, seq, 0, aff);
+  }
   if (count) *count += s.count;
 }
 
@@ -459,16 +559,16 @@ int64_t gso_enumerate(const gso_index *fwd, const gso_index *rev, uint64_t genom
   if (o->threshold > 0) { /* :66-76 */
     uint64_t count = 0;
     gso_counters scratch = {0, 0, 0};
-    inexact_search(fwd, kmer, use_pams, pam_len, npams, o->threshold, NULL, &count, &scratch);
+    inexact_search(fwd, kmer, use_pams, pam_len, npams, o->threshold, 0, 0, 0, NULL, &count, &scratch);
     if (count > 1) return -1;
-    inexact_search(rev, kmer, use_pams, pam_len, npams, o->threshold, NULL, &count, &scratch);
+    inexact_search(rev, kmer, use_pams, pam_len, npams, o->threshold, 0, 0, 0, NULL, &count, &scratch);
     if (count > 1) return -1;
   }
 
   int m = o->mismatches;
   mvec *fs = calloc(m + 1, sizeof(mvec)), *rs = calloc(m + 1, sizeof(mvec));
-  inexact_search(fwd, kmer, use_pams, pam_len, npams, m, fs, NULL, ctr); /* :82 */
-  inexact_search(rev, kmer, use_pams, pam_len, npams, m, rs, NULL, ctr); /* :83 */
+  inexact_search(fwd, kmer, use_pams, pam_len, npams, m, o->rna_bulges, o->dna_bulges, 1, fs, NULL, ctr); /* :82 */
+  inexact_search(rev, kmer, use_pams, pam_len, npams, m, o->rna_bulges, o->dna_bulges, 1, rs, NULL, ctr); /* :83 */
 
   size_t total = 0;
   for (int d = 0; d <= m; d++) {
@@ -491,6 +591,8 @@ int64_t gso_enumerate(const gso_index *fwd, const gso_index *rev, uint64_t genom
         h[w].ep = mt->ep;
         h[w].row = j;
         strcpy(h[w].sequence, mt->sequence);
+        h[w].dna_bulges = mt->dna_bulges;
+        h[w].rna_bulges = mt->rna_bulges;
         w++;
       }
     }
@@ -505,6 +607,8 @@ int64_t gso_enumerate(const gso_index *fwd, const gso_index *rev, uint64_t genom
         h[w].ep = mt->ep;
         h[w].row = j;
         strcpy(h[w].sequence, mt->sequence);
+        h[w].dna_bulges = mt->dna_bulges;
+        h[w].rna_bulges = mt->rna_bulges;
         w++;
       }
     }
@@ -742,7 +846,10 @@ char *gso_csv_lines(const char *const *chr_names, const uint64_t *chr_len, int n
       if (o->complete) {
         sb_addc(&lines, ',');
         sb_add(&lines, ms);
-        sb_add(&lines, ",0,0"); /* rna_bulges, dna_bulges */
+        sb_addc(&lines, ',');
+        sb_addi(&lines, h->rna_bulges); /* printer.hpp:235-239 */
+        sb_addc(&lines, ',');
+        sb_addi(&lines, h->dna_bulges);
       }
       if (nlines == lcap) {
         lcap *= 2;

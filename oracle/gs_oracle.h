@@ -48,6 +48,8 @@ typedef struct {
   uint64_t sp, ep;      /* SA interval of the match */
   uint64_t row;         /* SA row this hit came from */
   char sequence[48];    /* match.sequence (NUL terminated) */
+  uint32_t dna_bulges;  /* match.dna_bulges */
+  uint32_t rna_bulges;  /* match.rna_bulges */
 } gso_hit;
 
 typedef struct {
@@ -64,6 +66,8 @@ typedef struct {
   int64_t max_off_targets; /* --max-off-targets, -1 = none */
   int complete;            /* --mode complete */
   int threshold;           /* -t */
+  int rna_bulges;          /* --rna-bulges */
+  int dna_bulges;          /* --dna-bulges */
 } gso_opts;
 
 /* One guide: process.hpp:35-115.  Returns number of hits, *out malloc'ed in

@@ -17,7 +17,7 @@ ORACLE_DIR = ROOT / "oracle"
 class GsoHit(C.Structure):
     _fields_ = [("pos", C.c_int64), ("mismatches", C.c_uint32), ("index", C.c_uint32),
                 ("sp", C.c_uint64), ("ep", C.c_uint64), ("row", C.c_uint64),
-                ("sequence", C.c_char * 48)]
+                ("sequence", C.c_char * 48), ("dna_bulges", C.c_uint32), ("rna_bulges", C.c_uint32)]
 
 
 class GsoCounters(C.Structure):
@@ -27,7 +27,8 @@ class GsoCounters(C.Structure):
 class GsoOpts(C.Structure):
     _fields_ = [("mismatches", C.c_int), ("start", C.c_int), ("n_alt_pams", C.c_int),
                 ("alt_pams", C.POINTER(C.c_char_p)), ("max_off_targets", C.c_int64),
-                ("complete", C.c_int), ("threshold", C.c_int)]
+                ("complete", C.c_int), ("threshold", C.c_int), ("rna_bulges", C.c_int),
+                ("dna_bulges", C.c_int)]
 
 
 def build_oracle():
@@ -128,10 +129,10 @@ def ref():
 
 
 def make_opts(mismatches=3, start=False, alt_pams=(), max_off_targets=-1, complete=True,
-              threshold=-1):
+              threshold=-1, rna_bulges=0, dna_bulges=0):
     arr = (C.c_char_p * max(1, len(alt_pams)))(*[p.encode() for p in alt_pams])
     o = GsoOpts(mismatches, int(start), len(alt_pams), arr, max_off_targets, int(complete),
-                threshold)
+                threshold, rna_bulges, dna_bulges)
     o._keep = arr
     return o
 
