@@ -32,6 +32,8 @@ class GsHit(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("pos", "<i8"), ("key", "<u8")])
+HIT_EX_DTYPE = np.dtype([("pos", "<i8"), ("key_hi", "<u8"), ("key_lo", "<u8"), ("mismatches", "<u4"),
+                         ("dna_bulges", "u1"), ("rna_bulges", "u1"), ("index", "u1"), ("seq_len", "u1")])
 
 
 class GsResultView(C.Structure):
@@ -111,6 +113,17 @@ def lib():
     L.gs_format_header.argtypes = [C.POINTER(GsGenomeStructure), u32, C.POINTER(vp),
                                    C.POINTER(C.c_size_t)]
     L.gs_free.argtypes = [vp]
+    L.gs_enumerate_bulges.restype = i32
+    L.gs_enumerate_bulges.argtypes = [vp, vp, u64, u32, vp, u32, C.c_char_p, u32, u32, u32, u32, u32,
+                                      C.POINTER(vp)]
+    L.gs_result_ex_get.restype = i32
+    L.gs_result_ex_get.argtypes = [vp, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]
+    L.gs_result_ex_free.argtypes = [vp]
+    L.gs_decode_sequence_ex.restype = i32
+    L.gs_decode_sequence_ex.argtypes = [u64, u64, C.c_char_p]
+    L.gs_format_guide_ex.restype = i32
+    L.gs_format_guide_ex.argtypes = [C.POINTER(GsGenomeStructure), C.POINTER(GsKmer), vp, u64, u32, u32,
+                                     C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.gs_status_string.restype = C.c_char_p
     L.gs_status_string.argtypes = [i32]
     L.gs_version.restype = C.c_char_p
@@ -122,7 +135,9 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_index_genome_length", "gs_index_device_bytes", "gs_enumerate", "gs_enumerate_device",
            "gs_result_get", "gs_result_free", "gs_decode_sequence", "gs_rank_bwt4", "gs_resolve",
            "gs_index_meta", "gs_index_copy_sa", "gs_calculate_cfd", "gs_status_string", "gs_version",
-           "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text"]
+           "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text",
+           "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
+           "gs_format_guide_ex"]
 
 
 def _check(rc):
@@ -169,6 +184,27 @@ def sdsl_extract_text(index_file) -> np.ndarray:
     t = np.frombuffer(C.string_at(out, n.value), dtype=np.uint8).copy()
     lib().gs_free(out)
     return t
+
+
+def decode_sequence_ex(key_hi: int, key_lo: int) -> str:
+    buf = C.create_string_buffer(40)
+    _check(lib().gs_decode_sequence_ex(key_hi, key_lo, buf))
+    return buf.value.decode()
+
+
+def format_guide_ex(gs, gid, sequence, pam, sense_positive, hits, mismatches, sam=False, complete=True,
+                    start=False, max_off_targets=-1) -> str:
+    """hits: numpy HIT_EX_DTYPE array of this guide (bulge path)"""
+    hits = np.ascontiguousarray(hits, dtype=HIT_EX_DTYPE)
+    k = GsKmer(gid.encode(), sequence.encode(), pam.encode(), int(sense_positive))
+    out, n = C.c_void_p(), C.c_size_t()
+    flags = ((GS_TEXT_SAM if sam else 0) | (GS_TEXT_COMPLETE if complete else 0) |
+             (GS_FLAG_PAM_AT_START if start else 0))
+    _check(lib().gs_format_guide_ex(C.byref(gs), C.byref(k), hits.ctypes.data, hits.shape[0], mismatches,
+                                    flags, max_off_targets, C.byref(out), C.byref(n)))
+    s = C.string_at(out, n.value).decode()
+    lib().gs_free(out)
+    return s
 
 
 def decode_sequence(guide: str, P: int, key: int, flags: int = 0) -> str:
@@ -280,6 +316,30 @@ class GenomeIndex:
         finally:
             lib().gs_result_free(r)
         return offsets, hits, stats
+
+    def enumerate_bulges(self, seqs, pams, mismatches=3, rna_bulges=0, dna_bulges=0, alt_pams=(),
+                         start=False):
+        """bulge-aware search (index.hpp:250-375) -> (offsets uint64[n+1], hits HIT_EX_DTYPE[])"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        n, L = seqs.shape
+        pams = np.ascontiguousarray(pams, dtype=np.uint8)
+        P = pams.shape[1] if pams.ndim == 2 else 0
+        pams = pams.reshape(n, P)
+        alt = b"".join(p.encode() for p in alt_pams)
+        r = C.c_void_p()
+        _check(lib().gs_enumerate_bulges(self._h, seqs.ctypes.data, n, L, pams.ctypes.data if P else None, P,
+                                         alt if alt_pams else None, len(alt_pams), mismatches, rna_bulges,
+                                         dna_bulges, GS_FLAG_PAM_AT_START if start else 0, C.byref(r)))
+        try:
+            ng, po, ph = C.c_uint64(), C.c_void_p(), C.c_void_p()
+            _check(lib().gs_result_ex_get(r, C.byref(ng), C.byref(po), C.byref(ph)))
+            offsets = np.frombuffer(C.string_at(po, 8 * (n + 1)), dtype=np.uint64).copy()
+            nh = int(offsets[-1])
+            hits = (np.frombuffer(C.string_at(ph, 32 * nh), dtype=HIT_EX_DTYPE).copy() if nh
+                    else np.empty(0, dtype=HIT_EX_DTYPE))
+        finally:
+            lib().gs_result_ex_free(r)
+        return offsets, hits
 
     def enumerate_device(self, d_guides_ptr, n, L, d_pams_ptr, P, mismatches=3, alt_pams=(),
                          start=False, stream=None, faithful=False):

@@ -94,41 +94,20 @@ struct decoded_hit {
   std::string sequence;       /* match.sequence */
   std::string match_sequence; /* complement(match.sequence), printer.hpp:232,264 */
   std::string pam;            /* printer.hpp:139-143 */
+  uint32_t rna_bulges = 0, dna_bulges = 0;
 };
 
 }  // namespace
 
-extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kmer *k,
-                                     const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
-                                     uint32_t flags, int64_t max_off_targets, char **out_text,
-                                     size_t *out_len) {
-  if (!gs || !k || !k->id || !k->sequence || !k->pam || (n_hits && !hits) || !out_text)
-    return GS_ERR_ARG;
+static gs_status format_decoded(const gs_genome_structure *gs, const gs_kmer *k,
+                                const std::vector<std::vector<decoded_hit>> &off, uint32_t mismatches,
+                                uint32_t flags, int64_t max_off_targets, char **out_text, size_t *out_len) {
   const bool start = flags & GS_FLAG_PAM_AT_START;
   const bool sam = flags & GS_TEXT_SAM;
   const bool complete = flags & GS_TEXT_COMPLETE;
   const std::string seq(k->sequence), pam(k->pam);
   const uint32_t L = (uint32_t)seq.size(), P = (uint32_t)pam.size();
   const std::string sequence = start ? pam + seq : seq + pam;
-
-  /* split by distance; hits arrive in canonical order (distance ascending) */
-  std::vector<std::vector<decoded_hit>> off(mismatches + 1);
-  std::vector<char> buf(L + P + 1);
-  for (uint64_t h = 0; h < n_hits; h++) {
-    const uint32_t d = GS_KEY_MISMATCHES(hits[h].key);
-    if (d > mismatches) return GS_ERR_ARG;
-    gs_status rc = gs_decode_sequence(k->sequence, L, P, flags & GS_FLAG_PAM_AT_START, hits[h].key,
-                                      buf.data());
-    if (rc != GS_OK) return rc;
-    decoded_hit dh;
-    dh.pos = hits[h].pos;
-    dh.mismatches = d;
-    dh.sequence = buf.data();
-    dh.match_sequence = complement(dh.sequence);
-    dh.pam = dh.match_sequence.size() < 20 ? std::string() : dh.match_sequence.substr(20, 3);
-    off[d].push_back(std::move(dh));
-  }
-
   std::string out;
   if (!sam) {
     /* printer.hpp:245-300 */
@@ -159,7 +138,10 @@ extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kme
         if (complete) {
           line += ',';
           line += h.match_sequence;
-          line += ",0,0"; /* rna_bulges, dna_bulges */
+          line += ',';
+          line += std::to_string(h.rna_bulges); /* printer.hpp:235-239 */
+          line += ',';
+          line += std::to_string(h.dna_bulges);
         }
         lines.push_back(std::move(line));
         cfd_sum += gs_calculate_cfd(k->sequence, h.match_sequence.c_str(), h.pam.c_str());
@@ -249,6 +231,73 @@ extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kme
   *out_text = p;
   if (out_len) *out_len = out.size();
   return GS_OK;
+}
+
+extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kmer *k,
+                                     const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
+                                     uint32_t flags, int64_t max_off_targets, char **out_text,
+                                     size_t *out_len) {
+  if (!gs || !k || !k->id || !k->sequence || !k->pam || (n_hits && !hits) || !out_text)
+    return GS_ERR_ARG;
+  const uint32_t L = (uint32_t)strlen(k->sequence), P = (uint32_t)strlen(k->pam);
+  /* split by distance; hits arrive in canonical order (distance ascending) */
+  std::vector<std::vector<decoded_hit>> off(mismatches + 1);
+  std::vector<char> buf(L + P + 1);
+  for (uint64_t h = 0; h < n_hits; h++) {
+    const uint32_t d = GS_KEY_MISMATCHES(hits[h].key);
+    if (d > mismatches) return GS_ERR_ARG;
+    gs_status rc = gs_decode_sequence(k->sequence, L, P, flags & GS_FLAG_PAM_AT_START, hits[h].key,
+                                      buf.data());
+    if (rc != GS_OK) return rc;
+    decoded_hit dh;
+    dh.pos = hits[h].pos;
+    dh.mismatches = d;
+    dh.sequence = buf.data();
+    dh.match_sequence = complement(dh.sequence);
+    dh.pam = dh.match_sequence.size() < 20 ? std::string() : dh.match_sequence.substr(20, 3);
+    off[d].push_back(std::move(dh));
+  }
+  return format_decoded(gs, k, off, mismatches, flags, max_off_targets, out_text, out_len);
+}
+
+extern "C" gs_status gs_decode_sequence_ex(uint64_t key_hi, uint64_t key_lo, char *out) {
+  if (!out) return GS_ERR_ARG;
+  static const char SYM[11] = {0, '.', 'A', 'C', 'G', 'N', 'T', 'a', 'c', 'g', 't'};
+  uint32_t n = 0;
+  for (uint32_t i = 0; i < 32; i++) {
+    const uint32_t c = (uint32_t)((i < 16 ? key_hi >> (60 - 4 * i) : key_lo >> (60 - 4 * (i - 16))) & 15u);
+    if (c == 0) break;
+    if (c > 10) return GS_ERR_ARG;
+    out[n++] = SYM[c];
+  }
+  out[n] = 0;
+  return GS_OK;
+}
+
+extern "C" gs_status gs_format_guide_ex(const gs_genome_structure *gs, const gs_kmer *k,
+                                        const gs_hit_ex *hits, uint64_t n_hits, uint32_t mismatches,
+                                        uint32_t flags, int64_t max_off_targets, char **out_text,
+                                        size_t *out_len) {
+  if (!gs || !k || !k->id || !k->sequence || !k->pam || (n_hits && !hits) || !out_text)
+    return GS_ERR_ARG;
+  std::vector<std::vector<decoded_hit>> off(mismatches + 1);
+  char buf[40];
+  for (uint64_t h = 0; h < n_hits; h++) {
+    if (hits[h].mismatches > mismatches) return GS_ERR_ARG;
+    gs_status rc = gs_decode_sequence_ex(hits[h].key_hi, hits[h].key_lo, buf);
+    if (rc != GS_OK) return rc;
+    decoded_hit dh;
+    dh.pos = hits[h].pos;
+    dh.mismatches = hits[h].mismatches;
+    dh.sequence = buf;
+    dh.match_sequence = complement(dh.sequence);
+    /* printer.hpp:139-143: substr(20, 3) whatever the bulges did to the alignment */
+    dh.pam = dh.match_sequence.size() < 20 ? std::string() : dh.match_sequence.substr(20, 3);
+    dh.rna_bulges = hits[h].rna_bulges;
+    dh.dna_bulges = hits[h].dna_bulges;
+    off[dh.mismatches].push_back(std::move(dh));
+  }
+  return format_decoded(gs, k, off, mismatches, flags, max_off_targets, out_text, out_len);
 }
 
 extern "C" gs_status gs_format_header(const gs_genome_structure *gs, uint32_t flags, char **out_text,

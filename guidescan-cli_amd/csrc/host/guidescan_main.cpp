@@ -226,10 +226,7 @@ int do_enumerate(int argc, char **argv) {
   }
   if (prefix.empty() || kmers_file.empty() || output.empty()) return usage();
   if ((format != "csv" && format != "sam") || (mode != "succinct" && mode != "complete")) return usage();
-  if (rna > 0 || dna > 0) {
-    std::cerr << "error: --rna-bulges/--dna-bulges are not implemented on the device path yet\n";
-    return 1;
-  }
+  const bool bulges = rna > 0 || dna > 0;
   genome_structure gs;
   if (!read_gs(prefix + ".gs", gs)) {
     std::cerr << "error: No genome structure file " << prefix << ".gs\n";
@@ -328,14 +325,28 @@ int do_enumerate(int argc, char **argv) {
       gs_result_free(cres);
     }
     gs_result *res = nullptr;
-    rc = gs_enumerate(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P, alts.data(),
-                      n_alt, (uint32_t)mismatches, sflags, &res);
+    gs_result_ex *resx = nullptr;
+    gs_result_view v;
+    memset(&v, 0, sizeof v);
+    const uint64_t *xoff = nullptr;
+    const gs_hit_ex *xhits = nullptr;
+    if (!bulges) {
+      rc = gs_enumerate(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P, alts.data(),
+                        n_alt, (uint32_t)mismatches, sflags, &res);
+    } else {
+      /* bulge-aware search: index.hpp:250-375 behind gs_enumerate_bulges */
+      rc = gs_enumerate_bulges(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P,
+                               alts.data(), n_alt, (uint32_t)mismatches, (uint32_t)rna, (uint32_t)dna,
+                               sflags, &resx);
+    }
     if (rc != GS_OK) {
       std::cerr << "error: " << gs_status_string(rc) << "\n";
       return 1;
     }
-    gs_result_view v;
-    gs_result_get(res, &v);
+    if (!bulges)
+      gs_result_get(res, &v);
+    else
+      gs_result_ex_get(resx, nullptr, &xoff, &xhits);
     /* format in parallel over contiguous guide ranges, write in input order (-n 1 order) */
     unsigned nt = fmt_threads ? fmt_threads : std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
@@ -352,9 +363,16 @@ int do_enumerate(int argc, char **argv) {
           if (skip[g - done]) continue;
           const kmer_row &k = kmers[g];
           gs_kmer ck{k.id.c_str(), k.sequence.c_str(), k.pam.c_str(), k.sense == "+" ? 1 : 0};
-          const uint64_t b = v.guide_offsets[g - done], e = v.guide_offsets[g - done + 1];
-          const gs_status r = gs_format_guide(&cgs, &ck, v.hits + b, e - b, (uint32_t)mismatches,
-                                              tflags | sflags, max_off, &tx, &tl);
+          gs_status r;
+          if (!bulges) {
+            const uint64_t b = v.guide_offsets[g - done], e = v.guide_offsets[g - done + 1];
+            r = gs_format_guide(&cgs, &ck, v.hits + b, e - b, (uint32_t)mismatches, tflags | sflags, max_off,
+                                &tx, &tl);
+          } else {
+            const uint64_t b = xoff[g - done], e = xoff[g - done + 1];
+            r = gs_format_guide_ex(&cgs, &ck, xhits + b, e - b, (uint32_t)mismatches, tflags | sflags,
+                                   max_off, &tx, &tl);
+          }
           if (r != GS_OK) {
             prc[t] = r;
             return;
@@ -372,7 +390,8 @@ int do_enumerate(int argc, char **argv) {
       }
       out.write(parts[t].data(), (std::streamsize)parts[t].size());
     }
-    gs_result_free(res);
+    if (res) gs_result_free(res);
+    if (resx) gs_result_ex_free(resx);
     done = end;
   }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

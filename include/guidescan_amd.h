@@ -189,6 +189,40 @@ gs_status gs_format_header(const gs_genome_structure *gs, uint32_t flags, char *
                            size_t *out_len);
 void gs_free(void *p);
 
+/* ---- bulge-aware search (include/genomics/index.hpp:250-375) ------------------------------ */
+
+/* One hit of the bulge-aware path, 32 bytes.  match.sequence can hold '.', lower-case bulge bases
+ * and has no fixed length, so it travels as 4-bit codes, position 0 in the top nibble of key_hi:
+ * 0 = end, 1 '.', 2 'A', 3 'C', 4 'G', 5 'N', 6 'T', 7 'a', 8 'c', 9 'g', 10 't'
+ * (numeric order == ASCII order == the reference's std::set<match> order). */
+typedef struct {
+  int64_t pos;
+  uint64_t key_hi, key_lo;
+  uint32_t mismatches;
+  uint8_t dna_bulges, rna_bulges;
+  uint8_t index;   /* 0 forward index, 1 reverse index */
+  uint8_t seq_len; /* symbols in key_hi:key_lo */
+} gs_hit_ex;
+
+typedef struct gs_result_ex gs_result_ex;
+
+/* gs_enumerate with --rna-bulges / --dna-bulges > 0: replaces genome_index::inexact_search's
+ * bulge-aware branch (index.hpp:394-397 -> 250-375, max_bulge_size = 1 as process.hpp:82-83 calls
+ * it) plus the same set ordering and resolve() expansion.  Hits per guide in canonical order. */
+gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
+                              const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,
+                              uint32_t mismatches, uint32_t rna_bulges, uint32_t dna_bulges,
+                              uint32_t flags, gs_result_ex **out);
+gs_status gs_result_ex_get(const gs_result_ex *r, uint64_t *n_guides, const uint64_t **guide_offsets,
+                           const gs_hit_ex **hits);
+void gs_result_ex_free(gs_result_ex *r);
+/* match.sequence of a bulge-path hit; out needs 33 bytes */
+gs_status gs_decode_sequence_ex(uint64_t key_hi, uint64_t key_lo, char *out);
+/* gs_format_guide for bulge-path hits (rna_bulges / dna_bulges columns filled in) */
+gs_status gs_format_guide_ex(const gs_genome_structure *gs, const gs_kmer *k, const gs_hit_ex *hits,
+                             uint64_t n_hits, uint32_t mismatches, uint32_t flags,
+                             int64_t max_off_targets, char **out_text, size_t *out_len);
+
 /* CFD score of one hit (include/genomics/printer.hpp:98-113), float semantics preserved. */
 float gs_calculate_cfd(const char *sgrna, const char *match_sequence, const char *pam);
 

@@ -22,6 +22,12 @@ RUNS = {
     "m3_sam_max2": ["-m", "3", "--max-off-targets", "2", "--format", "sam"],
     "m2_csv_start": ["-m", "2", "--start"],
     "m2_csv_t1": ["-m", "2", "-t", "1"],
+    "m1_csv_rna1": ["-m", "1", "--rna-bulges", "1"],
+    "m1_csv_dna1": ["-m", "1", "--dna-bulges", "1"],
+    "m2_csv_rna1_dna1": ["-m", "2", "--rna-bulges", "1", "--dna-bulges", "1"],
+    "m1_sam_rna1_dna1": ["-m", "1", "--rna-bulges", "1", "--dna-bulges", "1", "--format", "sam"],
+    "m0_csv_rna2_dna2": ["-m", "0", "--rna-bulges", "2", "--dna-bulges", "2"],
+    "m1_csv_dna1_nag_start": ["-m", "1", "--dna-bulges", "1", "-a", "NAG", "--start"],
 }
 
 
@@ -40,13 +46,20 @@ def test_cli_output_is_byte_identical(toy, indexed, name):
     out = indexed / f"{name}.{ext}"
     subprocess.run([str(CLI), "enumerate", str(indexed / "toy"), "-f", str(toy["dir"] / "kmers.csv"),
                     "-o", str(out), "-n", "1"] + RUNS[name], check=True, timeout=300)
-    assert out.read_bytes() == (toy["dir"] / f"ref_{name}.{ext}").read_bytes()
+    ref = toy["dir"] / f"ref_{name}.{ext}"
+    if ref.exists():
+        assert out.read_bytes() == ref.read_bytes()
+    else:  # large reference outputs are committed as a digest
+        import hashlib
+        digest, size = (toy["dir"] / f"ref_{name}.{ext}.sha256").read_text().split()
+        data = out.read_bytes()
+        assert len(data) == int(size) and hashlib.sha256(data).hexdigest() == digest
 
 
-def test_cli_rejects_unbuilt_modes(toy, indexed):
+def test_cli_rejects_bad_usage(toy, indexed):
     r = subprocess.run([str(CLI), "enumerate", str(indexed / "toy"), "-f", str(toy["dir"] / "kmers.csv"),
-                        "-o", str(indexed / "x.csv"), "--rna-bulges", "1"], timeout=60)
-    assert r.returncode == 1
+                        "-o", str(indexed / "x.csv"), "--format", "bam"], timeout=60)
+    assert r.returncode == 2
 
 
 def test_cli_reads_reference_index_files(toy, tmp_path):

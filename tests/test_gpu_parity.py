@@ -330,3 +330,33 @@ def test_repeat_guide_with_thousands_of_matches():
     finally:
         gidx.close()
         oidx.close()
+
+
+BULGE_CASES = [dict(m=1, rna=1, dna=0), dict(m=1, rna=0, dna=1), dict(m=2, rna=1, dna=1),
+               dict(m=0, rna=2, dna=2), dict(m=1, rna=0, dna=1, alt=("NAG",), start=True)]
+
+
+@pytest.mark.parametrize("cfg", BULGE_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_bulge_aware_search_bit_exact(toy_gpu, cfg):
+    """index.hpp:250-375 on the GPU: per guide the ordered list of
+    (pos, mismatches, index, match.sequence, dna_bulges, rna_bulges) equals the oracle's"""
+    toy, oidx, gidx = toy_gpu
+    m, rna, dna = cfg["m"], cfg["rna"], cfg["dna"]
+    alt, start = cfg.get("alt", ()), cfg.get("start", False)
+    for P, group in ((3, [k for k in toy["kmers"] if k.pam]), (0, [k for k in toy["kmers"] if not k.pam])):
+        seqs = np.array([list(k.sequence.encode()) for k in group], dtype=np.uint8)
+        pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8).reshape(len(group), P)
+        offsets, hits = gidx.enumerate_bulges(seqs, pams, mismatches=m, rna_bulges=rna, dna_bulges=dna,
+                                              alt_pams=alt if P else (), start=start)
+        opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start, rna_bulges=rna, dna_bulges=dna)
+        for i, k in enumerate(group):
+            _, ctr, raw = oidx.enumerate(k.sequence, k.pam, opts)
+            out, n = raw
+            exp = [(out[j].pos, out[j].mismatches, out[j].index, out[j].sequence.decode(),
+                    out[j].dna_bulges, out[j].rna_bulges) for j in range(n)]
+            ol.lib().gso_free(out)
+            h = hits[offsets[i]:offsets[i + 1]]
+            got = [(int(x["pos"]), int(x["mismatches"]), int(x["index"]),
+                    api.decode_sequence_ex(int(x["key_hi"]), int(x["key_lo"])), int(x["dna_bulges"]),
+                    int(x["rna_bulges"])) for x in h]
+            assert got == exp, (k.id, cfg)
