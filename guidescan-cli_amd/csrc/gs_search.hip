@@ -1395,7 +1395,9 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
  * Not tuned: no BASELINE config uses bulges; it exists so that the CLI covers the option.
  * ===================================================================================== */
 #define BSTACK 512 /* 32-byte nodes per wave */
+#ifndef BWAVES
 #define BWAVES 2
+#endif
 #define BFAN 10
 
 /* meta: t[5:0] mm[8:6] dna[11:9] rna[14:12] state[16:15] curr[17] slen[23:18] pamid[25:24] inpam[26] */
@@ -1449,8 +1451,9 @@ struct gs_bsearch_args {
   gs_brec *recs;             /* item s writes at recs[slot_off[s] ...]; nullptr = count only */
   const uint64_t *slot_off;
   uint32_t *counts;
-  uint32_t *work;
+  uint32_t *work;   /* [0] work-queue head, [1] error flag (iteration bound hit) */
   uint32_t n_items, L, P, m, max_rna, max_dna;
+  uint32_t max_iter; /* per-item iteration bound */
 };
 
 __global__ __launch_bounds__(WAVE *BWAVES) void k_search_bulge(gs_bsearch_args a) {
@@ -1472,8 +1475,10 @@ __global__ __launch_bounds__(WAVE *BWAVES) void k_search_bulge(gs_bsearch_args a
     const uint32_t guide = item - strand * n_guides;
     const uint32_t slot = 2u * guide + strand;
     const uint32_t *gp = (const uint32_t *)(a.guides + guide);
-    const uint64_t gr_q = ((uint64_t)__builtin_amdgcn_readfirstlane(gp[1]) << 32) |
-                          __builtin_amdgcn_readfirstlane(gp[0]);
+    /* readfirstlane returns int: go through uint32_t or bit 31 of the low word sign-extends */
+    const uint32_t gw0 = __builtin_amdgcn_readfirstlane(gp[0]);
+    const uint32_t gw1 = __builtin_amdgcn_readfirstlane(gp[1]);
+    const uint64_t gr_q = ((uint64_t)gw1 << 32) | gw0;
     const uint32_t gr_pam0 = __builtin_amdgcn_readfirstlane(gp[2]);
     const uint32_t gr_pam1 = __builtin_amdgcn_readfirstlane(gp[3]);
     const uint32_t gr_pam2 = __builtin_amdgcn_readfirstlane(gp[4]);
@@ -1522,7 +1527,15 @@ __global__ __launch_bounds__(WAVE *BWAVES) void k_search_bulge(gs_bsearch_args a
       }
     };
 
-    while (size > 0) {
+    /* every wave must drain: past the iteration bound the item gives up loudly (error flag)
+     * instead of spinning.  The exit and the tail below are deliberately free of
+     * lane-conditional blocks: with an `if (lane == 0)` at both ends of the item loop the
+     * compiler threaded lane 0 and lanes 1..63 through the back edge separately, so that the
+     * readfirstlane of the next item ran on a partial wave. */
+    uint32_t guard = 0;
+    bool bail = false;
+    while (size > 0 && !bail) {
+      bail = ++guard > a.max_iter;
       uint32_t w = size < WAVE ? size : WAVE;
       const uint32_t room = size < limit ? limit - size : 0u;
       const uint32_t fit = room / (BFAN - 1);
@@ -1632,7 +1645,8 @@ __global__ __launch_bounds__(WAVE *BWAVES) void k_search_bulge(gs_bsearch_args a
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
-    if (lane == 0) a.counts[slot] = n_match;
+    a.counts[slot] = n_match; /* same address, same value from every lane */
+    if (bail) atomicOr(&a.work[1], 1u);
   }
 }
 
@@ -1723,6 +1737,8 @@ extern "C" gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint6
   GS_HIP(hipSetDevice(ix->device));
   hipStream_t st = nullptr;
   const uint32_t n32 = (uint32_t)n;
+  const bool dbg = getenv("GS_DEBUG") != nullptr;
+#define BDBG(msg) do { if (dbg) { hipDeviceSynchronize(); fprintf(stderr, "[gs] bulge: %s\n", msg); fflush(stderr); } } while (0)
   gs_result_ex *res = new gs_result_ex();
   res->offsets.assign(n + 1, 0);
   if (n == 0) {
@@ -1768,6 +1784,7 @@ extern "C" gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint6
       return GS_ERR_UNSUPPORTED;
     }
   }
+  BDBG("prepared");
   gs_bsearch_args sa;
   sa.sd[0] = ix->strand[0].d;
   sa.sd[1] = ix->strand[1].d;
@@ -1782,13 +1799,31 @@ extern "C" gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint6
   sa.m = mismatches;
   sa.max_rna = rna_bulges;
   sa.max_dna = dna_bulges;
+  sa.max_iter = getenv("GS_BULGE_MAX_ITER") ? (uint32_t)atol(getenv("GS_BULGE_MAX_ITER")) : (1u << 26);
   const uint32_t grid_max = (uint32_t)g_num_cus(ix->device) * 4u;
   uint32_t grid = (2 * n32 + BWAVES - 1) / BWAVES;
   if (grid > grid_max) grid = grid_max;
   /* pass 1: count matches per (guide, strand) */
   hipLaunchKernelGGL(k_search_bulge, dim3(grid), dim3(WAVE * BWAVES), 0, st, sa);
+  BDBG("pass 1 done");
   std::vector<uint32_t> cnt(2 * n);
   GS_HIP(hipMemcpy(cnt.data(), d_cnt.p, 8 * n, hipMemcpyDeviceToHost));
+  {
+    uint32_t flag = 0;
+    GS_HIP(hipMemcpy(&flag, (uint32_t *)d_misc.p + 1, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+      gs_set_error("internal: bulge search exceeded its iteration bound");
+      return GS_ERR_DEVICE;
+    }
+    if (getenv("GS_DEBUG")) {
+      uint64_t tot = 0;
+      for (auto c : cnt) tot += c;
+      fprintf(stderr, "[gs] bulge pass 1: %llu match records for %llu guides; counts:", (unsigned long long)tot,
+              (unsigned long long)n);
+      for (size_t i = 0; i < cnt.size() && i < 16; i++) fprintf(stderr, " %u", cnt[i]);
+      fprintf(stderr, "\n");
+    }
+  }
   std::vector<uint64_t> soff(2 * n + 1, 0);
   for (size_t i = 0; i < 2 * n; i++) soff[i + 1] = soff[i] + cnt[i];
   const uint64_t T = soff.back();
@@ -1805,10 +1840,11 @@ extern "C" gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint6
   GS_TRY(d_b.get(sizeof(gs_brec) * T));
   GS_HIP(hipMemcpy(d_off.p, soff.data(), 8 * soff.size(), hipMemcpyHostToDevice));
   /* pass 2: fill at exact offsets */
-  GS_HIP(hipMemset(d_misc.p, 0, 4));
+  GS_HIP(hipMemset(d_misc.p, 0, 8));
   sa.recs = (gs_brec *)d_a.p;
   sa.slot_off = (const uint64_t *)d_off.p;
   hipLaunchKernelGGL(k_search_bulge, dim3(grid), dim3(WAVE * BWAVES), 0, st, sa);
+  BDBG("pass 2 done");
   /* canonical order: (guide, distance, index, sequence, row) */
   size_t tb = 0, tb2 = 0, tb3 = 0;
   GS_TRY(d_flag.get(4 * T));
@@ -1825,6 +1861,7 @@ extern "C" gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint6
   GS_TRY(d_tmp.get(tb + 16));
   size_t tbs = tb;
   GS_HIP(rocprim::merge_sort(d_tmp.p, tbs, (gs_brec *)d_a.p, (gs_brec *)d_b.p, (size_t)T, gs_brec_less(), st));
+  BDBG("sorted");
   const unsigned gT = (unsigned)((T + 255) / 256);
   hipLaunchKernelGGL(k_bulge_flags, dim3(gT), dim3(256), 0, st, (const gs_brec *)d_b.p, T, (uint32_t *)d_flag.p);
   tbs = tb;
@@ -1839,6 +1876,7 @@ extern "C" gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint6
   hipLaunchKernelGGL(k_bulge_compact, dim3(gT), dim3(256), 0, st, (const gs_brec *)d_b.p,
                      (const uint32_t *)d_flag.p, (const uint32_t *)d_pos.p, T, (gs_brec *)d_uq.p,
                      (unsigned long long *)d_c64.p, (uint32_t *)d_nm.p, (unsigned long long *)d_nh.p);
+  BDBG("compacted");
   std::vector<uint32_t> nm(n);
   std::vector<unsigned long long> nh(n);
   GS_HIP(hipMemcpy(nm.data(), d_nm.p, 4 * n, hipMemcpyDeviceToHost));
@@ -1875,6 +1913,7 @@ extern "C" gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint6
   la.genome_length = ix->genome_length;
   la.n_uq = (uint32_t)nuq;
   if (nuq) hipLaunchKernelGGL(k_bulge_locate, dim3((unsigned)nuq), dim3(WAVE), 0, st, la);
+  BDBG("located");
   res->hits.resize(H);
   if (H) GS_HIP(hipMemcpy(res->hits.data(), d_hits.p, sizeof(gs_hit_ex) * H, hipMemcpyDeviceToHost));
   GS_HIP(hipDeviceSynchronize());
