@@ -5,16 +5,16 @@
  * include, link or call this.  Only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, and only as the checker / baseline.
  *
- * Parity status (see oracle/README.md and DESIGN.md section 3):
+ * Parity status: PINNED against the reference itself, compiled in
+ * place from /root/reference by oracle/Makefile into oracle/_ref/ (g++ only):
  *   - rank_bwt / LF / C / char2comp / resolve_absolute / (reverse_)complement /
- *     CFD tables: PINNED against the reference's own sources compiled in place
- *     (oracle/_ref, built by oracle/Makefile from /root/reference).
- *   - inexact_search recursion, per-guide pipeline, printers, calculate_cfd:
- *     restated from include/genomics/{index,process,printer}.hpp.  Those headers
- *     cannot be compiled here without cmake-generated divsufsort.h, so for them
- *     parity is pinned only by (a) a brute-force Hamming scan of the text and
- *     (b) the known-answer facts SURVEY.md App. D records -> "parity unpinned"
- *     by a compiled reference for these rows.
+ *     CFD tables: against libgs_ref.so (wt_huff, byte_alphabet, structures.cxx,
+ *     sequences.cxx, doench.hpp), tests/test_oracle_vs_ref.py;
+ *   - inexact_search recursion (plain, N-wildcard PAM, bulge-aware), the per-guide
+ *     pipeline (PAM list, set order/dedupe, threshold, expansion, coordinates) and
+ *     the CSV/SAM printers incl. calculate_cfd: against gs_ref_enumerate (the
+ *     reference's index.hpp / process.hpp / printer.hpp + csa_wt, whole output
+ *     files compared), tests/test_oracle_vs_ref_pipeline.py.
  */
 #ifndef GS_ORACLE_H
 #define GS_ORACLE_H

@@ -11,9 +11,11 @@
  *   genomics::resolve_absolute    -- src/genomics/structures.cxx
  *   genomics::(reverse_)complement-- src/genomics/sequences.cxx
  *   genomics::mm_scores/pam_scores-- include/genomics/doench.hpp
- * What cannot: csa_wt.hpp, suffix_arrays.hpp (and therefore genomics/index.hpp,
- * process.hpp, printer.hpp) include construct_sa.hpp -> divsufsort.h, which only
- * exists after a cmake configure step.  Those are restated in gs_oracle.c.
+ * This library stays free of any build trick: it includes only headers that do
+ * not reach construct_sa.hpp -> divsufsort.h (cmake-generated).  The CSA itself,
+ * genomics/index.hpp, process.hpp and printer.hpp are compiled by the second
+ * target, ref_enumerate.cpp (include guards of the construction headers
+ * pre-defined; see there).
  *
  * The glue that csa_wt adds on top of these parts (operator[] = LF walk to the
  * next 1-in-64 SA sample, csa_wt.hpp:333-346; serialize order csa_wt.hpp:372-382)

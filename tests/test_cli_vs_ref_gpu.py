@@ -1,0 +1,76 @@
+"""Product vs the reference itself, on the GPU box: the C++ host (`guidescan enumerate`, HIP path
+through the C-ABI) must write the same file as oracle/_ref/gs_ref_enumerate — the reference's own
+index.hpp / process.hpp / printer.hpp compiled in place by oracle/Makefile — on fresh seeded
+genomes with planted repeat families, N runs and indel copies, over the option sets of
+test_oracle_vs_ref_pipeline.py (mismatches 0..4, CSV/SAM, succinct, alt PAMs, --start,
+--max-off-targets, --threshold, RNA/DNA bulges).  The prebuilt oracle/_ref binaries travel with the
+snapshot; nothing reads /root/reference here.  GPU only."""
+import subprocess
+
+import pytest
+
+import oracle_lib as ol
+import test_oracle_vs_ref_pipeline as pipe
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(pipe.ref is None or not pipe.SHIM.exists(), reason="oracle/_ref not built")]
+CLI = ol.ROOT / "guidescan-cli_amd" / "bin" / "guidescan"
+
+
+def cli_args(m=3, fmt="csv", complete=True, alt=(), maxo=-1, thr=-1, start=False, rna=0, dna=0):
+    a = ["-m", str(m), "--format", fmt, "--mode", "complete" if complete else "succinct"]
+    for p in alt:
+        a += ["-a", p]
+    if maxo >= 0:
+        a += ["--max-off-targets", str(maxo)]
+    if thr >= 0:
+        a += ["-t", str(thr)]
+    if start:
+        a.append("--start")
+    if rna:
+        a += ["--rna-bulges", str(rna)]
+    if dna:
+        a += ["--dna-bulges", str(dna)]
+    return a
+
+
+@pytest.mark.parametrize("seed", [201, 202, 203, 204])
+def test_cli_equals_compiled_reference_on_random_genomes(seed, tmp_path):
+    text, names, lengths, rows = pipe.random_case(seed)
+    kcsv = tmp_path / "kmers.csv"
+    pipe.synth.write_kmers_csv(kcsv, [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows],
+                               [names[0]] * len(rows), [1] * len(rows), [r[3] for r in rows])
+    # reference side: SDSL index files written through the compiled reference containers
+    oidx = ol.OracleIndex(text)
+    try:
+        pipe.write_reference_index(oidx, text.shape[0] + 1, tmp_path / "r.idx", names, lengths)
+    finally:
+        oidx.close()
+    # product side: genome text + structure, index built on the GPU by `enumerate` itself
+    text.tofile(tmp_path / "g.dna")
+    (tmp_path / "g.gs").write_text("".join(f"{a}\n{b}\n" for a, b in zip(names, lengths)))
+    for cfg in pipe.OPTION_SETS:
+        want = pipe.run_shim(tmp_path / "r.idx", kcsv, tmp_path / "want", **cfg)
+        out = tmp_path / "got"
+        subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(kcsv), "-o", str(out), "-n", "1"]
+                       + cli_args(**cfg), check=True, timeout=120)
+        assert out.read_bytes() == want, (seed, cfg)
+
+
+def test_cli_reading_reference_index_equals_compiled_reference(tmp_path):
+    """same, with the product importing the reference's own index files (gs_index_open_sdsl)"""
+    text, names, lengths, rows = pipe.random_case(301)
+    kcsv = tmp_path / "kmers.csv"
+    pipe.synth.write_kmers_csv(kcsv, [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows],
+                               [names[0]] * len(rows), [1] * len(rows), [r[3] for r in rows])
+    oidx = ol.OracleIndex(text)
+    try:
+        pipe.write_reference_index(oidx, text.shape[0] + 1, tmp_path / "r.idx", names, lengths)
+    finally:
+        oidx.close()
+    for cfg in (dict(m=3), dict(m=2, fmt="sam", alt=("NAG",)), dict(m=1, rna=1, dna=1)):
+        want = pipe.run_shim(tmp_path / "r.idx", kcsv, tmp_path / "want", **cfg)
+        out = tmp_path / "got"
+        subprocess.run([str(CLI), "enumerate", str(tmp_path / "r.idx"), "-f", str(kcsv), "-o", str(out), "-n", "1"]
+                       + cli_args(**cfg), check=True, timeout=120)
+        assert out.read_bytes() == want, cfg

@@ -1,7 +1,8 @@
-"""Oracle vs the survey-build reference outputs on the toy genome (CPU only).
+"""Oracle vs the reference's output files on the toy genome (CPU only).
 
-tests/golden/toy/ref_*.{csv,sam} were written by the guidescan binary the survey
-phase built (tools/make_survey_goldens.py explains their status).  Byte-for-byte
+tests/golden/toy/ref_*.{csv,sam} are written by the reference's enumerate pipeline
+(oracle/_ref/gs_ref_enumerate; tools/make_survey_goldens.py, and
+test_oracle_vs_ref_pipeline.py re-derives them when oracle/_ref is built).  Byte-for-byte
 equality of CSV and SAM text (-n 1 order) exercises every restated rule at once:
 search, set order/dedupe, locate, coordinates, boundary sentinel, CFD, of:H."""
 import pytest

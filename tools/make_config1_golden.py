@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """BASELINE config 1 end to end: sacCer3-sized synthetic genome (seeded), 1,000 NGG guides.
-Writes tests/golden/config1/kmers.csv and, when the survey-build reference binary is present
-(see tools/make_survey_goldens.py for its status), the reference's own output files for
--m 1 (csv) and -m 3 (csv, sam).  The genome itself is regenerated from the seed by the test."""
+Writes tests/golden/config1/kmers.csv and the reference's own output files for -m 1 (csv) and
+-m 3 (csv, sam), produced by oracle/_ref/gs_ref_enumerate (the reference's enumerate pipeline
+compiled in place by oracle/Makefile; tools/make_survey_goldens.py has the history).  The genome
+itself is regenerated from the seed by the tests."""
 import os
 import shutil
 import subprocess
@@ -15,7 +16,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 synth = import_module("guidescan-cli_amd.synth")
 OUT = ROOT / "tests" / "golden" / "config1"
-REFBIN = Path(os.environ.get("GS_SURVEY_REF_BIN", "/tmp/gs_ref/build/bin/guidescan"))
+SHIM = ROOT / "oracle" / "_ref" / "gs_ref_enumerate"
 
 
 def inputs():
@@ -31,22 +32,22 @@ def main():
         f.write("id,sequence,pam,chromosome,position,sense\n")
         for i in range(seqs.shape[0]):
             f.write(f"g{i},{seqs[i].tobytes().decode()},NGG,chr1,{int(pos[i]) + 1},{chr(strands[i])}\n")
-    if not REFBIN.exists():
-        print("reference binary absent: inputs only")
+    if not SHIM.exists():
+        print("oracle/_ref/gs_ref_enumerate absent (run `make -C oracle`): inputs only")
         return
+    sys.path.insert(0, str(ROOT / "tests"))
+    import oracle_lib as ol
+    import test_oracle_vs_ref_pipeline as pipe
     with tempfile.TemporaryDirectory(dir=str(ROOT / "tests")) as td:
         td = Path(td)
-        synth.write_fasta(td / "g.fa", text, names, lengths)
-        subprocess.run([str(REFBIN), "index", "--index", str(td / "g"), str(td / "g.fa")], check=True,
-                       timeout=1800, stdout=subprocess.DEVNULL)
-        for name, args in (("m1_csv", ["-m", "1"]), ("m3_csv", ["-m", "3"]),
-                           ("m3_sam", ["-m", "3", "--format", "sam"])):
-            ext = "sam" if "sam" in name else "csv"
-            subprocess.run([str(REFBIN), "enumerate", str(td / "g"), "-f", str(OUT / "kmers.csv"), "-o",
-                            str(td / f"o.{ext}"), "-n", "1"] + args, check=True, timeout=1800,
-                           stdout=subprocess.DEVNULL)
-            shutil.copy(td / f"o.{ext}", OUT / f"ref_{name}.{ext}")
-            print("wrote", name, (OUT / f"ref_{name}.{ext}").stat().st_size)
+        oidx = ol.OracleIndex(text)
+        pipe.write_reference_index(oidx, text.shape[0] + 1, td / "g", names, lengths)
+        oidx.close()
+        for name, cfg in (("m1_csv", dict(m=1)), ("m3_csv", dict(m=3)), ("m3_sam", dict(m=3, fmt="sam"))):
+            ext = cfg.get("fmt", "csv")
+            data = pipe.run_shim(td / "g", OUT / "kmers.csv", td / f"o.{ext}", **cfg)
+            (OUT / f"ref_{name}.{ext}").write_bytes(data)
+            print("wrote", name, len(data))
 
 
 if __name__ == "__main__":

@@ -1,16 +1,18 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/toy/* inputs and (when available) reference outputs.
+"""Generate tests/golden/toy/* inputs and reference outputs.
 
 Inputs (FASTA, kmers CSV, .gs) are produced from a fixed seed by this script.
 
-Expected outputs come from the guidescan binary that the SURVEY phase built in
-this container (cmake build of /root/reference with the
-`download` TU stubbed; found at /tmp/gs_ref/build/bin/guidescan).  That build
-CANNOT be reproduced by this repo's own recipe (oracle/Makefile may not run cmake
-or provide generated headers), so these files are labelled
-"survey-build reference outputs": supplementary evidence for the restated parts
-of the oracle, not an oracle/_ref artefact.  If the binary is absent the script
-only regenerates the inputs and leaves committed outputs untouched.
+Expected outputs are written by the reference itself, built by THIS repository's recipe:
+oracle/_ref/gs_ref_enumerate (oracle/Makefile: the reference's index.hpp / process.hpp /
+printer.hpp / src/genomics/*.cxx and SDSL's csa_wt compiled in place with g++).  The index files
+it loads (toy.idx.forward/.reverse) are written from the oracle's suffix array through the compiled
+reference containers (ref_write_index_file).
+
+History: the files were first produced by the guidescan binary the SURVEY phase built with cmake
+(/tmp/gs_ref/build/bin/guidescan, incl. its own `index` command); the bytes did
+not change when regenerated this way, and tests/test_oracle_vs_ref_pipeline.py re-derives every
+one of them on each run.  GS_SURVEY_REF_BIN=<guidescan binary> still selects that binary.
 """
 import os
 import subprocess
@@ -24,7 +26,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 synth = import_module("guidescan-cli_amd.synth")
 OUT = ROOT / "tests" / "golden" / "toy"
-REFBIN = Path(os.environ.get("GS_SURVEY_REF_BIN", "/tmp/gs_ref/build/bin/guidescan"))
+REFBIN = Path(os.environ["GS_SURVEY_REF_BIN"]) if "GS_SURVEY_REF_BIN" in os.environ else None
+SHIM = ROOT / "oracle" / "_ref" / "gs_ref_enumerate"
 
 RUNS = {
     # name: extra enumerate args
@@ -126,28 +129,66 @@ def build_inputs():
     return text
 
 
-def run_reference():
-    if not REFBIN.exists():
-        print(f"{REFBIN} absent: inputs regenerated only")
-        return
+def shim_args(args):
+    """enumerate flags -> positional arguments of oracle/ref_enumerate.cpp"""
+    o = dict(m="0", rna="0", dna="0", thr="-1", maxo="-1", start="0", fmt="csv", mode="complete", alt=[])
+    it = iter(args)
+    for a in it:
+        if a == "-m":
+            o["m"] = next(it)
+        elif a == "--rna-bulges":
+            o["rna"] = next(it)
+        elif a == "--dna-bulges":
+            o["dna"] = next(it)
+        elif a == "-t":
+            o["thr"] = next(it)
+        elif a == "--max-off-targets":
+            o["maxo"] = next(it)
+        elif a == "--start":
+            o["start"] = "1"
+        elif a == "--format":
+            o["fmt"] = next(it)
+        elif a == "--mode":
+            o["mode"] = next(it)
+        elif a == "-a":
+            o["alt"].append(next(it))
+    return [o["fmt"], o["mode"], o["m"], o["rna"], o["dna"], o["thr"], o["maxo"], o["start"]] + o["alt"]
+
+
+def run_reference(text):
     import shutil
     import tempfile
+    if REFBIN is None and not SHIM.exists():
+        print("oracle/_ref/gs_ref_enumerate absent (run `make -C oracle`): inputs regenerated only")
+        return
     with tempfile.TemporaryDirectory(dir=str(ROOT / "tests")) as td:
         td = Path(td)
         shutil.copy(OUT / "toy.fa", td / "toy.fa")
         shutil.copy(OUT / "kmers.csv", td / "kmers.csv")
-        subprocess.run([str(REFBIN), "index", "--index", str(td / "toy.idx"), str(td / "toy.fa")],
-                       check=True, timeout=600, stdout=subprocess.DEVNULL)
-        gs = (td / "toy.idx.gs").read_text()
-        assert gs == (OUT / "toy.gs").read_text(), "genome structure mismatch"
+        if REFBIN is not None:
+            subprocess.run([str(REFBIN), "index", "--index", str(td / "toy.idx"), str(td / "toy.fa")],
+                           check=True, timeout=600, stdout=subprocess.DEVNULL)
+            assert (td / "toy.idx.gs").read_text() == (OUT / "toy.gs").read_text(), "genome structure mismatch"
+        else:
+            sys.path.insert(0, str(ROOT / "tests"))
+            import oracle_lib as ol
+            import test_oracle_vs_ref_pipeline as pipe
+            seqio = import_module("guidescan-cli_amd.seqio")
+            ftext, names, lengths = seqio.parse_fasta(OUT / "toy.fa")
+            oidx = ol.OracleIndex(ftext)
+            pipe.write_reference_index(oidx, ftext.shape[0] + 1, td / "toy.idx", names, lengths)
+            oidx.close()
         for f in ("toy.idx.forward", "toy.idx.reverse"):
             shutil.copy(td / f, OUT / f)
         for name, args in RUNS.items():
             ext = "sam" if "sam" in name else "csv"
             outp = td / f"{name}.{ext}"
-            subprocess.run([str(REFBIN), "enumerate", str(td / "toy.idx"), "-f", str(td / "kmers.csv"),
-                            "-o", str(outp), "-n", "1"] + args, check=True, timeout=600,
-                           stdout=subprocess.DEVNULL)
+            if REFBIN is not None:
+                cmd = [str(REFBIN), "enumerate", str(td / "toy.idx"), "-f", str(td / "kmers.csv"),
+                       "-o", str(outp), "-n", "1"] + args
+            else:
+                cmd = [str(SHIM), str(td / "toy.idx"), str(td / "kmers.csv"), str(outp)] + shim_args(args)
+            subprocess.run(cmd, check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             dst = OUT / f"ref_{name}.{ext}"
             sha = OUT / f"ref_{name}.{ext}.sha256"
             for old in (dst, sha):
@@ -163,5 +204,4 @@ def run_reference():
 
 
 if __name__ == "__main__":
-    build_inputs()
-    run_reference()
+    run_reference(build_inputs())
