@@ -87,6 +87,12 @@ void *ref_index_build(const uint8_t *bwt, const uint32_t *sa, uint64_t n, const 
   }
   return r;
 }
+/* same, from the text (n-1 bytes, the sentinel is implied): BWT[i] = T[SA[i]-1] */
+void *ref_index_build_text(const uint8_t *text, const uint32_t *sa, uint64_t n, const char *tmp) {
+  std::vector<uint8_t> bwt(n);
+  for (uint64_t i = 0; i < n; i++) bwt[i] = sa[i] ? text[sa[i] - 1] : 0;
+  return ref_index_build(bwt.data(), sa, n, tmp);
+}
 void ref_index_free(void *p) { delete (ref_index *)p; }
 
 uint64_t ref_rank_bwt(void *p, uint64_t i, uint8_t c) { return ((ref_index *)p)->wt.rank(i, c); }

@@ -12,7 +12,7 @@
  * sdsl::csa_wt<wt_huff<>,64,8192> + sdsl::load_from_file.  This file only does
  * what do_enumerate_cmd (src/guidescan.cxx:181-258) does around them -- fill
  * enumerate_cmd_options from argv, load the three index files, write the
- * header, run ONE thread -- because src/guidescan.cxx itself also holds the
+ * header, start the worker thread(s) -- because src/guidescan.cxx itself also holds the
  * `index` and `download` commands, which need sdsl::construct (divsufsort.h,
  * cmake-generated) and libcurl headers.
  *
@@ -33,6 +33,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sdsl/suffix_arrays.hpp>
@@ -87,17 +88,26 @@ int main(int argc, char **argv) {
   else
     genomics::write_csv_header(output, complete);
 
+  /* kmers dealt round-robin to the threads (src/guidescan.cxx:226-231); one thread unless
+   * GS_REF_THREADS says otherwise (bench.py's cpu_baseline leg; row order then varies) */
+  if (const char *e = std::getenv("GS_REF_THREADS")) opts.nthreads = std::max(1, std::atoi(e));
   genomics::kmers_file_producer kmer_p(opts.kmers_file);
-  std::vector<genomics::kmer> kmers;
+  std::vector<std::vector<genomics::kmer>> kmers(opts.nthreads);
   genomics::kmer k;
-  while (kmer_p.get_next_kmer(k)) kmers.push_back(k);
+  size_t kmer_count = 0;
+  for (; kmer_p.get_next_kmer(k); kmer_count++) kmers[kmer_count % opts.nthreads].push_back(k);
 
   std::mutex output_mtx;
   std::atomic<uint64_t> done(0);
   const auto t0 = std::chrono::steady_clock::now();
-  genomics::process_kmers_to_stream<t_wt, t_sa_dens, t_isa_dens>(gi_forward, gi_reverse, opts, kmers, output,
-                                                                 output_mtx, done, kmers.size(), t0, complete);
+  std::vector<std::thread> threads;
+  for (size_t i = 0; i < opts.nthreads; i++)
+    threads.emplace_back(genomics::process_kmers_to_stream<t_wt, t_sa_dens, t_isa_dens>, std::cref(gi_forward),
+                         std::cref(gi_reverse), std::cref(opts), std::cref(kmers[i]), std::ref(output),
+                         std::ref(output_mtx), std::ref(done), kmer_count, t0, complete);
+  for (auto &t : threads) t.join();
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  std::cerr << "gs_ref_enumerate: " << kmers.size() << " kmers in " << secs << " s\n";
+  std::cerr << "gs_ref_enumerate: " << kmer_count << " kmers in " << secs << " s on " << opts.nthreads
+            << " thread(s)\n";
   return 0;
 }

@@ -100,6 +100,8 @@ def ref():
         R = C.CDLL(str(so))
         R.ref_index_build.restype = C.c_void_p
         R.ref_index_build.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p]
+        R.ref_index_build_text.restype = C.c_void_p
+        R.ref_index_build_text.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_char_p]
         R.ref_index_free.argtypes = [C.c_void_p]
         R.ref_rank_bwt.restype = C.c_uint64
         R.ref_rank_bwt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint8]
