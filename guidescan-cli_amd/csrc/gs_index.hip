@@ -480,18 +480,21 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   hipLaunchKernelGGL(k_ptab_finish, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, entries);
   uint32_t *ctx = nullptr;
   if (!getenv("GS_NO_CTX")) {
-    GS_HIP(hipMalloc(&ctx, 4 * s->n));
+    GS_HIP(hipMalloc(&ctx, 4 * s->n + 16)); /* one row group of padding (k_search reads groups of four) */
     hipLaunchKernelGGL(k_ctx_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
                        (const uint32_t *)s->sa, s->n, k, ctx, tab);
     s->bytes += 4 * s->n;
   }
   uint4 *rot = nullptr;
   if (ctx && k >= 4 && !getenv("GS_NO_ROT")) {
-    const uint32_t kp = k - 2;
-    if (hipMalloc(&rot, bytes * kp) == hipSuccess) {
-      for (uint32_t p = 0; p < kp; p++)
+    /* one copy per step 0..k-2: steps 0..k-3 serve the budget-0 variants (their last
+     * substituted step), step k-2 the budget-1 variants (substitutions of the second-last
+     * symbol next to each other) */
+    const uint32_t nrot = k - 1;
+    if (hipMalloc(&rot, bytes * nrot) == hipSuccess) {
+      for (uint32_t p = 0; p < nrot; p++)
         hipLaunchKernelGGL(k_rot_copy, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, rot, k, p);
-      s->bytes += bytes * kp;
+      s->bytes += bytes * nrot;
     } else {
       rot = nullptr; /* not enough memory: the plain table serves every class */
       (void)hipGetLastError();

@@ -56,9 +56,11 @@ struct gs_search_args {
   uint32_t jmax; /* min(m, pt_k-2, 7) */
   /* context verification: L+P-pt_k (<= 16) symbols remain after the table depth; 0 = disabled */
   uint32_t v_rem;
+  uint32_t v_max; /* intervals up to this many rows are resolved row by row from ctx[] (<= 1023) */
+  uint32_t dbg_skip; /* timing experiments only (GS_DBG_SKIP): 1 = no verification, 2 = no seeds kept */
 };
 
-#define VERIFY_MAX 32u /* intervals up to this many rows are resolved row by row from ctx[] */
+#define VERIFY_MAX_DEFAULT 256u
 
 #define SEED_LOW 128 /* refill the stacks from the prefix table when they hold this few nodes */
 
@@ -266,15 +268,19 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
          * remaining budget allows.  Same node set at depth k as the walk (index.hpp:182-248). */
         const uint32_t k = a.pt_k, kp = k - 2u;
         const uint32_t bud = m - sj;
-        const uint32_t E = bud >= 2u ? 16u : bud == 1u ? 7u : 1u;
         /* budget-0 variants with >= 1 substitution use the rotated table of their LAST
          * substituted step: the three substitutions there sit in neighbouring lanes and in one
-         * 64-byte line, so three variants cost one request */
+         * 64-byte line, so three variants cost one request.  Budget-1 variants take 8 lanes:
+         * four with the second-last symbol exact (one line of the plain table: the last symbol
+         * runs) and four with the last symbol exact (one line of the rotated copy of step k-2:
+         * the second-last symbol runs; the all-exact entry there is a duplicate and idles). */
         const bool rot = sd.ptab_rot != nullptr && bud == 0u && sj >= 1u;
+        const bool rot2 = sd.ptab_rot != nullptr && bud == 1u;
+        const uint32_t E = bud >= 2u ? 16u : bud == 1u ? (rot2 ? 8u : 7u) : 1u;
         const uint32_t span = s_plan[8u + sj] * (rot ? 3u : E);
         const uint32_t l = spos + lane;
-        const bool act = l < span;
-        const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 7u ? l / 7u : l;
+        bool act = l < span;
+        const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
         const uint32_t u = l - ci * (rot ? 3u : E);
         uint32_t mask = act ? s_plan[s_plan[sj] + ci] : 0u;
         uint32_t pidx = pidx0;
@@ -302,6 +308,13 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         } else if (E == 16u) {
           s2 = u >> 2;
           s1 = u & 3u;
+        } else if (E == 8u) {
+          if (u < 4u) {
+            s1 = u;
+          } else {
+            s2 = u - 4u;
+            act = act && s2 != q2;
+          }
         } else if (E == 7u) {
           if (u >= 1u && u <= 3u) s2 = (q2 + u) & 3u;
           if (u >= 4u) s1 = (q1 + u - 3u) & 3u;
@@ -315,6 +328,10 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
             const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
                                   ((pidx >> sh) & 3u);
             ent = sd.ptab_rot[((size_t)plast << (2u * k)) + ridx];
+          } else if (rot2 && u >= 4u) {
+            /* copy of step k-2: its symbol (bits 3:2 of pidx) and the last one swap places */
+            const uint32_t ridx = (pidx & ~15u) | ((pidx & 3u) << 2) | ((pidx >> 2) & 3u);
+            ent = sd.ptab_rot[((size_t)kp << (2u * k)) + ridx];
           } else {
             ent = sd.ptab[pidx];
           }
@@ -326,7 +343,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         const uint64_t amask = bl == 0u ? allow3[0] : bl == 1u ? allow3[1] : bl == 2u ? allow3[2] : ~0ull;
         const uint64_t emask = ((uint64_t)ent.w << 32) | ent.z;
         const bool hopeless = use_mask3 && (ent.y >> 31) == 0u && (emask & amask) == 0ull;
-        const bool live = act && ecnt != 0u && !hopeless;
+        const bool live = act && ecnt != 0u && !hopeless && !(a.dbg_skip & 2u);
         const uint32_t c2 = s2 == q2 ? 0u : 1u + s2 - (s2 > q2 ? 1u : 0u);
         const uint32_t c1 = s1 == q1 ? 0u : 1u + s1 - (s1 > q1 ? 1u : 0u);
         const uint32_t kk = sj + mm;
@@ -335,7 +352,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
                                ((uint64_t)c1 << (50u - 2u * (kp + 1u)));
         /* small, exception-free intervals are resolved right here against ctx[]; the rest
          * continue as ordinary nodes (k < L: never terminal) */
-        const bool ver = live && a.v_rem != 0u && (ent.y >> 31) == 0u && ecnt <= VERIFY_MAX;
+        const bool ver = live && a.v_rem != 0u && (ent.y >> 31) == 0u && ecnt <= a.v_max;
         route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
         /* The v_rem symbols left of each suffix are in ctx[row], nearest first, i.e. in
          * consumption order: compare the remaining guide symbols under the remaining budget,
@@ -344,42 +361,59 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
          * The rows of all verifying seeds of this step are flattened over the lanes (row slot s
          * -> lane s mod 64), so consecutive lanes read consecutive ctx words: one coalesced
          * 4-byte load per lane per 64 rows instead of one scattered load per row per lane. */
-        const uint32_t vcnt = ver ? ecnt : 0u;
-        uint32_t incl = vcnt;
+        /* Rows are handed out in groups of four consecutive rows of one seed: lane l of a pass
+         * takes groups 2l and 2l+1, finds the owner seed of each (seeds mark their first group,
+         * a running max spreads the marks) and reads its four ctx words with one 16-byte load,
+         * so consecutive lanes read consecutive 16-byte pieces (coalesced) and the owner lookup
+         * is paid once per four rows.  ctx[] is padded by one group. */
+        const uint32_t vcnt = (ver && !(a.dbg_skip & 1u)) ? ecnt : 0u;
+        const uint32_t vgrp = (vcnt + 3u) >> 2;
+        uint32_t incl = vgrp;
 #pragma unroll
         for (int o = 1; o < WAVE; o <<= 1) {
           const uint32_t up = __shfl_up(incl, o);
           if ((int)lane >= o) incl += up;
         }
-        const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1);
+        const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
+        if (a.dbg_skip & 4u) { /* experiment counters */
+          const uint32_t c_act = __popcll(__ballot(act)), c_ne = __popcll(__ballot(act && ecnt != 0u)),
+                         c_live = __popcll(__ballot(live)), c_ver = __popcll(__ballot(ver));
+          if (lane == 0) {
+            atomicAdd(&a.stats[4], c_act);
+            atomicAdd(&a.stats[5], c_ne);
+            atomicAdd(&a.stats[6], c_live);
+            atomicAdd(&a.stats[7], c_ver);
+            atomicAdd(&a.stats[8], R);
+            atomicAdd(&a.stats[9], (R + 127u) / 128u);
+            atomicAdd(&a.stats[10], 1ull);
+            atomicAdd(&a.stats[11 + (bud > 3u ? 3u : bud)], c_ver);
+          }
+        }
         if (R) {
-          const uint32_t excl = incl - vcnt;
-          /* scratch above the X stack: 64 seed descriptors + 256 owner markers = 128 entries
-           * (xs+gs <= 192 here, so [xs, xs+128) cannot reach the G stack at the top of the
-           * 320-entry array) */
+          const uint32_t excl = incl - vgrp;
+          /* scratch above the X stack: 64 seed descriptors + 128 owner markers = 96 entries
+           * (xs+gs <= 192 here, so [xs, xs+96) cannot reach the G stack at the top of the
+           * 320-entry array).  descriptor.y = first group (14 bits) | mismatches so far << 14 |
+           * rows << 17 */
           uint4 *scr = stk + xs;
-          uint4 *own4 = stk + xs + WAVE;
-          uint32_t *own = (uint32_t *)own4;
-          scr[lane] = make_uint4(ent.x, excl | (kk << 12), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+          uint2 *own2 = (uint2 *)(stk + xs + WAVE);
+          uint32_t *own = (uint32_t *)own2;
+          scr[lane] = make_uint4(ent.x, excl | (kk << 14) | (vcnt << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
           const uint32_t g = L - k; /* guide symbols left */
           const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
           const uint32_t qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
-          for (uint32_t base = 0; base < R; base += 4u * WAVE) {
-            /* 256 row slots per pass, lane l takes slots base+4l .. base+4l+3 (consecutive rows
-             * of one interval as a rule).  Owner seed of a slot: seeds mark their first slot (or
-             * slot 0 when they straddle the pass start); a running max spreads the marks. */
-            own4[lane] = make_uint4(0u, 0u, 0u, 0u);
+          for (uint32_t base = 0; base < R; base += 2u * WAVE) {
+            own2[lane] = make_uint2(0u, 0u);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (vcnt) {
-              if (excl >= base && excl < base + 4u * WAVE) own[excl - base] = lane + 1u;
-              if (excl < base && excl + vcnt > base) own[0] = lane + 1u;
+            if (vgrp) {
+              if (excl >= base && excl < base + 2u * WAVE) own[excl - base] = lane + 1u;
+              if (excl < base && excl + vgrp > base) own[0] = lane + 1u;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint4 mk = own4[lane];
-            uint32_t o0 = mk.x, o1 = mk.y > o0 ? mk.y : o0, o2 = mk.z > o1 ? mk.z : o1,
-                     o3 = mk.w > o2 ? mk.w : o2;
-            uint32_t run = o3; /* inclusive max-scan over lanes, then shift to exclusive */
+            const uint2 mk = own2[lane];
+            uint32_t o0 = mk.x, o1 = mk.y > o0 ? mk.y : o0;
+            uint32_t run = o1; /* inclusive max-scan over lanes, then shift to exclusive */
 #pragma unroll
             for (int o = 1; o < WAVE; o <<= 1) {
               const uint32_t up = __shfl_up(run, o);
@@ -389,51 +423,66 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
             if (lane == 0) prev = 0u;
             o0 = o0 > prev ? o0 : prev;
             o1 = o1 > prev ? o1 : prev;
-            o2 = o2 > prev ? o2 : prev;
-            o3 = o3 > prev ? o3 : prev;
-            const uint32_t ow[4] = {o0, o1, o2, o3};
-            uint32_t wv[4], rowv[4], kkv[4];
-            uint4 dsc[4];
-            bool onv[4];
+            const uint32_t ow[2] = {o0, o1};
+            uint4 wq[2], dsc[2];
+            uint32_t row0[2], nrow[2], kkv[2];
 #pragma unroll
-            for (uint32_t jj = 0; jj < 4u; ++jj) { /* four independent loads in flight */
-              const uint32_t slot = base + 4u * lane + jj;
-              onv[jj] = slot < R;
+            for (uint32_t jj = 0; jj < 2u; ++jj) { /* two independent 16-byte loads in flight */
+              const uint32_t grp = base + 2u * lane + jj;
+              const bool on = grp < R;
               dsc[jj] = make_uint4(0u, 0u, 0u, 0u);
-              if (onv[jj]) dsc[jj] = scr[ow[jj] - 1u];
-              rowv[jj] = dsc[jj].x + (slot - (dsc[jj].y & 0xFFFu));
-              kkv[jj] = (dsc[jj].y >> 12) & 7u;
-              wv[jj] = 0u;
-              if (onv[jj]) wv[jj] = sd.ctx[rowv[jj]];
+              if (on) dsc[jj] = scr[ow[jj] - 1u];
+              const uint32_t r0 = (grp - (dsc[jj].y & 0x3FFFu)) << 2; /* first row of the group in its seed */
+              const uint32_t cnt = dsc[jj].y >> 17;
+              row0[jj] = dsc[jj].x + r0;
+              nrow[jj] = on ? (cnt - r0 < 4u ? cnt - r0 : 4u) : 0u;
+              kkv[jj] = (dsc[jj].y >> 14) & 7u;
+              wq[jj] = make_uint4(0u, 0u, 0u, 0u);
+              if (on) {
+                const uint32_t *cp = sd.ctx + row0[jj];
+                wq[jj] = make_uint4(cp[0], cp[1], cp[2], cp[3]);
+              }
             }
 #pragma unroll
-            for (uint32_t jj = 0; jj < 4u; ++jj) {
-              const uint32_t w = wv[jj];
-              const uint32_t x = (w ^ qrem) & gmask;
-              const uint32_t mmv = __popc((x | (x >> 1)) & 0x55555555u);
-              const bool gok = onv[jj] && kkv[jj] + mmv <= m;
-              if (!__ballot(gok)) continue;
+            for (uint32_t jj = 0; jj < 2u; ++jj) {
+              const uint32_t wv[4] = {wq[jj].x, wq[jj].y, wq[jj].z, wq[jj].w};
+              uint32_t mmv[4];
+              bool gokv[4];
+              bool any = false;
+#pragma unroll
+              for (uint32_t r = 0; r < 4u; ++r) {
+                const uint32_t x = (wv[r] ^ qrem) & gmask;
+                mmv[r] = __popc((x | (x >> 1)) & 0x55555555u);
+                gokv[r] = r < nrow[jj] && kkv[jj] + mmv[r] <= m;
+                any = any || gokv[r];
+              }
+              if (!__ballot(any)) continue;
               const uint64_t spath = (((uint64_t)dsc[jj].w << 32) | dsc[jj].z) & PATH_MASK;
-              for (uint32_t pj = 0; pj < npams; ++pj) {
-                const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-                bool ok = gok;
-                uint64_t ppath = 0;
-                for (uint32_t u = 0; u < P; ++u) {
-                  const uint32_t pc = (pw >> (3u * u)) & 7u;
-                  const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-                  ok = ok && (pc == 4u || pc == tb);
-                  ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+#pragma unroll
+              for (uint32_t r = 0; r < 4u; ++r) {
+                if (!__ballot(gokv[r])) continue;
+                const uint32_t w = wv[r];
+                for (uint32_t pj = 0; pj < npams; ++pj) {
+                  const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+                  bool ok = gokv[r];
+                  uint64_t ppath = 0;
+                  for (uint32_t u = 0; u < P; ++u) {
+                    const uint32_t pc = (pw >> (3u * u)) & 7u;
+                    const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+                    ok = ok && (pc == 4u || pc == tb);
+                    ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+                  }
+                  if (!__ballot(ok)) continue;
+                  uint64_t gpath = 0;
+                  for (uint32_t v = 0; v < g; ++v) {
+                    const uint32_t qc = (qrem >> (2u * v)) & 3u;
+                    const uint32_t tb = (w >> (2u * v)) & 3u;
+                    const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+                    gpath |= (uint64_t)code << (50u - 2u * (k + v));
+                  }
+                  const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv[r]) << 56) | spath | gpath | ppath;
+                  route(ok, true, false, row0[jj] + r, row0[jj] + r, mmeta, 1u);
                 }
-                if (!__ballot(ok)) continue;
-                uint64_t gpath = 0;
-                for (uint32_t v = 0; v < g; ++v) {
-                  const uint32_t qc = (qrem >> (2u * v)) & 3u;
-                  const uint32_t tb = (w >> (2u * v)) & 3u;
-                  const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-                  gpath |= (uint64_t)code << (50u - 2u * (k + v));
-                }
-                const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv) << 56) | spath | gpath | ppath;
-                route(ok, true, false, rowv[jj], rowv[jj], mmeta, 1u);
               }
             }
           }
@@ -1119,6 +1168,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.pt_k = 0;
     sa.jmax = 0;
     sa.v_rem = 0;
+    sa.v_max = VERIFY_MAX_DEFAULT;
+    if (const char *e = getenv("GS_VERIFY_MAX")) {
+      const long v = atol(e);
+      sa.v_max = v < 1 ? 1u : v > 1023 ? 1023u : (uint32_t)v;
+    }
+    sa.dbg_skip = getenv("GS_DBG_SKIP") ? (uint32_t)atol(getenv("GS_DBG_SKIP")) : 0u;
     sa.plan_words = 0;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
@@ -1140,6 +1195,14 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 4 * (size_t)sa.plan_words, st, sa);
     GS_HIP(hipEventRecord(ix->ev[2], st));
     GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
+    if (sa.dbg_skip & 4u) {
+      unsigned long long c[16];
+      GS_HIP(hipMemcpy(c, d_stats, sizeof(c), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[gs] seeds: lanes %llu nonempty %llu live %llu verified %llu (by budget 0..3: %llu %llu %llu %llu) "
+              "rows %llu passes %llu steps %llu for %u guides\n", c[4], c[5], c[6], c[7], c[11], c[12], c[13], c[14],
+              c[8], c[9], c[10], ng);
+      GS_HIP(hipMemsetAsync((char *)d_stats + 32, 0, 96, st));
+    }
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
     float ms = 0.f;
