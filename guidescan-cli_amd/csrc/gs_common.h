@@ -47,14 +47,26 @@ struct gs_strand_dev {
    * nearest first, 2 bits each (A,C,G,T = 0..3).  Lets a small interval at depth k be resolved
    * against the rest of the pattern with one 4-byte read per row instead of an Occ walk. */
   const uint32_t *ctx;
+  /* inverse suffix array (isa[sa[r]] = r), n entries, or nullptr: turns a text position found
+   * through the other strand's index into this strand's row (two-sided seeding) */
+  const uint32_t *isa;
 };
 
 struct gs_strand {
   gs_strand_dev d{};
-  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ptab_rot = nullptr;
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ptab_rot = nullptr, *isa = nullptr;
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;
+};
+
+/* a maximal run of 'N' bytes in the forward text with the bytes around it (host side; used per
+ * batch to list the few windows where a PAM 'N' can meet a literal N, index.hpp:139-149) */
+#define GS_NRUN_FLANK 40
+struct gs_nrun {
+  uint64_t start, len;
+  uint8_t left[GS_NRUN_FLANK];  /* text[start-40 .. start), 0 beyond the text */
+  uint8_t right[GS_NRUN_FLANK]; /* text[start+len .. start+len+40) */
 };
 
 struct gs_buffer {
@@ -77,6 +89,9 @@ struct gs_index {
   void *d_combo = nullptr;         /* uint32 masks, all j concatenated */
   uint32_t combo_off[10] = {0};    /* start of the masks with j mismatches */
   uint32_t combo_cnt[10] = {0};    /* C(pt_k-2, j) */
+  uint32_t combo_words = 0;        /* words of the full plan; d_combo holds room for a second one */
+  std::vector<gs_nrun> nruns_text; /* 'N' runs of the forward text */
+  gs_buffer w_cand;                /* per-batch literal-N candidate windows (device) */
 };
 
 #define GS_HIP(expr)                                                              \

@@ -136,6 +136,7 @@ void gs_strand_free(gs_strand *s) {
   if (s->ptab) hipFree(s->ptab);
   if (s->ctx) hipFree(s->ctx);
   if (s->ptab_rot) hipFree(s->ptab_rot);
+  if (s->isa) hipFree(s->isa);
   *s = gs_strand();
 }
 
@@ -468,6 +469,11 @@ __global__ void k_rot_copy(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p)
   rot[((uint64_t)p << (2 * k)) + j] = tab[i];
 }
 
+__global__ void k_isa_build(const uint32_t *sa, uint64_t n, uint32_t *isa) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) isa[sa[r]] = (uint32_t)r;
+}
+
 static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hipStream_t st) {
   if (!k) return GS_OK;
   const uint64_t entries = 1ull << (2 * k);
@@ -500,7 +506,19 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
       (void)hipGetLastError();
     }
   }
+  uint32_t *isa = nullptr;
+  if (rot && !getenv("GS_NO_BIDIR")) {
+    if (hipMalloc(&isa, 4 * s->n) == hipSuccess) {
+      hipLaunchKernelGGL(k_isa_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, (const uint32_t *)s->sa, s->n, isa);
+      s->bytes += 4 * s->n;
+    } else {
+      isa = nullptr;
+      (void)hipGetLastError();
+    }
+  }
   GS_HIP(hipStreamSynchronize(st));
+  s->isa = isa;
+  s->d.isa = isa;
   s->ptab_rot = rot;
   s->d.ptab_rot = rot;
   s->ptab = tab;
@@ -530,9 +548,32 @@ static gs_status build_seed_plan(gs_index *ix, uint32_t k) {
     ix->combo_off[j] = masks[j];
     ix->combo_cnt[j] = cnt;
   }
-  GS_HIP(hipMalloc(&ix->d_combo, 4 * masks.size()));
+  /* room for a second, filtered plan written per batch (two-sided seeding) */
+  ix->combo_words = (uint32_t)masks.size();
+  GS_HIP(hipMalloc(&ix->d_combo, 8 * masks.size()));
   GS_HIP(hipMemcpy(ix->d_combo, masks.data(), 4 * masks.size(), hipMemcpyHostToDevice));
   return GS_OK;
+}
+
+/* maximal runs of 'N' in the forward text, with 40 bytes of text on either side */
+static void scan_n_runs(const uint8_t *text, uint64_t len, std::vector<gs_nrun> &out) {
+  out.clear();
+  uint64_t pos = 0;
+  while (pos < len) {
+    const uint8_t *hit = (const uint8_t *)memchr(text + pos, 'N', len - pos);
+    if (!hit) break;
+    gs_nrun r;
+    r.start = (uint64_t)(hit - text);
+    uint64_t e = r.start;
+    while (e < len && text[e] == 'N') e++;
+    r.len = e - r.start;
+    for (uint64_t j = 0; j < GS_NRUN_FLANK; j++) {
+      r.left[j] = r.start >= GS_NRUN_FLANK - j ? text[r.start - (GS_NRUN_FLANK - j)] : 0;
+      r.right[j] = e + j < len ? text[e + j] : 0;
+    }
+    out.push_back(r);
+    pos = e;
+  }
 }
 
 /* ---------------- C-ABI: index lifecycle -------------------------------------- */
@@ -574,6 +615,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
     if (rc == GS_OK) rc = build_ptab(d_t, &ix->strand[s], pk, st);
   }
   if (rc == GS_OK) rc = build_seed_plan(ix, pk);
+  if (rc == GS_OK) scan_n_runs(text, len, ix->nruns_text);
   hipFree(d_fwd);
   hipFree(d_rev);
   if (rc != GS_OK) {
@@ -603,7 +645,7 @@ extern "C" void gs_index_close(gs_index *ix) {
                        &ix->w_ovf_list, &ix->w_grec2, &ix->w_slots2, &ix->w_counts2, &ix->w_nmatch2,
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_a, &ix->w_h_b, &ix->w_h_flag, &ix->w_h_pos,
                        &ix->w_h_uq, &ix->w_h_uqg, &ix->w_h_cnt, &ix->w_h_scan, &ix->w_h_nh, &ix->w_h_first,
-                       &ix->w_h_tmp};
+                       &ix->w_h_tmp, &ix->w_cand};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)

@@ -58,6 +58,15 @@ struct gs_search_args {
   uint32_t v_rem;
   uint32_t v_max; /* intervals up to this many rows are resolved row by row from ctx[] (<= 1023) */
   uint32_t dbg_skip; /* timing experiments only (GS_DBG_SKIP): 1 = no verification, 2 = no seeds kept */
+  /* two-sided seeding: X = the first v_rem consumed guide symbols.
+   * Sites with fewer than `tau` substitutions in X are seeded from this strand's table with
+   * the filtered plan at plan2_off; sites with >= tau (hence <= 1 in the rest) are seeded from
+   * the OTHER strand's table, where the PAM and the rest of the guide are consumed first. */
+  uint32_t bidir, tau;
+  uint32_t plan2_off;          /* word offset of the filtered plan inside the LDS copy */
+  uint32_t plan2_src;          /* and inside combo[] */
+  const uint64_t *cand[2];     /* per strand: windows holding a literal N under the PAM (guide part, 2 bits/symbol) */
+  uint32_t n_cand[2];
 };
 
 #define VERIFY_MAX_DEFAULT 256u
@@ -136,13 +145,17 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot) {
  * base - which need Occ of one base and have at most one child; G (grows down) holds nodes
  * that still branch (k < m), PAM 'N' wildcards and PAM fan-out nodes.  ~89 % of all nodes are
  * X nodes, and an X iteration costs ~1/4 of the instructions of a G one. */
-__global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a) {
+#ifndef GS_WAVES_EU
+#define GS_WAVES_EU 6 /* 80 VGPRs: measured best of 4..8 (two-sided seeding, hg38-sized) */
+#endif
+__global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(GS_WAVES_EU, GS_WAVES_EU))) void k_search(gs_search_args a) {
   __shared__ uint4 s_stack[SEARCH_WAVES][STACK_ENTRIES];
   extern __shared__ uint32_t s_plan[]; /* seeding plan: one LDS read instead of a global one */
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t lane = lane_id();
   uint4 *stk = s_stack[wave];
-  for (uint32_t i = threadIdx.x; i < a.plan_words; i += WAVE * SEARCH_WAVES) s_plan[i] = a.combo[i];
+  for (uint32_t i = threadIdx.x; i < a.plan_words; i += WAVE * SEARCH_WAVES)
+    s_plan[i] = a.combo[(a.bidir && i >= a.plan2_off) ? i - a.plan2_off + a.plan2_src : i];
   __syncthreads();
   unsigned long long n_ext = 0, n_ovf = 0;
   const uint32_t L = a.L, P = a.P, m = a.m;
@@ -227,6 +240,162 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
       }
     };
 
+
+    /* ---- context verification (both seeding directions) --------------------------------
+     * Every lane may bring one small interval [vsp, vsp+vcnt) at the table depth with kk
+     * substitutions so far and its path in cmeta.  The v_rem symbols left of each suffix are in
+     * ctx[row], nearest first, i.e. in consumption order.
+     *   modeB == false (this strand's table): compare the remaining guide symbols under the
+     *     remaining budget, then each PAM pattern exactly ('N' = any base).  A hit is the row
+     *     itself; its text position is SA[row] - v_rem (key bit 0, k_locate).
+     *   modeB == true (other strand's table, PAM and the rest of the guide already consumed):
+     *     the remaining symbols are the complemented first v_rem guide symbols, last first;
+     *     a row counts when it has >= tau substitutions there (fewer belong to the other
+     *     direction) and fits the budget.  The hit is reported as the row of THIS strand's
+     *     suffix array that starts at the same site (SA of the other strand -> position ->
+     *     ISA of this strand), so records look exactly like the ones the walk produces.
+     * Rows are handed out in groups of four consecutive rows of one seed: lane l of a pass
+     * takes groups 2l and 2l+1, finds the owner seed of each (seeds mark their first group, a
+     * running max spreads the marks) and reads its four ctx words with one 16-byte load, so
+     * consecutive lanes read consecutive 16-byte pieces (coalesced) and the owner lookup is
+     * paid once per four rows.  ctx[] is padded by one group. */
+    auto verify = [&](const bool modeB, const uint32_t vcnt, const uint32_t vsp, const uint32_t kk,
+                      const uint64_t cmeta) __attribute__((always_inline)) {
+      const uint32_t k = a.pt_k;
+      const gs_strand_dev &sv = modeB ? a.sd[strand ^ 1u] : sd;
+      const uint32_t vgrp = (vcnt + 3u) >> 2;
+      uint32_t incl = vgrp;
+#pragma unroll
+      for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if ((int)lane >= o) incl += up;
+      }
+      const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
+      if (!R) return;
+      const uint32_t excl = incl - vgrp;
+      /* scratch above the X stack: 64 seed descriptors + 128 owner markers = 96 entries
+       * (xs+gs <= 192 here, so [xs, xs+96) cannot reach the G stack at the top of the
+       * 320-entry array).  descriptor.y = first group (14 bits) | mismatches so far << 14 |
+       * rows << 17 */
+      uint4 *scr = stk + xs;
+      uint2 *own2 = (uint2 *)(stk + xs + WAVE);
+      uint32_t *own = (uint32_t *)own2;
+      scr[lane] = make_uint4(vsp, excl | (kk << 14) | (vcnt << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+      const uint32_t g = modeB ? a.v_rem : L - k; /* guide symbols among the remaining ones */
+      const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
+      uint32_t qrem;
+      if (modeB) {
+        qrem = 0;
+        for (uint32_t j = 0; j < g; ++j) qrem |= (3u - ((uint32_t)(gr_q >> (2u * (g - 1u - j))) & 3u)) << (2u * j);
+      } else {
+        qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
+      }
+      for (uint32_t base = 0; base < R; base += 2u * WAVE) {
+        own2[lane] = make_uint2(0u, 0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (vgrp) {
+          if (excl >= base && excl < base + 2u * WAVE) own[excl - base] = lane + 1u;
+          if (excl < base && excl + vgrp > base) own[0] = lane + 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint2 mk = own2[lane];
+        uint32_t o0 = mk.x, o1 = mk.y > o0 ? mk.y : o0;
+        uint32_t run = o1; /* inclusive max-scan over lanes, then shift to exclusive */
+#pragma unroll
+        for (int o = 1; o < WAVE; o <<= 1) {
+          const uint32_t up = __shfl_up(run, o);
+          if ((int)lane >= o && up > run) run = up;
+        }
+        uint32_t prev = __shfl_up(run, 1);
+        if (lane == 0) prev = 0u;
+        o0 = o0 > prev ? o0 : prev;
+        o1 = o1 > prev ? o1 : prev;
+        const uint32_t ow[2] = {o0, o1};
+        uint4 wq[2], dsc[2];
+        uint32_t row0[2], nrow[2], kkv[2];
+#pragma unroll
+        for (uint32_t jj = 0; jj < 2u; ++jj) { /* two independent 16-byte loads in flight */
+          const uint32_t grp = base + 2u * lane + jj;
+          const bool on = grp < R;
+          dsc[jj] = make_uint4(0u, 0u, 0u, 0u);
+          if (on) dsc[jj] = scr[ow[jj] - 1u];
+          const uint32_t r0 = (grp - (dsc[jj].y & 0x3FFFu)) << 2; /* first row of the group in its seed */
+          const uint32_t cnt = dsc[jj].y >> 17;
+          row0[jj] = dsc[jj].x + r0;
+          nrow[jj] = on ? (cnt - r0 < 4u ? cnt - r0 : 4u) : 0u;
+          kkv[jj] = (dsc[jj].y >> 14) & 7u;
+          wq[jj] = make_uint4(0u, 0u, 0u, 0u);
+          if (on) {
+            const uint32_t *cp = sv.ctx + row0[jj];
+            wq[jj] = make_uint4(cp[0], cp[1], cp[2], cp[3]);
+          }
+        }
+#pragma unroll
+        for (uint32_t jj = 0; jj < 2u; ++jj) {
+          const uint32_t wv[4] = {wq[jj].x, wq[jj].y, wq[jj].z, wq[jj].w};
+          uint32_t mmv[4];
+          bool gokv[4];
+          bool any = false;
+#pragma unroll
+          for (uint32_t r = 0; r < 4u; ++r) {
+            const uint32_t x = (wv[r] ^ qrem) & gmask;
+            mmv[r] = __popc((x | (x >> 1)) & 0x55555555u);
+            gokv[r] = r < nrow[jj] && kkv[jj] + mmv[r] <= m && (!modeB || mmv[r] >= a.tau);
+            any = any || gokv[r];
+          }
+          if (!__ballot(any)) continue;
+          const uint64_t spath = (((uint64_t)dsc[jj].w << 32) | dsc[jj].z) & PATH_MASK;
+#pragma unroll
+          for (uint32_t r = 0; r < 4u; ++r) {
+            if (!__ballot(gokv[r])) continue;
+            const uint32_t w = wv[r];
+            if (modeB) {
+              uint64_t gpath = 0;
+              for (uint32_t j = 0; j < g; ++j) {
+                const uint32_t t = g - 1u - j;
+                const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+                const uint32_t tb = 3u - ((w >> (2u * j)) & 3u); /* the base as this strand reads it */
+                const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+                gpath |= (uint64_t)code << (50u - 2u * t);
+              }
+              uint32_t rowA = 0;
+              if (gokv[r]) {
+                /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
+                const uint32_t pB = sv.sa[row0[jj] + r];
+                const uint32_t sA = (sd.n - 1u) - (pB - g) - (L + P);
+                rowA = sd.isa[sA];
+              }
+              const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv[r]) << 56) | spath | gpath;
+              route(gokv[r], true, false, rowA, rowA, mmeta, 0u);
+              continue;
+            }
+            for (uint32_t pj = 0; pj < npams; ++pj) {
+              const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+              bool ok = gokv[r];
+              uint64_t ppath = 0;
+              for (uint32_t u = 0; u < P; ++u) {
+                const uint32_t pc = (pw >> (3u * u)) & 7u;
+                const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+                ok = ok && (pc == 4u || pc == tb);
+                ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+              }
+              if (!__ballot(ok)) continue;
+              uint64_t gpath = 0;
+              for (uint32_t v = 0; v < g; ++v) {
+                const uint32_t qc = (qrem >> (2u * v)) & 3u;
+                const uint32_t tb = (w >> (2u * v)) & 3u;
+                const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+                gpath |= (uint64_t)code << (50u - 2u * (k + v));
+              }
+              const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv[r]) << 56) | spath | gpath | ppath;
+              route(ok, true, false, row0[jj] + r, row0[jj] + r, mmeta, 1u);
+            }
+          }
+        }
+      }
+    };
+
     /* seeding state (all wave-uniform): mismatch count j of the prefix variants being
      * enumerated, substitution index sub in [0,3^j), position in the (combination, entry) space */
     uint32_t sj = 0, ssub = 0, spos = 0, spow = 1;
@@ -258,6 +427,87 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
+    /* ---- two-sided seeding: the sites with >= tau substitutions among the first v_rem
+     * consumed guide symbols (set X) have at most one in the rest, so they are cheap to
+     * enumerate from the other end: on the other strand the same site reads reversed and
+     * complemented, and a backward search there consumes the PAM first, then the guide from
+     * its last consumed symbol down to X.  Its depth-k seeds are PAM expansions x (no or one
+     * substitution among the k-P guide symbols): a few dozen instead of thousands.  What they
+     * cannot see - a flagged or oversized interval, a literal N under the PAM, a PAM pattern
+     * with more than two N - makes the item fall back to one-sided seeding with the full plan. */
+    const uint32_t *pl = s_plan;
+    if (a.bidir && seeding) {
+      bool fallback = false;
+      const gs_strand_dev &sb = a.sd[strand ^ 1u];
+      const uint32_t k = a.pt_k, sx = a.v_rem, nY = k - P;
+      const uint32_t ncand = a.n_cand[strand];
+      for (uint32_t c0 = 0; c0 < ncand; c0 += WAVE) {
+        bool reach = false;
+        if (c0 + lane < ncand) {
+          const uint64_t x = a.cand[strand][c0 + lane] ^ gr_q;
+          const uint64_t nz = (x | (x >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
+          const uint32_t tot = __popcll(nz), jx = __popcll(nz & ((1ull << (2u * sx)) - 1ull));
+          reach = tot <= m && jx >= a.tau;
+        }
+        if (__ballot(reach)) fallback = true;
+      }
+      for (uint32_t pj = 0; pj < npams && !fallback; ++pj) {
+        const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+        uint32_t nn = 0;
+        for (uint32_t u = 0; u < P; ++u) nn += ((pw >> (3u * u)) & 7u) == 4u;
+        if (nn > 2u) {
+          fallback = true;
+          break;
+        }
+        for (uint32_t e = 0; e < (1u << (2u * nn)) && !fallback; ++e) {
+          /* the k-mer of the other strand: step P-1-u holds the complement of PAM symbol u, step
+           * P+y the complement of guide symbol L-1-y */
+          uint32_t pidxb = 0, ee = e;
+          uint64_t ppath = 0;
+          for (uint32_t u = 0; u < P; ++u) {
+            const uint32_t pc = (pw >> (3u * u)) & 7u;
+            uint32_t base = pc;
+            if (pc == 4u) {
+              base = ee & 3u;
+              ee >>= 2;
+            }
+            ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
+            pidxb |= (3u - base) << (2u * (k - P + u));
+          }
+          for (uint32_t y = 0; y < nY; ++y)
+            pidxb |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (k - 1u - P - y));
+          /* lane 0: no substitution; lane 1+3y+d: digit d at guide symbol L-1-y */
+          const bool act = lane < 1u + 3u * nY;
+          const uint32_t v = act ? lane : 0u;
+          const uint32_t y = v ? (v - 1u) / 3u : 0u, d = v ? (v - 1u) - 3u * y : 0u;
+          uint32_t pidx = pidxb;
+          uint64_t path = ppath;
+          if (v) {
+            const uint32_t t = L - 1u - y;
+            const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+            const uint32_t sym = (qc + 1u + d) & 3u;
+            path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
+            pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
+          }
+          uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+          if (act) ent = sb.ptab[pidx];
+          const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
+          const uint32_t kk = v ? 1u : 0u;
+          const bool live = act && ecnt != 0u;
+          if (__ballot(live && ((ent.y >> 31) != 0u || ecnt > a.v_max))) {
+            fallback = true;
+            break;
+          }
+          const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
+          verify(true, live ? ecnt : 0u, ent.x, kk, cmeta);
+        }
+      }
+      if (fallback)
+        n_match = 0; /* whatever the other strand found so far is found again below */
+      else
+        pl = s_plan + a.plan2_off;
+    }
+
     for (;;) {
       const uint32_t total = xs + gs;
       if (seeds_left && total <= SEED_LOW) {
@@ -277,12 +527,12 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
         const bool rot = sd.ptab_rot != nullptr && bud == 0u && sj >= 1u;
         const bool rot2 = sd.ptab_rot != nullptr && bud == 1u;
         const uint32_t E = bud >= 2u ? 16u : bud == 1u ? (rot2 ? 8u : 7u) : 1u;
-        const uint32_t span = s_plan[8u + sj] * (rot ? 3u : E);
+        const uint32_t span = pl[8u + sj] * (rot ? 3u : E);
         const uint32_t l = spos + lane;
         bool act = l < span;
         const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
         const uint32_t u = l - ci * (rot ? 3u : E);
-        uint32_t mask = act ? s_plan[s_plan[sj] + ci] : 0u;
+        uint32_t mask = act ? pl[pl[sj] + ci] : 0u;
         uint32_t pidx = pidx0;
         uint64_t path = 0;
         uint32_t sub = ssub;
@@ -361,132 +611,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
          * The rows of all verifying seeds of this step are flattened over the lanes (row slot s
          * -> lane s mod 64), so consecutive lanes read consecutive ctx words: one coalesced
          * 4-byte load per lane per 64 rows instead of one scattered load per row per lane. */
-        /* Rows are handed out in groups of four consecutive rows of one seed: lane l of a pass
-         * takes groups 2l and 2l+1, finds the owner seed of each (seeds mark their first group,
-         * a running max spreads the marks) and reads its four ctx words with one 16-byte load,
-         * so consecutive lanes read consecutive 16-byte pieces (coalesced) and the owner lookup
-         * is paid once per four rows.  ctx[] is padded by one group. */
-        const uint32_t vcnt = (ver && !(a.dbg_skip & 1u)) ? ecnt : 0u;
-        const uint32_t vgrp = (vcnt + 3u) >> 2;
-        uint32_t incl = vgrp;
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-          const uint32_t up = __shfl_up(incl, o);
-          if ((int)lane >= o) incl += up;
-        }
-        const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
-        if (a.dbg_skip & 4u) { /* experiment counters */
-          const uint32_t c_act = __popcll(__ballot(act)), c_ne = __popcll(__ballot(act && ecnt != 0u)),
-                         c_live = __popcll(__ballot(live)), c_ver = __popcll(__ballot(ver));
-          if (lane == 0) {
-            atomicAdd(&a.stats[4], c_act);
-            atomicAdd(&a.stats[5], c_ne);
-            atomicAdd(&a.stats[6], c_live);
-            atomicAdd(&a.stats[7], c_ver);
-            atomicAdd(&a.stats[8], R);
-            atomicAdd(&a.stats[9], (R + 127u) / 128u);
-            atomicAdd(&a.stats[10], 1ull);
-            atomicAdd(&a.stats[11 + (bud > 3u ? 3u : bud)], c_ver);
-          }
-        }
-        if (R) {
-          const uint32_t excl = incl - vgrp;
-          /* scratch above the X stack: 64 seed descriptors + 128 owner markers = 96 entries
-           * (xs+gs <= 192 here, so [xs, xs+96) cannot reach the G stack at the top of the
-           * 320-entry array).  descriptor.y = first group (14 bits) | mismatches so far << 14 |
-           * rows << 17 */
-          uint4 *scr = stk + xs;
-          uint2 *own2 = (uint2 *)(stk + xs + WAVE);
-          uint32_t *own = (uint32_t *)own2;
-          scr[lane] = make_uint4(ent.x, excl | (kk << 14) | (vcnt << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
-          const uint32_t g = L - k; /* guide symbols left */
-          const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
-          const uint32_t qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
-          for (uint32_t base = 0; base < R; base += 2u * WAVE) {
-            own2[lane] = make_uint2(0u, 0u);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (vgrp) {
-              if (excl >= base && excl < base + 2u * WAVE) own[excl - base] = lane + 1u;
-              if (excl < base && excl + vgrp > base) own[0] = lane + 1u;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const uint2 mk = own2[lane];
-            uint32_t o0 = mk.x, o1 = mk.y > o0 ? mk.y : o0;
-            uint32_t run = o1; /* inclusive max-scan over lanes, then shift to exclusive */
-#pragma unroll
-            for (int o = 1; o < WAVE; o <<= 1) {
-              const uint32_t up = __shfl_up(run, o);
-              if ((int)lane >= o && up > run) run = up;
-            }
-            uint32_t prev = __shfl_up(run, 1);
-            if (lane == 0) prev = 0u;
-            o0 = o0 > prev ? o0 : prev;
-            o1 = o1 > prev ? o1 : prev;
-            const uint32_t ow[2] = {o0, o1};
-            uint4 wq[2], dsc[2];
-            uint32_t row0[2], nrow[2], kkv[2];
-#pragma unroll
-            for (uint32_t jj = 0; jj < 2u; ++jj) { /* two independent 16-byte loads in flight */
-              const uint32_t grp = base + 2u * lane + jj;
-              const bool on = grp < R;
-              dsc[jj] = make_uint4(0u, 0u, 0u, 0u);
-              if (on) dsc[jj] = scr[ow[jj] - 1u];
-              const uint32_t r0 = (grp - (dsc[jj].y & 0x3FFFu)) << 2; /* first row of the group in its seed */
-              const uint32_t cnt = dsc[jj].y >> 17;
-              row0[jj] = dsc[jj].x + r0;
-              nrow[jj] = on ? (cnt - r0 < 4u ? cnt - r0 : 4u) : 0u;
-              kkv[jj] = (dsc[jj].y >> 14) & 7u;
-              wq[jj] = make_uint4(0u, 0u, 0u, 0u);
-              if (on) {
-                const uint32_t *cp = sd.ctx + row0[jj];
-                wq[jj] = make_uint4(cp[0], cp[1], cp[2], cp[3]);
-              }
-            }
-#pragma unroll
-            for (uint32_t jj = 0; jj < 2u; ++jj) {
-              const uint32_t wv[4] = {wq[jj].x, wq[jj].y, wq[jj].z, wq[jj].w};
-              uint32_t mmv[4];
-              bool gokv[4];
-              bool any = false;
-#pragma unroll
-              for (uint32_t r = 0; r < 4u; ++r) {
-                const uint32_t x = (wv[r] ^ qrem) & gmask;
-                mmv[r] = __popc((x | (x >> 1)) & 0x55555555u);
-                gokv[r] = r < nrow[jj] && kkv[jj] + mmv[r] <= m;
-                any = any || gokv[r];
-              }
-              if (!__ballot(any)) continue;
-              const uint64_t spath = (((uint64_t)dsc[jj].w << 32) | dsc[jj].z) & PATH_MASK;
-#pragma unroll
-              for (uint32_t r = 0; r < 4u; ++r) {
-                if (!__ballot(gokv[r])) continue;
-                const uint32_t w = wv[r];
-                for (uint32_t pj = 0; pj < npams; ++pj) {
-                  const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-                  bool ok = gokv[r];
-                  uint64_t ppath = 0;
-                  for (uint32_t u = 0; u < P; ++u) {
-                    const uint32_t pc = (pw >> (3u * u)) & 7u;
-                    const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-                    ok = ok && (pc == 4u || pc == tb);
-                    ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
-                  }
-                  if (!__ballot(ok)) continue;
-                  uint64_t gpath = 0;
-                  for (uint32_t v = 0; v < g; ++v) {
-                    const uint32_t qc = (qrem >> (2u * v)) & 3u;
-                    const uint32_t tb = (w >> (2u * v)) & 3u;
-                    const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-                    gpath |= (uint64_t)code << (50u - 2u * (k + v));
-                  }
-                  const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv[r]) << 56) | spath | gpath | ppath;
-                  route(ok, true, false, row0[jj] + r, row0[jj] + r, mmeta, 1u);
-                }
-              }
-            }
-          }
-        }
+        verify(false, (ver && !(a.dbg_skip & 1u)) ? ecnt : 0u, ent.x, kk, cmeta);
         /* advance the (j, sub, pos) cursor */
         spos += WAVE;
         if (spos >= span) {
@@ -496,7 +621,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) void k_search(gs_search_args a)
             do {
               ++sj;
               spow *= 3u;
-            } while (sj <= a.jmax && s_plan[8u + sj] == 0u);
+            } while (sj <= a.jmax && pl[8u + sj] == 0u);
             if (sj > a.jmax) seeds_left = false;
           }
         }
@@ -1145,6 +1270,114 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     v_rem = L + P - ix->pt_k;
   uint32_t *d_nlist = d_work + 2;
 
+  /* two-sided seeding (k_search): possible when set X (the first v_rem consumed guide symbols)
+   * lies inside the plan's positions, the PAM fits the table depth and both inverse suffix
+   * arrays exist */
+  bool bidir = false;
+  uint32_t tau = 0, plan2_off = 0, plan_total = 0;
+  uint32_t n_cand[2] = {0, 0};
+  const uint64_t *d_cand[2] = {nullptr, nullptr};
+  if (v_rem != 0 && mismatches >= 2 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
+      L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !getenv("GS_NO_BIDIR")) {
+    bidir = true;
+    tau = mismatches - 1 > 2 ? mismatches - 1 : 2;
+    /* filtered plan: position masks with fewer than tau bits inside X */
+    const uint32_t kp = ix->pt_k - 2;
+    uint32_t jmax = mismatches < kp ? mismatches : kp;
+    if (jmax > 7) jmax = 7;
+    const uint32_t xmask = (1u << v_rem) - 1u;
+    std::vector<uint32_t> plan2(16, 0u);
+    for (uint32_t j = 0; j <= 7; j++) {
+      plan2[j] = (uint32_t)plan2.size();
+      uint32_t cnt = 0;
+      if (j <= jmax)
+        for (uint32_t mk = 0; mk < (1u << kp); mk++)
+          if ((uint32_t)__builtin_popcount(mk) == j && (uint32_t)__builtin_popcount(mk & xmask) < tau) {
+            plan2.push_back(mk);
+            cnt++;
+          }
+      plan2[8 + j] = cnt;
+    }
+    plan2_off = ix->combo_off[jmax] + ix->combo_cnt[jmax]; /* right after the words of the full plan in use */
+    plan_total = plan2_off + (uint32_t)plan2.size();
+    if (plan2.size() > ix->combo_words) {
+      bidir = false;
+    } else {
+      GS_HIP(hipMemcpyAsync((uint32_t *)ix->d_combo + ix->combo_words, plan2.data(), 4 * plan2.size(),
+                            hipMemcpyHostToDevice, st));
+      GS_HIP(hipStreamSynchronize(st)); /* plan2 is a local */
+    }
+  }
+  if (bidir) {
+    /* windows where a literal 'N' of the genome lies under the PAM (index.hpp:139-149) and the
+     * guide part is plain A,C,G,T: only the walk finds those, so a guide that reaches one with
+     * >= tau substitutions in X is searched one-sided.  Window of strand s, left to right:
+     * P PAM symbols (last consumed first), then the guide symbols L-1 .. 0. */
+    std::vector<uint64_t> cand[2];
+    const uint32_t W = L + P;
+    const uint64_t len = ix->genome_length;
+    auto code = [](uint8_t c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
+    for (const gs_nrun &r : ix->nruns_text) {
+      auto at = [&](int64_t pos) -> uint8_t { /* forward text around the run */
+        if (pos < 0 || (uint64_t)pos >= len) return 0;
+        if ((uint64_t)pos < r.start) return r.start - pos <= GS_NRUN_FLANK ? r.left[GS_NRUN_FLANK - (r.start - pos)] : 0;
+        if ((uint64_t)pos < r.start + r.len) return 'N';
+        const uint64_t o = pos - (r.start + r.len);
+        return o < GS_NRUN_FLANK ? r.right[o] : 0;
+      };
+      const int64_t s0 = (int64_t)r.start, e0 = (int64_t)(r.start + r.len);
+      /* forward strand: the run's tail under the window's first P symbols */
+      for (int64_t i = e0 - (int64_t)P; i < e0; i++) {
+        if (i < 0 || (uint64_t)i + W > len) continue;
+        bool ok = true;
+        uint64_t q = 0;
+        for (uint32_t o = 0; o < W && ok; o++) {
+          const uint8_t c = at(i + o);
+          if (o < P) {
+            ok = c == 'N' || code(c) >= 0;
+          } else {
+            const int cc = code(c);
+            ok = cc >= 0;
+            if (ok) q |= (uint64_t)cc << (2u * (L - 1u - (o - P)));
+          }
+        }
+        if (ok) cand[0].push_back(q);
+      }
+      /* reverse strand: its window is the forward window read backwards and complemented, so the
+       * run's head lies under the forward window's last P symbols and guide symbol t sits at
+       * forward offset t, complemented */
+      for (int64_t j = s0 + 1 - (int64_t)W; j <= s0 + (int64_t)P - (int64_t)W; j++) {
+        if (j < 0 || (uint64_t)j + W > len) continue;
+        bool ok = true;
+        uint64_t q = 0;
+        for (uint32_t o = 0; o < W && ok; o++) {
+          const uint8_t c = at(j + o);
+          if (o >= L) {
+            ok = c == 'N' || code(c) >= 0;
+          } else {
+            const int cc = code(c);
+            ok = cc >= 0;
+            if (ok) q |= (uint64_t)(3 - cc) << (2u * o);
+          }
+        }
+        if (ok) cand[1].push_back(q);
+      }
+    }
+    n_cand[0] = (uint32_t)cand[0].size();
+    n_cand[1] = (uint32_t)cand[1].size();
+    if (n_cand[0] + n_cand[1]) {
+      if ((rc = gs_reserve(ix->w_cand, 8 * (size_t)(n_cand[0] + n_cand[1]))) != GS_OK) return rc;
+      uint64_t *dc = (uint64_t *)ix->w_cand.p;
+      if (n_cand[0]) GS_HIP(hipMemcpy(dc, cand[0].data(), 8 * (size_t)n_cand[0], hipMemcpyHostToDevice));
+      if (n_cand[1]) GS_HIP(hipMemcpy(dc + n_cand[0], cand[1].data(), 8 * (size_t)n_cand[1], hipMemcpyHostToDevice));
+      d_cand[0] = dc;
+      d_cand[1] = dc + n_cand[0];
+    }
+    if (getenv("GS_DEBUG"))
+      fprintf(stderr, "[gs] two-sided seeding: tau %u, X = first %u symbols, literal-N windows %u + %u\n", tau, v_rem,
+              n_cand[0], n_cand[1]);
+  }
+
   auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
                         uint32_t cap_, unsigned long long h_stats[2],
                         const uint64_t *slot_off = nullptr) -> gs_status {
@@ -1174,6 +1407,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       sa.v_max = v < 1 ? 1u : v > 1023 ? 1023u : (uint32_t)v;
     }
     sa.dbg_skip = getenv("GS_DBG_SKIP") ? (uint32_t)atol(getenv("GS_DBG_SKIP")) : 0u;
+    sa.bidir = 0;
+    sa.tau = 0;
+    sa.plan2_off = 0;
+    sa.plan2_src = 0;
+    sa.cand[0] = sa.cand[1] = nullptr;
+    sa.n_cand[0] = sa.n_cand[1] = 0;
     sa.plan_words = 0;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
@@ -1185,6 +1424,17 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       sa.jmax = jmax;
       sa.v_rem = v_rem;
       sa.plan_words = ix->combo_off[jmax] + ix->combo_cnt[jmax];
+      if (bidir) {
+        sa.bidir = 1;
+        sa.tau = tau;
+        sa.plan2_off = plan2_off;
+        sa.plan2_src = ix->combo_words;
+        sa.plan_words = plan_total;
+        sa.cand[0] = d_cand[0];
+        sa.cand[1] = d_cand[1];
+        sa.n_cand[0] = n_cand[0];
+        sa.n_cand[1] = n_cand[1];
+      }
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
      * their LDS stacks allow (8 at 20 KiB each = 32 waves per CU) */

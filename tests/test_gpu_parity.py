@@ -184,7 +184,7 @@ def test_match_slot_overflow_retry():
         oidx.close()
 
 
-@pytest.mark.parametrize("pk", ["8", "10", "12"])
+@pytest.mark.parametrize("pk", ["8", "10", "12", "13"])
 def test_context_verification_paths_bit_exact(toy, pk, monkeypatch):
     """force deep prefix tables so that intervals are resolved through ctx[] (the hg38-size
     code path) on small genomes: toy (literal-N PAM, boundaries, repeats) and a 2 Mbp genome"""
@@ -208,7 +208,7 @@ def test_context_verification_paths_bit_exact(toy, pk, monkeypatch):
         oidx.close()
 
 
-@pytest.mark.parametrize("pk", ["9", "11"])
+@pytest.mark.parametrize("pk", ["9", "11", "13"])
 def test_context_verification_medium_genome(pk, monkeypatch):
     monkeypatch.setenv("GS_PREFIX_K", pk)
     text, names, lengths = synth.make_genome([900_000, 700_000, 400_000], seed=5)
@@ -233,6 +233,58 @@ def test_context_verification_medium_genome(pk, monkeypatch):
             assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, (i, pk)
             total += len(exp)
         assert total > 200
+    finally:
+        gidx.close()
+        oidx.close()
+
+
+@pytest.mark.parametrize("pk,L", [("13", 20), ("11", 16), ("12", 18)])
+def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
+    """the table depth that makes k_search seed from both strands (sites with >= 2 substitutions
+    among the first consumed symbols come from the other strand's table): a genome with a repeat
+    family whose copies carry 0..4 substitutions anywhere, on both strands, some of them with a
+    literal N under the PAM's N (only the one-sided walk sees those), plus N runs"""
+    monkeypatch.setenv("GS_PREFIX_K", pk)
+    monkeypatch.setenv("GS_DEBUG", "1")
+    rng = np.random.default_rng(int(pk) * 100 + L)
+    text, names, lengths = synth.make_genome([150_000, 90_000], seed=int(pk), n_blocks=False)
+    text = text.copy()
+    fam = text[1000:1000 + L].copy()
+    text[1000 + L:1003 + L] = np.frombuffer(b"AGG", np.uint8)
+    for c in range(160):
+        site = fam.copy()
+        for j in rng.choice(L, size=int(rng.integers(0, 5)), replace=False):
+            site[j] = rng.choice([x for x in b"ACGT" if x != site[j]])
+        pam = bytes(rng.choice([b"AGG", b"CGG", b"TGG", b"GGG", b"NGG", b"NGG", b"AAG", b"NAG", b"ANG"]))
+        w = np.concatenate([site, np.frombuffer(pam, np.uint8)])
+        if c % 2:
+            w = synth.reverse_complement_bytes(w)
+        at = int(rng.integers(3000, text.shape[0] - 100))
+        text[at:at + L + 3] = w
+    for _ in range(6):
+        at = int(rng.integers(3000, text.shape[0] - 3000))
+        text[at:at + int(rng.integers(1, 60))] = ord("N")
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        sampled, _, _, _ = synth.sample_guides(text, 40, seed=3, L=L)
+        guides = [fam.tobytes().decode(), synth.reverse_complement_bytes(fam).tobytes().decode()]
+        guides += [sampled[i].tobytes().decode() for i in range(sampled.shape[0])]
+        seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (len(guides), 1))
+        for cfg in (dict(m=3), dict(m=2), dict(m=4), dict(m=3, alt=("NAG",)), dict(m=3, start=True),
+                    dict(m=5, alt=("NAG", "NGA"))):
+            m, alt, start = cfg["m"], cfg.get("alt", ()), cfg.get("start", False)
+            opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
+            capfd.readouterr()
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=start)
+            assert "two-sided seeding" in capfd.readouterr().err, cfg
+            total = 0
+            for i, g in enumerate(guides):
+                exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3, start)
+                assert gpu_hits_as_records(offsets, hits, i, g, 3, start) == exp, (i, cfg, pk)
+                total += len(exp)
+            assert total > 100 or start
     finally:
         gidx.close()
         oidx.close()
