@@ -178,6 +178,14 @@ def main():
                    "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes},
     }
 
+    if rank == 0:
+        # the device steps either side of the path (untimed side figures, never part of `value`):
+        # CFD/specificity of the last batch's hits and the candidate-guide scan of chromosome 1
+        try:
+            out["detail"]["next_rows"] = side_steps(torch, api, gidx, d_seqs, d_pams, batch, nb - 1, L, P, m,
+                                                    text, names, lengths)
+        except Exception as e:
+            print(f"[bench] side steps failed: {e!r}", file=sys.stderr)
     if args.verify:
         out["verify"] = verify_last_batch(torch, gidx, d_seqs, d_pams, batch, nb - 1, L, P, m, text, seqs)
     if rank == 0 and world == 1 and args.cpu_sample != 0:
@@ -215,6 +223,40 @@ def recorded_traffic(workload, batch, m):
         if rec["workload"] == workload and rec["batch"] == batch and rec["mismatches"] == m:
             return rec["fetch_bytes"] + rec["write_bytes"], rec["source"]
     return None, None
+
+
+def side_steps(torch, api, gidx, d_seqs, d_pams, batch, i, L, P, m, text, names, lengths):
+    """gs_score_device on the hits of one batch and gs_kmers_generate on the first chromosome, both
+    with inputs and outputs resident in HBM; wall-clock around the (synchronous) calls."""
+    s = d_seqs[i * batch:(i + 1) * batch]
+    p = d_pams[i * batch:(i + 1) * batch]
+    d_off, d_hits, st = gidx.enumerate_device(s.data_ptr(), batch, L, p.data_ptr(), P, mismatches=m)
+    gs = api.make_genome_structure(names, lengths)
+    d_cfd = torch.empty(max(1, st["n_hits"]), dtype=torch.float32, device="cuda")
+    d_spec = torch.empty(batch, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        gidx.score_device(gs, s.data_ptr(), batch, L, P, d_off, d_hits, d_cfd.data_ptr(), d_spec.data_ptr())
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    spec = d_spec.cpu().numpy()
+    out = {"score_ms": best * 1e3, "score_hits": int(st["n_hits"]),
+           "score_hits_per_s": st["n_hits"] / best if best > 0 else None,
+           "specificity_mean": float(spec.mean()), "specificity_min": float(spec.min())}
+    del d_cfd, d_spec
+    n0 = int(lengths[0])
+    d_chr = torch.from_numpy(text[:n0]).cuda()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    km = api.generate_kmers(None, "NGG", 20, device=torch.cuda.current_device(), chrm_device_ptr=d_chr.data_ptr(),
+                            chrm_len=n0)
+    dt = time.perf_counter() - t0
+    out.update({"kmers_chr": names[0], "kmers_bp": n0, "kmers_found": km.n, "kmers_ms": dt * 1e3,
+                "kmers_bp_per_s": n0 / dt})
+    km.close()
+    return out
 
 
 def verify_last_batch(torch, gidx, d_seqs, d_pams, batch, i, L, P, m, text, seqs):

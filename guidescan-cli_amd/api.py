@@ -124,6 +124,17 @@ def lib():
     L.gs_format_guide_ex.restype = i32
     L.gs_format_guide_ex.argtypes = [C.POINTER(GsGenomeStructure), C.POINTER(GsKmer), vp, u64, u32, u32,
                                      C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.gs_score_device.restype = i32
+    L.gs_score_device.argtypes = [vp, vp, u64, u32, u32, u32, C.c_int64, C.POINTER(GsGenomeStructure), vp, vp,
+                                  vp, vp, vp]
+    L.gs_score.restype = i32
+    L.gs_score.argtypes = [vp, vp, u64, u32, u32, u32, C.c_int64, C.POINTER(GsGenomeStructure), vp, vp, vp, vp]
+    L.gs_kmers_generate.restype = i32
+    L.gs_kmers_generate.argtypes = [i32, vp, u64, i32, C.c_char_p, u32, u32, vp, C.POINTER(vp)]
+    L.gs_kmers_get.restype = i32
+    L.gs_kmers_get.argtypes = [vp, i32, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp),
+                               C.POINTER(vp)]
+    L.gs_kmers_free.argtypes = [vp]
     L.gs_status_string.restype = C.c_char_p
     L.gs_status_string.argtypes = [i32]
     L.gs_version.restype = C.c_char_p
@@ -137,7 +148,8 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_index_meta", "gs_index_copy_sa", "gs_calculate_cfd", "gs_status_string", "gs_version",
            "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text",
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
-           "gs_format_guide_ex"]
+           "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
+           "gs_kmers_free"]
 
 
 def _check(rc):
@@ -175,6 +187,59 @@ def format_guide(gs, gid, sequence, pam, sense_positive, hits, mismatches, sam=F
     s = C.string_at(out, n.value).decode()
     lib().gs_free(out)
     return s
+
+
+class DeviceKmers:
+    """Candidate guides of one chromosome, resident in HBM (gs_kmers_generate).  `seqs_ptr` /
+    `pams_ptr` are raw device addresses in the layout GenomeIndex.enumerate_device takes."""
+
+    def __init__(self, handle, k, P):
+        self._h, self.k, self.P = handle, k, P
+        n, a, b, c, d = C.c_uint64(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().gs_kmers_get(handle, 1, C.byref(n), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        self.n = int(n.value)
+        self.seqs_ptr, self.pams_ptr, self.pos_ptr, self.sense_ptr = a.value, b.value, c.value, d.value
+
+    def to_host(self):
+        """-> (seqs uint8[n,k], pams uint8[n,P], positions uint32[n] 1-based, senses uint8[n])"""
+        n, a, b, c, d = C.c_uint64(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().gs_kmers_get(self._h, 0, C.byref(n), C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        m = int(n.value)
+        if m == 0:
+            return (np.empty((0, self.k), np.uint8), np.empty((0, self.P), np.uint8), np.empty(0, np.uint32),
+                    np.empty(0, np.uint8))
+        seqs = np.frombuffer(C.string_at(a, m * self.k), dtype=np.uint8).reshape(m, self.k).copy()
+        pams = np.frombuffer(C.string_at(b, m * self.P), dtype=np.uint8).reshape(m, self.P).copy()
+        pos = np.frombuffer(C.string_at(c, 4 * m), dtype=np.uint32).copy()
+        sense = np.frombuffer(C.string_at(d, m), dtype=np.uint8).copy()
+        return seqs, pams, pos, sense
+
+    def close(self):
+        if self._h:
+            lib().gs_kmers_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def generate_kmers(chrm, pam="NGG", k=20, start=False, device=0, chrm_device_ptr=None, chrm_len=None):
+    """scripts/generate_kmers.py:70-118 for ONE chromosome on the GPU -> DeviceKmers.
+    chrm: bytes / uint8 array (host), or pass chrm_device_ptr + chrm_len for text already in HBM."""
+    h = C.c_void_p()
+    flags = GS_FLAG_PAM_AT_START if start else 0
+    if chrm_device_ptr is not None:
+        _check(lib().gs_kmers_generate(device, chrm_device_ptr, int(chrm_len), 1, pam.encode(), k, flags, None,
+                                       C.byref(h)))
+    else:
+        arr = np.frombuffer(bytes(chrm), dtype=np.uint8) if not isinstance(chrm, np.ndarray) else \
+            np.ascontiguousarray(chrm, dtype=np.uint8)
+        _check(lib().gs_kmers_generate(device, arr.ctypes.data if arr.size else None, arr.shape[0], 0,
+                                       pam.encode(), k, flags, None, C.byref(h)))
+    return DeviceKmers(h, k, len(pam))
 
 
 def sdsl_extract_text(index_file) -> np.ndarray:
@@ -316,6 +381,28 @@ class GenomeIndex:
         finally:
             lib().gs_result_free(r)
         return offsets, hits, stats
+
+    def score(self, gs, seqs, P, offsets, hits, sam=False, start=False, max_off_targets=-1, want_cfd=True):
+        """CFD per hit and specificity per guide on the device (printer.hpp:98-113, 115-170, 251-297)
+        -> (cfd float32[n_hits] or None, specificity float32[n])"""
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        n, L = seqs.shape
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        cfd = np.empty(hits.shape[0], dtype=np.float32) if want_cfd else None
+        spec = np.empty(n, dtype=np.float32)
+        flags = (GS_TEXT_SAM if sam else 0) | (GS_FLAG_PAM_AT_START if start else 0)
+        _check(lib().gs_score(self._h, seqs.ctypes.data, n, L, P, flags, max_off_targets, C.byref(gs),
+                              offsets.ctypes.data, hits.ctypes.data if hits.shape[0] else None,
+                              cfd.ctypes.data if want_cfd and hits.shape[0] else None, spec.ctypes.data))
+        return cfd, spec
+
+    def score_device(self, gs, d_guides_ptr, n, L, P, d_offsets_ptr, d_hits_ptr, d_cfd_ptr, d_spec_ptr,
+                     sam=False, start=False, max_off_targets=-1, stream=None):
+        """device-resident variant: all pointers are raw device addresses"""
+        flags = (GS_TEXT_SAM if sam else 0) | (GS_FLAG_PAM_AT_START if start else 0)
+        _check(lib().gs_score_device(self._h, d_guides_ptr, n, L, P, flags, max_off_targets, C.byref(gs),
+                                     d_offsets_ptr, d_hits_ptr, stream, d_cfd_ptr, d_spec_ptr))
 
     def enumerate_bulges(self, seqs, pams, mismatches=3, rna_bulges=0, dna_bulges=0, alt_pams=(),
                          start=False):

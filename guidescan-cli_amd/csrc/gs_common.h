@@ -81,7 +81,9 @@ struct gs_index {
   /* per-handle workspace, grown on demand, reused across calls */
   gs_buffer w_guides, w_slots, w_counts, w_nmatch, w_nhits, w_offsets, w_hits, w_misc, w_blocksums,
       w_grec, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_a, w_h_b,
-      w_h_flag, w_h_pos, w_h_uq, w_h_uqg, w_h_cnt, w_h_scan, w_h_nh, w_h_first, w_h_tmp;
+      w_h_flag, w_h_pos, w_h_uq, w_h_uqg, w_h_cnt, w_h_scan, w_h_nh, w_h_first, w_h_tmp,
+      w_score, w_score_io, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
+      w_km_keys, w_km_keys2, w_km_tmp, w_km_text, w_km_out; /* gs_kmers.hip */
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   /* prefix-table seeding plan: position masks of every mismatch combination over the first
    * pt_k-2 query symbols, grouped by mismatch count j (gs_index.hip: build_seed_plan) */

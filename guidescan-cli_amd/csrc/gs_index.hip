@@ -645,7 +645,7 @@ extern "C" void gs_index_close(gs_index *ix) {
                        &ix->w_ovf_list, &ix->w_grec2, &ix->w_slots2, &ix->w_counts2, &ix->w_nmatch2,
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_a, &ix->w_h_b, &ix->w_h_flag, &ix->w_h_pos,
                        &ix->w_h_uq, &ix->w_h_uqg, &ix->w_h_cnt, &ix->w_h_scan, &ix->w_h_nh, &ix->w_h_first,
-                       &ix->w_h_tmp, &ix->w_cand};
+                       &ix->w_h_tmp, &ix->w_cand, &ix->w_score, &ix->w_score_io};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)

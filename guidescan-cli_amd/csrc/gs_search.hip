@@ -866,72 +866,77 @@ struct gs_order_args {
   uint32_t n, cap;
 };
 
-/* one wavefront per guide; dynamic LDS: 2*cap uint4 (records) + 2*cap uint4 (sorted) */
-__global__ __launch_bounds__(WAVE) void k_order(gs_order_args a) {
+/* One wavefront per guide at a time, ORDER_WAVES wavefronts per workgroup, guides dealt to the
+ * waves grid-stride (a launch of one single-wave workgroup per guide with one atomic each was
+ * latency bound: 12 ms per 1 M guides).  Dynamic LDS per wave: 2*cap uint4 (records) + 2*cap
+ * uint4 (sorted).  The loop body has no lane-conditional blocks (compiler pitfall):
+ * per-guide results are stored by all lanes to the same address. */
+#define ORDER_WAVES 4
+__global__ __launch_bounds__(WAVE *ORDER_WAVES) void k_order(gs_order_args a) {
   extern __shared__ uint4 s_mem[];
-  const uint32_t g = blockIdx.x;
   const uint32_t lane = lane_id();
-  if (g >= a.n) return;
+  const uint32_t wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
   const uint32_t cap = a.cap;
-  uint32_t c0 = a.counts[2 * g], c1 = a.counts[2 * g + 1];
-  if (c0 > cap || c1 > cap) {
-    /* more matches than slots: this guide is redone with larger slots (host side); the
-     * redo's totals are patched in before the scan */
-    if (lane == 0) {
+  uint4 *rec = s_mem + (size_t)wave * 4u * cap;
+  uint4 *srt = rec + 2u * cap;
+  uint32_t total_out = 0;
+  for (uint32_t g = blockIdx.x * nw + wave; g < a.n; g += gridDim.x * nw) {
+    const uint32_t c0 = a.counts[2 * g], c1 = a.counts[2 * g + 1];
+    if (c0 > cap || c1 > cap) {
+      /* more matches than slots: this guide is redone with larger slots (host side); the
+       * redo's totals are patched in before the scan */
       a.nmatch[g] = 0;
       a.nhits[g] = 0;
+      continue;
     }
-    return;
-  }
-  const uint32_t M = c0 + c1;
-  uint4 *rec = s_mem;
-  uint4 *srt = s_mem + 2 * cap;
-  uint4 *base = a.slots + (size_t)g * 2 * cap;
-  for (uint32_t i = lane; i < M; i += WAVE) rec[i] = i < c0 ? base[i] : base[cap + (i - c0)];
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  /* rank sort: ascending (key, original index) */
-  for (uint32_t i = lane; i < M; i += WAVE) {
-    const uint4 me = rec[i];
-    const uint64_t key = ((uint64_t)me.y << 32) | me.x;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < M; j++) {
-      const uint4 o = rec[j];
-      const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
-      rank += (ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < i)));
-    }
-    srt[rank] = me;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  /* dedupe equal sequences (std::set keeps the first), compact, count hits */
-  uint32_t n_out = 0, hits = 0;
-  for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
-    const uint32_t i = i0 + lane;
-    bool keep = false;
-    uint4 me = make_uint4(0, 0, 0, 0);
-    if (i < M) {
-      me = srt[i];
-      keep = true;
-      if (i > 0) {
-        const uint4 pv = srt[i - 1];
-        keep = !(pv.x == me.x && pv.y == me.y && pv.z == me.z); /* same sequence, same rows */
+    const uint32_t M = c0 + c1;
+    uint4 *base = a.slots + (size_t)g * 2 * cap;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (uint32_t i = lane; i < M; i += WAVE) rec[i] = i < c0 ? base[i] : base[cap + (i - c0)];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    /* rank sort: ascending (key, original index) */
+    for (uint32_t i = lane; i < M; i += WAVE) {
+      const uint4 me = rec[i];
+      const uint64_t key = ((uint64_t)me.y << 32) | me.x;
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < M; j++) {
+        const uint4 o = rec[j];
+        const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
+        rank += (ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < i)));
       }
+      srt[rank] = me;
     }
-    const uint64_t kb = __ballot(keep);
-    const uint32_t cnt = keep ? (me.w - me.z + 1u) : 0u;
-    if (keep) base[n_out + lanes_below(kb)] = make_uint4(me.x, me.y, me.z, cnt);
-    n_out += __popcll(kb);
-    /* wave sum of cnt */
-    uint32_t s = cnt;
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    hits += s;
-  }
-  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    /* dedupe equal sequences (std::set keeps the first), compact, count hits */
+    uint32_t n_out = 0, hits = 0;
+    for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
+      const uint32_t i = i0 + lane;
+      bool keep = false;
+      uint4 me = make_uint4(0, 0, 0, 0);
+      if (i < M) {
+        me = srt[i];
+        keep = true;
+        if (i > 0) {
+          const uint4 pv = srt[i - 1];
+          keep = !(pv.x == me.x && pv.y == me.y && pv.z == me.z); /* same sequence, same rows */
+        }
+      }
+      const uint64_t kb = __ballot(keep);
+      const uint32_t cnt = keep ? (me.w - me.z + 1u) : 0u;
+      if (keep) base[n_out + lanes_below(kb)] = make_uint4(me.x, me.y, me.z, cnt);
+      n_out += __popcll(kb);
+      /* wave sum of cnt */
+      uint32_t s = cnt;
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      hits += s;
+    }
     a.nmatch[g] = n_out;
     a.nhits[g] = hits;
-    if (n_out) atomicAdd(&a.stats[2], (unsigned long long)n_out);
+    total_out += n_out;
   }
+  if (lane == 0 && total_out) atomicAdd(&a.stats[2], (unsigned long long)total_out);
 }
 
 /* ---- exclusive scan of nhits (uint32) into uint64 offsets ------------------- */
@@ -1470,11 +1475,18 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     oa.stats = d_stats;
     oa.n = ng;
     oa.cap = cap_;
-    const size_t lds = sizeof(uint4) * 4 * (size_t)cap_;
+    /* four waves per workgroup while their sort buffers fit (4 KiB per wave at cap 64); eight
+     * workgroups per CU resident, twice that many launched so the tail balances */
+    const uint32_t ow = cap_ <= 128 ? ORDER_WAVES : 1u;
+    const size_t lds = sizeof(uint4) * 4 * (size_t)cap_ * ow;
     if (lds > 64 * 1024)
       GS_HIP(hipFuncSetAttribute((const void *)k_order, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)lds));
-    hipLaunchKernelGGL(k_order, dim3(ng), dim3(WAVE), lds, st, oa);
+    uint32_t grid = (ng + ow - 1) / ow;
+    const uint32_t gmax = (uint32_t)cus * 16u;
+    if (grid > gmax) grid = gmax;
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_order, dim3(grid), dim3(WAVE * ow), lds, st, oa);
     return GS_OK;
   };
   auto run_locate = [&](const uint4 *matches, const uint32_t *nmatch, const uint32_t *gmap, uint32_t ng,

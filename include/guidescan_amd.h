@@ -226,6 +226,47 @@ gs_status gs_format_guide_ex(const gs_genome_structure *gs, const gs_kmer *k, co
 /* CFD score of one hit (include/genomics/printer.hpp:98-113), float semantics preserved. */
 float gs_calculate_cfd(const char *sgrna, const char *match_sequence, const char *pam);
 
+/* ---- scoring on the device ---------------------------------- */
+
+/* CFD of every hit and specificity of every guide of an enumerate result, computed in HBM.
+ * Replaces calculate_cfd (printer.hpp:98-113) and the aggregation loops of get_csv_lines
+ * (printer.hpp:251-297; flags without GS_TEXT_SAM) or off_target_fields (printer.hpp:115-170;
+ * GS_TEXT_SAM): float sum of the CFDs in canonical hit order, hits dropped by resolve_absolute
+ * (structures.cxx:46-48) left out, --max-off-targets applied per distance exactly as each loop
+ * does, `+1` unless a perfect hit with an xGG PAM exists, specificity = 1/sum.  Bit-identical
+ * to gs_calculate_cfd / gs_format_guide.
+ *   d_guides  : n*L ASCII bytes as passed to gs_enumerate_device
+ *   d_offsets, d_hits : what gs_enumerate_device returned (or any CSR hit list in that layout)
+ *   flags     : GS_FLAG_PAM_AT_START as passed to gs_enumerate, GS_TEXT_SAM selects the SAM rule
+ *   d_cfd     : float[n_hits] or NULL;  d_specificity : float[n] */
+gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L, uint32_t P,
+                          uint32_t flags, int64_t max_off_targets, const gs_genome_structure *gs,
+                          const void *d_offsets, const void *d_hits, void *stream, void *d_cfd,
+                          void *d_specificity);
+/* Same with host arrays in and out (copies inside). */
+gs_status gs_score(gs_index *ix, const char *guides, uint64_t n, uint32_t L, uint32_t P, uint32_t flags,
+                   int64_t max_off_targets, const gs_genome_structure *gs, const uint64_t *offsets,
+                   const gs_hit *hits, float *cfd, float *specificity);
+
+/* ---- candidate-guide generation on the device ------------------- */
+
+typedef struct gs_kmers gs_kmers;
+
+/* Every PAM site of ONE chromosome (one FASTA record, any case) in the reference script's order.
+ * Replaces find_all_kmers / find_kmers (scripts/generate_kmers.py:70-118): + strand sites per
+ * concrete PAM expansion ('N' -> A,C,T,G), then - strand sites per reverse-complemented
+ * expansion, each in position order; protospacers with non-ACGT symbols or cut by the record's
+ * ends dropped.  `chr` is a host pointer, or a device pointer when chr_on_device != 0.
+ * flags: GS_FLAG_PAM_AT_START (--start). */
+gs_status gs_kmers_generate(int device, const uint8_t *chr, uint64_t chr_len, int chr_on_device,
+                            const char *pam, uint32_t k, uint32_t flags, void *stream, gs_kmers **out);
+/* n records: seqs n*k ASCII, pams n*P ASCII (the pattern), positions uint32 (1-based protospacer
+ * or PAM start as the script prints it), senses '+'/'-'.  on_device != 0: pointers into HBM, in
+ * the layout gs_enumerate_device takes; else host copies owned by the object. */
+gs_status gs_kmers_get(gs_kmers *km, int on_device, uint64_t *n, const void **seqs, const void **pams,
+                       const void **positions, const void **senses);
+void gs_kmers_free(gs_kmers *km);
+
 const char *gs_status_string(gs_status s);
 const char *gs_version(void);
 

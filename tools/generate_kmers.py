@@ -17,6 +17,8 @@ if __name__ == "__main__":
     ap.add_argument("--min-chr-length", type=int, default=0)
     ap.add_argument("--prefix", default="")
     ap.add_argument("--start", action="store_true")
+    ap.add_argument("--device", type=int, default=None,
+                    help="scan on this GPU (gs_kmers_generate) instead of the numpy restatement")
     a = ap.parse_args()
     kmers.write_kmers_csv(sys.stdout, kmers.fasta_records(a.fasta), a.pam, a.kmer_length, a.start, a.prefix,
-                          a.min_chr_length)
+                          a.min_chr_length, a.device)
