@@ -47,6 +47,9 @@ struct gs_strand_dev {
    * nearest first, 2 bits each (A,C,G,T = 0..3).  Lets a small interval at depth k be resolved
    * against the rest of the pattern with one 4-byte read per row instead of an Occ walk. */
   const uint32_t *ctx;
+  /* the nearest 8 of them (low 16 bits of ctx[r]): the first level of the verification reads
+   * these, 8 rows per 16-byte load, and only the few surviving rows touch ctx[] */
+  const uint16_t *ctx16;
   /* inverse suffix array (isa[sa[r]] = r), n entries, or nullptr: turns a text position found
    * through the other strand's index into this strand's row (two-sided seeding) */
   const uint32_t *isa;
@@ -54,7 +57,7 @@ struct gs_strand_dev {
 
 struct gs_strand {
   gs_strand_dev d{};
-  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ptab_rot = nullptr, *isa = nullptr;
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ctx16 = nullptr, *ptab_rot = nullptr, *isa = nullptr;
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;

