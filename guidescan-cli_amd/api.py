@@ -9,13 +9,15 @@ GS_ERR_DEVICE from the library, surfaced as GsError.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
 import numpy as np
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libgsamd.so"
+# GS_LIB_PATH: another build of the same library (kernel tuning experiments); default in-tree
+LIB_PATH = Path(os.environ.get("GS_LIB_PATH", str(PKG / "libgsamd.so")))
 
 GS_FLAG_PAM_AT_START = 1
 GS_FLAG_FAITHFUL_WALK = 2

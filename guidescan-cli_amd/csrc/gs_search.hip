@@ -151,6 +151,31 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t ballot) {
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
 }
 
+/* ---- wave64 inclusive scans in seven DPP instructions (row_shr 1,2,3 of the input, row_shr 4
+ * and 8 of the partial result under bank masks, then row_bcast 15 and 31 under row masks):
+ * a __shfl_up ladder costs six LDS-crossbar round trips and about thirty instructions ---- */
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) { /* lanes without a source read 0 */
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t x) {
+  uint32_t v = x + dpp_or_zero<0x111>(x) + dpp_or_zero<0x112>(x) + dpp_or_zero<0x113>(x);
+  v += dpp_or_zero<0x114, 0xF, 0xE>(v);
+  v += dpp_or_zero<0x118, 0xF, 0xC>(v);
+  v += dpp_or_zero<0x142, 0xA>(v);
+  v += dpp_or_zero<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ uint32_t umax32(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
+  uint32_t v = umax32(umax32(x, dpp_or_zero<0x111>(x)), umax32(dpp_or_zero<0x112>(x), dpp_or_zero<0x113>(x)));
+  v = umax32(v, dpp_or_zero<0x114, 0xF, 0xE>(v));
+  v = umax32(v, dpp_or_zero<0x118, 0xF, 0xC>(v));
+  v = umax32(v, dpp_or_zero<0x142, 0xA>(v));
+  v = umax32(v, dpp_or_zero<0x143, 0xC>(v));
+  return v;
+}
+
 /* ---- search: one wavefront per (guide, strand) ----------------------------
  * Two LDS stacks per wave share one 8 KiB array: X (grows up) holds "single-symbol" nodes -
  * mismatch budget spent (index.hpp:230 returns before the substitution loop) or a fixed PAM
@@ -290,12 +315,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       if (lane < take) mine = dsrc[lane];
       const uint32_t vcnt = mine.y >> 17;
       const uint32_t vgrp = (vcnt + 7u) >> 3;
-      uint32_t incl = vgrp;
-#pragma unroll
-      for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o);
-        if ((int)lane >= o) incl += up;
-      }
+      const uint32_t incl = wave_incl_sum(vgrp);
       const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
       if (!R) return;
       const uint32_t excl = incl - vgrp;
@@ -328,14 +348,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint2 mk = own2[lane];
         uint32_t o0 = mk.x, o1 = mk.y > o0 ? mk.y : o0;
-        uint32_t run = o1; /* inclusive max-scan over lanes, then shift to exclusive */
-#pragma unroll
-        for (int o = 1; o < WAVE; o <<= 1) {
-          const uint32_t up = __shfl_up(run, o);
-          if ((int)lane >= o && up > run) run = up;
-        }
-        uint32_t prev = __shfl_up(run, 1);
-        if (lane == 0) prev = 0u;
+        const uint32_t run = wave_incl_max(o1); /* inclusive max-scan over lanes, then shift to exclusive */
+        const uint32_t prev = dpp_or_zero<0x138>(run); /* wave_shr:1, lane 0 reads 0 */
         o0 = o0 > prev ? o0 : prev;
         o1 = o1 > prev ? o1 : prev;
         const uint32_t ow[2] = {o0, o1};
