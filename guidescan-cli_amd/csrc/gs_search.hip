@@ -72,7 +72,13 @@ struct gs_search_args {
   uint32_t plan2_src;          /* and inside combo[] */
   const uint64_t *cand[2];     /* per strand: windows holding a literal N under the PAM (guide part, 2 bits/symbol) */
   uint32_t n_cand[2];
+  /* second class of the other strand's seeds: sites with exactly m-1
+   * substitutions in O (the guide symbols both tables cover) and none in the rest of the other
+   * strand's k-mer.  bcomb_off: word offset (LDS plan) of the nbc position masks with m-1 bits over
+   * the O symbols (bit y = guide symbol L-1-y); bpow = 3^(m-1) digit combinations each. */
+  uint32_t bnew, bcomb_off, nbc, bpow;
 };
+#define DSC_FLAG 27u /* descriptor.y bit: the seed's lower bound is the alternate one (see verify) */
 
 #define VERIFY_MAX_DEFAULT 256u
 
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       uint4 mine = make_uint4(0u, 0u, 0u, 0u);
       if (lane < take) mine = dsrc[lane];
-      const uint32_t vcnt = mine.y >> 17;
+      const uint32_t vcnt = (mine.y >> 17) & 0x3FFu;
       const uint32_t vgrp = (vcnt + 7u) >> 3;
       const uint32_t incl = wave_incl_sum(vgrp);
       const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
@@ -334,9 +340,15 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       const uint32_t g8 = g < 8u ? g : 8u;
       const uint32_t gm8 = (1u << (2u * g8)) - 1u;
       const uint32_t q2x = (qrem & gm8) * 0x00010001u, gm2x = gm8 * 0x00010001u;
-      /* modeB rows need >= tau substitutions among all g symbols: at least tau - (g - g8) of them
-       * show in the first g8 */
-      const uint32_t lowb = (modeB && a.tau > g - g8) ? a.tau - (g - g8) : 0u;
+      /* lower bound on the substitutions among the g remaining guide symbols, per seed:
+       *   this strand's seeds: none; flagged (no substitution in X, m-1 in O): >= 1, because the
+       *     sites without one belong to the other strand's second class;
+       *   other strand's seeds: >= tau (fewer belong to this strand's seeds); flagged (second
+       *     class): none.
+       * The first level sees g8 of the g symbols: at least bound - (g - g8) of them show there. */
+      const uint32_t lo_plain = modeB ? a.tau : 0u, lo_flag = modeB ? 0u : 1u;
+      const uint32_t lo8_plain = lo_plain > g - g8 ? lo_plain - (g - g8) : 0u;
+      const uint32_t lo8_flag = lo_flag > g - g8 ? lo_flag - (g - g8) : 0u;
       for (uint32_t base = 0; base < R; base += 2u * WAVE) {
         own2[lane] = make_uint2(0u, 0u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -354,7 +366,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         o1 = o1 > prev ? o1 : prev;
         const uint32_t ow[2] = {o0, o1};
         uint4 wq[2], dsc[2];
-        uint32_t row0[2], nrow[2], kkv[2];
+        uint32_t row0[2], nrow[2], kkv[2], lo8[2];
 #pragma unroll
         for (uint32_t jj = 0; jj < 2u; ++jj) { /* two independent 16-byte loads in flight */
           const uint32_t grp = base + 2u * lane + jj;
@@ -362,10 +374,11 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           dsc[jj] = make_uint4(0u, 0u, 0u, 0u);
           if (on) dsc[jj] = dsrc[ow[jj] - 1u];
           const uint32_t r0 = (grp - (dsc[jj].y & 0x3FFFu)) << 3; /* first row of the group in its seed */
-          const uint32_t cnt = dsc[jj].y >> 17;
+          const uint32_t cnt = (dsc[jj].y >> 17) & 0x3FFu;
           row0[jj] = dsc[jj].x + r0;
           nrow[jj] = on ? (cnt - r0 < 8u ? cnt - r0 : 8u) : 0u;
           kkv[jj] = (dsc[jj].y >> 14) & 7u;
+          lo8[jj] = ((dsc[jj].y >> DSC_FLAG) & 1u) ? lo8_flag : lo8_plain;
           wq[jj] = make_uint4(0u, 0u, 0u, 0u);
           if (on) wq[jj] = load16_a2(sv.ctx16 + row0[jj]);
         }
@@ -378,8 +391,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
             const uint32_t x = (wv[h] ^ q2x) & gm2x;
             const uint32_t y = (x | (x >> 1)) & 0x55555555u;
             const uint32_t m0 = __popc(y & 0xFFFFu), m1 = __popc(y >> 16);
-            const bool ok0 = 2u * h < nrow[jj] && kkv[jj] + m0 <= m && m0 >= lowb;
-            const bool ok1 = 2u * h + 1u < nrow[jj] && kkv[jj] + m1 <= m && m1 >= lowb;
+            const bool ok0 = 2u * h < nrow[jj] && kkv[jj] + m0 <= m && m0 >= lo8[jj];
+            const bool ok1 = 2u * h + 1u < nrow[jj] && kkv[jj] + m1 <= m && m1 >= lo8[jj];
             cm |= (ok0 ? 1u : 0u) << (8u * jj + 2u * h);
             cm |= (ok1 ? 1u : 0u) << (8u * jj + 2u * h + 1u);
           }
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           if (has) w = sv.ctx[row];
           const uint32_t xf = (w ^ qrem) & gmask;
           const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
-          const bool gok = has && kv + mmv <= m && (!modeB || mmv >= a.tau);
+          const bool gok = has && kv + mmv <= m && mmv >= (((dd.y >> DSC_FLAG) & 1u) ? lo_flag : lo_plain);
           if (!__ballot(gok)) continue;
           const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PATH_MASK;
           if (modeB) {
@@ -487,6 +500,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
      * cannot see - a flagged or oversized interval, a literal N under the PAM, a PAM pattern
      * with more than two N - makes the item fall back to one-sided seeding with the full plan. */
     const uint32_t *pl = s_plan;
+    bool twosided = false; /* the other strand took its classes: the filtered plan is in use */
     if (a.bidir && seeding) {
       bool fallback = false;
       const gs_strand_dev &sb = a.sd[strand ^ 1u];
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           const uint64_t x = a.cand[strand][c0 + lane] ^ gr_q;
           const uint64_t nz = (x | (x >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
           const uint32_t tot = __popcll(nz), jx = __popcll(nz & ((1ull << (2u * sx)) - 1ull));
-          reach = tot <= m && jx >= a.tau;
+          reach = tot <= m && (jx >= a.tau || a.bnew != 0u);
         }
         if (__ballot(reach)) fallback = true;
       }
@@ -527,39 +541,79 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           }
           for (uint32_t y = 0; y < nY; ++y)
             pidxb |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (k - 1u - P - y));
-          /* lane 0: no substitution; lane 1+3y+d: digit d at guide symbol L-1-y */
-          const bool act = lane < 1u + 3u * nY;
-          const uint32_t v = act ? lane : 0u;
-          const uint32_t y = v ? (v - 1u) / 3u : 0u, d = v ? (v - 1u) - 3u * y : 0u;
-          uint32_t pidx = pidxb;
-          uint64_t path = ppath;
-          if (v) {
-            const uint32_t t = L - 1u - y;
-            const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
-            const uint32_t sym = (qc + 1u + d) & 3u;
-            path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
-            pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
+          /* lane space of one expansion: 0 = no substitution; 1+3y+d = digit d at guide symbol
+           * L-1-y (first class); then the second class: combination ci of m-1 symbols of O x
+           * their 3^(m-1) digits, the digit of the last consumed symbol running fastest, so the
+           * three lanes that differ only there share one 64-byte line of that step's rotated
+           * copy (or of the plain table when it is the k-mer's last step) */
+          const uint32_t n1 = 1u + 3u * nY;
+          const uint32_t nlanes = n1 + (a.bnew ? a.nbc * a.bpow : 0u);
+          for (uint32_t c0 = 0; c0 < nlanes && !fallback; c0 += WAVE) {
+            const uint32_t idx = c0 + lane;
+            const bool act = idx < nlanes;
+            uint32_t pidx = pidxb;
+            uint64_t path = ppath;
+            uint32_t kk = 0u, slast = 0xFFFFFFFFu, flag = 0u;
+            auto subst = [&](uint32_t y, uint32_t d) __attribute__((always_inline)) {
+              const uint32_t t = L - 1u - y;
+              const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+              const uint32_t sym = (qc + 1u + d) & 3u;
+              path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
+              pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
+            };
+            if (act && idx >= 1u && idx < n1) {
+              const uint32_t y = (idx - 1u) / 3u, d = (idx - 1u) - 3u * y;
+              subst(y, d);
+              kk = 1u;
+              slast = P + y;
+            } else if (act && idx >= n1) {
+              const uint32_t i2 = idx - n1;
+              const uint32_t ci = i2 / a.bpow;
+              uint32_t dg = i2 - ci * a.bpow;
+              uint32_t mk = s_plan[a.bcomb_off + ci];
+              slast = P + (31u - (uint32_t)__clz((int)mk));
+              for (uint32_t i = 0; i + 1u < m; ++i) {
+                const uint32_t y = 31u - (uint32_t)__clz((int)mk);
+                mk &= ~(1u << y);
+                const uint32_t d = dg % 3u;
+                dg /= 3u;
+                subst(y, d);
+              }
+              kk = m - 1u;
+              flag = 1u;
+            }
+            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+            if (act) {
+              if (slast <= k - 2u && sb.ptab_rot != nullptr) {
+                const uint32_t sh = 2u * (k - 1u - slast);
+                const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
+                                      ((pidx >> sh) & 3u);
+                ent = sb.ptab_rot[((size_t)slast << (2u * k)) + ridx];
+              } else {
+                ent = sb.ptab[pidx];
+              }
+            }
+            const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
+            const bool live = act && ecnt != 0u;
+            if (__ballot(live && ((ent.y >> 31) != 0u || ecnt > a.v_max))) {
+              fallback = true;
+              break;
+            }
+            const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
+            /* the queue is empty here (one-sided seeding has not started) */
+            vq[lane] = make_uint4(ent.x, (kk << 14) | ((live ? ecnt : 0u) << 17) | (flag << DSC_FLAG), (uint32_t)cmeta,
+                                  (uint32_t)(cmeta >> 32));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            verify(true, WAVE, vq);
           }
-          uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-          if (act) ent = sb.ptab[pidx];
-          const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
-          const uint32_t kk = v ? 1u : 0u;
-          const bool live = act && ecnt != 0u;
-          if (__ballot(live && ((ent.y >> 31) != 0u || ecnt > a.v_max))) {
-            fallback = true;
-            break;
-          }
-          const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
-          /* the queue is empty here (one-sided seeding has not started) */
-          vq[lane] = make_uint4(ent.x, (kk << 14) | ((live ? ecnt : 0u) << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          verify(true, WAVE, vq);
         }
       }
-      if (fallback)
+      if (fallback) {
         n_match = 0; /* whatever the other strand found so far is found again below */
-      else
+      } else {
         pl = s_plan + a.plan2_off;
+        twosided = true;
+      }
     }
 
     for (;;) {
@@ -587,6 +641,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
         const uint32_t u = l - ci * (rot ? 3u : E);
         uint32_t mask = act ? pl[pl[sj] + ci] : 0u;
+        /* substitutions inside X (the first v_rem consumed symbols); the others lie in O */
+        const uint32_t ax = __popc(mask & ((1u << a.v_rem) - 1u));
         uint32_t pidx = pidx0;
         uint64_t path = 0;
         uint32_t sub = ssub;
@@ -625,6 +681,14 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         }
         const uint32_t mm = (s2 != q2) + (s1 != q1);
         pidx ^= ((q2 ^ s2) << 2) | (q1 ^ s1);
+        /* with the other strand's second class active, sites with m-1 substitutions in O and none
+         * in the symbols after the table depth are found there: a seed with one more in X can
+         * reach nothing else and is dropped before its table read; a seed with none in X keeps
+         * only the rows with at least one substitution further on (DSC_FLAG) */
+        const bool two = twosided && a.bnew != 0u;
+        const uint32_t otot = sj - ax + mm;
+        if (two && ax == 1u && otot + 1u == m) act = false;
+        const uint32_t lowf = (two && ax == 0u && otot + 1u == m) ? 1u : 0u;
         uint4 ent = make_uint4(0u, 0u, 0u, 0u);
         if (act) {
           if (rot) {
@@ -657,6 +721,18 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         /* small, exception-free intervals are resolved right here against ctx[]; the rest
          * continue as ordinary nodes (k < L: never terminal) */
         const bool ver = live && a.v_rem != 0u && (ent.y >> 31) == 0u && ecnt <= a.v_max;
+        if (two && __ballot(lowf != 0u && live && !ver)) {
+          /* such a seed would have to be walked, and the walk cannot tell its rows apart from
+           * the ones the other strand already reported: redo the item one-sided, full plan */
+          n_match = 0;
+          xs = gs = 0;
+          qn = 0;
+          sj = ssub = spos = 0;
+          spow = 1;
+          pl = s_plan;
+          twosided = false;
+          continue;
+        }
         route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
         /* The verifying seeds wait in the queue until a pass can be filled: about a quarter of
          * a step's 64 lanes survive the context mask, and a pass (prefix sums, owner lookup,
@@ -667,7 +743,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           if (bq) {
             if (push)
               vq[qn + lanes_below(bq)] =
-                  make_uint4(ent.x, (kk << 14) | (ecnt << 17), (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+                  make_uint4(ent.x, (kk << 14) | (ecnt << 17) | (lowf << DSC_FLAG), (uint32_t)cmeta,
+                             (uint32_t)(cmeta >> 32));
             qn += __popcll(bq);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           }
@@ -1345,8 +1422,9 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   /* two-sided seeding (k_search): possible when set X (the first v_rem consumed guide symbols)
    * lies inside the plan's positions, the PAM fits the table depth and both inverse suffix
    * arrays exist */
-  bool bidir = false;
-  uint32_t tau = 0, plan2_off = 0, plan_total = 0;
+  bool bidir = false, bnew = false;
+  uint32_t tau = 0, plan2_off = 0, plan_total = 0, bpow = 0, bcomb_off = 0;
+  std::vector<uint32_t> bcomb;
   uint32_t n_cand[2] = {0, 0};
   const uint64_t *d_cand[2] = {nullptr, nullptr};
   if (v_rem != 0 && mismatches >= 2 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
@@ -1358,18 +1436,40 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     uint32_t jmax = mismatches < kp ? mismatches : kp;
     if (jmax > 7) jmax = 7;
     const uint32_t xmask = (1u << v_rem) - 1u;
+    /* second class of the other strand (k_search): m-1 substitutions in O = the guide symbols
+     * both tables cover (consumption steps v_rem .. k-1), none after the table depth */
+    const uint32_t osz = ix->pt_k - v_rem; /* |O| = 2k - L - P */
+    if (mismatches - 1 <= osz && !getenv("GS_NO_BNEW")) {
+      uint32_t pw = 1;
+      for (uint32_t i = 0; i + 1 < mismatches; i++) pw *= 3;
+      /* bit y = guide symbol L-1-y; O = y in [L-k, k-P-1] */
+      const uint32_t ylo = L - ix->pt_k;
+      for (uint32_t mk = 0; mk < (1u << osz); mk++)
+        if ((uint32_t)__builtin_popcount(mk) == mismatches - 1) bcomb.push_back(mk << ylo);
+      if (bcomb.size() * (size_t)pw <= 4096) {
+        bnew = true;
+        bpow = pw;
+      } else {
+        bcomb.clear();
+      }
+    }
     std::vector<uint32_t> plan2(16, 0u);
     for (uint32_t j = 0; j <= 7; j++) {
       plan2[j] = (uint32_t)plan2.size();
       uint32_t cnt = 0;
       if (j <= jmax)
-        for (uint32_t mk = 0; mk < (1u << kp); mk++)
-          if ((uint32_t)__builtin_popcount(mk) == j && (uint32_t)__builtin_popcount(mk & xmask) < tau) {
-            plan2.push_back(mk);
-            cnt++;
-          }
+        for (uint32_t mk = 0; mk < (1u << kp); mk++) {
+          const uint32_t ax = (uint32_t)__builtin_popcount(mk & xmask);
+          if ((uint32_t)__builtin_popcount(mk) != j || ax >= tau) continue;
+          /* one substitution in X and m-1 in O: the whole variant belongs to the second class */
+          if (bnew && ax == 1 && j - ax == mismatches - 1) continue;
+          plan2.push_back(mk);
+          cnt++;
+        }
       plan2[8 + j] = cnt;
     }
+    bcomb_off = (uint32_t)plan2.size();
+    plan2.insert(plan2.end(), bcomb.begin(), bcomb.end());
     plan2_off = ix->combo_off[jmax] + ix->combo_cnt[jmax]; /* right after the words of the full plan in use */
     plan_total = plan2_off + (uint32_t)plan2.size();
     if (plan2.size() > ix->combo_words) {
@@ -1485,6 +1585,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.plan2_src = 0;
     sa.cand[0] = sa.cand[1] = nullptr;
     sa.n_cand[0] = sa.n_cand[1] = 0;
+    sa.bnew = sa.bcomb_off = sa.nbc = sa.bpow = 0;
     sa.plan_words = 0;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
@@ -1506,6 +1607,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
         sa.cand[1] = d_cand[1];
         sa.n_cand[0] = n_cand[0];
         sa.n_cand[1] = n_cand[1];
+        if (bnew) {
+          sa.bnew = 1;
+          sa.bcomb_off = plan2_off + bcomb_off;
+          sa.nbc = (uint32_t)bcomb.size();
+          sa.bpow = bpow;
+        }
       }
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
