@@ -540,7 +540,9 @@ static gs_status build_seed_plan(gs_index *ix, uint32_t k) {
   ix->pt_k = k;
   if (!k) return GS_OK;
   const uint32_t kp = k - 2;
-  std::vector<uint32_t> masks(16, 0u); /* [0..7] offsets, [8..15] counts, then the masks */
+  /* header (k_search, gs_search_args::combo): [c] offset, [32+c] count, [64+c] meta of class c; the
+   * full plan has one class per substitution count j, extension budget "all that is left" */
+  std::vector<uint32_t> masks(96, 0u);
   for (uint32_t j = 0; j <= 7; j++) {
     masks[j] = (uint32_t)masks.size();
     uint32_t cnt = 0;
@@ -550,13 +552,14 @@ static gs_status build_seed_plan(gs_index *ix, uint32_t k) {
           masks.push_back(m);
           cnt++;
         }
-    masks[8 + j] = cnt;
+    masks[32 + j] = cnt;
+    masks[64 + j] = j | (15u << 4);
     ix->combo_off[j] = masks[j];
     ix->combo_cnt[j] = cnt;
   }
   /* room for a second, filtered plan written per batch (two-sided seeding) */
   ix->combo_words = (uint32_t)masks.size();
-  GS_HIP(hipMalloc(&ix->d_combo, 8 * masks.size()));
+  GS_HIP(hipMalloc(&ix->d_combo, 8 * masks.size() + 1024));
   GS_HIP(hipMemcpy(ix->d_combo, masks.data(), 4 * masks.size(), hipMemcpyHostToDevice));
   return GS_OK;
 }

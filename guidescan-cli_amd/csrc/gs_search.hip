@@ -53,12 +53,15 @@ struct gs_search_args {
   unsigned long long *stats; /* [0] n_ext, [1] overflow items */
   uint32_t n_items, L, P, m, cap;
   /* prefix-table seeding (pt_k = 0: walk from the root) */
-  /* seeding plan in device memory: [0..7] offset of the masks with j bits, [8..15] their
-   * count C(pt_k-2, j), then the position masks over the first pt_k-2 steps */
+  /* seeding plan in device memory: up to GS_PLAN_CLASSES classes of position masks over the
+   * first pt_k-2 steps.  Header: [c] offset of class c's masks, [32+c] their count, [64+c] meta =
+   * j | eb << 4: j = substitutions per mask, eb = how many more the two-symbol extension may
+   * add (15: the whole remaining budget m-j).  The full plan has one class per j; the filtered
+   * plan of two-sided seeding splits them by the number of substitutions inside X. */
   const uint32_t *combo;
   uint32_t plan_words; /* words of the plan the kernel needs (copied to LDS per workgroup) */
   uint32_t pt_k; /* table depth k; seeds are the depth-k nodes */
-  uint32_t jmax; /* min(m, pt_k-2, 7) */
+  uint32_t ncls, ncls2; /* classes of the full and of the filtered plan */
   /* context verification: L+P-pt_k (<= 16) symbols remain after the table depth; 0 = disabled */
   uint32_t v_rem;
   uint32_t v_max; /* intervals up to this many rows are resolved row by row from ctx[] (<= 1023) */
@@ -81,6 +84,8 @@ struct gs_search_args {
 #define DSC_FLAG 27u /* descriptor.y bit: the seed's lower bound is the alternate one (see verify) */
 
 #define VERIFY_MAX_DEFAULT 256u
+#define GS_PLAN_CLASSES 32u
+#define GS_PLAN_HEADER (3u * GS_PLAN_CLASSES)
 
 #define SEED_LOW_MAX 128 /* refill the stacks from the prefix table when they hold this few nodes */
 
@@ -461,7 +466,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
 
     /* seeding state (all wave-uniform): mismatch count j of the prefix variants being
      * enumerated, substitution index sub in [0,3^j), position in the (combination, entry) space */
-    uint32_t sj = 0, ssub = 0, spos = 0, spow = 1;
+    uint32_t sc = 0, ssub = 0, spos = 0; /* class, digit combination, lane position */
+    uint32_t ncls = a.ncls;
     uint32_t qn = 0; /* seeds waiting in the verification queue */
     const bool seeding = a.pt_k != 0;
     bool seeds_left = seeding;
@@ -612,6 +618,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         n_match = 0; /* whatever the other strand found so far is found again below */
       } else {
         pl = s_plan + a.plan2_off;
+        ncls = a.ncls2;
         twosided = true;
       }
     }
@@ -625,7 +632,11 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
          * j <= m substitutions and, one table entry per lane, the two-symbol extensions the
          * remaining budget allows.  Same node set at depth k as the walk (index.hpp:182-248). */
         const uint32_t k = a.pt_k, kp = k - 2u;
-        const uint32_t bud = m - sj;
+        const uint32_t cmeta_w = pl[2u * GS_PLAN_CLASSES + sc];
+        const uint32_t sj = cmeta_w & 15u;
+        const uint32_t bud = (cmeta_w >> 4) == 15u ? m - sj : (cmeta_w >> 4); /* extension budget */
+        uint32_t spow = 1u;
+        for (uint32_t i = 0; i < sj; ++i) spow *= 3u;
         /* budget-0 variants with >= 1 substitution use the rotated table of their LAST
          * substituted step: the three substitutions there sit in neighbouring lanes and in one
          * 64-byte line, so three variants cost one request.  Budget-1 variants take 8 lanes:
@@ -635,12 +646,12 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         const bool rot = sd.ptab_rot != nullptr && bud == 0u && sj >= 1u;
         const bool rot2 = sd.ptab_rot != nullptr && bud == 1u;
         const uint32_t E = bud >= 2u ? 16u : bud == 1u ? (rot2 ? 8u : 7u) : 1u;
-        const uint32_t span = pl[8u + sj] * (rot ? 3u : E);
+        const uint32_t span = pl[GS_PLAN_CLASSES + sc] * (rot ? 3u : E);
         const uint32_t l = spos + lane;
         bool act = l < span;
         const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
         const uint32_t u = l - ci * (rot ? 3u : E);
-        uint32_t mask = act ? pl[pl[sj] + ci] : 0u;
+        uint32_t mask = act ? pl[pl[sc] + ci] : 0u;
         /* substitutions inside X (the first v_rem consumed symbols); the others lie in O */
         const uint32_t ax = __popc(mask & ((1u << a.v_rem) - 1u));
         uint32_t pidx = pidx0;
@@ -727,9 +738,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           n_match = 0;
           xs = gs = 0;
           qn = 0;
-          sj = ssub = spos = 0;
-          spow = 1;
+          sc = ssub = spos = 0;
           pl = s_plan;
+          ncls = a.ncls;
           twosided = false;
           continue;
         }
@@ -756,10 +767,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           if (++ssub >= (rot ? spow / 3u : spow)) {
             ssub = 0;
             do {
-              ++sj;
-              spow *= 3u;
-            } while (sj <= a.jmax && pl[8u + sj] == 0u);
-            if (sj > a.jmax) seeds_left = false;
+              ++sc;
+            } while (sc < ncls && pl[GS_PLAN_CLASSES + sc] == 0u);
+            if (sc >= ncls) seeds_left = false;
           }
         }
         /* drain from the tail: the last `take` descriptors, no shifting; everything once the
@@ -1423,7 +1433,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
    * lies inside the plan's positions, the PAM fits the table depth and both inverse suffix
    * arrays exist */
   bool bidir = false, bnew = false;
-  uint32_t tau = 0, plan2_off = 0, plan_total = 0, bpow = 0, bcomb_off = 0;
+  uint32_t tau = 0, plan2_off = 0, plan_total = 0, bpow = 0, bcomb_off = 0, ncls2 = 0;
   std::vector<uint32_t> bcomb;
   uint32_t n_cand[2] = {0, 0};
   const uint64_t *d_cand[2] = {nullptr, nullptr};
@@ -1453,26 +1463,37 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
         bcomb.clear();
       }
     }
-    std::vector<uint32_t> plan2(16, 0u);
-    for (uint32_t j = 0; j <= 7; j++) {
-      plan2[j] = (uint32_t)plan2.size();
-      uint32_t cnt = 0;
-      if (j <= jmax)
+    /* filtered plan: position masks with fewer than tau bits inside X, one class per (j, bits
+     * inside X = 0 / 1 / more).  With the second class active, a variant with one substitution in
+     * X may add at most m-2 in O (m-1 belong to the other strand), which caps its extension
+     * budget at m-1-j: the class shrinks from 16 to 8 lanes or from 8 lanes to the three
+     * neighbours of one rotated-table line, or disappears */
+    std::vector<uint32_t> plan2(96, 0u);
+    for (uint32_t j = 0; j <= jmax; j++)
+      for (uint32_t g = 0; g < 3; g++) {
+        if (ncls2 >= 32) break;
+        int eb = 15;
+        if (bnew && g == 1) eb = (int)mismatches - 1 - (int)j;
+        if (eb < 0) continue;
+        const uint32_t c = ncls2;
+        plan2[c] = (uint32_t)plan2.size();
+        uint32_t cnt = 0;
         for (uint32_t mk = 0; mk < (1u << kp); mk++) {
           const uint32_t ax = (uint32_t)__builtin_popcount(mk & xmask);
-          if ((uint32_t)__builtin_popcount(mk) != j || ax >= tau) continue;
-          /* one substitution in X and m-1 in O: the whole variant belongs to the second class */
-          if (bnew && ax == 1 && j - ax == mismatches - 1) continue;
+          if ((uint32_t)__builtin_popcount(mk) != j || ax >= tau || (ax < 2 ? ax : 2) != g) continue;
           plan2.push_back(mk);
           cnt++;
         }
-      plan2[8 + j] = cnt;
-    }
+        if (!cnt) continue;
+        plan2[32 + c] = cnt;
+        plan2[64 + c] = j | ((uint32_t)eb << 4);
+        ncls2++;
+      }
     bcomb_off = (uint32_t)plan2.size();
     plan2.insert(plan2.end(), bcomb.begin(), bcomb.end());
     plan2_off = ix->combo_off[jmax] + ix->combo_cnt[jmax]; /* right after the words of the full plan in use */
     plan_total = plan2_off + (uint32_t)plan2.size();
-    if (plan2.size() > ix->combo_words) {
+    if (plan2.size() > ix->combo_words + 256) {
       bidir = false;
     } else {
       GS_HIP(hipMemcpyAsync((uint32_t *)ix->d_combo + ix->combo_words, plan2.data(), 4 * plan2.size(),
@@ -1571,7 +1592,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.cap = cap_;
     sa.combo = (const uint32_t *)ix->d_combo;
     sa.pt_k = 0;
-    sa.jmax = 0;
+    sa.ncls = sa.ncls2 = 0;
     sa.v_rem = 0;
     sa.v_max = VERIFY_MAX_DEFAULT;
     if (const char *e = getenv("GS_VERIFY_MAX")) {
@@ -1594,11 +1615,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       const uint32_t kp = ix->pt_k - 2;
       uint32_t jmax = mismatches < kp ? mismatches : kp;
       if (jmax > 7) jmax = 7;
-      sa.jmax = jmax;
+      sa.ncls = jmax + 1;
       sa.v_rem = v_rem;
       sa.plan_words = ix->combo_off[jmax] + ix->combo_cnt[jmax];
       if (bidir) {
         sa.bidir = 1;
+        sa.ncls2 = ncls2;
         sa.tau = tau;
         sa.plan2_off = plan2_off;
         sa.plan2_src = ix->combo_words;
