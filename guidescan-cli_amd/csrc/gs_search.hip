@@ -20,12 +20,16 @@
 #define WAVE 64
 #define SEARCH_WAVES 4 /* waves per workgroup */
 #ifndef STACK_ENTRIES
-#define STACK_ENTRIES 256 /* 16-byte nodes of the X/G stacks per wave */
+#define STACK_ENTRIES 224 /* 16-byte nodes of the X/G stacks per wave */
 #endif
 /* verification queue behind the stacks: seeds waiting for their context rows to be read
  * (VQ_CAP descriptors) and the owner markers of one verification pass (128 x uint32) */
-#define VQ_CAP 96
-#define VQ_DRAIN 32 /* verify as soon as this many seeds wait (a seeding step adds at most 64) */
+#ifndef VQ_CAP
+#define VQ_CAP 128
+#endif
+#ifndef VQ_DRAIN
+#define VQ_DRAIN 64 /* verify as soon as this many seeds wait (a seeding step adds at most 64) */
+#endif
 #define WAVE_LDS_ENTRIES (STACK_ENTRIES + VQ_CAP + 32) /* 6 KiB per wave -> 6 workgroups per CU */
 #define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
 
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         o1 = o1 > prev ? o1 : prev;
         const uint32_t ow[2] = {o0, o1};
         uint4 wq[2], dsc[2];
-        uint32_t row0[2], nrow[2], kkv[2], lo8[2];
+        uint32_t row0[2], nrow[2], kkv[2], okm[2];
 #pragma unroll
         for (uint32_t jj = 0; jj < 2u; ++jj) { /* two independent 16-byte loads in flight */
           const uint32_t grp = base + 2u * lane + jj;
@@ -383,7 +387,10 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           row0[jj] = dsc[jj].x + r0;
           nrow[jj] = on ? (cnt - r0 < 8u ? cnt - r0 : 8u) : 0u;
           kkv[jj] = (dsc[jj].y >> 14) & 7u;
-          lo8[jj] = ((dsc[jj].y >> DSC_FLAG) & 1u) ? lo8_flag : lo8_plain;
+          /* bit c set: c substitutions among the visible symbols are acceptable (lower bound ..
+           * budget left) */
+          const uint32_t lo8 = ((dsc[jj].y >> DSC_FLAG) & 1u) ? lo8_flag : lo8_plain;
+          okm[jj] = on ? (((2u << (m - kkv[jj])) - 1u) & ~((1u << lo8) - 1u)) : 0u;
           wq[jj] = make_uint4(0u, 0u, 0u, 0u);
           if (on) wq[jj] = load16_a2(sv.ctx16 + row0[jj]);
         }
@@ -396,12 +403,10 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
             const uint32_t x = (wv[h] ^ q2x) & gm2x;
             const uint32_t y = (x | (x >> 1)) & 0x55555555u;
             const uint32_t m0 = __popc(y & 0xFFFFu), m1 = __popc(y >> 16);
-            const bool ok0 = 2u * h < nrow[jj] && kkv[jj] + m0 <= m && m0 >= lo8[jj];
-            const bool ok1 = 2u * h + 1u < nrow[jj] && kkv[jj] + m1 <= m && m1 >= lo8[jj];
-            cm |= (ok0 ? 1u : 0u) << (8u * jj + 2u * h);
-            cm |= (ok1 ? 1u : 0u) << (8u * jj + 2u * h + 1u);
+            cm |= (((okm[jj] >> m0) & 1u) | (((okm[jj] >> m1) & 1u) << 1)) << (8u * jj + 2u * h);
           }
         }
+        cm &= ((1u << nrow[0]) - 1u) | (((1u << nrow[1]) - 1u) << 8); /* rows that exist */
         /* second level, one candidate row per lane per round (rare: a row passes the first
          * level with probability ~0.5 % at budget 1): the full 16-symbol word decides */
         while (__ballot(cm != 0u)) {
@@ -522,6 +527,17 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         }
         if (__ballot(reach)) fallback = true;
       }
+      /* context mask for the second class (one substitution left for X): the triples within one
+       * substitution of the three symbols the other strand consumes next - the complemented
+       * X symbols, last first */
+      uint64_t allow_b1 = ~0ull;
+      if (a.bnew && sx >= 3u) {
+        uint32_t q3b = 0;
+        for (uint32_t j = 0; j < 3u; ++j) q3b |= (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - j))) & 3u)) << (2u * j);
+        allow_b1 = 1ull << q3b;
+        for (uint32_t p3 = 0; p3 < 3u; ++p3)
+          for (uint32_t d = 1; d < 4u; ++d) allow_b1 |= 1ull << (q3b ^ (d << (2u * p3)));
+      }
       for (uint32_t pj = 0; pj < npams && !fallback; ++pj) {
         const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
         uint32_t nn = 0;
@@ -600,11 +616,13 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
               }
             }
             const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
-            const bool live = act && ecnt != 0u;
+            bool live = act && ecnt != 0u;
             if (__ballot(live && ((ent.y >> 31) != 0u || ecnt > a.v_max))) {
               fallback = true;
               break;
             }
+            /* second class: no row of the interval has a left context within its one substitution */
+            if (flag && ((((uint64_t)ent.w << 32) | ent.z) & allow_b1) == 0ull) live = false;
             const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
             /* the queue is empty here (one-sided seeding has not started) */
             vq[lane] = make_uint4(ent.x, (kk << 14) | ((live ? ecnt : 0u) << 17) | (flag << DSC_FLAG), (uint32_t)cmeta,
