@@ -471,7 +471,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
 
     /* seeding state (all wave-uniform): mismatch count j of the prefix variants being
      * enumerated, substitution index sub in [0,3^j), position in the (combination, entry) space */
-    uint32_t sc = 0, ssub = 0, spos = 0; /* class, digit combination, lane position */
+    uint32_t sc = 0, spos = 0; /* class, lane position inside the class */
     uint32_t ncls = a.ncls;
     uint32_t qn = 0; /* seeds waiting in the verification queue */
     const bool seeding = a.pt_k != 0;
@@ -664,21 +664,40 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         const bool rot = sd.ptab_rot != nullptr && bud == 0u && sj >= 1u;
         const bool rot2 = sd.ptab_rot != nullptr && bud == 1u;
         const uint32_t E = bud >= 2u ? 16u : bud == 1u ? (rot2 ? 8u : 7u) : 1u;
-        const uint32_t span = pl[GS_PLAN_CLASSES + sc] * (rot ? 3u : E);
+        /* The class's lane space is (position mask ci, digit combination, lane of the variant u),
+         * u fastest: a step takes the next 64 lanes of it, whatever variants they belong to, so
+         * small classes (one mask x 27 digit combinations x 3 lanes) do not cost a step per
+         * digit combination.  nsub = 3^sj digit combinations, a third of that when the last
+         * digit runs over the lanes. */
+        const uint32_t lanes_per = rot ? 3u : E;
+        const uint32_t nsub = rot ? spow / 3u : spow;
+        const uint32_t span = pl[GS_PLAN_CLASSES + sc] * nsub * lanes_per;
         const uint32_t l = spos + lane;
         bool act = l < span;
-        const uint32_t ci = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
-        const uint32_t u = l - ci * (rot ? 3u : E);
+        const uint32_t tv = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
+        const uint32_t u = l - tv * lanes_per;
+        uint32_t ci; /* tv = ci * nsub + digit combination; nsub is wave-uniform: constant divisors */
+        switch (nsub) {
+          case 1u: ci = tv; break;
+          case 3u: ci = tv / 3u; break;
+          case 9u: ci = tv / 9u; break;
+          case 27u: ci = tv / 27u; break;
+          case 81u: ci = tv / 81u; break;
+          case 243u: ci = tv / 243u; break;
+          case 729u: ci = tv / 729u; break;
+          default: ci = tv / nsub; break;
+        }
         uint32_t mask = act ? pl[pl[sc] + ci] : 0u;
         /* substitutions inside X (the first v_rem consumed symbols); the others lie in O */
         const uint32_t ax = __popc(mask & ((1u << a.v_rem) - 1u));
         uint32_t pidx = pidx0;
         uint64_t path = 0;
-        uint32_t sub = ssub;
+        uint32_t sub = tv - ci * nsub; /* < 3^7: thirds through a full-rate 24-bit multiply */
         uint32_t plast = 0;
         for (uint32_t i = 0; i < sj; ++i) { /* sj substitutions at the set bits of mask */
-          uint32_t d = sub % 3u; /* scalar */
-          sub /= 3u;
+          const uint32_t third = __umul24(sub, 43691u) >> 17; /* exact for sub < 2^17 */
+          uint32_t d = sub - 3u * third;
+          sub = third;
           if (rot && i + 1u == sj) d = u; /* the last step's digit runs over the lanes */
           const uint32_t t = mask ? (uint32_t)__builtin_ctz(mask) : 0u;
           mask &= mask - 1u;
@@ -756,7 +775,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           n_match = 0;
           xs = gs = 0;
           qn = 0;
-          sc = ssub = spos = 0;
+          sc = spos = 0;
           pl = s_plan;
           ncls = a.ncls;
           twosided = false;
@@ -782,13 +801,10 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         spos += WAVE;
         if (spos >= span) {
           spos = 0;
-          if (++ssub >= (rot ? spow / 3u : spow)) {
-            ssub = 0;
-            do {
-              ++sc;
-            } while (sc < ncls && pl[GS_PLAN_CLASSES + sc] == 0u);
-            if (sc >= ncls) seeds_left = false;
-          }
+          do {
+            ++sc;
+          } while (sc < ncls && pl[GS_PLAN_CLASSES + sc] == 0u);
+          if (sc >= ncls) seeds_left = false;
         }
         /* drain from the tail: the last `take` descriptors, no shifting; everything once the
          * seeds are exhausted (qn < VQ_DRAIN + 64 <= VQ_CAP always holds) */
