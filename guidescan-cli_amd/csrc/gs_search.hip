@@ -1864,19 +1864,29 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_gather_guides, dim3((n_o + 255) / 256), dim3(256), 0, st,
                        (const gs_guide_rec *)ix->w_grec.p, (const uint32_t *)ix->w_ovf_list.p, n_o,
                        (gs_guide_rec *)ix->w_grec2.p);
-    bool huge = false;
+    bool huge = false, counted = false;
     for (;;) {
       cap2 = cap2 >= 1024 ? cap2 * 2 : cap2 * 4;
       if (cap2 > 2048) {
         huge = true; /* counts2 of the last pass are exact: size the slots from them */
         break;
       }
+      counted = true;
       if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (size_t)cap2 * 2 * n_o)) != GS_OK) return rc;
       unsigned long long h2[2] = {0, 0};
       if ((rc = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
                            (uint32_t *)ix->w_counts2.p, cap2, h2)) != GS_OK)
         return rc;
       if (h2[1] == 0) break;
+    }
+    if (huge && !counted) {
+      /* the first capacity was already the largest an LDS sort takes (m >= 6): no pass has
+       * counted the redo list's matches yet - count them with zero-size slots */
+      if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4))) != GS_OK) return rc;
+      unsigned long long h2[2] = {0, 0};
+      if ((rc = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
+                           (uint32_t *)ix->w_counts2.p, 0, h2)) != GS_OK)
+        return rc;
     }
     if (!huge) {
       if ((rc = run_order((uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_counts2.p,

@@ -369,14 +369,15 @@ def test_repeat_guide_with_thousands_of_matches():
         others, _, _, _ = synth.sample_guides(text, 5, seed=4)
         seqs = np.concatenate([others[:2], np.array([list(site)], dtype=np.uint8), others[2:]])
         pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
-        for faithful in (False, True):
-            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
+        # m = 6 starts at the largest slot capacity: the redo list is counted by a pass of its own
+        for m, faithful in ((3, False), (3, True), (6, False)):
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, faithful=faithful)
             big = 0
             for i in range(seqs.shape[0]):
                 g = seqs[i].tobytes().decode()
-                exp, ctr = oracle_hits_as_records(oidx, g, "NGG", ol.make_opts(3), 3)
+                exp, ctr = oracle_hits_as_records(oidx, g, "NGG", ol.make_opts(m), 3)
                 got = gpu_hits_as_records(offsets, hits, i, g, 3)
-                assert got == exp, (i, faithful)
+                assert got == exp, (i, m, faithful)
                 big = max(big, len(set((e[2], e[3]) for e in exp)))
             assert big > 2048
     finally:
