@@ -298,7 +298,37 @@ def verify_last_batch(torch, gidx, d_seqs, d_pams, batch, i, L, P, m, text, seqs
         else:                                                  # forward index: - strand, pos = -start
             w = synth.reverse_complement_bytes(text[-pos[h]:-pos[h] + 23])
         assert np.array_equal(w[:20], q[:20]) and w[21] == ord("G") and w[22] == ord("G")
-    return {"guides": int(batch), "hits": int(n_hits), "distance0_hits_checked_vs_text": int(idx.size)}
+    out = {"guides": int(batch), "hits": int(n_hits), "distance0_hits_checked_vs_text": int(idx.size)}
+    # the same batch through the slower, more literal paths of the library must give the SAME
+    # BYTES: (a) one-sided seeding only (GS_NO_BIDIR: every site comes from this strand's table,
+    # no second class, the full plan), the whole batch; (b) the reference-order walk from the
+    # root (GS_FLAG_FAITHFUL_WALK: no table, no context arrays), the first 20,000 guides
+    off_d = torch.from_numpy(off.astype(np.int64)).cuda()
+    hits_d = torch.from_numpy(hits).cuda()
+
+    def fetch(n_g, **kw):
+        d_o, d_h, st2 = gidx.enumerate_device(s.data_ptr(), n_g, L, p.data_ptr(), P, mismatches=m, **kw)
+        o2 = torch.empty(n_g + 1, dtype=torch.int64, device="cuda")
+        h2 = torch.empty((st2["n_hits"], 2), dtype=torch.int64, device="cuda")
+        assert hip.hipMemcpy(o2.data_ptr(), d_o, 8 * (n_g + 1), 3) == 0
+        assert hip.hipMemcpy(h2.data_ptr(), d_h, 16 * st2["n_hits"], 3) == 0
+        return o2, h2, st2
+
+    os.environ["GS_NO_BIDIR"] = "1"
+    try:
+        o2, h2, st2 = fetch(batch)
+    finally:
+        del os.environ["GS_NO_BIDIR"]
+    assert torch.equal(o2, off_d) and torch.equal(h2, hits_d), "one-sided and two-sided seeding differ"
+    out["one_sided_identical_bytes"] = {"guides": int(batch), "hits": int(st2["n_hits"]),
+                                        "k_search_ms": round(st2["ms_search"], 1)}
+    nw = min(batch, 20000)
+    o3, h3, st3 = fetch(nw, faithful=True)
+    nh = int(off[nw])
+    assert torch.equal(o3, off_d[:nw + 1]) and torch.equal(h3, hits_d[:nh]), "walk and fast path differ"
+    out["reference_order_walk_identical_bytes"] = {"guides": int(nw), "hits": nh,
+                                                   "k_search_ms": round(st3["ms_search"], 1)}
+    return out
 
 
 def cpu_baseline(text, gidx, seqs, pams, m, sample):
