@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
 }
 
 /* ---- search: one wavefront per (guide, strand) ----------------------------
- * Two LDS stacks per wave share one 8 KiB array: X (grows up) holds "single-symbol" nodes -
+ * Two LDS stacks per wave share one 3.5 KiB array (STACK_ENTRIES nodes): X (grows up) holds "single-symbol" nodes -
  * mismatch budget spent (index.hpp:230 returns before the substitution loop) or a fixed PAM
  * base - which need Occ of one base and have at most one child; G (grows down) holds nodes
  * that still branch (k < m), PAM 'N' wildcards and PAM fan-out nodes.  ~89 % of all nodes are
@@ -210,6 +210,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     s_plan[i] = a.combo[(a.bidir && i >= a.plan2_off) ? i - a.plan2_off + a.plan2_src : i];
   __syncthreads();
   unsigned long long n_ext = 0, n_ovf = 0;
+  uint32_t n_two = 0, n_fb = 0, n_rst = 0; /* items seeded from both strands / fallen back / redone */
   const uint32_t L = a.L, P = a.P, m = a.m;
   const uint32_t T_end = L + P;
   const uint32_t reserve = (MAX_FANOUT - 1) * (T_end + 2);
@@ -634,7 +635,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       }
       if (fallback) {
         n_match = 0; /* whatever the other strand found so far is found again below */
+        n_fb++;
       } else {
+        n_two++;
         pl = s_plan + a.plan2_off;
         ncls = a.ncls2;
         twosided = true;
@@ -773,6 +776,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           /* such a seed would have to be walked, and the walk cannot tell its rows apart from
            * the ones the other strand already reported: redo the item one-sided, full plan */
           n_match = 0;
+          n_rst++;
           xs = gs = 0;
           qn = 0;
           sc = spos = 0;
@@ -968,6 +972,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
   if (lane == 0) {
     if (n_ext) atomicAdd(&a.stats[0], n_ext);
     if (n_ovf) atomicAdd(&a.stats[1], n_ovf);
+    if (n_two) atomicAdd(&a.stats[4], (unsigned long long)n_two);
+    if (n_fb) atomicAdd(&a.stats[5], (unsigned long long)n_fb);
+    if (n_rst) atomicAdd(&a.stats[6], (unsigned long long)n_rst);
   }
 }
 
@@ -1672,7 +1679,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       }
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
-     * their LDS stacks allow (8 at 20 KiB each = 32 waves per CU) */
+     * their LDS (stacks + verification queue: 6 KiB per wave) allows: 6 at 24 KiB = 24 waves per CU */
     uint32_t grid = (uint32_t)cus * (160u * 1024u / (WAVE_LDS_ENTRIES * 16u * SEARCH_WAVES));
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
@@ -1680,14 +1687,6 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 4 * (size_t)sa.plan_words, st, sa);
     GS_HIP(hipEventRecord(ix->ev[2], st));
     GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
-    if (sa.dbg_skip & 4u) {
-      unsigned long long c[16];
-      GS_HIP(hipMemcpy(c, d_stats, sizeof(c), hipMemcpyDeviceToHost));
-      fprintf(stderr, "[gs] seeds: lanes %llu nonempty %llu live %llu verified %llu (by budget 0..3: %llu %llu %llu %llu) "
-              "rows %llu passes %llu steps %llu for %u guides\n", c[4], c[5], c[6], c[7], c[11], c[12], c[13], c[14],
-              c[8], c[9], c[10], ng);
-      GS_HIP(hipMemsetAsync((char *)d_stats + 32, 0, 96, st));
-    }
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
     float ms = 0.f;
@@ -1932,9 +1931,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_huge_locate, dim3(h_n_uq), dim3(WAVE), 0, st, ha);
   }
   GS_HIP(hipEventRecord(ix->ev[3], st));
-  unsigned long long h_stats3[3] = {0, 0, 0};
+  unsigned long long h_stats3[7] = {0, 0, 0, 0, 0, 0, 0};
   GS_HIP(hipMemcpyAsync(h_stats3, d_stats, sizeof(h_stats3), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
+  if (bidir && getenv("GS_DEBUG"))
+    fprintf(stderr, "[gs] items: seeded from both strands %llu, fallen back before seeding %llu, redone one-sided %llu%s\n",
+            h_stats3[4], h_stats3[5], h_stats3[6], bnew ? " (second class on)" : "");
   GS_HIP(hipGetLastError());
   if (d_offsets) *d_offsets = ix->w_offsets.p;
   if (d_hits) *d_hits = ix->w_hits.p;

@@ -238,14 +238,9 @@ def test_context_verification_medium_genome(pk, monkeypatch):
         oidx.close()
 
 
-@pytest.mark.parametrize("pk,L", [("13", 20), ("11", 16), ("12", 18)])
-def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
-    """the table depth that makes k_search seed from both strands (sites with >= 2 substitutions
-    among the first consumed symbols come from the other strand's table): a genome with a repeat
-    family whose copies carry 0..4 substitutions anywhere, on both strands, some of them with a
-    literal N under the PAM's N (only the one-sided walk sees those), plus N runs"""
-    monkeypatch.setenv("GS_PREFIX_K", pk)
-    monkeypatch.setenv("GS_DEBUG", "1")
+def two_sided_genome(pk, L):
+    """a genome with a repeat family whose copies carry 0..4 substitutions anywhere, on both
+    strands, some of them with a literal N under the PAM's N, plus N runs"""
     rng = np.random.default_rng(int(pk) * 100 + L)
     text, names, lengths = synth.make_genome([150_000, 90_000], seed=int(pk), n_blocks=False)
     text = text.copy()
@@ -264,6 +259,82 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
     for _ in range(6):
         at = int(rng.integers(3000, text.shape[0] - 3000))
         text[at:at + int(rng.integers(1, 60))] = ord("N")
+    return text, fam
+
+
+def test_two_sided_fallback_and_redo_paths(monkeypatch, capfd):
+    """the escape routes of two-sided seeding, forced by shrinking the largest interval the context
+    arrays may resolve (GS_VERIFY_MAX): an oversized interval among the other strand's seeds
+    makes the item fall back before seeding; one among this strand's seeds that share sites with
+    the other strand's second class makes the item start over one-sided.  Hits stay bit-exact,
+    and both routes are actually taken (the library counts them under GS_DEBUG)."""
+    import re
+    monkeypatch.setenv("GS_PREFIX_K", "13")
+    monkeypatch.setenv("GS_DEBUG", "1")
+    text, fam = two_sided_genome("13", 20)
+    # a second family without literal-N PAMs (those send every guide near the first family back to
+    # one-sided seeding before it starts): 60 copies on the + strand that share positions 0..12
+    # and differ, at most once, in 13..19, each with a concrete xGG PAM
+    rng = np.random.default_rng(99)
+    fam2 = np.frombuffer(b"TCAGGATCGTACCTGAAGTC", np.uint8)
+    for c in range(60):
+        site = fam2.copy()
+        if c % 2:
+            j = int(rng.integers(13, 20))
+            site[j] = rng.choice([x for x in b"ACGT" if x != site[j]])
+        w = np.concatenate([site, np.frombuffer(bytes(rng.choice([b"AGG", b"CGG", b"TGG", b"GGG"])), np.uint8)])
+        at = 5000 + 1500 * c
+        text[at:at + 23] = w
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        sampled, _, _, _ = synth.sample_guides(text, 120, seed=8)
+        guides = [fam.tobytes().decode(), synth.reverse_complement_bytes(fam).tobytes().decode(),
+                  fam2.tobytes().decode()]
+        # members of the second family with substitutions at guide positions inside O (at this depth
+        # X = 0..9, O = 10..12): undoing them gives this strand's seed the family's whole 13-symbol
+        # prefix (60 rows) while the other strand's seed, which also spells the PAM, stays small
+        # (a few rows) - with GS_VERIFY_MAX between the two the item is redone one-sided
+        swap = {65: 67, 67: 71, 71: 84, 84: 65}
+        for pos in ((10, 11), (11,), (10, 12), (12,)):
+            g2 = fam2.copy()
+            for q in pos:
+                g2[q] = swap[int(g2[q])]
+            guides.append(g2.tobytes().decode())
+        guides += [sampled[i].tobytes().decode() for i in range(sampled.shape[0])]
+        seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (len(guides), 1))
+        seen = dict(both=0, fallback=0, redone=0)
+        for m in (3, 2):
+            opts = ol.make_opts(mismatches=m)
+            expected = [oracle_hits_as_records(oidx, g, "NGG", opts, 3)[0] for g in guides]
+            for vmax in ("1", "3", "9", "14", "256"):
+                monkeypatch.setenv("GS_VERIFY_MAX", vmax)
+                capfd.readouterr()
+                offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m)
+                err = capfd.readouterr().err
+                mt = re.search(r"both strands (\d+), fallen back before seeding (\d+), redone one-sided (\d+)", err)
+                assert mt, err
+                seen["both"] += int(mt.group(1))
+                seen["fallback"] += int(mt.group(2))
+                seen["redone"] += int(mt.group(3))
+                for i, g in enumerate(guides):
+                    assert gpu_hits_as_records(offsets, hits, i, g, 3) == expected[i], (i, m, vmax)
+        assert seen["both"] > 0 and seen["fallback"] > 0 and seen["redone"] > 0, seen
+    finally:
+        gidx.close()
+        oidx.close()
+
+
+@pytest.mark.parametrize("pk,L", [("13", 20), ("11", 16), ("12", 18)])
+def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
+    """the table depth that makes k_search seed from both strands (sites with >= 2 substitutions
+    among the first consumed symbols come from the other strand's table): a genome with a repeat
+    family whose copies carry 0..4 substitutions anywhere, on both strands, some of them with a
+    literal N under the PAM's N (only the one-sided walk sees those), plus N runs"""
+    monkeypatch.setenv("GS_PREFIX_K", pk)
+    monkeypatch.setenv("GS_DEBUG", "1")
+    text, fam = two_sided_genome(pk, L)
     oidx = ol.OracleIndex(text)
     gidx = api.GenomeIndex.build(text, device=0)
     try:
