@@ -410,9 +410,12 @@ __global__ void k_ptab_build(const uint8_t *text, const uint32_t *sa, uint64_t n
 
 static uint32_t choose_prefix_k(uint64_t n) {
   if (const char *e = getenv("GS_PREFIX_K")) return (uint32_t)atoi(e);
-  /* deepest level at which k-mers still average ~8+ rows; capped so the table stays <= 4 GiB */
+  /* deepest level at which k-mers still average 2+ rows; capped so the table stays <= 4 GiB.
+   * (Until the two-level context check the rule was 8+ rows; a chr1-sized genome then got k = 12,
+   * one short of what two-sided seeding needs for 20+3-mers, and ran 6 times slower than at 13:
+   * 166 vs 27 ms per 1 M guides.  Fewer rows per interval also sharpen the context mask.) */
   uint32_t k = 0;
-  uint64_t v = n / 8;
+  uint64_t v = n / 2;
   while (v >= 4) {
     v >>= 2;
     k++;
