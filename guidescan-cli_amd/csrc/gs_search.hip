@@ -1683,6 +1683,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     uint32_t grid = (uint32_t)cus * (160u * 1024u / (WAVE_LDS_ENTRIES * 16u * SEARCH_WAVES));
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
+    if (getenv("GS_DEBUG")) {
+      int occ = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search, WAVE * SEARCH_WAVES, 4 * (size_t)sa.plan_words);
+      fprintf(stderr, "[gs] k_search: grid %u x %u threads, LDS %zu + %zu B per workgroup, %d workgroups per CU resident\n",
+              grid, WAVE * SEARCH_WAVES, sizeof(uint4) * WAVE_LDS_ENTRIES * SEARCH_WAVES, 4 * (size_t)sa.plan_words, occ);
+    }
     GS_HIP(hipEventRecord(ix->ev[1], st));
     hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 4 * (size_t)sa.plan_words, st, sa);
     GS_HIP(hipEventRecord(ix->ev[2], st));
