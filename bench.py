@@ -178,6 +178,15 @@ def main():
                    "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes},
     }
 
+    if traffic:
+        # what actually binds k_search: 64-byte random requests (FETCH_SIZE / 64) against the
+        # memory system's random-request ceiling measured by tools/gather_bench
+        fetch = next(r["fetch_bytes"] for r in json.loads((ROOT / "profiles" / "traffic.json").read_text())
+                     if r["workload"] == args.workload and r["batch"] == batch and r["mismatches"] == m)
+        out["roofline"]["random_requests"] = {
+            "per_guide": fetch / 64.0 / batch, "achieved_per_s": fetch / 64.0 / search_s if search_s > 0 else None,
+            "ceiling_per_s": [5.0e10, 5.5e10], "unit": "64-byte requests",
+            "note": "FETCH_SIZE of the recorded PMC pass over this run's HIP-event launch time"}
     if rank == 0:
         # the device steps either side of the path (untimed side figures, never part of `value`):
         # CFD/specificity of the last batch's hits and the candidate-guide scan of chromosome 1
