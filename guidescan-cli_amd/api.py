@@ -111,6 +111,9 @@ def lib():
     L.gs_format_guide.restype = i32
     L.gs_format_guide.argtypes = [C.POINTER(GsGenomeStructure), C.POINTER(GsKmer), vp, u64, u32, u32,
                                   C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.gs_format_guide_scored.restype = i32
+    L.gs_format_guide_scored.argtypes = [C.POINTER(GsGenomeStructure), C.POINTER(GsKmer), vp, u64, u32, u32,
+                                         C.c_int64, C.c_float, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.gs_format_header.restype = i32
     L.gs_format_header.argtypes = [C.POINTER(GsGenomeStructure), u32, C.POINTER(vp),
                                    C.POINTER(C.c_size_t)]
@@ -151,7 +154,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text",
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
-           "gs_kmers_free"]
+           "gs_kmers_free", "gs_format_guide_scored"]
 
 
 def _check(rc):
@@ -177,15 +180,21 @@ def format_header(gs, sam=False, complete=True) -> str:
 
 
 def format_guide(gs, gid, sequence, pam, sense_positive, hits, mismatches, sam=False, complete=True,
-                 start=False, max_off_targets=-1) -> str:
-    """hits: numpy HIT_DTYPE array of this guide (canonical order, as gs_enumerate returns)"""
+                 start=False, max_off_targets=-1, specificity=None) -> str:
+    """hits: numpy HIT_DTYPE array of this guide (canonical order, as gs_enumerate returns);
+    specificity: the guide's float from GenomeIndex.score (then the host does no CFD arithmetic)"""
     hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
     k = GsKmer(gid.encode(), sequence.encode(), pam.encode(), int(sense_positive))
     out, n = C.c_void_p(), C.c_size_t()
     flags = ((GS_TEXT_SAM if sam else 0) | (GS_TEXT_COMPLETE if complete else 0) |
              (GS_FLAG_PAM_AT_START if start else 0))
-    _check(lib().gs_format_guide(C.byref(gs), C.byref(k), hits.ctypes.data, hits.shape[0], mismatches,
-                                 flags, max_off_targets, C.byref(out), C.byref(n)))
+    if specificity is None:
+        _check(lib().gs_format_guide(C.byref(gs), C.byref(k), hits.ctypes.data, hits.shape[0], mismatches,
+                                     flags, max_off_targets, C.byref(out), C.byref(n)))
+    else:
+        _check(lib().gs_format_guide_scored(C.byref(gs), C.byref(k), hits.ctypes.data, hits.shape[0],
+                                            mismatches, flags, max_off_targets, float(specificity),
+                                            C.byref(out), C.byref(n)))
     s = C.string_at(out, n.value).decode()
     lib().gs_free(out)
     return s

@@ -99,9 +99,12 @@ struct decoded_hit {
 
 }  // namespace
 
+/* spec: the guide's specificity when the caller already has it (gs_score / gs_score_device:
+ * the same float, computed on the device); nullptr = compute CFD and the sum here */
 static gs_status format_decoded(const gs_genome_structure *gs, const gs_kmer *k,
                                 const std::vector<std::vector<decoded_hit>> &off, uint32_t mismatches,
-                                uint32_t flags, int64_t max_off_targets, char **out_text, size_t *out_len) {
+                                uint32_t flags, int64_t max_off_targets, char **out_text, size_t *out_len,
+                                const float *spec = nullptr) {
   const bool start = flags & GS_FLAG_PAM_AT_START;
   const bool sam = flags & GS_TEXT_SAM;
   const bool complete = flags & GS_TEXT_COMPLETE;
@@ -144,7 +147,7 @@ static gs_status format_decoded(const gs_genome_structure *gs, const gs_kmer *k,
           line += std::to_string(h.dna_bulges);
         }
         lines.push_back(std::move(line));
-        cfd_sum += gs_calculate_cfd(k->sequence, h.match_sequence.c_str(), h.pam.c_str());
+        if (!spec) cfd_sum += gs_calculate_cfd(k->sequence, h.match_sequence.c_str(), h.pam.c_str());
       }
     }
     if (none) { /* :189-199 */
@@ -158,6 +161,7 @@ static gs_status format_decoded(const gs_genome_structure *gs, const gs_kmer *k,
       float specificity = 0.0f;
       if (!perfect) cfd_sum += 1;
       if (cfd_sum > 0) specificity = 1 / cfd_sum;
+      if (spec) specificity = *spec;
       const std::string sp = f2s(specificity);
       for (const auto &l : lines) {
         out += l;
@@ -183,7 +187,7 @@ static gs_status format_decoded(const gs_genome_structure *gs, const gs_kmer *k,
         char st;
         if (resolve_absolute(gs, h.pos, L, P, &s, &st) < 0) continue;
         hex_le(hex, (uint64_t)h.pos);
-        cfd_sum += gs_calculate_cfd(k->sequence, h.match_sequence.c_str(), h.pam.c_str());
+        if (!spec) cfd_sum += gs_calculate_cfd(k->sequence, h.match_sequence.c_str(), h.pam.c_str());
         n_off++;
       }
       hex_le(hex, (uint64_t)d);
@@ -192,6 +196,7 @@ static gs_status format_decoded(const gs_genome_structure *gs, const gs_kmer *k,
     float specificity = 0.0f;
     if (!perfect) cfd_sum += 1;
     if (cfd_sum > 0) specificity = 1 / cfd_sum;
+    if (spec) specificity = *spec;
     /* one line per distance-0 hit, printer.hpp:314-357 */
     for (const decoded_hit &h : off[0]) {
       int64_t s = 0;
@@ -233,10 +238,10 @@ static gs_status format_decoded(const gs_genome_structure *gs, const gs_kmer *k,
   return GS_OK;
 }
 
-extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kmer *k,
-                                     const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
-                                     uint32_t flags, int64_t max_off_targets, char **out_text,
-                                     size_t *out_len) {
+static gs_status format_guide_impl(const gs_genome_structure *gs, const gs_kmer *k,
+                                   const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
+                                   uint32_t flags, int64_t max_off_targets, char **out_text,
+                                   size_t *out_len, const float *spec) {
   if (!gs || !k || !k->id || !k->sequence || !k->pam || (n_hits && !hits) || !out_text)
     return GS_ERR_ARG;
   const uint32_t L = (uint32_t)strlen(k->sequence), P = (uint32_t)strlen(k->pam);
@@ -257,7 +262,22 @@ extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kme
     dh.pam = dh.match_sequence.size() < 20 ? std::string() : dh.match_sequence.substr(20, 3);
     off[d].push_back(std::move(dh));
   }
-  return format_decoded(gs, k, off, mismatches, flags, max_off_targets, out_text, out_len);
+  return format_decoded(gs, k, off, mismatches, flags, max_off_targets, out_text, out_len, spec);
+}
+
+extern "C" gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kmer *k,
+                                     const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
+                                     uint32_t flags, int64_t max_off_targets, char **out_text,
+                                     size_t *out_len) {
+  return format_guide_impl(gs, k, hits, n_hits, mismatches, flags, max_off_targets, out_text, out_len, nullptr);
+}
+
+extern "C" gs_status gs_format_guide_scored(const gs_genome_structure *gs, const gs_kmer *k,
+                                            const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
+                                            uint32_t flags, int64_t max_off_targets, float specificity,
+                                            char **out_text, size_t *out_len) {
+  return format_guide_impl(gs, k, hits, n_hits, mismatches, flags, max_off_targets, out_text, out_len,
+                           &specificity);
 }
 
 extern "C" gs_status gs_decode_sequence_ex(uint64_t key_hi, uint64_t key_lo, char *out) {

@@ -343,10 +343,21 @@ int do_enumerate(int argc, char **argv) {
       std::cerr << "error: " << gs_status_string(rc) << "\n";
       return 1;
     }
-    if (!bulges)
+    /* specificity of every guide of the batch on the device (printer.hpp:98-170, 251-297 behind
+     * gs_score): the formatting threads below only print */
+    std::vector<float> spec;
+    if (!bulges) {
       gs_result_get(res, &v);
-    else
+      spec.resize(end - done);
+      rc = gs_score(ix, seqs.data(), end - done, (uint32_t)L, (uint32_t)P, tflags | sflags, max_off, &cgs,
+                    v.guide_offsets, v.hits, nullptr, spec.data());
+      if (rc != GS_OK) {
+        std::cerr << "error: " << gs_status_string(rc) << "\n";
+        return 1;
+      }
+    } else {
       gs_result_ex_get(resx, nullptr, &xoff, &xhits);
+    }
     /* format in parallel over contiguous guide ranges, write in input order (-n 1 order) */
     unsigned nt = fmt_threads ? fmt_threads : std::thread::hardware_concurrency();
     if (nt < 1) nt = 1;
@@ -366,8 +377,8 @@ int do_enumerate(int argc, char **argv) {
           gs_status r;
           if (!bulges) {
             const uint64_t b = v.guide_offsets[g - done], e = v.guide_offsets[g - done + 1];
-            r = gs_format_guide(&cgs, &ck, v.hits + b, e - b, (uint32_t)mismatches, tflags | sflags, max_off,
-                                &tx, &tl);
+            r = gs_format_guide_scored(&cgs, &ck, v.hits + b, e - b, (uint32_t)mismatches, tflags | sflags,
+                                       max_off, spec[g - done], &tx, &tl);
           } else {
             const uint64_t b = xoff[g - done], e = xoff[g - done + 1];
             r = gs_format_guide_ex(&cgs, &ck, xhits + b, e - b, (uint32_t)mismatches, tflags | sflags,

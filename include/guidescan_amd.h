@@ -184,6 +184,14 @@ typedef struct { /* the kmer fields the printers use, include/genomics/structure
 gs_status gs_format_guide(const gs_genome_structure *gs, const gs_kmer *k, const gs_hit *hits,
                           uint64_t n_hits, uint32_t mismatches, uint32_t flags,
                           int64_t max_off_targets, char **out_text, size_t *out_len);
+/* Same lines with the guide's specificity supplied by the caller - the float gs_score /
+ * gs_score_device computed on the device for the same hits, flags and max_off_targets - so the
+ * host formats text only (no CFD arithmetic per hit).  What the C++ host (`guidescan enumerate`)
+ * calls. */
+gs_status gs_format_guide_scored(const gs_genome_structure *gs, const gs_kmer *k, const gs_hit *hits,
+                                 uint64_t n_hits, uint32_t mismatches, uint32_t flags,
+                                 int64_t max_off_targets, float specificity, char **out_text,
+                                 size_t *out_len);
 /* write_sam_header / write_csv_header (include/genomics/printer.hpp:173-187) */
 gs_status gs_format_header(const gs_genome_structure *gs, uint32_t flags, char **out_text,
                            size_t *out_len);

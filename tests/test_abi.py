@@ -177,6 +177,44 @@ def test_product_printers_reproduce_reference_files(toy, name):
     assert "".join(out) == (toy["dir"] / f"ref_{name}.{ext}").read_text()
 
 
+def test_format_guide_scored_prints_the_given_specificity(toy):
+    """gs_format_guide_scored: same lines as gs_format_guide, with the specificity the caller
+    brings (the device's float) in place of the host's own CFD sum"""
+    import struct
+    gs = api.make_genome_structure(toy["names"], toy["lengths"])
+    oidx = ol.OracleIndex(toy["text"])
+    opts = ol.make_opts(mismatches=3)
+    n_checked = 0
+    try:
+        for k in toy["kmers"][:12]:
+            hits, ctr, raw = oidx.enumerate(k.sequence, k.pam, opts)
+            ol.lib().gso_free(raw[0])
+            rec = np.array([(pos, encode_key(k.sequence, seq, mm, idx, len(k.pam)))
+                            for pos, mm, idx, seq, row in hits], dtype=api.HIT_DTYPE).reshape(-1)
+            for sam in (False, True):
+                own = api.format_guide(gs, k.id, k.sequence, k.pam, k.positive, rec, 3, sam=sam)
+                fake = api.format_guide(gs, k.id, k.sequence, k.pam, k.positive, rec, 3, sam=sam, specificity=0.25)
+                if not own:
+                    assert fake == ""
+                    continue
+                if len(hits) == 0:
+                    assert fake == own   # the no-hit CSV row carries the literal 1.0
+                    continue
+                sep, tag = ("\t", "sp:f:") if sam else (",", "")
+                for lo, lf in zip(own.splitlines(), fake.splitlines()):
+                    assert lo.rsplit(sep, 1)[0] == lf.rsplit(sep, 1)[0]
+                    assert lf.rsplit(sep, 1)[1] == tag + "0.250000"
+                # feeding back the host's own value (as the nearest float) reproduces its text
+                val = float(own.splitlines()[0].rsplit(sep, 1)[1][len(tag):])
+                again = api.format_guide(gs, k.id, k.sequence, k.pam, k.positive, rec, 3, sam=sam,
+                                         specificity=struct.unpack("f", struct.pack("f", val))[0])
+                assert again == own
+                n_checked += 1
+    finally:
+        oidx.close()
+    assert n_checked >= 4
+
+
 def test_sdsl_importer_recovers_the_genome_text(toy):
     """the reference's on-disk index files (written by the survey build) -> genome text"""
     synth = import_module("guidescan-cli_amd.synth")
