@@ -132,6 +132,40 @@ def test_new_entry_points_validate_arguments_before_touching_a_device():
         assert e.value.status == 2
 
 
+def test_header_binds_from_plain_c(tmp_path):
+    """the boundary is a C ABI: a C99 translation unit includes the header, links the library and
+    calls host-side entry points (no GPU needed); a compute call without a device reports an error"""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <string.h>
+#include "guidescan_amd.h"
+int main(void) {
+  char out[32];
+  /* key of a perfect hit: no mismatches, forward index, PAM codes A G G */
+  uint64_t path = ((uint64_t)0 << (49 - 40)) | ((uint64_t)2 << (49 - 40 - 3)) | ((uint64_t)2 << (49 - 40 - 6));
+  if (gs_decode_sequence("ACGTACGTACGTACGTACGT", 20, 3, 0, path << 8, out) != GS_OK) return 2;
+  printf("%s %s %s\n", gs_version(), out, gs_status_string(GS_ERR_ARG));
+  gs_kmers *km = 0;
+  gs_status rc = gs_kmers_generate(0, (const uint8_t *)"ACGT", 4, 0, "NGR", 20, 0, 0, &km);
+  printf("%d %.6f\n", (int)rc, gs_calculate_cfd("ACGTACGTACGTACGTACGT", "ACGTACGTACGTACGTACGT", "AGG"));
+  return 0;
+}
+""")
+    exe = tmp_path / "abi"
+    pkg = ol.ROOT / "guidescan-cli_amd"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", str(ol.ROOT / "include"), str(src), "-o", str(exe),
+                    "-L", str(pkg), "-lgsamd", f"-Wl,-rpath,{pkg}"], check=True, timeout=120)
+    r = subprocess.run([str(exe)], check=True, capture_output=True, text=True, timeout=60)
+    l1, l2 = r.stdout.strip().splitlines()
+    assert "gfx950" in l1 and "TGCATGCATGCATGCATGCAAGG" in l1 and "bad argument" in l1
+    assert l2 == "3 1.000000"
+
+
 def test_product_does_not_import_oracle():
     """the product package never references oracle/ (the judge checks exactly this)"""
     pkg = ol.ROOT / "guidescan-cli_amd"
