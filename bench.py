@@ -255,6 +255,23 @@ def side_steps(torch, api, gidx, d_seqs, d_pams, batch, i, L, P, m, text, names,
            "score_hits_per_s": st["n_hits"] / best if best > 0 else None,
            "specificity_mean": float(spec.mean()), "specificity_min": float(spec.min())}
     del d_cfd, d_spec
+    # the host-pointer entry point (gs_enumerate: guides copied in, CSR hit list copied out over
+    # PCIe, host vectors allocated) on the same batch: SURVEY 8d's rate (ii); never `value`
+    import ctypes as C
+    h_seqs = np.ascontiguousarray(s.cpu().numpy())
+    h_pams = np.ascontiguousarray(p.cpu().numpy())
+    L_ = api.lib()
+    best_h = None
+    for _ in range(2):
+        r = C.c_void_p()
+        t0 = time.perf_counter()
+        rc = L_.gs_enumerate(gidx._h, h_seqs.ctypes.data, batch, L, h_pams.ctypes.data, P, None, 0, m, 0, C.byref(r))
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(L_.gs_status_string(rc).decode())
+        L_.gs_result_free(r)
+        best_h = dt if best_h is None else min(best_h, dt)
+    out.update({"host_pointer_call_ms": best_h * 1e3, "host_pointer_guides_per_s": batch / best_h})
     n0 = int(lengths[0])
     d_chr = torch.from_numpy(text[:n0]).cuda()
     torch.cuda.synchronize()
