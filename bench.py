@@ -56,13 +56,20 @@ def main():
                     help="after timing, check full-size properties of the last batch (on-target found, order)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` by itself: this process never touches the GPU; it starts the
+        # N ranks as children (one process per GPU under torch.distributed.run) and relays rank
+        # 0's JSON line
+        raise SystemExit(launch_ranks(args))
+    if os.environ.get("GS_BENCH_STUB"):
+        raise SystemExit(stub_main(args))
+
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the enumerate path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -82,7 +89,7 @@ def main():
         batch = args.batch
     m = args.mismatches
     t0 = time.time()
-    text, names, lengths = synth.make_genome(lengths, seed=1, probs=probs)
+    text, names, lengths = shared_genome(synth, args.workload, lengths, probs, dist, local_rank)
     t_gen = time.time() - t0
     t0 = time.time()
     gidx = api.GenomeIndex.build(text, device=local_rank)
@@ -218,6 +225,103 @@ def main():
     gidx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def genome_file(workload):
+    return os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                        f"gs_bench_{workload}_{os.environ.get('MASTER_PORT', os.getpid())}.u8")
+
+
+def shared_genome(synth, workload, lengths, probs, dist, local_rank):
+    """The synthetic genome text, generated ONCE per node: with several ranks, local rank 0 (or the
+    launcher, see launch_ranks) fills a file in /dev/shm and every rank maps it, so eight ranks do
+    not each spend the generation time and 3.1 GB of host memory."""
+    path = os.environ.get("GS_BENCH_TEXT")
+    total = int(sum(lengths))
+    if path and os.path.exists(path) and os.path.getsize(path) == total:
+        text = np.memmap(path, dtype=np.uint8, mode="r")
+        names, lengths = [f"chr{i + 1}" for i in range(len(lengths))], [int(x) for x in lengths]
+        return text, names, lengths
+    if dist is None or dist.get_world_size() == 1:
+        return synth.make_genome(lengths, seed=1, probs=probs)
+    path = genome_file(workload)
+    if local_rank == 0:
+        mm = np.lib.format.open_memmap(path + ".npy", mode="w+", dtype=np.uint8, shape=(total,))
+        synth.make_genome(lengths, seed=1, probs=probs, out=mm)
+        mm.flush()
+        del mm
+    dist.barrier()
+    text = np.load(path + ".npy", mmap_mode="r")
+    dist.barrier()
+    if local_rank == 0:
+        os.unlink(path + ".npy")  # the mappings keep the pages until the ranks exit
+    return text, [f"chr{i + 1}" for i in range(len(lengths))], [int(x) for x in lengths]
+
+
+def launch_ranks(args, extra_env=None, module="torch.distributed.run"):
+    """Parent of an N-GPU run started as plain `python bench.py --gpus N`: generate the genome once
+    into /dev/shm, start N ranks with torch.distributed.run (one per GPU, rendezvous on 127.0.0.1)
+    as a child process, relay their output, return the child's exit code.  Nothing here initialises
+    the GPU (a process that has must not be replaced or forked into ranks)."""
+    import socket
+    import subprocess
+    synth = import_module("guidescan-cli_amd.synth")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(extra_env or {})
+    path = None
+    if args.workload in WORKLOADS:
+        lens_name, _, probs = WORKLOADS[args.workload]
+        lengths = [synth.CHR1_LENGTH] if lens_name == "CHR1" else getattr(synth, lens_name)
+        path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
+                            f"gs_bench_{args.workload}_{port}.u8")
+        mm = np.memmap(path, dtype=np.uint8, mode="w+", shape=(int(sum(lengths)),))
+        synth.make_genome(lengths, seed=1, probs=probs, out=mm)
+        mm.flush()
+        del mm
+        env["GS_BENCH_TEXT"] = path
+    cmd = [sys.executable, "-m", module, "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    try:
+        return subprocess.run(cmd, env=env).returncode
+    finally:
+        if path and os.path.exists(path):
+            os.unlink(path)
+
+
+def stub_main(args):
+    """GS_BENCH_STUB=1: rehearsal of the multi-rank plumbing WITHOUT a GPU (tests/test_distributed_gloo.py):
+    launcher -> torch.distributed.run -> gloo rendezvous on 127.0.0.1 -> genome shared through
+    /dev/shm -> barriers around K counted steps -> MAX over ranks -> one JSON line from rank 0.  The
+    step is a checksum of the rank's guide shard; the line is marked "stub" and is not a measurement."""
+    import torch
+    import torch.distributed as dist
+    synth = import_module("guidescan-cli_amd.synth")
+    parallel = import_module("guidescan-cli_amd.parallel")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        return f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dist.init_process_group("gloo")
+    lens_name, batch, probs = WORKLOADS[args.workload]
+    lengths = [synth.CHR1_LENGTH] if lens_name == "CHR1" else getattr(synth, lens_name)
+    batch = args.batch or batch
+    text, names, lengths = shared_genome(synth, args.workload, lengths, probs, dist, int(os.environ.get("LOCAL_RANK", "0")))
+    seqs, pams, _, _ = synth.sample_guides(text, batch, seed=1000 + rank)
+    acc = []
+    elapsed = parallel.timed_steps(lambda i: acc.append(int(seqs.sum()) + i), args.steps, args.warmup, lambda: None, dist)
+    sums = [None] * world
+    dist.all_gather_object(sums, (int(text[::4097].astype(np.int64).sum()), len(acc)))
+    if rank == 0:
+        print(json.dumps({"stub": True, "metric": "plumbing rehearsal (no GPU)", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "value": batch * args.steps * world / max(elapsed, 1e-9),
+                          "unit": "guides/s", "text_checksums": [s[0] for s in sums],
+                          "steps_run_per_rank": [s[1] for s in sums],
+                          "shared_text": bool(os.environ.get("GS_BENCH_TEXT"))}), flush=True)
+    dist.destroy_process_group()
+    return 0
 
 
 def recorded_traffic(workload, batch, m):

@@ -29,22 +29,42 @@ def reverse_complement_bytes(text: np.ndarray) -> np.ndarray:
     return _COMP[text[::-1]]
 
 
-def make_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), n_blocks=True):
+def _fill_bases(text, s, e, seed, cum):
+    """bytes [s, e) of the i.i.d. stream: draw i of the PCG64(seed) stream decides base i, so any
+    chunking (and any number of threads) gives the same text"""
+    bg = np.random.PCG64(seed)
+    bg.advance(s)
+    u = np.random.Generator(bg).random(e - s)
+    idx = (u >= cum[0]).view(np.uint8) + (u >= cum[1]).view(np.uint8) + (u >= cum[2]).view(np.uint8)
+    text[s:e] = _ACGT[idx]
+
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def make_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), n_blocks=True, out=None, threads=None):
     """Return (text uint8[sum(lengths)], names, lengths).
 
     i.i.d. bases; when n_blocks, each chromosome longer than 100 kb gets 10 kb
     telomeric N runs and one centromeric N block of ~1.2 % of its length
-    (SURVEY.md section 8d, C2/C3)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
+    (SURVEY.md section 8d, C2/C3).  Chunks are filled by a thread pool, each from the
+    seed's stream advanced to its own offset: the bytes do not depend on the thread count.
+    `out`: a preallocated uint8 array (e.g. an np.memmap in /dev/shm shared by the ranks)."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
     total = int(sum(lengths))
     cum = np.cumsum(np.asarray(probs, dtype=np.float64))
-    text = np.empty(total, dtype=np.uint8)
-    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    text = np.empty(total, dtype=np.uint8) if out is None else out
+    assert text.shape[0] == total and text.dtype == np.uint8
     chunk = 1 << 24
-    for s in range(0, total, chunk):
-        e = min(total, s + chunk)
-        u = rng.random(e - s)
-        text[s:e] = lut[np.minimum(np.searchsorted(cum, u, side="right"), 3)]
+    spans = [(s, min(total, s + chunk)) for s in range(0, total, chunk)]
+    nt = threads or min(16, os.cpu_count() or 1)
+    if nt > 1 and len(spans) > 1:
+        with ThreadPoolExecutor(nt) as ex:
+            list(ex.map(lambda se: _fill_bases(text, se[0], se[1], seed, cum), spans))
+    else:
+        for s, e in spans:
+            _fill_bases(text, s, e, seed, cum)
     off = 0
     for ln in lengths:
         if n_blocks and ln > 100_000:

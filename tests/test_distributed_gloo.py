@@ -66,3 +66,39 @@ def test_world2_gloo_sharded_equals_unsharded(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(out)), nprocs=2, join=True)
     assert out.read_text().startswith("ok")
+
+
+def _run_bench_stub(cmd, env_extra):
+    import json
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GS_BENCH_STUB="1", **env_extra)
+    env.pop("RANK", None)
+    env.pop("GS_BENCH_TEXT", None)
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout        # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no external launcher) starts two ranks, shares one genome file
+    through /dev/shm and prints one line; rehearsed on gloo with the stub step (no GPU here)"""
+    j = _run_bench_stub([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
+                         "--workload", "saccer3", "--batch", "64"], {})
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["shared_text"] is True
+    assert j["steps_run_per_rank"] == [4, 4]
+    assert len(set(j["text_checksums"])) == 1
+
+
+def test_bench_under_the_drivers_torchrun_command():
+    """the driver's own N>1 command line (torch.distributed.run ... bench.py --gpus N): local rank 0
+    generates the genome, the other rank maps it"""
+    port = 23000 + os.getpid() % 2000
+    j = _run_bench_stub([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2",
+                         "--steps", "2", "--warmup", "1", "--workload", "saccer3", "--batch", "64"], {})
+    assert j["n_gpus"] == 2 and j["shared_text"] is False
+    assert len(set(j["text_checksums"])) == 1
