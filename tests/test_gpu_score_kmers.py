@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from test_kmers import find_all_kmers_ref
+from kmers_golden import check_properties, expected_rows, golden_cases
 
 api = import_module("guidescan-cli_amd.api")
 synth = import_module("guidescan-cli_amd.synth")
@@ -178,15 +178,24 @@ def test_score_rejects_bad_arguments(toy_gpu):
 
 # ---- candidate-guide generation ---------------------------------------------------------------
 
-@pytest.mark.parametrize("pam,k,start", [("NGG", 20, False), ("NAG", 20, False), ("NGG", 20, True),
-                                         ("TTTN", 23, True), ("NNGAAT", 21, False), ("NNN", 5, False),
-                                         ("AGG", 20, False)])
-def test_device_kmers_match_reference_loops(pam, k, start):
-    rng = np.random.default_rng(5)
+@pytest.mark.parametrize("case", golden_cases(), ids=lambda c: c["name"])
+def test_device_kmers_equal_the_reference_scripts_rows(case):
+    """gs_kmers_generate against the rows the reference's own script gave (tests/golden/kmers): PAMs at
+    the record ends, lower case, N runs, --start, NNGAAT, NNN, records shorter than a site"""
+    got = kmers.find_all_kmers_device(case["record"].encode(), case["pam"], case["k"], case["start"])
+    assert got == expected_rows(case)
+
+
+@pytest.mark.parametrize("pam,k,start", [("NGG", 20, False), ("NGN", 19, True), ("TTTN", 23, True),
+                                         ("NNGAAT", 21, False), ("NNN", 5, False), ("AGG", 20, False)])
+def test_device_kmers_have_the_site_properties(pam, k, start):
+    """independent brute force: every reported site is a site, every site is reported once, order =
+    strand, PAM expansion, position"""
+    rng = np.random.default_rng(5 + k)
     seq = "".join(rng.choice(list("ACGTNacgt"), 6000, p=[.22, .22, .22, .22, .04, .02, .02, .02, .02]))
-    seq = "GG" + seq + "CC"          # PAMs at the very ends: negative / short slices
+    seq = "GG" + seq + "CC"          # PAMs at the very ends
     got = kmers.find_all_kmers_device(seq.encode(), pam, k, start)
-    assert got == find_all_kmers_ref(pam, k, seq, end=not start)
+    check_properties(seq, pam, k, start, got)
     assert len(got) >= 3
 
 

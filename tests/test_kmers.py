@@ -1,75 +1,48 @@
-"""Candidate-guide generation vs a literal restatement of the reference script's loops
-(scripts/generate_kmers.py:71-125; str.find based, as there).  CPU only."""
+"""Candidate-guide generation (the numpy restatement in guidescan-cli_amd/kmers.py) against the rows
+the reference's own script produced (tests/golden/kmers, made by tools/make_kmers_goldens.py) and
+against an independent brute-force property check.  CPU only."""
 import io
 from importlib import import_module
 
 import numpy as np
 import pytest
 
+from kmers_golden import check_properties, expected_rows, golden_cases
+
 kmers = import_module("guidescan-cli_amd.kmers")
 
-NUCS = list("ACTG")
-NUC_MAP = {"A": "T", "T": "A", "C": "G", "G": "C"}
+CASES = golden_cases()
 
 
-def revcom(dna):
-    return "".join(list(map(lambda n: NUC_MAP[n], list(dna)))[::-1])
+def test_goldens_present():
+    assert len(CASES) >= 10 and sum(len(c["rows"]) for c in CASES) > 1000
 
 
-def find_kmers_ref(pam, k, chrm, forward=True, end=True):
-    index = 0
-    while True:
-        index = chrm.find(pam, index)
-        if index == -1:
-            break
-        if end:
-            if forward:
-                kmer, position = chrm[index - k:index], index - k
-            else:
-                kmer, position = chrm[index + len(pam):index + k + len(pam)], index
-        else:
-            if forward:
-                kmer, position = chrm[index + len(pam):index + k + len(pam)], index
-            else:
-                kmer, position = chrm[index - k:index], index - k
-        index += 1
-        if position < 0:
-            continue
-        yield kmer.upper(), position + 1
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_pam_set_order(case):
+    assert kmers.pam_set(case["pam"]) == case["pam_set"]
 
 
-def find_all_kmers_ref(pam, k, chrm, end=True):
-    chrm = str(chrm).upper()
-    ps = kmers.pam_set(pam)
-    out = []
-    for p in ps:
-        for kmer, pos in find_kmers_ref(p, k, chrm, end=end):
-            if len(kmer) != k or not all(n in NUCS for n in kmer):
-                continue
-            out.append((kmer, pos, "+"))
-    for p in map(revcom, ps):
-        for kmer, pos in find_kmers_ref(p, k, chrm, forward=False, end=end):
-            if len(kmer) != k or not all(n in NUCS for n in kmer):
-                continue
-            out.append((revcom(kmer), pos, "-"))
-    return out
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_rows_equal_the_reference_scripts(case):
+    got = kmers.find_all_kmers(case["record"].encode(), case["pam"], case["k"], case["start"])
+    assert got == expected_rows(case)
+    assert all(r[3] == case["pam"] for r in case["rows"])     # the pam column is the PATTERN
 
 
-def test_pam_set_order():
-    assert kmers.pam_set("NGG") == ["AGG", "CGG", "TGG", "GGG"]
-    assert kmers.pam_set("NNG")[:5] == ["AAG", "ACG", "ATG", "AGG", "CAG"]
-    assert kmers.pam_set("TTTV".replace("V", "N")) == ["TTTA", "TTTC", "TTTT", "TTTG"]
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_golden_rows_have_the_site_properties(case):
+    """the fixtures themselves against the brute-force checker (it shares no code with either side)"""
+    check_properties(case["record"], case["pam"], case["k"], case["start"], expected_rows(case))
 
 
-@pytest.mark.parametrize("pam,k,start", [("NGG", 20, False), ("NAG", 20, False), ("NGG", 20, True),
-                                         ("TTTN", 23, True), ("NNGRRT".replace("R", "A"), 21, False)])
-def test_matches_reference_loops(pam, k, start):
-    rng = np.random.default_rng(5)
-    seq = "".join(rng.choice(list("ACGTNacgt"), 6000, p=[.22, .22, .22, .22, .04, .02, .02, .02, .02]))
-    seq = "GG" + seq + "CC"          # PAMs at the very ends: negative / short slices
-    got = kmers.find_all_kmers(seq.encode(), pam, k, start)
-    assert got == find_all_kmers_ref(pam, k, seq, end=not start)
-    assert len(got) >= 3
+@pytest.mark.parametrize("pam,k,start", [("NGG", 20, False), ("NGN", 19, True), ("TTTN", 23, True), ("NNGAAT", 21, False)])
+def test_random_records_have_the_site_properties(pam, k, start):
+    rng = np.random.default_rng(len(pam) * 100 + k)
+    rec = "".join(rng.choice(list("ACGTNacgt"), 3000, p=[.22, .22, .22, .22, .04, .02, .02, .02, .02]))
+    got = kmers.find_all_kmers(rec.encode(), pam, k, start)
+    assert len(got) > 3
+    check_properties(rec, pam, k, start, got)
 
 
 def test_csv_rows(tmp_path):
