@@ -45,6 +45,11 @@ class GsResultView(C.Structure):
                 ("ms_search", C.c_float), ("ms_total", C.c_float)]
 
 
+class GsSaReport(C.Structure):
+    _fields_ = [("rows", C.c_uint64), ("not_permutation", C.c_uint64), ("sampled", C.c_uint64),
+                ("out_of_order", C.c_uint64), ("undecided", C.c_uint64), ("bwt_mismatch", C.c_uint64)]
+
+
 class GsGenomeStructure(C.Structure):
     _fields_ = [("chr_names", C.POINTER(C.c_char_p)), ("chr_lengths", C.POINTER(C.c_uint64)),
                 ("n_chr", C.c_uint32)]
@@ -106,6 +111,8 @@ def lib():
     L.gs_index_meta.argtypes = [vp, i32, vp, C.POINTER(u64)]
     L.gs_index_copy_sa.restype = i32
     L.gs_index_copy_sa.argtypes = [vp, i32, vp]
+    L.gs_index_verify_sa.restype = i32
+    L.gs_index_verify_sa.argtypes = [vp, i32, vp, u64, u64, u64, C.POINTER(GsSaReport)]
     L.gs_calculate_cfd.restype = C.c_float
     L.gs_calculate_cfd.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
     L.gs_format_guide.restype = i32
@@ -154,7 +161,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text",
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
-           "gs_kmers_free", "gs_format_guide_scored"]
+           "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa"]
 
 
 def _check(rc):
@@ -359,6 +366,14 @@ class GenomeIndex:
         out = np.empty(n, dtype=np.uint32)
         _check(lib().gs_index_copy_sa(self._h, strand, out.ctypes.data))
         return out
+
+    def verify_sa(self, text, strand=0, samples=1 << 20, seed=1):
+        """self-check from the text alone -> dict of gs_sa_report (all counters but rows/sampled must be 0)"""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        rep = GsSaReport()
+        _check(lib().gs_index_verify_sa(self._h, strand, text.ctypes.data, text.shape[0], samples, seed,
+                                        C.byref(rep)))
+        return {k: int(getattr(rep, k)) for k, _ in GsSaReport._fields_}
 
     def enumerate(self, seqs: np.ndarray, pams: np.ndarray, mismatches=3, alt_pams=(), start=False,
                   faithful=False):

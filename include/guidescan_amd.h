@@ -157,6 +157,23 @@ gs_status gs_index_meta(const gs_index *ix, int strand, uint64_t C_acgtn[5], uin
 /* copy the device-resident suffix array back (n = size entries) */
 gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out);
 
+/* Self-check of a resident index from the genome text alone (no suffix-array builder involved):
+ * the suffix array of `strand` is a permutation of [0, n) (all rows), n_samples evenly spread
+ * adjacent row pairs are in suffix order by direct comparison of the text, and the BWT symbol
+ * each sampled row's Occ block holds is text[SA[row]-1].  `text` = the forward genome text as given
+ * to gs_index_build.  Stands where the reference relies on sdsl::construct being right
+ * (sdsl/include/sdsl/construct.hpp:121-166); used by the parity tests at n > 2^31. */
+typedef struct {
+  uint64_t rows;            /* n = text length + 1 */
+  uint64_t not_permutation; /* rows whose value is out of range or was seen before */
+  uint64_t sampled;         /* adjacent pairs compared */
+  uint64_t out_of_order;    /* pairs with suffix(SA[r]) >= suffix(SA[r+1]) */
+  uint64_t undecided;       /* pairs still equal after 65536 comparison steps (N runs are skipped) */
+  uint64_t bwt_mismatch;    /* sampled rows whose block symbol differs from the text */
+} gs_sa_report;
+gs_status gs_index_verify_sa(gs_index *ix, int strand, const uint8_t *text, uint64_t len,
+                             uint64_t n_samples, uint64_t seed, gs_sa_report *report);
+
 /* ---- text encoders: the step right after the path (host side) ---------------------------- */
 
 typedef struct {

@@ -1,0 +1,320 @@
+"""BASELINE configs 2-5 at their real sizes, on the GPU box (`pytest -m gpu`).
+
+ * config 2: chr1-sized index (249 Mbp), 100,000 guides, <= 3 mismatches
+ * config 3: hg38-sized index (3.09 Gbp, both strands in HBM), 1,000,000 guides, <= 3 mismatches
+ * config 4: genome-wide NGG candidates of a chromosome, scanned on the device and enumerated from HBM
+ * config 5: hg38-sized index at <= 6 mismatches with CFD / specificity
+
+What is compared with what:
+ * the timed fast path (two-sided seeding) vs one-sided seeding (GS_NO_BIDIR) vs the reference-order
+   walk from the root (GS_FLAG_FAITHFUL_WALK): same bytes; keys ascending; every sampled guide's own
+   site reported at distance 0 at its own coordinate and strand, and its text equals guide + PAM;
+ * the suffix arrays against the genome text alone (gs_index_verify_sa: permutation test on every
+   row, suffix order and BWT symbol on >= 10^7 sampled rows) - nothing borrowed from the GPU builder;
+ * the product's CSV lines (device search + device scoring + gs_format_guide_scored) against the
+   lines the REFERENCE ITSELF writes for the same guides: oracle/_ref/gs_ref_enumerate (the
+   reference's index.hpp / process.hpp / printer.hpp compiled in place) run on this host over index
+   files written through the compiled SDSL containers.  Done at hg38 size for sampled guides and
+   genome-wide candidates at m = 3 and for config 5's depth at m = 6.
+
+The reference legs need oracle/_ref (prebuilt, travels with the snapshot); nothing reads
+/root/reference.  The SDSL index files are written by background threads while the GPU tests run."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+import tempfile
+import threading
+import time
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+api = import_module("guidescan-cli_amd.api")
+synth = import_module("guidescan-cli_amd.synth")
+
+pytestmark = pytest.mark.gpu
+SHIM = ol.ORACLE_DIR / "_ref" / "gs_ref_enumerate"
+NGG = np.frombuffer(b"NGG", np.uint8)
+
+
+def _hip():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return hip
+
+
+def device_result_to_torch(torch, hip, d_off, d_hits, n, n_hits):
+    off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    hits = torch.empty((max(n_hits, 1), 2), dtype=torch.int64, device="cuda")
+    assert hip.hipMemcpy(off.data_ptr(), d_off, 8 * (n + 1), 3) == 0
+    if n_hits:
+        assert hip.hipMemcpy(hits.data_ptr(), d_hits, 16 * n_hits, 3) == 0
+    return off, hits[:n_hits]
+
+
+def check_batch_properties(text, seqs, positions, strands, off, pos, key):
+    """size-independent properties of one batch's CSR hit list (numpy arrays on the host)"""
+    n = seqs.shape[0]
+    assert off[0] == 0 and off[-1] == pos.shape[0] and np.all(np.diff(off) >= 0)
+    seg = np.repeat(np.arange(n), np.diff(off))
+    same = seg[1:] == seg[:-1]
+    assert np.all(key[1:][same] >= key[:-1][same]), "keys not ascending within a guide"
+    assert np.all((key & np.uint64(0xFF)) == 0)
+    # every sampled site is reported at distance 0 at its own coordinate and strand: + strand sites
+    # come from the reverse index with pos = p + 22 (inclusive end), - strand sites from the forward
+    # index with pos = -p (process.hpp:104,111)
+    want = np.where(strands == ord("+"), positions + 22, -positions)
+    d0 = (key >> np.uint64(61)) == 0
+    hit_is_own = d0 & (pos == want[seg])
+    found = np.zeros(n, dtype=bool)
+    found[seg[hit_is_own]] = True
+    assert found.all(), f"{int((~found).sum())} guides lack their own site at distance 0"
+    # the index bit agrees with the sign convention, and the text under every distance-0 hit of a
+    # sample equals guide + xGG
+    idx = np.nonzero(d0)[0][:: max(1, int(d0.sum()) // 20000)]
+    rev = ((key[idx] >> np.uint64(60)) & np.uint64(1)).astype(bool)
+    for h, r in zip(idx, rev):
+        g = seqs[seg[h]]
+        if r:
+            w = text[pos[h] - 22:pos[h] + 1]
+        else:
+            w = synth.reverse_complement_bytes(text[-pos[h]:-pos[h] + 23])
+        assert np.array_equal(w[:20], g) and w[21] == ord("G") and w[22] == ord("G")
+    return int(idx.size)
+
+
+def three_paths_same_bytes(torch, gidx, d_seqs, d_pams, n, m, n_walk):
+    """two-sided seeding == one-sided seeding (whole batch) == reference-order walk (first n_walk)"""
+    hip = _hip()
+    d_off, d_hits, st = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
+    off, hits = device_result_to_torch(torch, hip, d_off, d_hits, n, st["n_hits"])
+    os.environ["GS_NO_BIDIR"] = "1"
+    try:
+        d_o, d_h, st2 = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
+        o2, h2 = device_result_to_torch(torch, hip, d_o, d_h, n, st2["n_hits"])
+    finally:
+        del os.environ["GS_NO_BIDIR"]
+    assert torch.equal(o2, off) and torch.equal(h2, hits), "one-sided and two-sided seeding differ"
+    d_o, d_h, st3 = gidx.enumerate_device(d_seqs.data_ptr(), n_walk, 20, d_pams.data_ptr(), 3, mismatches=m,
+                                          faithful=True)
+    o3, h3 = device_result_to_torch(torch, hip, d_o, d_h, n_walk, st3["n_hits"])
+    nh = int(off[n_walk].item())
+    assert torch.equal(o3, off[:n_walk + 1]) and torch.equal(h3, hits[:nh]), "walk and fast path differ"
+    return off.cpu().numpy(), hits.cpu().numpy(), st, st3
+
+
+# ---- config 2 ------------------------------------------------------------------------------------
+
+def test_config2_chr1_sized_100k_guides_m3():
+    """BASELINE config 2 at its real size: 249 Mbp index, 100,000 guides, <= 3 mismatches"""
+    import torch
+    text, names, lengths = synth.make_genome([synth.CHR1_LENGTH], seed=1)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        for s in (0, 1):   # 2.5e8 rows: suffix order / BWT symbol on 4M sampled rows, permutation on all
+            rep = gidx.verify_sa(text, strand=s, samples=1 << 22, seed=5 + s)
+            assert rep["rows"] == text.shape[0] + 1 and rep["sampled"] == 1 << 22
+            assert rep["not_permutation"] == rep["out_of_order"] == rep["undecided"] == rep["bwt_mismatch"] == 0, rep
+        n = 100_000
+        seqs, pams, pos, strands = synth.sample_guides(text, n, seed=21)
+        d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+        off, hits, st, st_walk = three_paths_same_bytes(torch, gidx, d_seqs, d_pams, n, 3, n)
+        assert st["n_hits"] == off[-1] >= n
+        check_batch_properties(text, seqs, pos, strands, off, hits[:, 0], hits[:, 1].view(np.uint64))
+        # host-pointer entry point: same bytes as the device-pointer one
+        off_h, hits_h, _ = gidx.enumerate(seqs, pams, mismatches=3)
+        assert np.array_equal(off_h.astype(np.int64), off)
+        assert hits_h.tobytes() == np.ascontiguousarray(hits).tobytes()
+        # oracle spot check on 64 guides (its index is built from the suffix arrays verified above)
+        oidx = ol.OracleIndex(text, sa_provider=lambda s: gidx.suffix_array(s), nthreads=16)
+        try:
+            opts = ol.make_opts(mismatches=3)
+            for i in range(0, n, n // 64):
+                g = seqs[i].tobytes().decode()
+                exp, ctr, raw = oidx.enumerate(g, "NGG", opts)
+                ol.lib().gso_free(raw[0])
+                got = [(int(h["pos"]), int(h["key"]) >> 61, (int(h["key"]) >> 60) & 1,
+                        api.decode_sequence(g, 3, int(h["key"]))) for h in hits_h[off_h[i]:off_h[i + 1]]]
+                assert got == [(e[0], e[1], e[2], e[3]) for e in exp], i
+        finally:
+            oidx.close()
+    finally:
+        gidx.close()
+
+
+# ---- configs 3, 4, 5: one hg38-sized index for the whole group -------------------------------------
+
+class Hg38:
+    """the hg38-sized genome, its device index, and (in the background) the reference's index files"""
+
+    def __init__(self):
+        t0 = time.time()
+        self.text, self.names, self.lengths = synth.make_genome(synth.GRCH38_LENGTHS, seed=1)
+        self.t_gen = time.time() - t0
+        t0 = time.time()
+        self.gidx = api.GenomeIndex.build(self.text, device=0)
+        self.t_build = time.time() - t0
+        self.gs = api.make_genome_structure(self.names, self.lengths)
+        self.dir = tempfile.mkdtemp(prefix="gs_full_")
+        self.ref_ok = ol.ref() is not None and SHIM.exists()
+        self.ref_err = []
+        self.threads = []
+        self.t_files = None
+        if self.ref_ok:
+            self._t0 = time.time()
+            for strand, suffix in ((0, ".forward"), (1, ".reverse")):
+                th = threading.Thread(target=self._write_strand, args=(strand, suffix))
+                th.start()
+                self.threads.append(th)
+            with open(os.path.join(self.dir, "g.gs"), "w") as f:
+                f.write("".join(f"{a}\n{b}\n" for a, b in zip(self.names, self.lengths)))
+
+    def _write_strand(self, strand, suffix):
+        """<prefix>.forward / .reverse through the compiled reference containers (ctypes releases the GIL)"""
+        try:
+            ref = ol.ref()
+            n = self.text.shape[0] + 1
+            sa = self.gidx.suffix_array(strand)
+            st = np.ascontiguousarray(self.text if strand == 0 else synth.reverse_complement_bytes(self.text))
+            h = ref.ref_index_build_text(st.ctypes.data, sa.ctypes.data, n,
+                                         os.path.join(self.dir, f"tmp{strand}.sdsl").encode())
+            assert ref.ref_write_index_file(h, os.path.join(self.dir, "g" + suffix).encode()) == 0
+            ref.ref_index_free(h)
+        except Exception as e:  # surfaced by reference_prefix()
+            self.ref_err.append(repr(e))
+
+    def reference_prefix(self):
+        if not self.ref_ok:
+            pytest.skip("oracle/_ref not built")
+        for th in self.threads:
+            th.join()
+        if self.threads:
+            self.t_files = time.time() - self._t0
+            self.threads = []
+        assert not self.ref_err, self.ref_err
+        return os.path.join(self.dir, "g")
+
+    def run_reference(self, tag, ids, seqs, m, threads):
+        """kmers CSV -> the compiled reference (CSV, complete) -> sorted data lines"""
+        prefix = self.reference_prefix()
+        kcsv, out = os.path.join(self.dir, tag + ".kmers.csv"), os.path.join(self.dir, tag + ".out.csv")
+        synth.write_kmers_csv(kcsv, ids, [s.tobytes().decode() for s in seqs], ["NGG"] * len(ids),
+                              [self.names[0]] * len(ids), [1] * len(ids), ["+"] * len(ids))
+        env = dict(os.environ, GS_REF_THREADS=str(threads))
+        subprocess.run([str(SHIM), prefix, kcsv, out, "csv", "complete", str(m), "0", "0", "-1", "-1", "0"],
+                       env=env, check=True, timeout=1500, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        with open(out) as f:
+            lines = f.read().splitlines()
+        os.unlink(out)
+        return lines[0], sorted(lines[1:])
+
+    def product_lines(self, ids, seqs, m):
+        """the same guides through the product: search, device scoring, text lines -> sorted data lines"""
+        n = len(ids)
+        pams = np.tile(NGG, (n, 1))
+        off, hits, st = self.gidx.enumerate(seqs, pams, mismatches=m)
+        _, spec = self.gidx.score(self.gs, seqs, 3, off, hits, want_cfd=False)
+        out = []
+        for i in range(n):
+            txt = api.format_guide(self.gs, ids[i], seqs[i].tobytes().decode(), "NGG", True,
+                                   hits[off[i]:off[i + 1]], m, specificity=spec[i])
+            out += txt.splitlines()
+        return sorted(out), int(off[-1])
+
+    def close(self):
+        for th in self.threads:
+            th.join()
+        self.gidx.close()
+        shutil.rmtree(self.dir, ignore_errors=True)
+
+
+@pytest.fixture(scope="module")
+def hg38():
+    h = Hg38()
+    yield h
+    h.close()
+
+
+def test_hg38_suffix_arrays_against_the_text_alone(hg38):
+    """n = 3.09e9 > 2^31: both suffix arrays are permutations, 2^24 (1.7e7) evenly spread adjacent
+    row pairs per strand are in suffix order by direct text comparison, and the Occ blocks hold the
+    BWT symbol text[SA[r]-1] on those rows"""
+    for s in (0, 1):
+        rep = hg38.gidx.verify_sa(hg38.text, strand=s, samples=1 << 24, seed=11 + s)
+        assert rep["rows"] == hg38.text.shape[0] + 1 and rep["sampled"] == 1 << 24
+        assert rep["not_permutation"] == 0 and rep["out_of_order"] == 0 and rep["bwt_mismatch"] == 0, rep
+        assert rep["undecided"] == 0, rep
+
+
+def test_config3_hg38_sized_1M_guides_m3(hg38):
+    """BASELINE config 3: 1,000,000 guides, <= 3 mismatches: the timed path, one-sided seeding and
+    the reference-order walk (first 20,000 guides) return the same bytes; order and own-site properties"""
+    import torch
+    n = 1_000_000
+    seqs, pams, pos, strands = synth.sample_guides(hg38.text, n, seed=1000)
+    d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+    off, hits, st, st_walk = three_paths_same_bytes(torch, hg38.gidx, d_seqs, d_pams, n, 3, 20_000)
+    assert st["n_hits"] == off[-1] >= n
+    checked = check_batch_properties(hg38.text, seqs, pos, strands, off, hits[:, 0], hits[:, 1].view(np.uint64))
+    assert checked >= 10_000
+    hg38.sampled = (seqs, pos, strands)
+
+
+def test_config3_and_4_hg38_lines_equal_the_compiled_reference(hg38):
+    """hg38-sized parity against process.hpp:35-128 itself: 4,096 sampled guides (config 3) and 512
+    genome-wide candidates (config 4: NGG sites of a 46.7 Mbp chromosome scanned on the device and
+    enumerated from HBM), <= 3 mismatches: every CSV line the reference writes, specificity included"""
+    import torch
+    text = hg38.text
+    # config 4 on one GPU: candidates of chr21 (index 20), from HBM, every one finds itself
+    c = 20
+    c_off = int(sum(hg38.lengths[:c]))
+    d_chr = torch.from_numpy(np.ascontiguousarray(text[c_off:c_off + hg38.lengths[c]])).cuda()
+    km = api.generate_kmers(None, "NGG", 20, device=0, chrm_device_ptr=d_chr.data_ptr(), chrm_len=hg38.lengths[c])
+    try:
+        assert km.n > 4_000_000
+        kseqs, kpams, kpos, ksense = km.to_host()
+        hip = _hip()
+        total_hits, batch = 0, 1 << 20
+        for b0 in range(0, km.n, batch):
+            nb = min(batch, km.n - b0)
+            d_off, d_hits, st = hg38.gidx.enumerate_device(km.seqs_ptr + b0 * 20, nb, 20, km.pams_ptr + b0 * 3, 3,
+                                                           mismatches=3)
+            off, hits = device_result_to_torch(torch, hip, d_off, d_hits, nb, st["n_hits"])
+            assert bool((off[1:] > off[:-1]).all()), "a candidate without any hit (not even itself)"
+            total_hits += st["n_hits"]
+            if b0 == 0:   # own-site property of the first batch (positions are 1-based, chromosome-relative)
+                p0 = c_off + kpos[:nb].astype(np.int64) - 1
+                check_batch_properties(text, kseqs[:nb], p0, ksense[:nb], off.cpu().numpy(),
+                                       hits[:, 0].cpu().numpy(), hits[:, 1].cpu().numpy().view(np.uint64))
+        assert total_hits >= km.n
+    finally:
+        km.close()
+    del d_chr
+    rng = np.random.default_rng(4)
+    pick = np.sort(rng.choice(kseqs.shape[0], 512, replace=False))
+    seqs_s, _, _, _ = synth.sample_guides(text, 4096, seed=1001)
+    seqs = np.concatenate([seqs_s, kseqs[pick]])
+    ids = [f"s{i}" for i in range(4096)] + [f"chr21:{int(kpos[j])}:{chr(ksense[j])}" for j in pick]
+    got, n_hits = hg38.product_lines(ids, seqs, 3)
+    header, want = hg38.run_reference("m3", ids, seqs, 3, os.cpu_count() or 8)
+    assert header.startswith("id,sequence,")
+    assert len(want) >= len(ids) and len(got) == len(want)
+    assert got == want
+
+
+def test_config5_hg38_depth_m6_lines_equal_the_compiled_reference(hg38):
+    """BASELINE config 5's depth: <= 6 mismatches + CFD at hg38 size, 64 guides: ~1e4 hits per guide;
+    every CSV line (coordinates, match sequences, distances, specificity from k_score) equals the
+    reference's"""
+    seqs, _, _, _ = synth.sample_guides(hg38.text, 64, seed=1000)
+    ids = [f"d{i}" for i in range(64)]
+    got, n_hits = hg38.product_lines(ids, seqs, 6)
+    assert n_hits > 64 * 5000
+    header, want = hg38.run_reference("m6", ids, seqs, 6, 64)
+    assert len(got) == len(want)
+    assert got == want

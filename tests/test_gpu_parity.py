@@ -382,44 +382,6 @@ def test_config1_saccer3_sized_1k_guides_m1():
         oidx.close()
 
 
-def test_full_size_properties_chr1_sized():
-    """chr1-sized genome (249 Mbp, BASELINE config 2's index), 20k guides, <= 3 mismatches:
-    size-independent properties + an oracle spot check"""
-    text, names, lengths = synth.make_genome([synth.CHR1_LENGTH], seed=1)
-    Lg = text.shape[0]
-    gidx = api.GenomeIndex.build(text, device=0)
-    try:
-        seqs, pams, pos, strands = synth.sample_guides(text, 20000, seed=21)
-        offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=3)
-        off2, hits2, stats2 = gidx.enumerate(seqs, pams, mismatches=3, faithful=True)
-        # (1) the prefix-table/context path and the reference-order walk give the same bytes
-        assert np.array_equal(offsets, off2)
-        assert hits.tobytes() == hits2.tobytes()
-        # (2) canonical order: keys ascending within every guide
-        for i in range(0, 20000, 97):
-            k = hits["key"][offsets[i]:offsets[i + 1]]
-            assert np.all(k[:-1] <= k[1:])
-        # (3) every sampled site is reported at distance 0 at its own coordinate and strand:
-        #     + strand sites come from the reverse index with pos = p + 22 (inclusive end),
-        #     - strand sites from the forward index with pos = -p   (process.hpp:104,111)
-        for i in range(20000):
-            h = hits[offsets[i]:offsets[i + 1]]
-            d0 = h[(h["key"] >> np.uint64(61)) == 0]
-            want = int(pos[i]) + 22 if strands[i] == ord("+") else -int(pos[i])
-            assert want in d0["pos"].tolist(), i
-        assert stats["n_hits"] == offsets[-1] >= 20000
-        # (4) oracle spot check (index from the GPU's suffix arrays, verified elsewhere)
-        oidx = ol.OracleIndex(text, sa_provider=lambda s: gidx.suffix_array(s), nthreads=8)
-        opts = ol.make_opts(mismatches=3)
-        for i in range(0, 20000, 500):
-            g = seqs[i].tobytes().decode()
-            exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
-            assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, i
-        oidx.close()
-    finally:
-        gidx.close()
-
-
 def test_repeat_guide_with_thousands_of_matches():
     """a guide whose (guide, strand) match count exceeds the LDS sort (2048): exact-size redo,
     device-wide comparator sort, per-record locate - still bit-exact and in CSR order"""
