@@ -116,11 +116,18 @@ def main():
 
     # N_ext is a property of the input under the REFERENCE's traversal
     # rules.  The timed path skips the input-independent top of the tree through the prefix
-    # table, so it is measured here, untimed, with the reference-order walk on a sample.
-    ns = min(batch, 20000)
+    # table, so it is measured here, untimed, with the reference-order walk on a sample (sized so
+    # that the walk stays around a second: it is ~10^5 extensions per guide at m = 3, 3.5e7 at m = 6).
+    ns = min(batch, {0: 20000, 1: 20000, 2: 20000, 3: 20000, 4: 4000, 5: 600}.get(m, 128))
     _, _, st_ref = gidx.enumerate_device(d_seqs.data_ptr(), ns, L, d_pams.data_ptr(), P, mismatches=m,
                                          faithful=True)
     n_ext_ref_per_guide = st_ref["n_ext"] / ns
+    # The bytes THIS algorithm asks the memory system for: one untimed pass of the first batch
+    # through the counting instantiation of k_search (same code, plus a tally of the distinct
+    # 64-byte lines every load instruction requests; include/guidescan_amd.h GS_FLAG_COUNT_REQUESTS)
+    _, _, st_cnt = gidx.enumerate_device(d_seqs.data_ptr(), batch, L, d_pams.data_ptr(), P, mismatches=m,
+                                         count_requests=True)
+    req = gidx.last_counters()
 
     for i in range(args.warmup):
         step(i)
@@ -147,13 +154,22 @@ def main():
     guides_total = batch * K * world
     value = guides_total / elapsed
 
-    # roofline of the dominant kernel (k_search): algorithmic bytes = 128 B per extended
-    # node (two 64-byte Occ blocks), per launch, over the kernel's
-    # HIP-event duration measured inside the library on the launch stream.
-    alg_bytes_per_launch = 128.0 * n_ext_ref_per_guide * batch
+    # Roofline of the dominant kernel (k_search), HBM bound.  Algorithmic bytes of the algorithm that
+    # runs: every load k_search issues is a random access that moves one 64-byte line (Occ block,
+    # table line of four entries, eight 16-bit context words, one context word, one SA/ISA entry), so
+    # B = 64 B x distinct lines requested (counted per load instruction by the counting pass above)
+    # + 16 B per match record written.  achieved = B per launch / the launch's HIP-event duration
+    # (measured inside the library on the launch stream), against the 8 TB/s HBM3E peak.
+    # `traffic` is what the memory side actually moved (FETCH_SIZE + WRITE_SIZE from separate
+    # rocprofv3 --pmc passes of this command, profiles/traffic.json) - only when that file was
+    # recorded with these kernel sources; more than B means re-reads, less means cache hits.
+    lines = {k: req[k] for k in ("table_lines", "ctx16_lines", "ctx_words", "sa_isa_gathers", "occ_lines")}
+    n_lines = sum(lines.values())
+    alg_bytes_per_launch = 64.0 * n_lines + 16.0 * st_cnt["n_matches"]
     search_s = (ms_search / K) / 1e3
     achieved = alg_bytes_per_launch / search_s / 1e9 if search_s > 0 else 0.0
     traffic, traffic_src = recorded_traffic(args.workload, batch, m)
+    ref_bytes = 128.0 * n_ext_ref_per_guide * batch
     out = {
         "metric": f"guides/sec off-target enum, <={m} mismatches",
         "value": value,
@@ -176,24 +192,33 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src,
                      "alg_bytes_per_launch": alg_bytes_per_launch,
-                     "avg_launch_ms": ms_search / K},
-        "detail": {"n_ext_per_guide": n_ext_ref_per_guide, "n_ext_sample": ns,
-                   "executed_ext_per_guide": n_ext / (batch * K), "hits_per_guide": n_hits / (batch * K),
+                     "avg_launch_ms": ms_search / K,
+                     "requests_per_guide": {k: v / batch for k, v in lines.items()},
+                     "random_requests": {
+                         "per_guide": n_lines / batch, "unit": "64-byte lines",
+                         "achieved_per_s": n_lines / search_s if search_s > 0 else None,
+                         "ceiling_per_s": [5.0e10, 5.5e10],
+                         "frac_of_ceiling": (n_lines / search_s / 5.5e10) if search_s > 0 else None,
+                         "note": "the memory system's measured rate of random 64-byte line requests "
+                                 "(tools/gather_bench, profiles/r01_gather_calibration.txt) is what binds "
+                                 "this kernel before bytes do"},
+                     # SURVEY 8d's figure, kept for comparison: the bytes the REFERENCE'S traversal
+                     # (128 B per extended node, N_ext from the reference-order walk on a sample) would
+                     # need for this batch.  Not what this kernel does: table, context mask, context
+                     # arrays and two-sided seeding skip that work.
+                     "reference_traversal": {"alg_bytes_per_launch": ref_bytes,
+                                             "n_ext_per_guide": n_ext_ref_per_guide, "n_ext_sample": ns,
+                                             "bytes_vs_this_algorithm": ref_bytes / alg_bytes_per_launch
+                                             if alg_bytes_per_launch else None}},
+        "detail": {"executed_ext_per_guide": n_ext / (batch * K), "hits_per_guide": n_hits / (batch * K),
                    "prefix_table_k": os.environ.get("GS_PREFIX_K", "auto"),
                    "k_search_ms_per_step": per_step_ms,
                    "device_ms_total_per_step": ms_total / K, "index_build_s": t_index,
-                   "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes},
+                   "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes,
+                   "items_two_sided": req["items_two_sided"], "items_one_sided": req["items_one_sided"],
+                   "overflow_items_first_pass": req["overflow_items"]},
     }
 
-    if traffic:
-        # what actually binds k_search: 64-byte random requests (FETCH_SIZE / 64) against the
-        # memory system's random-request ceiling measured by tools/gather_bench
-        fetch = next(r["fetch_bytes"] for r in json.loads((ROOT / "profiles" / "traffic.json").read_text())
-                     if r["workload"] == args.workload and r["batch"] == batch and r["mismatches"] == m)
-        out["roofline"]["random_requests"] = {
-            "per_guide": fetch / 64.0 / batch, "achieved_per_s": fetch / 64.0 / search_s if search_s > 0 else None,
-            "ceiling_per_s": [5.0e10, 5.5e10], "unit": "64-byte requests",
-            "note": "FETCH_SIZE of the recorded PMC pass over this run's HIP-event launch time"}
     if rank == 0:
         # the device steps either side of the path (untimed side figures, never part of `value`):
         # CFD/specificity of the last batch's hits and the candidate-guide scan of chromosome 1
@@ -324,16 +349,28 @@ def stub_main(args):
     return 0
 
 
+def kernel_stamp():
+    """sha256 of the sources that decide k_search's memory traffic"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gs_search.hip", "gs_device.h", "gs_common.h", "gs_index.hip"):
+        h.update((ROOT / "guidescan-cli_amd" / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def recorded_traffic(workload, batch, m):
     """HBM-side bytes of one k_search launch (FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be
     read from inside this process: they come from separate `rocprofv3 --pmc` passes of this same
-    command, committed under profiles/ (calibration: DESIGN.md section 6).  None when no pass
-    was recorded for this exact workload."""
+    command (tools/profile_round.sh), summarised in profiles/traffic.json by tools/make_traffic_json.py
+    together with a hash of the kernel sources.  None when no pass was recorded for this exact
+    workload WITH THESE SOURCES (a stale number is worse than none)."""
     f = ROOT / "profiles" / "traffic.json"
     if not f.exists():
         return None, None
+    stamp = kernel_stamp()
     for rec in json.loads(f.read_text()):
-        if rec["workload"] == workload and rec["batch"] == batch and rec["mismatches"] == m:
+        if (rec["workload"] == workload and rec["batch"] == batch and rec["mismatches"] == m
+                and rec.get("kernel_sha") == stamp):
             return rec["fetch_bytes"] + rec["write_bytes"], rec["source"]
     return None, None
 

@@ -21,6 +21,7 @@ LIB_PATH = Path(os.environ.get("GS_LIB_PATH", str(PKG / "libgsamd.so")))
 
 GS_FLAG_PAM_AT_START = 1
 GS_FLAG_FAITHFUL_WALK = 2
+GS_FLAG_COUNT_REQUESTS = 4
 
 
 class GsError(RuntimeError):
@@ -111,6 +112,8 @@ def lib():
     L.gs_index_meta.argtypes = [vp, i32, vp, C.POINTER(u64)]
     L.gs_index_copy_sa.restype = i32
     L.gs_index_copy_sa.argtypes = [vp, i32, vp]
+    L.gs_index_last_counters.restype = i32
+    L.gs_index_last_counters.argtypes = [vp, vp]
     L.gs_index_verify_sa.restype = i32
     L.gs_index_verify_sa.argtypes = [vp, i32, vp, u64, u64, u64, C.POINTER(GsSaReport)]
     L.gs_calculate_cfd.restype = C.c_float
@@ -161,7 +164,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text",
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
-           "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa"]
+           "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters"]
 
 
 def _check(rc):
@@ -454,12 +457,21 @@ class GenomeIndex:
             lib().gs_result_ex_free(r)
         return offsets, hits
 
+    def last_counters(self):
+        """k_search's counters of the last enumerate_device call (see gs_index_last_counters)"""
+        out = (C.c_uint64 * 16)()
+        _check(lib().gs_index_last_counters(self._h, out))
+        v = list(out)
+        return dict(n_ext=v[0], overflow_items=v[1], n_matches=v[2], items_two_sided=v[4], items_one_sided=v[5],
+                    table_lines=v[8], ctx16_lines=v[9], ctx_words=v[10], sa_isa_gathers=v[11], occ_lines=v[12])
+
     def enumerate_device(self, d_guides_ptr, n, L, d_pams_ptr, P, mismatches=3, alt_pams=(),
-                         start=False, stream=None, faithful=False):
+                         start=False, stream=None, faithful=False, count_requests=False):
         """Device-resident variant (what bench.py times): pointers are raw device addresses.
         Returns (d_offsets_ptr, d_hits_ptr, stats)."""
         alt = b"".join(p.encode() for p in alt_pams)
-        flags = (GS_FLAG_PAM_AT_START if start else 0) | (GS_FLAG_FAITHFUL_WALK if faithful else 0)
+        flags = ((GS_FLAG_PAM_AT_START if start else 0) | (GS_FLAG_FAITHFUL_WALK if faithful else 0) |
+                 (GS_FLAG_COUNT_REQUESTS if count_requests else 0))
         d_off, d_hits = C.c_void_p(), C.c_void_p()
         v = GsResultView()
         _check(lib().gs_enumerate_device(self._h, d_guides_ptr, n, L, d_pams_ptr, P,

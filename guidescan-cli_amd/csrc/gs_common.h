@@ -53,11 +53,19 @@ struct gs_strand_dev {
   /* inverse suffix array (isa[sa[r]] = r), n entries, or nullptr: turns a text position found
    * through the other strand's index into this strand's row (two-sided seeding) */
   const uint32_t *isa;
+  /* exception rows: the rows of valid k-mer intervals whose 16-symbol left
+   * context holds a symbol outside A,C,G,T or runs off the text start - ctx[] cannot say so (it
+   * stores 2 bits per symbol).  Sorted by row; exc_sym[i] = the 16 symbols as nibbles, nearest
+   * first: 0..3 A,C,G,T, 4 'N', 5 any other symbol, 6 before the text start.  A few rows per N run:
+   * the verification looks a row up here only when its table entry carries the flag. */
+  const uint32_t *exc_row;
+  const uint64_t *exc_sym;
+  uint32_t n_exc;
 };
 
 struct gs_strand {
   gs_strand_dev d{};
-  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ctx16 = nullptr, *ptab_rot = nullptr, *isa = nullptr;
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ctx16 = nullptr, *ptab_rot = nullptr, *isa = nullptr, *exc_row = nullptr, *exc_sym = nullptr;
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;
@@ -94,7 +102,9 @@ struct gs_index {
   void *d_combo = nullptr;         /* uint32 masks, all j concatenated */
   uint32_t combo_off[10] = {0};    /* start of the masks with j mismatches */
   uint32_t combo_cnt[10] = {0};    /* C(pt_k-2, j) */
-  uint32_t combo_words = 0;        /* words of the full plan; d_combo holds room for a second one */
+  uint32_t combo_words = 0;        /* words of the full plan */
+  uint32_t combo_cap = 0;          /* words d_combo holds: the per-batch plans of two-sided seeding follow the full plan */
+  unsigned long long last_counters[16] = {0}; /* k_search's stats array of the last gs_enumerate_device call */
   std::vector<gs_nrun> nruns_text; /* 'N' runs of the forward text */
   gs_buffer w_cand;                /* per-batch literal-N candidate windows (device) */
 };

@@ -138,6 +138,8 @@ void gs_strand_free(gs_strand *s) {
   if (s->ctx16) hipFree(s->ctx16);
   if (s->ptab_rot) hipFree(s->ptab_rot);
   if (s->isa) hipFree(s->isa);
+  if (s->exc_row) hipFree(s->exc_row);
+  if (s->exc_sym) hipFree(s->exc_sym);
   *s = gs_strand();
 }
 
@@ -436,15 +438,18 @@ __global__ void k_ptab_finish(uint4 *tab, uint64_t entries) {
 /* ctx[r] = 16 symbols preceding suffix SA[r] (nearest first); rows whose window holds a
  * non-ACGT symbol or runs off the text start flag their k-mer's table entry */
 __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t k,
-                            uint32_t *ctx, uint16_t *ctx16, uint4 *tab) {
+                            uint32_t *ctx, uint16_t *ctx16, uint4 *tab, uint32_t *exc_count,
+                            uint32_t *exc_row, uint64_t *exc_sym, uint32_t exc_cap) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const uint64_t p = sa[r];
   uint32_t w = 0;
+  uint64_t nib = 0;
   bool exc = false;
   for (uint32_t j = 1; j <= 16; j++) {
-    uint32_t cls = 5;
+    uint32_t cls = 6; /* before the text start */
     if (p >= j) cls = sym_class(text[p - j]);
+    nib |= (uint64_t)cls << (4 * (j - 1));
     if (cls > 3) {
       exc = true;
       cls = 0;
@@ -456,7 +461,14 @@ __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n,
   if (tab) {
     uint32_t c;
     if (kmer_code(text, n, p, k, c)) {
-      if (exc) atomicOr(&tab[c].y, 0x80000000u);
+      if (exc) {
+        atomicOr(&tab[c].y, 0x80000000u);
+        const uint32_t at = atomicAdd(exc_count, 1u);
+        if (at < exc_cap) {
+          exc_row[at] = (uint32_t)r;
+          exc_sym[at] = nib;
+        }
+      }
       /* which 3-symbol left contexts occur in this k-mer's interval */
       const uint32_t t = w & 63u;
       atomicOr(t < 32u ? &tab[c].z : &tab[c].w, 1u << (t & 31u));
@@ -494,8 +506,53 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   if (!getenv("GS_NO_CTX")) {
     GS_HIP(hipMalloc(&ctx, 4 * s->n + 16));
     GS_HIP(hipMalloc(&ctx16, 2 * s->n + 32)); /* one row group of padding (k_search reads groups of eight) */
-    hipLaunchKernelGGL(k_ctx_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
-                       (const uint32_t *)s->sa, s->n, k, ctx, ctx16, tab);
+    /* exception rows: counted in a first pass when the first guess is too small */
+    uint32_t *d_cnt = nullptr, *d_er = nullptr;
+    uint64_t *d_es = nullptr;
+    uint32_t cap = 1u << 16, h_cnt = 0;
+    GS_HIP(hipMalloc(&d_cnt, 4));
+    for (int pass = 0; pass < 2; pass++) {
+      GS_HIP(hipMalloc(&d_er, 4 * (size_t)cap));
+      GS_HIP(hipMalloc(&d_es, 8 * (size_t)cap));
+      GS_HIP(hipMemsetAsync(d_cnt, 0, 4, st));
+      hipLaunchKernelGGL(k_ctx_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
+                         (const uint32_t *)s->sa, s->n, k, ctx, ctx16, tab, d_cnt, d_er, d_es, cap);
+      GS_HIP(hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, st));
+      GS_HIP(hipStreamSynchronize(st));
+      if (h_cnt <= cap) break;
+      hipFree(d_er);
+      hipFree(d_es);
+      d_er = nullptr;
+      d_es = nullptr;
+      cap = h_cnt; /* flags and masks are set by atomicOr: a second pass changes nothing there */
+    }
+    hipFree(d_cnt);
+    if (h_cnt) {
+      std::vector<uint32_t> er(h_cnt);
+      std::vector<uint64_t> es(h_cnt);
+      GS_HIP(hipMemcpy(er.data(), d_er, 4 * (size_t)h_cnt, hipMemcpyDeviceToHost));
+      GS_HIP(hipMemcpy(es.data(), d_es, 8 * (size_t)h_cnt, hipMemcpyDeviceToHost));
+      std::vector<uint32_t> ord(h_cnt);
+      for (uint32_t i = 0; i < h_cnt; i++) ord[i] = i;
+      std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return er[a] < er[b]; });
+      std::vector<uint32_t> er2(h_cnt);
+      std::vector<uint64_t> es2(h_cnt);
+      for (uint32_t i = 0; i < h_cnt; i++) {
+        er2[i] = er[ord[i]];
+        es2[i] = es[ord[i]];
+      }
+      GS_HIP(hipMemcpy(d_er, er2.data(), 4 * (size_t)h_cnt, hipMemcpyHostToDevice));
+      GS_HIP(hipMemcpy(d_es, es2.data(), 8 * (size_t)h_cnt, hipMemcpyHostToDevice));
+      s->exc_row = d_er;
+      s->exc_sym = d_es;
+      s->d.exc_row = d_er;
+      s->d.exc_sym = d_es;
+      s->d.n_exc = h_cnt;
+      s->bytes += 12 * (size_t)h_cnt;
+    } else {
+      hipFree(d_er);
+      hipFree(d_es);
+    }
     s->bytes += 6 * s->n;
   }
   uint4 *rot = nullptr;
@@ -562,7 +619,8 @@ static gs_status build_seed_plan(gs_index *ix, uint32_t k) {
   }
   /* room for a second, filtered plan written per batch (two-sided seeding) */
   ix->combo_words = (uint32_t)masks.size();
-  GS_HIP(hipMalloc(&ix->d_combo, 8 * masks.size() + 1024));
+  ix->combo_cap = 2 * ix->combo_words + (1u << 15) + 1024u;
+  GS_HIP(hipMalloc(&ix->d_combo, 4 * (size_t)ix->combo_cap));
   GS_HIP(hipMemcpy(ix->d_combo, masks.data(), 4 * masks.size(), hipMemcpyHostToDevice));
   return GS_OK;
 }
@@ -664,6 +722,11 @@ extern "C" void gs_index_close(gs_index *ix) {
     if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
   if (ix->d_combo) hipFree(ix->d_combo);
   delete ix;
+}
+extern "C" gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]) {
+  if (!ix || !out) return GS_ERR_ARG;
+  for (int i = 0; i < 16; i++) out[i] = ix->last_counters[i];
+  return GS_OK;
 }
 extern "C" uint64_t gs_index_genome_length(const gs_index *ix) { return ix ? ix->genome_length : 0; }
 extern "C" uint64_t gs_index_device_bytes(const gs_index *ix) {

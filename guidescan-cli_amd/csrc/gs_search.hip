@@ -47,42 +47,48 @@ struct gs_search_args {
   const uint64_t *slot_off; /* optional: item s owns slots [slot_off[s], slot_off[s+1]) instead */
   uint32_t *counts;      /* [n_items] matches found (may exceed cap -> overflow) */
   uint32_t *work;        /* work-queue head */
-  unsigned long long *stats; /* [0] n_ext, [1] overflow items */
+  unsigned long long *stats; /* [0] n_ext, [1] overflow items, [4] two-sided items, [5] one-sided, [8..] request counters */
   uint32_t n_items, L, P, m, cap;
-  /* prefix-table seeding (pt_k = 0: walk from the root) */
-  /* seeding plan in device memory: up to GS_PLAN_CLASSES classes of position masks over the
-   * first pt_k-2 steps.  Header: [c] offset of class c's masks, [32+c] their count, [64+c] meta =
-   * j | eb << 4: j = substitutions per mask, eb = how many more the two-symbol extension may
-   * add (15: the whole remaining budget m-j).  The full plan has one class per j; the filtered
-   * plan of two-sided seeding splits them by the number of substitutions inside X. */
+  /* prefix-table seeding (pt_k = 0: walk from the root).  Seeding plans live in combo[]: the full
+   * plan at word 0 (one class per substitution count j over the first pt_k-2 steps), and - per
+   * batch, with two-sided seeding - this strand's filtered plan at planA_g followed by the other
+   * strand's plan at planB_g.  Plan of this strand: header [c] offset of class c's masks, [32+c]
+   * their count, [64+c] meta = j | eb << 4: j substitutions per mask, eb = how many more the
+   * two-symbol extension may add (15: the whole remaining budget m-j).  plan_lds != 0: the batch
+   * plans (or, one-sided, the full plan) are copied to LDS once per workgroup (plan_words words
+   * from combo + plan_src). */
   const uint32_t *combo;
-  uint32_t plan_words; /* words of the plan the kernel needs (copied to LDS per workgroup) */
+  uint32_t plan_words, plan_src, plan_lds;
   uint32_t pt_k; /* table depth k; seeds are the depth-k nodes */
-  uint32_t ncls, ncls2; /* classes of the full and of the filtered plan */
+  uint32_t ncls; /* classes of the full plan */
   /* context verification: L+P-pt_k (<= 16) symbols remain after the table depth; 0 = disabled */
   uint32_t v_rem;
-  uint32_t v_max; /* intervals up to this many rows are resolved row by row from ctx[] (<= 1023) */
+  uint32_t v_max; /* rows per queued descriptor (<= 1023): larger intervals are verified in pieces */
   uint32_t dbg_skip; /* timing experiments only (GS_DBG_SKIP): 1 = no verification, 2 = no seeds kept */
-  /* two-sided seeding: X = the first v_rem consumed guide symbols.
-   * Sites with fewer than `tau` substitutions in X are seeded from this strand's table with
-   * the filtered plan at plan2_off; sites with >= tau (hence <= 1 in the rest) are seeded from
-   * the OTHER strand's table, where the PAM and the rest of the guide are consumed first. */
-  uint32_t bidir, tau;
-  uint32_t plan2_off;          /* word offset of the filtered plan inside the LDS copy */
-  uint32_t plan2_src;          /* and inside combo[] */
-  const uint64_t *cand[2];     /* per strand: windows holding a literal N under the PAM (guide part, 2 bits/symbol) */
+  /* two-sided seeding.  X = the first v_rem consumed guide symbols (only
+   * this strand's table covers them), O = the next pt_k - v_rem (both tables), R = the rest of the
+   * guide (only the other strand's table, with the PAM).  A site with (a, o, b) substitutions in
+   * (X, O, R) is found from THIS strand's table when a < astar(o) and from the OTHER strand's
+   * table otherwise; astar holds 4 bits per o (15: this strand takes every a). */
+  uint32_t bidir, astar;
+  uint32_t planA_g, nclsA; /* this strand's filtered plan: word offset in combo[], classes */
+  uint32_t planB_g, nclsB; /* other strand's plan: header of 4 words per class {mask offset, lane
+                              prefix end, jb | lo << 4 | 3^jb << 8, magic for /3^jb}, then masks
+                              (bit y = guide symbol L-1-y) */
+  /* windows of this strand's text where a literal 'N' lies under the PAM (index.hpp:139-149) and
+   * the guide part is plain A,C,G,T: {q lo, q hi, PAM symbols (3 bits each: 0..3, 4 = N), text
+   * position of the site}.  The other strand's table cannot see them: its share of them is
+   * reported straight from this list. */
+  const uint4 *cand[2];
   uint32_t n_cand[2];
-  /* second class of the other strand's seeds: sites with exactly m-1
-   * substitutions in O (the guide symbols both tables cover) and none in the rest of the other
-   * strand's k-mer.  bcomb_off: word offset (LDS plan) of the nbc position masks with m-1 bits over
-   * the O symbols (bit y = guide symbol L-1-y); bpow = 3^(m-1) digit combinations each. */
-  uint32_t bnew, bcomb_off, nbc, bpow;
 };
-#define DSC_FLAG 27u /* descriptor.y bit: the seed's lower bound is the alternate one (see verify) */
+#define DSC_LO 27u  /* descriptor.y bits 29:27: fewest substitutions allowed among the remaining guide symbols */
+#define DSC_EXC 30u /* descriptor.y bit 30: the interval holds exception rows (gs_strand_dev::exc_row) */
 
-#define VERIFY_MAX_DEFAULT 256u
+#define VERIFY_MAX_DEFAULT 1023u
 #define GS_PLAN_CLASSES 32u
 #define GS_PLAN_HEADER (3u * GS_PLAN_CLASSES)
+#define GS_PLAN_LDS_MAX 3072u /* words of plan kept in LDS; larger plans are read from global memory */
 
 #define SEED_LOW_MAX 128 /* refill the stacks from the prefix table when they hold this few nodes */
 
@@ -91,21 +97,38 @@ struct gs_search_args {
  * mismatch budget spent (index.hpp:230 returns before the substitution loop) or a fixed PAM
  * base - which need Occ of one base and have at most one child; G (grows down) holds nodes
  * that still branch (k < m), PAM 'N' wildcards and PAM fan-out nodes.  ~89 % of all nodes are
- * X nodes, and an X iteration costs ~1/4 of the instructions of a G one. */
+ * X nodes, and an X iteration costs ~1/4 of the instructions of a G one.
+ * CNT: count the distinct 64-byte lines every load instruction asks for (bench.py's algorithmic
+ * bytes of THIS algorithm); the timed kernel is the CNT = false instantiation. */
 #ifndef GS_WAVES_EU
 #define GS_WAVES_EU 6 /* 80 VGPRs: measured best of 4..8 (two-sided seeding, hg38-sized) */
 #endif
+template <bool CNT>
 __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(GS_WAVES_EU, GS_WAVES_EU))) void k_search(gs_search_args a) {
   __shared__ uint4 s_stack[SEARCH_WAVES][WAVE_LDS_ENTRIES];
   extern __shared__ uint32_t s_plan[]; /* seeding plan: one LDS read instead of a global one */
   const uint32_t wave = threadIdx.x / WAVE;
   const uint32_t lane = lane_id();
   uint4 *stk = s_stack[wave];
-  for (uint32_t i = threadIdx.x; i < a.plan_words; i += WAVE * SEARCH_WAVES)
-    s_plan[i] = a.combo[(a.bidir && i >= a.plan2_off) ? i - a.plan2_off + a.plan2_src : i];
-  __syncthreads();
+  if (a.plan_lds) {
+    for (uint32_t i = threadIdx.x; i < a.plan_words; i += WAVE * SEARCH_WAVES) s_plan[i] = a.combo[a.plan_src + i];
+    __syncthreads();
+  }
   unsigned long long n_ext = 0, n_ovf = 0;
-  uint32_t n_two = 0, n_fb = 0, n_rst = 0; /* items seeded from both strands / fallen back / redone */
+  uint32_t n_two = 0, n_fb = 0; /* items seeded from both strands / one-sided although two-sided seeding is on */
+  /* request counters (CNT): table lines, ctx16 lines, ctx words, SA/ISA gathers of the search, Occ lines */
+  uint32_t c_tab = 0, c_c16 = 0, c_ctx = 0, c_isa = 0, c_occ = 0;
+  /* distinct 64-byte lines one load instruction asks for: lanes whose line differs from the
+   * previous active lane's (the access patterns here are runs of neighbouring lanes) */
+  auto count_lines = [&](uint32_t &acc, bool act, const void *p) __attribute__((always_inline)) {
+    if constexpr (CNT) {
+      const uint32_t line = (uint32_t)((uintptr_t)p >> 6);
+      const uint32_t prev = (uint32_t)__shfl_up((int)line, 1);
+      const int pact = __shfl_up((int)act, 1);
+      const bool fresh = act && (lane == 0u || !pact || prev != line);
+      acc += (uint32_t)__popcll(__ballot(fresh));
+    }
+  };
   const uint32_t L = a.L, P = a.P, m = a.m;
   const uint32_t T_end = L + P;
   const uint32_t reserve = (MAX_FANOUT - 1) * (T_end + 2);
@@ -196,18 +219,20 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
 
 
     /* ---- context verification (both seeding directions) --------------------------------
-     * Every lane may bring one small interval [vsp, vsp+vcnt) at the table depth with kk
+     * Every lane may bring one interval piece [vsp, vsp+vcnt) at the table depth with kk
      * substitutions so far and its path in cmeta.  The v_rem symbols left of each suffix are in
      * ctx[row], nearest first, i.e. in consumption order.
      *   modeB == false (this strand's table): compare the remaining guide symbols under the
-     *     remaining budget, then each PAM pattern exactly ('N' = any base).  A hit is the row
-     *     itself; its text position is SA[row] - v_rem (key bit 0, k_locate).
+     *     remaining budget, then each PAM pattern exactly ('N' = any base, or a literal 'N' of the
+     *     text on an exception row).  A hit is the row itself; its text position is SA[row] -
+     *     v_rem (key bit 0, k_locate).
      *   modeB == true (other strand's table, PAM and the rest of the guide already consumed):
      *     the remaining symbols are the complemented first v_rem guide symbols, last first;
-     *     a row counts when it has >= tau substitutions there (fewer belong to the other
-     *     direction) and fits the budget.  The hit is reported as the row of THIS strand's
-     *     suffix array that starts at the same site (SA of the other strand -> position ->
-     *     ISA of this strand), so records look exactly like the ones the walk produces.
+     *     a row counts when it has at least `lo` substitutions there (the descriptor's lower
+     *     bound: fewer belong to this strand's own seeds) and fits the budget.  The hit is
+     *     reported as the row of THIS strand's suffix array that starts at the same site (SA of
+     *     the other strand -> position -> ISA of this strand), so records look exactly like the
+     *     ones the walk produces.
      * Two levels.  ctx16[row] holds the nearest 8 of those symbols in 16 bits: rows are handed
      * out in groups of eight consecutive rows of one seed; lane l of a pass takes groups 2l and
      * 2l+1, finds the owner seed of each (seeds mark their first group, a running max spreads
@@ -215,12 +240,15 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
      * consecutive 16-byte pieces (coalesced), the owner lookup is paid once per eight rows, and
      * an interval of the mean size (11.5 rows at hg38 size) lies in 1.3 cache lines instead of
      * the 1.7 of 32-bit words.  The few rows whose visible guide symbols fit the budget are
-     * then decided from the full word ctx[row].  Both arrays are padded by one group. */
+     * then decided from the full word ctx[row] - and, when the table entry says the interval has
+     * exception rows (a symbol outside A,C,G,T within 16 symbols to the left), from the row's
+     * entry in the exception list, which holds the true symbols.  Both arrays are padded by one group. */
     auto verify = [&](const bool modeB, const uint32_t take, uint4 *dsrc) __attribute__((always_inline)) {
       const uint32_t k = a.pt_k;
       const gs_strand_dev &sv = modeB ? a.sd[strand ^ 1u] : sd;
       /* lane l < take brings seed descriptor dsrc[l] = {first row, mismatches so far << 14 |
-       * rows << 17, path lo, path hi}; the first group of each seed is added to .y here */
+       * rows << 17 | lower bound << 27 | exceptions << 30, path lo, path hi}; the first group of
+       * each seed is added to .y here */
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       uint4 mine = make_uint4(0u, 0u, 0u, 0u);
       if (lane < take) mine = dsrc[lane];
@@ -230,7 +258,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
       if (!R) return;
       const uint32_t excl = incl - vgrp;
-      /* descriptor.y = first group (14 bits) | mismatches so far << 14 | rows << 17 */
+      /* descriptor.y = first group (14 bits) | mismatches so far << 14 | rows << 17 | ... */
       if (lane < take) dsrc[lane].y = mine.y | excl;
       const uint32_t g = modeB ? a.v_rem : L - k; /* guide symbols among the remaining ones */
       const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
@@ -245,15 +273,6 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       const uint32_t g8 = g < 8u ? g : 8u;
       const uint32_t gm8 = (1u << (2u * g8)) - 1u;
       const uint32_t q2x = (qrem & gm8) * 0x00010001u, gm2x = gm8 * 0x00010001u;
-      /* lower bound on the substitutions among the g remaining guide symbols, per seed:
-       *   this strand's seeds: none; flagged (no substitution in X, m-1 in O): >= 1, because the
-       *     sites without one belong to the other strand's second class;
-       *   other strand's seeds: >= tau (fewer belong to this strand's seeds); flagged (second
-       *     class): none.
-       * The first level sees g8 of the g symbols: at least bound - (g - g8) of them show there. */
-      const uint32_t lo_plain = modeB ? a.tau : 0u, lo_flag = modeB ? 0u : 1u;
-      const uint32_t lo8_plain = lo_plain > g - g8 ? lo_plain - (g - g8) : 0u;
-      const uint32_t lo8_flag = lo_flag > g - g8 ? lo_flag - (g - g8) : 0u;
       for (uint32_t base = 0; base < R; base += 2u * WAVE) {
         own2[lane] = make_uint2(0u, 0u);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -284,11 +303,14 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           nrow[jj] = on ? (cnt - r0 < 8u ? cnt - r0 : 8u) : 0u;
           kkv[jj] = (dsc[jj].y >> 14) & 7u;
           /* bit c set: c substitutions among the visible symbols are acceptable (lower bound ..
-           * budget left) */
-          const uint32_t lo8 = ((dsc[jj].y >> DSC_FLAG) & 1u) ? lo8_flag : lo8_plain;
+           * budget left).  The first level sees g8 of the g symbols: at least lo - (g - g8) of the
+           * lo required ones show there. */
+          const uint32_t lo = (dsc[jj].y >> DSC_LO) & 7u;
+          const uint32_t lo8 = lo > g - g8 ? lo - (g - g8) : 0u;
           okm[jj] = on ? (((2u << (m - kkv[jj])) - 1u) & ~((1u << lo8) - 1u)) : 0u;
           wq[jj] = make_uint4(0u, 0u, 0u, 0u);
           if (on) wq[jj] = load16_a2(sv.ctx16 + row0[jj]);
+          count_lines(c_c16, on, sv.ctx16 + row0[jj]);
         }
         uint32_t cm = 0u; /* candidate rows of this lane: bit 8*jj + r */
 #pragma unroll
@@ -315,9 +337,41 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           const uint32_t kv = hi ? kkv[1] : kkv[0];
           uint32_t w = 0u;
           if (has) w = sv.ctx[row];
+          if constexpr (CNT) c_ctx += (uint32_t)__popcll(__ballot(has));
+          /* exception rows: the true symbols decide.  Under a guide symbol nothing outside
+           * A,C,G,T can match or be substituted (index.hpp:31,230-247); under a PAM 'N' a literal
+           * 'N' of the text matches (index.hpp:139-149) */
+          uint32_t nmask = 0u; /* bit u: the text holds a literal N under PAM symbol u */
+          bool excbad = false;
+          const bool fl = has && ((dd.y >> DSC_EXC) & 1u) != 0u;
+          if (__ballot(fl)) {
+            if (fl) {
+              uint32_t el = 0, eh = sv.n_exc;
+              while (el < eh) {
+                const uint32_t mid = (el + eh) >> 1;
+                if (sv.exc_row[mid] < row)
+                  el = mid + 1;
+                else
+                  eh = mid;
+              }
+              if (el < sv.n_exc && sv.exc_row[el] == row) {
+                const uint64_t nb = sv.exc_sym[el];
+                const uint32_t upto = modeB ? g : g + P;
+                for (uint32_t j = 0; j < upto; ++j) {
+                  const uint32_t c = (uint32_t)(nb >> (4u * j)) & 15u;
+                  if (c > 3u) {
+                    if (j < g || c != 4u)
+                      excbad = true;
+                    else
+                      nmask |= 1u << (j - g);
+                  }
+                }
+              }
+            }
+          }
           const uint32_t xf = (w ^ qrem) & gmask;
           const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
-          const bool gok = has && kv + mmv <= m && mmv >= (((dd.y >> DSC_FLAG) & 1u) ? lo_flag : lo_plain);
+          const bool gok = has && !excbad && kv + mmv <= m && mmv >= ((dd.y >> DSC_LO) & 7u);
           if (!__ballot(gok)) continue;
           const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PATH_MASK;
           if (modeB) {
@@ -336,6 +390,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
               const uint32_t sA = (sd.n - 1u) - (pB - g) - (L + P);
               rowA = sd.isa[sA];
             }
+            if constexpr (CNT) c_isa += 2u * (uint32_t)__popcll(__ballot(gok));
             const uint64_t mmeta = ((uint64_t)(kv + mmv) << 56) | spath | gpath;
             route(gok, true, false, rowA, rowA, mmeta, 0u);
             continue;
@@ -347,8 +402,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
             for (uint32_t u = 0; u < P; ++u) {
               const uint32_t pc = (pw >> (3u * u)) & 7u;
               const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-              ok = ok && (pc == 4u || pc == tb);
-              ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (49u - 2u * L - 3u * u);
+              const bool isn = ((nmask >> u) & 1u) != 0u;
+              ok = ok && (isn ? pc == 4u : (pc == 4u || pc == tb));
+              ppath |= (uint64_t)(isn ? 3u : (tb < 3u ? tb : 4u)) << (49u - 2u * L - 3u * u);
             }
             if (!__ballot(ok)) continue;
             uint64_t gpath = 0;
@@ -365,9 +421,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
       }
     };
 
-    /* seeding state (all wave-uniform): mismatch count j of the prefix variants being
-     * enumerated, substitution index sub in [0,3^j), position in the (combination, entry) space */
-    uint32_t sc = 0, spos = 0; /* class, lane position inside the class */
+    /* seeding state (all wave-uniform): class of the plan, lane position inside the class */
+    uint32_t sc = 0, spos = 0;
     uint32_t ncls = a.ncls;
     uint32_t qn = 0; /* seeds waiting in the verification queue */
     const bool seeding = a.pt_k != 0;
@@ -398,144 +453,199 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-    /* ---- two-sided seeding: the sites with >= tau substitutions among the first v_rem
-     * consumed guide symbols (set X) have at most one in the rest, so they are cheap to
-     * enumerate from the other end: on the other strand the same site reads reversed and
-     * complemented, and a backward search there consumes the PAM first, then the guide from
-     * its last consumed symbol down to X.  Its depth-k seeds are PAM expansions x (no or one
-     * substitution among the k-P guide symbols): a few dozen instead of thousands.  What they
-     * cannot see - a flagged or oversized interval, a literal N under the PAM, a PAM pattern
-     * with more than two N - makes the item fall back to one-sided seeding with the full plan. */
-    const uint32_t *pl = s_plan;
-    bool twosided = false; /* the other strand took its classes: the filtered plan is in use */
+    /* the plan this strand's seeding reads: the full plan (one-sided) or the batch's filtered plan;
+     * from LDS when it was copied there, else from global memory (L2-resident, a few KiB) */
+    uint32_t pl_g = 0;        /* word offset in combo[] */
+    uint32_t pl_l = 0;        /* word offset in s_plan[] */
+    bool pl_lds = a.plan_lds != 0u && !a.bidir; /* one-sided: LDS holds the full plan */
+    uint32_t astar_item = 0xFFFFFFFFu; /* one-sided: this strand takes every site */
+    auto PL = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
+      return pl_lds ? s_plan[pl_l + i] : a.combo[pl_g + i];
+    };
+
+    /* ---- two-sided seeding: a site with many substitutions among the first v_rem consumed
+     * guide symbols (set X) has few in the rest, so it is cheap to enumerate from the other end:
+     * on the other strand the same site reads reversed and complemented, and a backward search
+     * there consumes the PAM first, then the guide from its last consumed symbol down to X.
+     * Its depth-k seeds are PAM expansions x (o substitutions in O, b in R) for the classes
+     * (o, b) the batch's plan gives to that side, each verified with the lower bound
+     * a >= astar(o) against the other strand's ctx[].  What it cannot see - a literal N under
+     * the PAM - is reported from the batch's window list; a PAM pattern with more than two N
+     * makes the item one-sided with the full plan. */
     if (a.bidir && seeding) {
       bool fallback = false;
       const gs_strand_dev &sb = a.sd[strand ^ 1u];
       const uint32_t k = a.pt_k, sx = a.v_rem, nY = k - P;
-      const uint32_t ncand = a.n_cand[strand];
-      for (uint32_t c0 = 0; c0 < ncand; c0 += WAVE) {
-        bool reach = false;
-        if (c0 + lane < ncand) {
-          const uint64_t x = a.cand[strand][c0 + lane] ^ gr_q;
-          const uint64_t nz = (x | (x >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
-          const uint32_t tot = __popcll(nz), jx = __popcll(nz & ((1ull << (2u * sx)) - 1ull));
-          reach = tot <= m && (jx >= a.tau || a.bnew != 0u);
-        }
-        if (__ballot(reach)) fallback = true;
-      }
-      /* context mask for the second class (one substitution left for X): the triples within one
-       * substitution of the three symbols the other strand consumes next - the complemented
-       * X symbols, last first */
-      uint64_t allow_b1 = ~0ull;
-      if (a.bnew && sx >= 3u) {
-        uint32_t q3b = 0;
-        for (uint32_t j = 0; j < 3u; ++j) q3b |= (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - j))) & 3u)) << (2u * j);
-        allow_b1 = 1ull << q3b;
-        for (uint32_t p3 = 0; p3 < 3u; ++p3)
-          for (uint32_t d = 1; d < 4u; ++d) allow_b1 |= 1ull << (q3b ^ (d << (2u * p3)));
-      }
-      for (uint32_t pj = 0; pj < npams && !fallback; ++pj) {
+      for (uint32_t pj = 0; pj < npams; ++pj) {
         const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
         uint32_t nn = 0;
         for (uint32_t u = 0; u < P; ++u) nn += ((pw >> (3u * u)) & 7u) == 4u;
-        if (nn > 2u) {
-          fallback = true;
-          break;
-        }
-        for (uint32_t e = 0; e < (1u << (2u * nn)) && !fallback; ++e) {
-          /* the k-mer of the other strand: step P-1-u holds the complement of PAM symbol u, step
-           * P+y the complement of guide symbol L-1-y */
-          uint32_t pidxb = 0, ee = e;
-          uint64_t ppath = 0;
-          for (uint32_t u = 0; u < P; ++u) {
-            const uint32_t pc = (pw >> (3u * u)) & 7u;
-            uint32_t base = pc;
-            if (pc == 4u) {
-              base = ee & 3u;
-              ee >>= 2;
-            }
-            ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
-            pidxb |= (3u - base) << (2u * (k - P + u));
+        if (nn > 2u) fallback = true;
+      }
+      if (!fallback) {
+        /* literal-N windows within reach whose (a, o) belongs to the other side */
+        const uint32_t ncand = a.n_cand[strand];
+        const uint64_t lmask = (1ull << (2u * L)) - 1ull;
+        const uint64_t xmask = (1ull << (2u * sx)) - 1ull, komask = (1ull << (2u * k)) - 1ull;
+        for (uint32_t c0 = 0; c0 < ncand; c0 += WAVE) {
+          const bool in = c0 + lane < ncand;
+          uint4 ce = make_uint4(0u, 0u, 0u, 0u);
+          if (in) ce = a.cand[strand][c0 + lane];
+          const uint64_t cq = ((uint64_t)ce.y << 32) | ce.x;
+          const uint64_t x = cq ^ gr_q;
+          const uint64_t nz = (x | (x >> 1)) & 0x5555555555555555ull & lmask;
+          const uint32_t tot = __popcll(nz), jx = __popcll(nz & xmask), jo = __popcll(nz & komask & ~xmask);
+          const bool mine = in && tot <= m && jx >= ((a.astar >> (4u * (jo < 7u ? jo : 7u))) & 15u);
+          if (!__ballot(mine)) continue;
+          uint64_t gpath = 0;
+          for (uint32_t t = 0; t < L; ++t) {
+            const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u, tb = (uint32_t)(cq >> (2u * t)) & 3u;
+            const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
+            gpath |= (uint64_t)code << (50u - 2u * t);
           }
-          for (uint32_t y = 0; y < nY; ++y)
-            pidxb |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (k - 1u - P - y));
-          /* lane space of one expansion: 0 = no substitution; 1+3y+d = digit d at guide symbol
-           * L-1-y (first class); then the second class: combination ci of m-1 symbols of O x
-           * their 3^(m-1) digits, the digit of the last consumed symbol running fastest, so the
-           * three lanes that differ only there share one 64-byte line of that step's rotated
-           * copy (or of the plain table when it is the k-mer's last step) */
-          const uint32_t n1 = 1u + 3u * nY;
-          const uint32_t nlanes = n1 + (a.bnew ? a.nbc * a.bpow : 0u);
-          for (uint32_t c0 = 0; c0 < nlanes && !fallback; c0 += WAVE) {
-            const uint32_t idx = c0 + lane;
-            const bool act = idx < nlanes;
-            uint32_t pidx = pidxb;
-            uint64_t path = ppath;
-            uint32_t kk = 0u, slast = 0xFFFFFFFFu, flag = 0u;
-            auto subst = [&](uint32_t y, uint32_t d) __attribute__((always_inline)) {
-              const uint32_t t = L - 1u - y;
-              const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
-              const uint32_t sym = (qc + 1u + d) & 3u;
-              path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
-              pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
-            };
-            if (act && idx >= 1u && idx < n1) {
-              const uint32_t y = (idx - 1u) / 3u, d = (idx - 1u) - 3u * y;
-              subst(y, d);
-              kk = 1u;
-              slast = P + y;
-            } else if (act && idx >= n1) {
-              const uint32_t i2 = idx - n1;
-              const uint32_t ci = i2 / a.bpow;
-              uint32_t dg = i2 - ci * a.bpow;
-              uint32_t mk = s_plan[a.bcomb_off + ci];
-              slast = P + (31u - (uint32_t)__clz((int)mk));
-              for (uint32_t i = 0; i + 1u < m; ++i) {
+          uint32_t rowA = 0;
+          if (mine) rowA = sd.isa[ce.w];
+          if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(mine));
+          for (uint32_t pj = 0; pj < npams; ++pj) {
+            const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+            bool ok = mine;
+            uint64_t ppath = 0;
+            for (uint32_t u = 0; u < P; ++u) {
+              const uint32_t pc = (pw >> (3u * u)) & 7u, tb = (ce.z >> (3u * u)) & 7u;
+              ok = ok && (tb == 4u ? pc == 4u : (pc == 4u || pc == tb));
+              ppath |= (uint64_t)(tb == 4u ? 3u : (tb < 3u ? tb : 4u)) << (49u - 2u * L - 3u * u);
+            }
+            route(ok, true, false, rowA, rowA, ((uint64_t)tot << 56) | gpath | ppath, 0u);
+          }
+        }
+        /* context masks for the other strand's seeds: the triples within 0, 1, 2 substitutions of
+         * the three symbols it consumes next - the complemented X symbols, last first */
+        uint64_t allow_b[3] = {~0ull, ~0ull, ~0ull};
+        if (sx >= 3u) {
+          uint32_t q3b = 0;
+          for (uint32_t j = 0; j < 3u; ++j) q3b |= (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - j))) & 3u)) << (2u * j);
+          allow_b[0] = allow_b[1] = allow_b[2] = 0ull;
+          for (uint32_t t3 = 0; t3 < 64u; ++t3) {
+            const uint32_t x = t3 ^ q3b;
+            const uint32_t d = ((x & 3u) != 0u) + (((x >> 2) & 3u) != 0u) + (((x >> 4) & 3u) != 0u);
+            if (d <= 0u) allow_b[0] |= 1ull << t3;
+            if (d <= 1u) allow_b[1] |= 1ull << t3;
+            if (d <= 2u) allow_b[2] |= 1ull << t3;
+          }
+        }
+        const bool plb_lds = a.plan_lds != 0u;
+        const uint32_t plb_l = a.planB_g - a.plan_src; /* the batch plans are copied as one piece */
+        auto PLB = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
+          return plb_lds ? s_plan[plb_l + i] : a.combo[a.planB_g + i];
+        };
+        const uint32_t nclsB = a.nclsB;
+        const uint32_t nlanes = nclsB ? PLB(4u * (nclsB - 1u) + 1u) : 0u;
+        for (uint32_t pj = 0; pj < npams; ++pj) {
+          const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+          uint32_t nn = 0;
+          for (uint32_t u = 0; u < P; ++u) nn += ((pw >> (3u * u)) & 7u) == 4u;
+          for (uint32_t e = 0; e < (1u << (2u * nn)); ++e) {
+            /* the k-mer of the other strand: step P-1-u holds the complement of PAM symbol u, step
+             * P+y the complement of guide symbol L-1-y */
+            uint32_t pidxb = 0, ee = e;
+            uint64_t ppath = 0;
+            for (uint32_t u = 0; u < P; ++u) {
+              const uint32_t pc = (pw >> (3u * u)) & 7u;
+              uint32_t base = pc;
+              if (pc == 4u) {
+                base = ee & 3u;
+                ee >>= 2;
+              }
+              ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
+              pidxb |= (3u - base) << (2u * (k - P + u));
+            }
+            for (uint32_t y = 0; y < nY; ++y)
+              pidxb |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (k - 1u - P - y));
+            /* lane space of one expansion: the plan's classes one after the other; inside a class
+             * (position mask ci) x (3^jb digit combinations), the digit of the last consumed
+             * substituted symbol running fastest, so the three lanes that differ only there share
+             * one 64-byte line of that step's rotated copy (or of the plain table when it is the
+             * k-mer's last step) */
+            for (uint32_t c0 = 0; c0 < nlanes; c0 += WAVE) {
+              const uint32_t idx = c0 + lane;
+              const bool act = idx < nlanes;
+              uint32_t cls = 0, cbase = 0;
+              for (uint32_t c = 0; c + 1u < nclsB; ++c) {
+                const uint32_t ce = PLB(4u * c + 1u);
+                if (idx >= ce) {
+                  cls = c + 1u;
+                  cbase = ce;
+                }
+              }
+              const uint32_t cmw = PLB(4u * cls + 2u);
+              const uint32_t jb = cmw & 15u, lo = (cmw >> 4) & 15u, pw3 = cmw >> 8;
+              const uint32_t i2 = idx - cbase;
+              const uint32_t ci = jb ? __umulhi(i2, PLB(4u * cls + 3u)) : i2;
+              uint32_t dg = i2 - ci * pw3;
+              uint32_t mk = act ? PLB(PLB(4u * cls) + ci) : 0u;
+              uint32_t pidx = pidxb;
+              uint64_t path = ppath;
+              uint32_t slast = 0xFFFFFFFFu;
+              if (mk) slast = P + (31u - (uint32_t)__clz((int)mk));
+              while (mk) {
                 const uint32_t y = 31u - (uint32_t)__clz((int)mk);
                 mk &= ~(1u << y);
-                const uint32_t d = dg % 3u;
-                dg /= 3u;
-                subst(y, d);
+                const uint32_t third = __umul24(dg, 43691u) >> 17;
+                const uint32_t d = dg - 3u * third;
+                dg = third;
+                const uint32_t t = L - 1u - y;
+                const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+                const uint32_t sym = (qc + 1u + d) & 3u;
+                path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
+                pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
               }
-              kk = m - 1u;
-              flag = 1u;
-            }
-            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-            if (act) {
-              if (slast <= k - 2u && sb.ptab_rot != nullptr) {
-                const uint32_t sh = 2u * (k - 1u - slast);
-                const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
-                                      ((pidx >> sh) & 3u);
-                ent = sb.ptab_rot[((size_t)slast << (2u * k)) + ridx];
-              } else {
-                ent = sb.ptab[pidx];
+              uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+              {
+                const uint4 *ep = sb.ptab + pidx;
+                if (slast <= k - 2u && sb.ptab_rot != nullptr) {
+                  const uint32_t sh = 2u * (k - 1u - slast);
+                  const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
+                                        ((pidx >> sh) & 3u);
+                  ep = sb.ptab_rot + (((size_t)slast << (2u * k)) + ridx);
+                }
+                if (act) ent = *ep;
+                count_lines(c_tab, act, ep);
               }
+              const uint32_t ecnt = ent.y & 0x7FFFFFFFu, eflag = ent.y >> 31;
+              bool live = act && ecnt != 0u && !(a.dbg_skip & 2u);
+              /* no row of the interval has a left context within the budget left for X */
+              const uint32_t bl = m - jb;
+              const uint64_t am = bl == 0u ? allow_b[0] : bl == 1u ? allow_b[1] : bl == 2u ? allow_b[2] : ~0ull;
+              if (!eflag && ((((uint64_t)ent.w << 32) | ent.z) & am) == 0ull) live = false;
+              const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)jb << 56) | path;
+              /* the queue is empty here (one-sided seeding has not started); intervals larger than a
+               * descriptor holds are verified piece by piece */
+              uint32_t rem = (live && !(a.dbg_skip & 1u)) ? ecnt : 0u, first = ent.x;
+              do {
+                const uint32_t rows = rem < a.v_max ? rem : a.v_max;
+                vq[lane] = make_uint4(first, (jb << 14) | (rows << 17) | (lo << DSC_LO) | (eflag << DSC_EXC),
+                                      (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                verify(true, WAVE, vq);
+                first += rows;
+                rem -= rows;
+              } while (__ballot(rem != 0u));
             }
-            const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
-            bool live = act && ecnt != 0u;
-            if (__ballot(live && ((ent.y >> 31) != 0u || ecnt > a.v_max))) {
-              fallback = true;
-              break;
-            }
-            /* second class: no row of the interval has a left context within its one substitution */
-            if (flag && ((((uint64_t)ent.w << 32) | ent.z) & allow_b1) == 0ull) live = false;
-            const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
-            /* the queue is empty here (one-sided seeding has not started) */
-            vq[lane] = make_uint4(ent.x, (kk << 14) | ((live ? ecnt : 0u) << 17) | (flag << DSC_FLAG), (uint32_t)cmeta,
-                                  (uint32_t)(cmeta >> 32));
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            verify(true, WAVE, vq);
           }
         }
       }
       if (fallback) {
-        n_match = 0; /* whatever the other strand found so far is found again below */
         n_fb++;
+        pl_g = 0; /* the full plan, from global memory */
+        pl_lds = false;
       } else {
         n_two++;
-        pl = s_plan + a.plan2_off;
-        ncls = a.ncls2;
-        twosided = true;
+        astar_item = a.astar;
+        pl_g = a.planA_g;
+        pl_l = a.planA_g - a.plan_src;
+        pl_lds = a.plan_lds != 0u;
+        ncls = a.nclsA;
+        if (ncls == 0u) seeds_left = false;
       }
     }
 
@@ -548,7 +658,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
          * j <= m substitutions and, one table entry per lane, the two-symbol extensions the
          * remaining budget allows.  Same node set at depth k as the walk (index.hpp:182-248). */
         const uint32_t k = a.pt_k, kp = k - 2u;
-        const uint32_t cmeta_w = pl[2u * GS_PLAN_CLASSES + sc];
+        const uint32_t cmeta_w = PL(2u * GS_PLAN_CLASSES + sc);
         const uint32_t sj = cmeta_w & 15u;
         const uint32_t bud = (cmeta_w >> 4) == 15u ? m - sj : (cmeta_w >> 4); /* extension budget */
         uint32_t spow = 1u;
@@ -569,7 +679,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
          * digit runs over the lanes. */
         const uint32_t lanes_per = rot ? 3u : E;
         const uint32_t nsub = rot ? spow / 3u : spow;
-        const uint32_t span = pl[GS_PLAN_CLASSES + sc] * nsub * lanes_per;
+        const uint32_t span = PL(GS_PLAN_CLASSES + sc) * nsub * lanes_per;
         const uint32_t l = spos + lane;
         bool act = l < span;
         const uint32_t tv = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
@@ -585,7 +695,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           case 729u: ci = tv / 729u; break;
           default: ci = tv / nsub; break;
         }
-        uint32_t mask = act ? pl[pl[sc] + ci] : 0u;
+        uint32_t mask = act ? PL(PL(sc) + ci) : 0u;
         /* substitutions inside X (the first v_rem consumed symbols); the others lie in O */
         const uint32_t ax = __popc(mask & ((1u << a.v_rem) - 1u));
         uint32_t pidx = pidx0;
@@ -627,36 +737,33 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         }
         const uint32_t mm = (s2 != q2) + (s1 != q1);
         pidx ^= ((q2 ^ s2) << 2) | (q1 ^ s1);
-        /* with the other strand's second class active, sites with m-1 substitutions in O and none
-         * in the symbols after the table depth are found there: a seed with one more in X can
-         * reach nothing else and is dropped before its table read; a seed with none in X keeps
-         * only the rows with at least one substitution further on (DSC_FLAG) */
-        const bool two = twosided && a.bnew != 0u;
+        /* two-sided: with a substitutions in X and o in O the site is this strand's only when
+         * a < astar(o); the others come from the other strand's table (or its window list) */
         const uint32_t otot = sj - ax + mm;
-        if (two && ax == 1u && otot + 1u == m) act = false;
-        const uint32_t lowf = (two && ax == 0u && otot + 1u == m) ? 1u : 0u;
+        if (ax >= ((astar_item >> (4u * (otot < 7u ? otot : 7u))) & 15u) || sj + mm > m) act = false;
         uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-        if (act) {
+        {
+          const uint4 *ep = sd.ptab + pidx;
           if (rot) {
             const uint32_t sh = 2u * (k - 1u - plast);
             const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
                                   ((pidx >> sh) & 3u);
-            ent = sd.ptab_rot[((size_t)plast << (2u * k)) + ridx];
+            ep = sd.ptab_rot + (((size_t)plast << (2u * k)) + ridx);
           } else if (rot2 && u >= 4u) {
             /* copy of step k-2: its symbol (bits 3:2 of pidx) and the last one swap places */
             const uint32_t ridx = (pidx & ~15u) | ((pidx & 3u) << 2) | ((pidx >> 2) & 3u);
-            ent = sd.ptab_rot[((size_t)kp << (2u * k)) + ridx];
-          } else {
-            ent = sd.ptab[pidx];
+            ep = sd.ptab_rot + (((size_t)kp << (2u * k)) + ridx);
           }
+          if (act) ent = *ep;
+          count_lines(c_tab, act, ep);
         }
-        const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
+        const uint32_t ecnt = ent.y & 0x7FFFFFFFu, eflag = ent.y >> 31;
         /* context mask: drop the seed when none of the 3-symbol left contexts present in its
          * interval is within the remaining budget of the next three query symbols */
         const uint32_t bl = m - (sj + mm); /* budget left (>= 0 by construction) */
         const uint64_t amask = bl == 0u ? allow3[0] : bl == 1u ? allow3[1] : bl == 2u ? allow3[2] : ~0ull;
         const uint64_t emask = ((uint64_t)ent.w << 32) | ent.z;
-        const bool hopeless = use_mask3 && (ent.y >> 31) == 0u && (emask & amask) == 0ull;
+        const bool hopeless = use_mask3 && eflag == 0u && (emask & amask) == 0ull;
         const bool live = act && ecnt != 0u && !hopeless && !(a.dbg_skip & 2u);
         const uint32_t c2 = s2 == q2 ? 0u : 1u + s2 - (s2 > q2 ? 1u : 0u);
         const uint32_t c1 = s1 == q1 ? 0u : 1u + s1 - (s1 > q1 ? 1u : 0u);
@@ -664,53 +771,46 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path |
                                ((uint64_t)c2 << (50u - 2u * kp)) |
                                ((uint64_t)c1 << (50u - 2u * (kp + 1u)));
-        /* small, exception-free intervals are resolved right here against ctx[]; the rest
-         * continue as ordinary nodes (k < L: never terminal) */
-        const bool ver = live && a.v_rem != 0u && (ent.y >> 31) == 0u && ecnt <= a.v_max;
-        if (two && __ballot(lowf != 0u && live && !ver)) {
-          /* such a seed would have to be walked, and the walk cannot tell its rows apart from
-           * the ones the other strand already reported: redo the item one-sided, full plan */
-          n_match = 0;
-          n_rst++;
-          xs = gs = 0;
-          qn = 0;
-          sc = spos = 0;
-          pl = s_plan;
-          ncls = a.ncls;
-          twosided = false;
-          continue;
-        }
+        /* every interval is resolved right here against ctx[] (exception rows included, large
+         * ones in pieces); without the context arrays the seeds continue as ordinary nodes
+         * (k < L: never terminal) */
+        const bool ver = live && a.v_rem != 0u;
         route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
-        /* The verifying seeds wait in the queue until a pass can be filled: about a quarter of
-         * a step's 64 lanes survive the context mask, and a pass (prefix sums, owner lookup,
-         * row groups) costs the same instructions for 16 seeds as for 64. */
-        {
-          const bool push = ver && !(a.dbg_skip & 1u);
-          const uint64_t bq = __ballot(push);
-          if (bq) {
-            if (push)
-              vq[qn + lanes_below(bq)] =
-                  make_uint4(ent.x, (kk << 14) | (ecnt << 17) | (lowf << DSC_FLAG), (uint32_t)cmeta,
-                             (uint32_t)(cmeta >> 32));
-            qn += __popcll(bq);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          }
-        }
-        /* advance the (j, sub, pos) cursor */
+        /* advance the (class, position) cursor */
         spos += WAVE;
         if (spos >= span) {
           spos = 0;
           do {
             ++sc;
-          } while (sc < ncls && pl[GS_PLAN_CLASSES + sc] == 0u);
+          } while (sc < ncls && PL(GS_PLAN_CLASSES + sc) == 0u);
           if (sc >= ncls) seeds_left = false;
         }
-        /* drain from the tail: the last `take` descriptors, no shifting; everything once the
-         * seeds are exhausted (qn < VQ_DRAIN + 64 <= VQ_CAP always holds) */
-        while (qn >= VQ_DRAIN || (!seeds_left && qn != 0u)) {
-          const uint32_t take = qn < WAVE ? qn : WAVE;
-          qn -= take;
-          verify(false, take, vq + qn);
+        /* The verifying seeds wait in the queue until a pass can be filled: about a quarter of
+         * a step's 64 lanes survive the context mask, and a pass (prefix sums, owner lookup,
+         * row groups) costs the same instructions for 16 seeds as for 64.  Drain from the tail
+         * (no shifting): when at least VQ_DRAIN wait, when the next push might not fit, and
+         * everything once the seeds are exhausted. */
+        uint32_t rem = (ver && !(a.dbg_skip & 1u)) ? ecnt : 0u, first = ent.x;
+        for (;;) {
+          const uint64_t bq = __ballot(rem != 0u);
+          if (bq && qn + WAVE <= VQ_CAP) {
+            const uint32_t rows = rem < a.v_max ? rem : a.v_max;
+            if (rem != 0u)
+              vq[qn + lanes_below(bq)] = make_uint4(first, (kk << 14) | (rows << 17) | (eflag << DSC_EXC),
+                                                    (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+            qn += __popcll(bq);
+            first += rows;
+            rem -= rows;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            continue;
+          }
+          if (qn >= VQ_DRAIN || (bq && qn != 0u) || (!seeds_left && qn != 0u)) {
+            const uint32_t take = qn < WAVE ? qn : WAVE;
+            qn -= take;
+            verify(false, take, vq + qn);
+            continue;
+          }
+          break;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         continue;
@@ -747,6 +847,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           oa = occ1(blocks, sp >> GS_BLOCK_SHIFT, sp & (GS_BLOCK_ROWS - 1u), c);
           ob = occ1(blocks, ep >> GS_BLOCK_SHIFT, (ep & (GS_BLOCK_ROWS - 1u)) + 1u, c);
         }
+        if constexpr (CNT)
+          c_occ += (uint32_t)__popcll(__ballot(active)) +
+                   (uint32_t)__popcll(__ballot(active && (sp >> GS_BLOCK_SHIFT) != (ep >> GS_BLOCK_SHIFT)));
         const uint32_t Cc = c == 0 ? sd.C[0] : c == 1 ? sd.C[1] : c == 2 ? sd.C[2] : sd.C[3];
         const uint32_t t2 = t + 1u;
         const uint64_t cmeta =
@@ -785,6 +888,9 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         occ4(blocks, sp >> GS_BLOCK_SHIFT, sp & (GS_BLOCK_ROWS - 1u), a0, a1, a2, a3);
         occ4(blocks, ep >> GS_BLOCK_SHIFT, (ep & (GS_BLOCK_ROWS - 1u)) + 1u, b0, b1, b2, b3);
       }
+      if constexpr (CNT)
+        c_occ += (uint32_t)__popcll(__ballot(ext)) +
+                 (uint32_t)__popcll(__ballot(ext && (sp >> GS_BLOCK_SHIFT) != (ep >> GS_BLOCK_SHIFT)));
 
       /* which symbols may be tried, and what they cost */
       const bool inpam = t >= L;
@@ -869,7 +975,13 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     if (n_ovf) atomicAdd(&a.stats[1], n_ovf);
     if (n_two) atomicAdd(&a.stats[4], (unsigned long long)n_two);
     if (n_fb) atomicAdd(&a.stats[5], (unsigned long long)n_fb);
-    if (n_rst) atomicAdd(&a.stats[6], (unsigned long long)n_rst);
+    if constexpr (CNT) {
+      atomicAdd(&a.stats[8], (unsigned long long)c_tab);
+      atomicAdd(&a.stats[9], (unsigned long long)c_c16);
+      atomicAdd(&a.stats[10], (unsigned long long)c_ctx);
+      atomicAdd(&a.stats[11], (unsigned long long)c_isa);
+      atomicAdd(&a.stats[12], (unsigned long long)c_occ);
+    }
   }
 }
 
@@ -1282,6 +1394,49 @@ int gs_num_cus(int device) {
   return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
 }
 
+/* Which strand's table finds a site with (a, o, b) substitutions in (X, O, R)?  This strand's
+ * table covers X and O: a class of its seeds is a pair (a, o), and verifying such a seed against
+ * ctx[] finds every b the budget leaves.  The other strand's table covers O, R and the PAM: its
+ * classes are pairs (o, b), each finding every a.  For a fixed o the cells (a, b), a + b <= m - o,
+ * must each be covered by row a or by column b; the staircase shape makes every minimal cover
+ * "rows a < a*, columns b <= m - o - a*", so the plan is one threshold a*(o) per o.
+ * Cost of a class = its seeds x (table line share + chance to survive the context mask x a
+ * verification pass), the chances being those of an hg38-sized table (11.5 rows per k-mer). */
+static void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, double epam, uint32_t astar[8]) {
+  auto binom3 = [](uint32_t n, uint32_t j) -> double { /* C(n, j) 3^j */
+    if (j > n) return 0.0;
+    double v = 1;
+    for (uint32_t i = 0; i < j; i++) v = v * (n - i) / (i + 1) * 3.0;
+    return v;
+  };
+  static const double pass[4] = {0.17, 0.86, 1.0, 1.0};
+  auto seed_cost = [&](uint32_t budget_left, double verify) -> double {
+    return 0.35 + pass[budget_left < 3 ? budget_left : 3] * verify;
+  };
+  for (uint32_t o = 0; o < 8; o++) {
+    astar[o] = 15;
+    if (o > m || o > nO) continue;
+    const uint32_t M = m - o;
+    double best = -1;
+    for (uint32_t as = 0; as <= M + 1; as++) {
+      double c = 0;
+      for (uint32_t a = 0; a < as && a <= M; a++) c += binom3(nX, a) * seed_cost(M - a, 1.5);
+      if (as <= M) {
+        if (as > nX) continue; /* the other side would need more substitutions in X than X holds */
+        for (uint32_t b = 0; b + as <= M; b++) c += epam * binom3(nR, b) * seed_cost(M - b, 1.9);
+      }
+      if (best < 0 || c < best) {
+        best = c;
+        astar[o] = as <= M ? as : 15;
+      }
+    }
+  }
+  /* k_search sizes a class's two-symbol extension by the largest o it may reach: keep the
+   * thresholds non-increasing in o so that "allowed at o" implies "allowed below o" */
+  for (uint32_t o = 1; o < 8; o++)
+    if (astar[o] > astar[o - 1]) astar[o] = astar[o - 1];
+}
+
 extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,
                                          const void *d_guide_pams, uint32_t P, const char *alt_pams,
                                          uint32_t n_alt, uint32_t mismatches, uint32_t flags,
@@ -1364,81 +1519,132 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   /* two-sided seeding (k_search): possible when set X (the first v_rem consumed guide symbols)
    * lies inside the plan's positions, the PAM fits the table depth and both inverse suffix
    * arrays exist */
-  bool bidir = false, bnew = false;
-  uint32_t tau = 0, plan2_off = 0, plan_total = 0, bpow = 0, bcomb_off = 0, ncls2 = 0;
-  std::vector<uint32_t> bcomb;
+  bool bidir = false;
+  uint32_t astar_packed = 0xFFFFFFFFu, astar[8] = {15, 15, 15, 15, 15, 15, 15, 15};
+  uint32_t planA_g = 0, planB_g = 0, nclsA = 0, nclsB = 0, plan2_words = 0;
   uint32_t n_cand[2] = {0, 0};
-  const uint64_t *d_cand[2] = {nullptr, nullptr};
-  if (v_rem != 0 && mismatches >= 2 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
+  const uint4 *d_cand[2] = {nullptr, nullptr};
+  if (v_rem != 0 && mismatches >= 1 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
       L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !getenv("GS_NO_BIDIR")) {
-    bidir = true;
-    tau = mismatches - 1 > 2 ? mismatches - 1 : 2;
-    /* filtered plan: position masks with fewer than tau bits inside X */
-    const uint32_t kp = ix->pt_k - 2;
-    uint32_t jmax = mismatches < kp ? mismatches : kp;
-    if (jmax > 7) jmax = 7;
-    const uint32_t xmask = (1u << v_rem) - 1u;
-    /* second class of the other strand (k_search): m-1 substitutions in O = the guide symbols
-     * both tables cover (consumption steps v_rem .. k-1), none after the table depth */
-    const uint32_t osz = ix->pt_k - v_rem; /* |O| = 2k - L - P */
-    if (mismatches - 1 <= osz && !getenv("GS_NO_BNEW")) {
-      uint32_t pw = 1;
-      for (uint32_t i = 0; i + 1 < mismatches; i++) pw *= 3;
-      /* bit y = guide symbol L-1-y; O = y in [L-k, k-P-1] */
-      const uint32_t ylo = L - ix->pt_k;
-      for (uint32_t mk = 0; mk < (1u << osz); mk++)
-        if ((uint32_t)__builtin_popcount(mk) == mismatches - 1) bcomb.push_back(mk << ylo);
-      if (bcomb.size() * (size_t)pw <= 4096) {
-        bnew = true;
-        bpow = pw;
-      } else {
-        bcomb.clear();
+    const uint32_t k = ix->pt_k, kp = k - 2, m = mismatches;
+    const uint32_t nX = v_rem, nO = k - v_rem, nR = L - k; /* |X|, |O|, |R| */
+    /* PAM expansions the other strand enumerates per item (its table holds concrete bases only) */
+    double epam = 0;
+    {
+      const uint32_t np = P ? n_alt + 1 : 1;
+      for (uint32_t j = 0; j < np; j++) {
+        double e = 1;
+        for (uint32_t u = 0; u < P; u++) {
+          const char c = j < n_alt ? alt_pams[j * P + u] : 'N'; /* the guides' own PAM: taken as one wildcard pattern */
+          if (c == 'N' && (j < n_alt || u == 0)) e *= 4;
+        }
+        epam += e;
       }
     }
-    /* filtered plan: position masks with fewer than tau bits inside X, one class per (j, bits
-     * inside X = 0 / 1 / more).  With the second class active, a variant with one substitution in
-     * X may add at most m-2 in O (m-1 belong to the other strand), which caps its extension
-     * budget at m-1-j: the class shrinks from 16 to 8 lanes or from 8 lanes to the three
-     * neighbours of one rotated-table line, or disappears */
-    std::vector<uint32_t> plan2(96, 0u);
-    for (uint32_t j = 0; j <= jmax; j++)
-      for (uint32_t g = 0; g < 3; g++) {
-        if (ncls2 >= 32) break;
-        int eb = 15;
-        if (bnew && g == 1) eb = (int)mismatches - 1 - (int)j;
-        if (eb < 0) continue;
-        const uint32_t c = ncls2;
-        plan2[c] = (uint32_t)plan2.size();
-        uint32_t cnt = 0;
-        for (uint32_t mk = 0; mk < (1u << kp); mk++) {
-          const uint32_t ax = (uint32_t)__builtin_popcount(mk & xmask);
-          if ((uint32_t)__builtin_popcount(mk) != j || ax >= tau || (ax < 2 ? ax : 2) != g) continue;
-          plan2.push_back(mk);
-          cnt++;
-        }
-        if (!cnt) continue;
-        plan2[32 + c] = cnt;
-        plan2[64 + c] = j | ((uint32_t)eb << 4);
-        ncls2++;
+    gs_choose_astar(m, nX, nO, nR, epam, astar);
+    if (const char *e = getenv("GS_ASTAR")) { /* experiments: "2,2,1,1" */
+      uint32_t o = 0;
+      for (const char *p = e; *p && o < 8; o++) {
+        astar[o] = (uint32_t)strtoul(p, (char **)&p, 10);
+        if (*p == ',') p++;
       }
-    bcomb_off = (uint32_t)plan2.size();
-    plan2.insert(plan2.end(), bcomb.begin(), bcomb.end());
-    plan2_off = ix->combo_off[jmax] + ix->combo_cnt[jmax]; /* right after the words of the full plan in use */
-    plan_total = plan2_off + (uint32_t)plan2.size();
-    if (plan2.size() > ix->combo_words + 256) {
-      bidir = false;
-    } else {
-      GS_HIP(hipMemcpyAsync((uint32_t *)ix->d_combo + ix->combo_words, plan2.data(), 4 * plan2.size(),
-                            hipMemcpyHostToDevice, st));
-      GS_HIP(hipStreamSynchronize(st)); /* plan2 is a local */
+    }
+    bool any_b = false;
+    for (uint32_t o = 0; o <= m && o <= nO && o < 8; o++) any_b = any_b || astar[o] + o <= m;
+    if (any_b) {
+      bidir = true;
+      astar_packed = 0;
+      for (uint32_t o = 0; o < 8; o++) astar_packed |= (astar[o] > 15 ? 15u : astar[o]) << (4 * o);
+      /* this strand's filtered plan: one class per (j substitutions in the first k-2 steps, ax of
+       * them inside X), kept when ax < astar(j - ax); its two-symbol extension (both symbols lie
+       * in O) may add as many substitutions as astar still allows */
+      const uint32_t xmask = (1u << nX) - 1u;
+      std::vector<uint32_t> planA(GS_PLAN_HEADER, 0u);
+      const uint32_t jmax = m < kp ? m : kp;
+      for (uint32_t j = 0; j <= jmax && bidir; j++)
+        for (uint32_t ax = 0; ax <= j && ax <= nX; ax++) {
+          const uint32_t o0 = j - ax;
+          if (o0 >= 8 || ax >= astar[o0]) continue;
+          uint32_t eb = 0;
+          while (eb < 2 && j + eb + 1 <= m && o0 + eb + 1 < 8 && ax < astar[o0 + eb + 1]) eb++;
+          if (nclsA >= GS_PLAN_CLASSES) {
+            bidir = false;
+            break;
+          }
+          const uint32_t c = nclsA;
+          planA[c] = (uint32_t)planA.size();
+          uint32_t cnt = 0;
+          for (uint32_t mk = 0; mk < (1u << kp); mk++) {
+            if ((uint32_t)__builtin_popcount(mk) != j || (uint32_t)__builtin_popcount(mk & xmask) != ax) continue;
+            planA.push_back(mk);
+            cnt++;
+          }
+          if (!cnt) continue;
+          planA[GS_PLAN_CLASSES + c] = cnt;
+          planA[2 * GS_PLAN_CLASSES + c] = j | (eb << 4);
+          nclsA++;
+        }
+      /* the other strand's plan: classes (o, b) with astar(o) + o + b <= m; bit y of a mask = guide
+       * symbol L-1-y; O = y in [L-k, k-P-1], R = y in [0, L-k-1] */
+      std::vector<uint32_t> planB;
+      {
+        struct cls {
+          uint32_t o, b;
+        };
+        std::vector<cls> cl;
+        for (uint32_t o = 0; o <= m && o <= nO && o < 8; o++)
+          for (uint32_t b = 0; b <= nR && astar[o] + o + b <= m; b++)
+            if (astar[o] <= nX) cl.push_back({o, b});
+        nclsB = (uint32_t)cl.size();
+        if (nclsB > 32) bidir = false;
+        planB.assign(4 * (size_t)nclsB, 0u);
+        const uint32_t ylo = L - k;
+        uint32_t lanes = 0;
+        for (uint32_t c = 0; c < nclsB && bidir; c++) {
+          const uint32_t o = cl[c].o, b = cl[c].b, jb = o + b;
+          uint32_t pw3 = 1;
+          for (uint32_t i = 0; i < jb; i++) pw3 *= 3;
+          planB[4 * c] = (uint32_t)planB.size();
+          uint32_t cnt = 0;
+          for (uint32_t mo = 0; mo < (1u << nO); mo++) {
+            if ((uint32_t)__builtin_popcount(mo) != o) continue;
+            for (uint32_t mr = 0; mr < (1u << nR); mr++) {
+              if ((uint32_t)__builtin_popcount(mr) != b) continue;
+              planB.push_back((mo << ylo) | mr);
+              cnt++;
+            }
+          }
+          const uint64_t span = (uint64_t)cnt * pw3;
+          if (span + lanes >= (1u << 20)) { /* the lane arithmetic of k_search is exact below 2^20 */
+            bidir = false;
+            break;
+          }
+          lanes += (uint32_t)span;
+          planB[4 * c + 1] = lanes;
+          planB[4 * c + 2] = jb | (astar[o] << 4) | (pw3 << 8);
+          planB[4 * c + 3] = jb ? (uint32_t)((0x100000000ull + pw3 - 1) / pw3) : 0u;
+        }
+      }
+      plan2_words = (uint32_t)(planA.size() + planB.size());
+      if (bidir && ix->combo_words + plan2_words > ix->combo_cap) bidir = false;
+      if (bidir) {
+        planA_g = ix->combo_words;
+        planB_g = ix->combo_words + (uint32_t)planA.size();
+        std::vector<uint32_t> both(planA);
+        both.insert(both.end(), planB.begin(), planB.end());
+        GS_HIP(hipMemcpyAsync((uint32_t *)ix->d_combo + ix->combo_words, both.data(), 4 * both.size(),
+                              hipMemcpyHostToDevice, st));
+        GS_HIP(hipStreamSynchronize(st)); /* `both` is a local */
+      }
     }
   }
   if (bidir) {
     /* windows where a literal 'N' of the genome lies under the PAM (index.hpp:139-149) and the
-     * guide part is plain A,C,G,T: only the walk finds those, so a guide that reaches one with
-     * >= tau substitutions in X is searched one-sided.  Window of strand s, left to right:
-     * P PAM symbols (last consumed first), then the guide symbols L-1 .. 0. */
-    std::vector<uint64_t> cand[2];
+     * guide part is plain A,C,G,T: the other strand's table cannot hold them (its k-mers spell the
+     * PAM), so its share of them is reported from this list.  Window of strand s, left to right:
+     * P PAM symbols (last consumed first), then the guide symbols L-1 .. 0.  Entry = {q lo, q hi,
+     * PAM symbols in consumption order (3 bits each, 4 = N), position of the site in the strand's text}. */
+    std::vector<uint4> cand[2];
     const uint32_t W = L + P;
     const uint64_t len = ix->genome_length;
     auto code = [](uint8_t c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
@@ -1451,64 +1657,72 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
         return o < GS_NRUN_FLANK ? r.right[o] : 0;
       };
       const int64_t s0 = (int64_t)r.start, e0 = (int64_t)(r.start + r.len);
-      /* forward strand: the run's tail under the window's first P symbols */
+      /* forward strand: the run's tail under the window's first P symbols; text offset o < P holds
+       * the PAM symbol of consumption step P-1-o */
       for (int64_t i = e0 - (int64_t)P; i < e0; i++) {
         if (i < 0 || (uint64_t)i + W > len) continue;
         bool ok = true;
         uint64_t q = 0;
+        uint32_t pc = 0;
         for (uint32_t o = 0; o < W && ok; o++) {
           const uint8_t c = at(i + o);
           if (o < P) {
             ok = c == 'N' || code(c) >= 0;
+            if (ok) pc |= (uint32_t)(c == 'N' ? 4 : code(c)) << (3u * (P - 1u - o));
           } else {
             const int cc = code(c);
             ok = cc >= 0;
             if (ok) q |= (uint64_t)cc << (2u * (L - 1u - (o - P)));
           }
         }
-        if (ok) cand[0].push_back(q);
+        if (ok) cand[0].push_back(make_uint4((uint32_t)q, (uint32_t)(q >> 32), pc, (uint32_t)i));
       }
       /* reverse strand: its window is the forward window read backwards and complemented, so the
-       * run's head lies under the forward window's last P symbols and guide symbol t sits at
-       * forward offset t, complemented */
+       * run's head lies under the forward window's last P symbols; guide symbol t sits at forward
+       * offset t, complemented; PAM step u at forward offset L+u, complemented */
       for (int64_t j = s0 + 1 - (int64_t)W; j <= s0 + (int64_t)P - (int64_t)W; j++) {
         if (j < 0 || (uint64_t)j + W > len) continue;
         bool ok = true;
         uint64_t q = 0;
+        uint32_t pc = 0;
         for (uint32_t o = 0; o < W && ok; o++) {
           const uint8_t c = at(j + o);
           if (o >= L) {
             ok = c == 'N' || code(c) >= 0;
+            if (ok) pc |= (uint32_t)(c == 'N' ? 4 : 3 - code(c)) << (3u * (o - L));
           } else {
             const int cc = code(c);
             ok = cc >= 0;
             if (ok) q |= (uint64_t)(3 - cc) << (2u * o);
           }
         }
-        if (ok) cand[1].push_back(q);
+        if (ok) cand[1].push_back(make_uint4((uint32_t)q, (uint32_t)(q >> 32), pc, (uint32_t)(len - ((uint64_t)j + W))));
       }
     }
     n_cand[0] = (uint32_t)cand[0].size();
     n_cand[1] = (uint32_t)cand[1].size();
     if (n_cand[0] + n_cand[1]) {
-      if ((rc = gs_reserve(ix->w_cand, 8 * (size_t)(n_cand[0] + n_cand[1]))) != GS_OK) return rc;
-      uint64_t *dc = (uint64_t *)ix->w_cand.p;
-      if (n_cand[0]) GS_HIP(hipMemcpy(dc, cand[0].data(), 8 * (size_t)n_cand[0], hipMemcpyHostToDevice));
-      if (n_cand[1]) GS_HIP(hipMemcpy(dc + n_cand[0], cand[1].data(), 8 * (size_t)n_cand[1], hipMemcpyHostToDevice));
+      if ((rc = gs_reserve(ix->w_cand, 16 * (size_t)(n_cand[0] + n_cand[1]))) != GS_OK) return rc;
+      uint4 *dc = (uint4 *)ix->w_cand.p;
+      if (n_cand[0]) GS_HIP(hipMemcpy(dc, cand[0].data(), 16 * (size_t)n_cand[0], hipMemcpyHostToDevice));
+      if (n_cand[1]) GS_HIP(hipMemcpy(dc + n_cand[0], cand[1].data(), 16 * (size_t)n_cand[1], hipMemcpyHostToDevice));
       d_cand[0] = dc;
       d_cand[1] = dc + n_cand[0];
     }
     if (getenv("GS_DEBUG"))
-      fprintf(stderr, "[gs] two-sided seeding: tau %u, X = first %u symbols, literal-N windows %u + %u\n", tau, v_rem,
-              n_cand[0], n_cand[1]);
+      fprintf(stderr, "[gs] two-sided seeding: astar %u,%u,%u,%u,%u,%u,%u,%u over |X|=%u |O|=%u |R|=%u, %u + %u classes, "
+              "plan %u words, literal-N windows %u + %u\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
+              astar[6], astar[7], v_rem, ix->pt_k - v_rem, L - ix->pt_k, nclsA, nclsB, plan2_words, n_cand[0], n_cand[1]);
   }
 
+  const bool count_req = (flags & GS_FLAG_COUNT_REQUESTS) != 0;
   auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
                         uint32_t cap_, unsigned long long h_stats[2],
                         const uint64_t *slot_off = nullptr) -> gs_status {
     GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 16, st)); /* n_ext, overflow items */
     GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
     gs_search_args sa;
+    memset(&sa, 0, sizeof(sa));
     sa.sd[0] = ix->strand[0].d;
     sa.sd[1] = ix->strand[1].d;
     sa.guides = guides;
@@ -1523,23 +1737,13 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     sa.m = mismatches;
     sa.cap = cap_;
     sa.combo = (const uint32_t *)ix->d_combo;
-    sa.pt_k = 0;
-    sa.ncls = sa.ncls2 = 0;
-    sa.v_rem = 0;
     sa.v_max = VERIFY_MAX_DEFAULT;
     if (const char *e = getenv("GS_VERIFY_MAX")) {
       const long v = atol(e);
       sa.v_max = v < 1 ? 1u : v > 1023 ? 1023u : (uint32_t)v;
     }
     sa.dbg_skip = getenv("GS_DBG_SKIP") ? (uint32_t)atol(getenv("GS_DBG_SKIP")) : 0u;
-    sa.bidir = 0;
-    sa.tau = 0;
-    sa.plan2_off = 0;
-    sa.plan2_src = 0;
-    sa.cand[0] = sa.cand[1] = nullptr;
-    sa.n_cand[0] = sa.n_cand[1] = 0;
-    sa.bnew = sa.bcomb_off = sa.nbc = sa.bpow = 0;
-    sa.plan_words = 0;
+    sa.astar = 0xFFFFFFFFu;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
        * substitutions x the two-symbol extensions the remaining budget allows */
@@ -1550,38 +1754,40 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       sa.ncls = jmax + 1;
       sa.v_rem = v_rem;
       sa.plan_words = ix->combo_off[jmax] + ix->combo_cnt[jmax];
+      sa.plan_src = 0;
       if (bidir) {
         sa.bidir = 1;
-        sa.ncls2 = ncls2;
-        sa.tau = tau;
-        sa.plan2_off = plan2_off;
-        sa.plan2_src = ix->combo_words;
-        sa.plan_words = plan_total;
+        sa.astar = astar_packed;
+        sa.planA_g = planA_g;
+        sa.nclsA = nclsA;
+        sa.planB_g = planB_g;
+        sa.nclsB = nclsB;
+        sa.plan_words = plan2_words;
+        sa.plan_src = ix->combo_words;
         sa.cand[0] = d_cand[0];
         sa.cand[1] = d_cand[1];
         sa.n_cand[0] = n_cand[0];
         sa.n_cand[1] = n_cand[1];
-        if (bnew) {
-          sa.bnew = 1;
-          sa.bcomb_off = plan2_off + bcomb_off;
-          sa.nbc = (uint32_t)bcomb.size();
-          sa.bpow = bpow;
-        }
       }
+      sa.plan_lds = sa.plan_words <= (getenv("GS_PLAN_LDS") ? (uint32_t)atol(getenv("GS_PLAN_LDS")) : 1024u) ? 1u : 0u;
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
-     * their LDS (stacks + verification queue: 6 KiB per wave) allows: 6 at 24 KiB = 24 waves per CU */
-    uint32_t grid = (uint32_t)cus * (160u * 1024u / (WAVE_LDS_ENTRIES * 16u * SEARCH_WAVES));
+     * their LDS (stacks + verification queue: 6 KiB per wave, + the plan) allows */
+    const size_t dyn = sa.plan_lds ? 4 * (size_t)sa.plan_words : 0;
+    uint32_t grid = (uint32_t)cus * (uint32_t)(160u * 1024u / (WAVE_LDS_ENTRIES * 16u * SEARCH_WAVES + dyn));
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
     if (getenv("GS_DEBUG")) {
       int occ = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search, WAVE * SEARCH_WAVES, 4 * (size_t)sa.plan_words);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search<false>, WAVE * SEARCH_WAVES, dyn);
       fprintf(stderr, "[gs] k_search: grid %u x %u threads, LDS %zu + %zu B per workgroup, %d workgroups per CU resident\n",
-              grid, WAVE * SEARCH_WAVES, sizeof(uint4) * WAVE_LDS_ENTRIES * SEARCH_WAVES, 4 * (size_t)sa.plan_words, occ);
+              grid, WAVE * SEARCH_WAVES, sizeof(uint4) * WAVE_LDS_ENTRIES * SEARCH_WAVES, dyn, occ);
     }
     GS_HIP(hipEventRecord(ix->ev[1], st));
-    hipLaunchKernelGGL(k_search, dim3(grid), dim3(WAVE * SEARCH_WAVES), 4 * (size_t)sa.plan_words, st, sa);
+    if (count_req)
+      hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+    else
+      hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
     GS_HIP(hipEventRecord(ix->ev[2], st));
     GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
@@ -1828,12 +2034,13 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_huge_locate, dim3(h_n_uq), dim3(WAVE), 0, st, ha);
   }
   GS_HIP(hipEventRecord(ix->ev[3], st));
-  unsigned long long h_stats3[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long h_stats3[16] = {0};
   GS_HIP(hipMemcpyAsync(h_stats3, d_stats, sizeof(h_stats3), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   if (bidir && getenv("GS_DEBUG"))
-    fprintf(stderr, "[gs] items: seeded from both strands %llu, fallen back before seeding %llu, redone one-sided %llu%s\n",
-            h_stats3[4], h_stats3[5], h_stats3[6], bnew ? " (second class on)" : "");
+    fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu\n",
+            h_stats3[4], h_stats3[5]);
+  memcpy(ix->last_counters, h_stats3, sizeof(h_stats3));
   GS_HIP(hipGetLastError());
   if (d_offsets) *d_offsets = ix->w_offsets.p;
   if (d_hits) *d_hits = ix->w_hits.p;

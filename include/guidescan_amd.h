@@ -69,6 +69,10 @@ typedef struct {
  * shortcut).  Same hits; n_ext then equals the reference traversal's node count.  Without it
  * n_ext counts only the extensions actually executed below the table depth. */
 #define GS_FLAG_FAITHFUL_WALK 2u
+/* Measurement only: run the counting instantiation of the search kernel, which tallies the distinct
+ * 64-byte lines each of its load instructions asks for (gs_index_last_counters).  Same results,
+ * slower; never set in a timed call. */
+#define GS_FLAG_COUNT_REQUESTS 4u
 
 typedef struct {
   uint64_t n_guides;
@@ -110,6 +114,13 @@ gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out);
 gs_status gs_sdsl_extract_text(const char *index_file, uint8_t **text, uint64_t *len);
 
 void gs_index_close(gs_index *ix);
+/* Work counters of the last gs_enumerate_device call on this handle: [0] extensions executed by the
+ * Occ walk, [1] items whose matches overflowed their slots, [2] distinct matches, [4] items seeded
+ * from both strands' tables, [5] items seeded one-sided although two-sided seeding was on; with
+ * GS_FLAG_COUNT_REQUESTS also the 64-byte lines requested by the search kernel: [8] prefix-table
+ * lines, [9] 16-bit context lines, [10] 32-bit context words, [11] SA/ISA gathers of the search,
+ * [12] Occ block lines.  (the bytes the roofline is priced on.) */
+gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]);
 uint64_t gs_index_genome_length(const gs_index *ix); /* sum of chromosome lengths (no sentinel) */
 uint64_t gs_index_device_bytes(const gs_index *ix);
 
