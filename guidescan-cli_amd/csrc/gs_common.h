@@ -91,10 +91,15 @@ struct gs_index {
   gs_strand strand[2];
   /* per-handle workspace, grown on demand, reused across calls */
   gs_buffer w_guides, w_slots, w_counts, w_nmatch, w_nhits, w_offsets, w_hits, w_misc, w_blocksums,
-      w_grec, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_a, w_h_b,
-      w_h_flag, w_h_pos, w_h_uq, w_h_uqg, w_h_cnt, w_h_scan, w_h_nh, w_h_first, w_h_tmp,
-      w_score, w_score_io, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
-      w_km_keys, w_km_keys2, w_km_tmp, w_km_text, w_km_out; /* gs_kmers.hip */
+      w_grec, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_tmp,
+      /* device-wide ordering of guides with more matches than an LDS sort holds (gs_search.hip) */
+      w_b_src, w_b_cnt, w_b_prefix, w_b_recs, w_b_w0, w_b_w0b, w_b_w1, w_b_idx, w_b_idxb, w_b_keep, w_b_keeps,
+      w_b_rows, w_b_rowss, w_b_redo_pos,
+      w_score, w_score_io; /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
+  /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
+  double seen_mean[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+  double seen_max[8] = {0};
+  uint64_t seen_key[8] = {0};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   /* prefix-table seeding plan: position masks of every mismatch combination over the first
    * pt_k-2 query symbols, grouped by mismatch count j (gs_index.hip: build_seed_plan) */

@@ -713,9 +713,10 @@ extern "C" void gs_index_close(gs_index *ix) {
   gs_buffer *bufs[] = {&ix->w_guides, &ix->w_slots, &ix->w_counts, &ix->w_nmatch, &ix->w_nhits,
                        &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec,
                        &ix->w_ovf_list, &ix->w_grec2, &ix->w_slots2, &ix->w_counts2, &ix->w_nmatch2,
-                       &ix->w_nhits2, &ix->w_h_off, &ix->w_h_a, &ix->w_h_b, &ix->w_h_flag, &ix->w_h_pos,
-                       &ix->w_h_uq, &ix->w_h_uqg, &ix->w_h_cnt, &ix->w_h_scan, &ix->w_h_nh, &ix->w_h_first,
-                       &ix->w_h_tmp, &ix->w_cand, &ix->w_score, &ix->w_score_io};
+                       &ix->w_nhits2, &ix->w_h_off, &ix->w_h_tmp, &ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix,
+                       &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx, &ix->w_b_idxb,
+                       &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_redo_pos,
+                       &ix->w_cand, &ix->w_score, &ix->w_score_io};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)

@@ -17,6 +17,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <cmath>
+
 #define SEARCH_WAVES 4 /* waves per workgroup */
 #ifndef STACK_ENTRIES
 #define STACK_ENTRIES 224 /* 16-byte nodes of the X/G stacks per wave */
@@ -1066,16 +1068,20 @@ struct gs_order_args {
 
 /* One wavefront per guide at a time, ORDER_WAVES wavefronts per workgroup, guides dealt to the
  * waves grid-stride (a launch of one single-wave workgroup per guide with one atomic each was
- * latency bound: 12 ms per 1 M guides).  Dynamic LDS per wave: 2*cap uint4 (records) + 2*cap
- * uint4 (sorted).  The loop body has no lane-conditional blocks (compiler pitfall):
- * per-guide results are stored by all lanes to the same address. */
+ * latency bound: 12 ms per 1 M guides).  Dynamic LDS per wave: 2*cap uint4 (records) + ORDER_SMALL
+ * uint4 (rank-sort output).  Up to ORDER_SMALL records a guide is rank-sorted (M^2/64 compares per
+ * lane: 11 at the 26 records of an m = 3 guide); larger guides go through a bitonic network in
+ * place (log^2 N / 2 steps of N/128 compare-exchanges per lane: at the 1,440 records of an m = 5
+ * guide 2.1 k per lane instead of 32 k).  The loop body has no lane-conditional blocks (DESIGN.md
+ * 5b, compiler pitfall): per-guide results are stored by all lanes to the same address. */
 #define ORDER_WAVES 4
+#define ORDER_SMALL 128u
 __global__ __launch_bounds__(WAVE *ORDER_WAVES) void k_order(gs_order_args a) {
   extern __shared__ uint4 s_mem[];
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
   const uint32_t cap = a.cap;
-  uint4 *rec = s_mem + (size_t)wave * 4u * cap;
+  uint4 *rec = s_mem + (size_t)wave * (2u * cap + ORDER_SMALL);
   uint4 *srt = rec + 2u * cap;
   uint32_t total_out = 0;
   for (uint32_t g = blockIdx.x * nw + wave; g < a.n; g += gridDim.x * nw) {
@@ -1093,17 +1099,42 @@ __global__ __launch_bounds__(WAVE *ORDER_WAVES) void k_order(gs_order_args a) {
     for (uint32_t i = lane; i < M; i += WAVE) rec[i] = i < c0 ? base[i] : base[cap + (i - c0)];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    /* rank sort: ascending (key, original index) */
-    for (uint32_t i = lane; i < M; i += WAVE) {
-      const uint4 me = rec[i];
-      const uint64_t key = ((uint64_t)me.y << 32) | me.x;
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < M; j++) {
-        const uint4 o = rec[j];
-        const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
-        rank += (ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < i)));
+    const uint4 *sorted = srt;
+    if (M <= ORDER_SMALL) {
+      /* rank sort: ascending (key, first row, original index) */
+      for (uint32_t i = lane; i < M; i += WAVE) {
+        const uint4 me = rec[i];
+        const uint64_t key = ((uint64_t)me.y << 32) | me.x;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < M; j++) {
+          const uint4 o = rec[j];
+          const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
+          rank += (ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < i)));
+        }
+        srt[rank] = me;
       }
-      srt[rank] = me;
+    } else {
+      /* bitonic network over N = the next power of two, padded with records that sort last */
+      uint32_t N = 2u * ORDER_SMALL;
+      while (N < M) N <<= 1;
+      for (uint32_t i = M + lane; i < N; i += WAVE) rec[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      for (uint32_t kk = 2; kk <= N; kk <<= 1)
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          for (uint32_t t = lane; t < (N >> 1); t += WAVE) {
+            const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), hi = lo | j;
+            const uint4 A = rec[lo], B = rec[hi];
+            const uint64_t ka = ((uint64_t)A.y << 32) | A.x, kb = ((uint64_t)B.y << 32) | B.x;
+            const bool gt = ka > kb || (ka == kb && A.z > B.z);
+            if (gt == ((lo & kk) == 0u)) {
+              rec[lo] = B;
+              rec[hi] = A;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
+      sorted = rec;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1114,10 +1145,10 @@ __global__ __launch_bounds__(WAVE *ORDER_WAVES) void k_order(gs_order_args a) {
       bool keep = false;
       uint4 me = make_uint4(0, 0, 0, 0);
       if (i < M) {
-        me = srt[i];
+        me = sorted[i];
         keep = true;
         if (i > 0) {
-          const uint4 pv = srt[i - 1];
+          const uint4 pv = sorted[i - 1];
           keep = !(pv.x == me.x && pv.y == me.y && pv.z == me.z); /* same sequence, same rows */
         }
       }
@@ -1135,6 +1166,83 @@ __global__ __launch_bounds__(WAVE *ORDER_WAVES) void k_order(gs_order_args a) {
     total_out += n_out;
   }
   if (lane == 0 && total_out) atomicAdd(&a.stats[2], (unsigned long long)total_out);
+}
+
+/* The same for guides with hundreds to thousands of matches (cap > 128): one 256-thread workgroup
+ * per guide at a time, the bitonic network spread over its four waves (a single wave needs 2.1 k
+ * compare-exchange rounds for the 1,440 records of an m = 5 guide), LDS sized by the largest guide
+ * of the batch (`nmax` records, a power of two) rather than by the slot capacity. */
+__global__ __launch_bounds__(256) void k_order_wg(gs_order_args a, uint32_t nmax) {
+  extern __shared__ uint4 s_mem[];
+  uint4 *rec = s_mem;
+  __shared__ uint32_t s_nout, s_hits;
+  const uint32_t tid = threadIdx.x, lane = lane_id();
+  const uint32_t cap = a.cap;
+  uint32_t total_out = 0;
+  for (uint32_t g = blockIdx.x; g < a.n; g += gridDim.x) {
+    const uint32_t c0 = a.counts[2 * g], c1 = a.counts[2 * g + 1];
+    const uint32_t M = c0 + c1;
+    if (c0 > cap || c1 > cap || M > nmax) { /* redone with larger slots (host side) */
+      if (tid == 0) {
+        a.nmatch[g] = 0;
+        a.nhits[g] = 0;
+      }
+      continue;
+    }
+    uint4 *base = a.slots + (size_t)g * 2 * cap;
+    uint32_t N = 64;
+    while (N < M) N <<= 1;
+    __syncthreads(); /* the previous guide's compaction has finished reading rec[] */
+    for (uint32_t i = tid; i < N; i += 256)
+      rec[i] = i < c0 ? base[i] : i < M ? base[cap + (i - c0)] : make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    for (uint32_t kk = 2; kk <= N; kk <<= 1)
+      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+        __syncthreads();
+        for (uint32_t t = tid; t < (N >> 1); t += 256) {
+          const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), hi = lo | j;
+          const uint4 A = rec[lo], B = rec[hi];
+          const uint64_t ka = ((uint64_t)A.y << 32) | A.x, kb = ((uint64_t)B.y << 32) | B.x;
+          const bool gt = ka > kb || (ka == kb && A.z > B.z);
+          if (gt == ((lo & kk) == 0u)) {
+            rec[lo] = B;
+            rec[hi] = A;
+          }
+        }
+      }
+    __syncthreads();
+    /* dedupe equal sequences (std::set keeps the first), compact, count hits: the first wave alone */
+    if (tid < WAVE) {
+      uint32_t n_out = 0, hits = 0;
+      for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        bool keep = false;
+        uint4 me = make_uint4(0, 0, 0, 0);
+        if (i < M) {
+          me = rec[i];
+          keep = true;
+          if (i > 0) {
+            const uint4 pv = rec[i - 1];
+            keep = !(pv.x == me.x && pv.y == me.y && pv.z == me.z);
+          }
+        }
+        const uint64_t kb = __ballot(keep);
+        const uint32_t cnt = keep ? (me.w - me.z + 1u) : 0u;
+        if (keep) base[n_out + lanes_below(kb)] = make_uint4(me.x, me.y, me.z, cnt);
+        n_out += __popcll(kb);
+        uint32_t s = cnt;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        hits += s;
+      }
+      if (lane == 0) {
+        a.nmatch[g] = n_out;
+        a.nhits[g] = hits;
+      }
+      total_out += n_out;
+    }
+  }
+  (void)s_nout;
+  (void)s_hits;
+  if (tid == 0 && total_out) atomicAdd(&a.stats[2], (unsigned long long)total_out);
 }
 
 /* ---- exclusive scan of nhits (uint32) into uint64 offsets ------------------- */
@@ -1286,89 +1394,103 @@ __global__ void k_gather_guides(const gs_guide_rec *in, const uint32_t *list, ui
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_o) out[i] = in[list[i]];
 }
+__global__ void k_gather_counts(const uint32_t *counts, const uint32_t *list, uint32_t n_o, uint32_t *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_o) {
+    out[2 * i] = counts[2 * list[i]];
+    out[2 * i + 1] = counts[2 * list[i] + 1];
+  }
+}
 __global__ void k_patch_overflow(const uint32_t *list, uint32_t n_o, const uint32_t *nhits2,
                                  uint32_t *nhits) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_o) nhits[list[i]] = nhits2[i];
 }
 
-/* ---- guides with more matches than an LDS sort can hold (repeat-derived guides) ---------
- * Their records are written at exact per-item offsets, tagged with the guide, ordered by one
- * device-wide comparator sort, made unique, and located one wavefront per record. */
-struct gs_hrec {
-  uint4 rec;  /* {key_lo, key_hi, sp, ep} */
-  uint32_t g; /* position of the guide in the redo list */
-  uint32_t pad[3];
+/* ---- guides with more matches than an LDS sort can hold: repeat-derived guides at any budget,
+ * every guide at <= 6 mismatches on a genome of this size (~5,400 matches per item).  Their match
+ * records are compacted into one array (item order = guide order), ordered by two stable
+ * device-wide radix sorts - (key low bits, first row), then (guide, key high bits) - made unique,
+ * scanned, and located one thread per record.  No per-guide atomics, no comparator sort. ---- */
+struct gs_big_src {   /* where the records of one set item live */
+  uint64_t off;       /* element offset */
+  uint32_t alt;       /* 0: main slot array, 1: the exact-size redo array */
 };
-struct gs_hrec_less {
-  __host__ __device__ bool operator()(const gs_hrec &a, const gs_hrec &b) const {
-    if (a.g != b.g) return a.g < b.g;
-    const uint64_t ka = ((uint64_t)a.rec.y << 32) | a.rec.x, kb = ((uint64_t)b.rec.y << 32) | b.rec.x;
-    if (ka != kb) return ka < kb;
-    return a.rec.z < b.rec.z;
-  }
-};
-__global__ void k_huge_tag(const uint4 *slots, const uint64_t *slot_off, uint32_t n_items, gs_hrec *out) {
-  /* one workgroup per item */
+/* one workgroup per set item: copy its records to the compact array and build the two sort words */
+__global__ __launch_bounds__(256) void k_big_compact(const uint4 *slots_main, const uint4 *slots_alt,
+                                                     const gs_big_src *src, const unsigned long long *prefix,
+                                                     uint32_t n_items, uint4 *recs, unsigned long long *w0,
+                                                     unsigned long long *w1, uint32_t *idx) {
   const uint32_t item = blockIdx.x;
   if (item >= n_items) return;
-  const uint64_t b = slot_off[item], e = slot_off[item + 1];
-  for (uint64_t r = b + threadIdx.x; r < e; r += blockDim.x) {
-    gs_hrec h;
-    h.rec = slots[r];
-    h.g = item >> 1;
-    h.pad[0] = h.pad[1] = h.pad[2] = 0;
-    out[r] = h;
+  const unsigned long long b = prefix[item], e = prefix[item + 1];
+  const gs_big_src s = src[item];
+  const uint4 *in = (s.alt ? slots_alt : slots_main) + s.off;
+  const unsigned long long g = item >> 1;
+  for (unsigned long long r = b + threadIdx.x; r < e; r += blockDim.x) {
+    const uint4 v = in[r - b];
+    recs[r] = v;
+    w0[r] = ((unsigned long long)(v.x >> 8) << 32) | v.z; /* key bits 31:8, first row */
+    w1[r] = (g << 32) | v.y;                                /* guide, key bits 63:32 */
+    idx[r] = (uint32_t)r;
   }
 }
-/* flag[r] = 1 when sorted record r starts a new (guide, key, sp) */
-__global__ void k_huge_flags(const gs_hrec *srt, uint64_t T, uint32_t *flag) {
+__global__ void k_big_gather_w1(const unsigned long long *w1, const uint32_t *idx, uint64_t T,
+                                unsigned long long *out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < T) out[r] = w1[idx[r]];
+}
+/* keep[r] = 1 when sorted record r starts a new (guide, key, first row); rows[r] = its row count */
+__global__ void k_big_flags(const uint4 *recs, const uint32_t *idx, const unsigned long long *w1s, uint64_t T,
+                            uint32_t *keep, unsigned long long *rows) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= T) return;
+  const uint4 c = recs[idx[r]];
   bool f = true;
-  if (r > 0) {
-    const gs_hrec &p = srt[r - 1], &c = srt[r];
-    f = !(p.g == c.g && p.rec.x == c.rec.x && p.rec.y == c.rec.y && p.rec.z == c.rec.z);
+  if (r > 0 && (w1s[r - 1] >> 32) == (w1s[r] >> 32)) {
+    const uint4 p = recs[idx[r - 1]];
+    f = !(p.x == c.x && p.y == c.y && p.z == c.z);
   }
-  flag[r] = f ? 1u : 0u;
+  keep[r] = f ? 1u : 0u;
+  rows[r] = f ? (unsigned long long)(c.w - c.z + 1u) : 0ull;
 }
-/* compact unique records: uq[pos] = {key, sp, cnt}, cnt64[pos] = rows, per-guide totals */
-__global__ void k_huge_compact(const gs_hrec *srt, const uint32_t *flag, const uint32_t *pos, uint64_t T,
-                               uint4 *uq, uint32_t *uq_g, unsigned long long *cnt64, uint32_t *nmatch,
-                               unsigned long long *nhits64) {
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= T || !flag[r]) return;
-  const gs_hrec h = srt[r];
-  const uint32_t c = h.rec.w - h.rec.z + 1u;
-  const uint32_t p = pos[r];
-  uq[p] = make_uint4(h.rec.x, h.rec.y, h.rec.z, c);
-  uq_g[p] = h.g;
-  cnt64[p] = c;
-  atomicAdd(&nmatch[h.g], 1u);
-  atomicAdd(&nhits64[h.g], (unsigned long long)c);
+/* per guide of the set: unique matches and hits from the two scans (guide g owns the sorted
+ * positions [prefix[2g], prefix[2g+2]): the compact array is in guide order and the sort keeps it) */
+__global__ void k_big_totals(const unsigned long long *prefix, const uint32_t *keep_scan,
+                             const unsigned long long *row_scan, uint32_t n_set, uint32_t *nmatch,
+                             uint32_t *nhits, uint32_t *err) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_set) return;
+  const unsigned long long b = prefix[2 * g], e = prefix[2 * g + 2];
+  nmatch[g] = keep_scan[e] - keep_scan[b];
+  const unsigned long long h = row_scan[e] - row_scan[b];
+  if (h >> 32) atomicOr(err, 1u); /* more than 2^32 hits for one guide */
+  nhits[g] = (uint32_t)h;
 }
-/* one wavefront per unique record: write its hits at the guide's CSR offset */
-struct gs_hlocate_args {
+struct gs_blocate2_args {
   gs_strand_dev sd[2];
-  const uint4 *uq;
-  const uint32_t *uq_g;
-  const unsigned long long *hit_scan; /* exclusive scan of cnt over all unique records */
-  const unsigned long long *guide_first; /* hit_scan value at each guide's first record */
-  const uint32_t *list;                  /* redo list position -> guide index */
+  const uint4 *recs;
+  const uint32_t *idx;
+  const unsigned long long *w1s;
+  const uint32_t *keep;
+  const unsigned long long *row_scan;
+  const unsigned long long *prefix;
+  const uint32_t *gmap; /* set position -> guide of the batch (nullptr: identity) */
   const uint64_t *offsets;
   gs_hit *hits;
-  uint64_t genome_length;
-  uint32_t n_uq, v_rem;
+  uint64_t genome_length, T;
+  uint32_t v_rem;
 };
-__global__ __launch_bounds__(WAVE) void k_huge_locate(gs_hlocate_args a) {
-  const uint32_t r = blockIdx.x;
-  if (r >= a.n_uq) return;
-  const uint4 m = a.uq[r];
-  const uint32_t g = a.uq_g[r];
+__global__ void k_big_locate(gs_blocate2_args a) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.T || !a.keep[r]) return;
+  const uint4 m = a.recs[a.idx[r]];
+  const uint32_t g = (uint32_t)(a.w1s[r] >> 32);
   const uint64_t key = ((uint64_t)m.y << 32) | m.x;
   const uint32_t strand = (uint32_t)(key >> 60) & 1u;
-  gs_hit *out = a.hits + a.offsets[a.list[g]] + (a.hit_scan[r] - a.guide_first[g]);
-  for (uint32_t h = lane_id(); h < m.w; h += WAVE) {
+  gs_hit *out = a.hits + a.offsets[a.gmap ? a.gmap[g] : g] + (a.row_scan[r] - a.row_scan[a.prefix[2 * g]]);
+  const uint32_t cnt = m.w - m.z + 1u;
+  for (uint32_t h = 0; h < cnt; ++h) {
     const uint64_t sa = (uint64_t)a.sd[strand].sa[m.z + h] - ((key & 1ull) ? a.v_rem : 0u);
     gs_hit o;
     o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
@@ -1376,16 +1498,86 @@ __global__ __launch_bounds__(WAVE) void k_huge_locate(gs_hlocate_args a) {
     out[h] = o;
   }
 }
+/* sources of the set items: the main slot array, or - for guides on the redo list - the exact-size array */
+__global__ void k_big_sources(const uint32_t *counts_main, const uint32_t *redo_pos, const uint64_t *slot_off2,
+                              const uint32_t *counts2, uint32_t n_items, uint32_t cap, gs_big_src *src,
+                              unsigned long long *cnt64) {
+  const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+  if (item >= n_items) return;
+  gs_big_src s;
+  uint32_t c;
+  /* no main array: the set IS the redo list, set guide j = redo position j */
+  const uint32_t rp = counts_main ? (redo_pos ? redo_pos[item >> 1] : 0xFFFFFFFFu) : (item >> 1);
+  if (rp != 0xFFFFFFFFu) {
+    const uint32_t it2 = 2u * rp + (item & 1u);
+    s.off = slot_off2[it2];
+    s.alt = 1u;
+    c = counts2[it2];
+  } else {
+    s.off = (uint64_t)item * cap;
+    s.alt = 0u;
+    c = counts_main[item];
+  }
+  src[item] = s;
+  cnt64[item] = c;
+}
+__global__ void k_fill_u32(uint32_t *p, uint32_t v, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+__global__ void k_mark_redo(const uint32_t *list, uint32_t n_o, uint32_t *redo_pos) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_o) redo_pos[list[i]] = i;
+}
+/* sum and maximum of the per-item match counts (slot sizing of the next batch) */
+__global__ void k_count_stats(const uint32_t *counts, uint32_t n_items, unsigned long long *out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = i < n_items ? counts[i] : 0;
+  unsigned long long mx = v;
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_xor(v, o);
+    const unsigned long long x = __shfl_xor(mx, o);
+    mx = x > mx ? x : mx;
+  }
+  if (lane_id() == 0) {
+    if (v) atomicAdd(&out[0], v);
+    atomicMax(&out[1], mx);
+  }
+}
 
 /* ---- host side of the pipeline ---------------------------------------------- */
-static uint32_t default_cap(uint32_t m, uint64_t n_rows) {
-  /* expected matches per (guide, strand) on a repeat-free genome is ~ n_rows/4^(L) * sum C(L,k)3^k;
-   * start small and let the overflow retry grow it */
-  (void)n_rows;
+/* slots per (guide, strand) of the first pass.  Up to three mismatches: 64 and the overflow redo
+ * takes the tail.  Beyond: from the mean count the previous batch at this budget showed on this
+ * index (Poisson-like on a repeat-free genome: mean + 8 sigma), else from the expected count of a
+ * uniform genome: sites x sum_k C(L,k) 3^k / 4^L x PAM share.  Whatever does not fit is redone
+ * with exact sizes, so a wrong guess costs time, not hits. */
+static uint32_t choose_cap(const gs_index *ix, uint32_t m, uint32_t L, uint32_t P, uint32_t n_alt, uint32_t flags) {
   if (m <= 3) return 64;
-  if (m == 4) return 256;
-  if (m == 5) return 1024;
-  return 2048;
+  double mean = -1, seen_max = 0;
+  const uint64_t key = ((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START);
+  if (m < 8 && ix->seen_mean[m] >= 0 && ix->seen_key[m] == key) {
+    mean = ix->seen_mean[m];
+    seen_max = ix->seen_max[m];
+  }
+  if (mean < 0) {
+    double v = 0, c = 1;
+    for (uint32_t k = 0; k <= m && k <= L; k++) {
+      v += c;
+      c = c * 3.0 * (L - k) / (k + 1);
+    }
+    for (uint32_t i = 0; i < L; i++) v /= 4.0;
+    mean = v * (double)ix->strand[0].n * (n_alt + 1) / (P >= 2 ? 16.0 : P == 1 ? 4.0 : 1.0) * 1.3;
+  }
+  /* counts spread wider than Poisson (base composition of the guide): half again the mean on
+   * top, and the largest count the last batch showed unless a repeat-derived guide made it huge */
+  double want = 1.5 * mean + 8.0 * sqrt(mean > 1 ? mean : 1) + 64;
+  if (seen_max > want) want = seen_max * 1.05 < 3.0 * mean + 64 ? seen_max * 1.05 : 3.0 * mean + 64;
+  if (const char *e = getenv("GS_SLOT_CAP")) want = atof(e);
+  uint32_t cap = 64;
+  while (cap < want && cap < 256) cap <<= 1;
+  if (want > 256) cap = (uint32_t)((want + 255) / 256) * 256;
+  if (cap > (1u << 20)) cap = 1u << 20;
+  return cap;
 }
 
 int gs_num_cus(int device) {
@@ -1455,7 +1647,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     if (!ix->ev[i]) GS_HIP(hipEventCreate(&ix->ev[i]));
 
   const uint32_t n32 = (uint32_t)n;
-  uint32_t cap = default_cap(mismatches, ix->strand[0].n);
+  uint32_t cap = choose_cap(ix, mismatches, L, P, P ? n_alt : 0, flags);
   gs_status rc;
   /* misc: [0..15] uint64 stats ; then work counter / invalid counter */
   if ((rc = gs_reserve(ix->w_misc, 256)) != GS_OK) return rc;
@@ -1798,7 +1990,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     return GS_OK;
   };
   auto run_order = [&](uint4 *slots, const uint32_t *counts, uint32_t *nmatch, uint32_t *nhits,
-                       uint32_t ng, uint32_t cap_) -> gs_status {
+                       uint32_t ng, uint32_t cap_, uint32_t max_item) -> gs_status {
     gs_order_args oa;
     oa.slots = slots;
     oa.counts = counts;
@@ -1807,13 +1999,24 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     oa.stats = d_stats;
     oa.n = ng;
     oa.cap = cap_;
-    /* four waves per workgroup while their sort buffers fit (4 KiB per wave at cap 64); eight
-     * workgroups per CU resident, twice that many launched so the tail balances */
-    const uint32_t ow = cap_ <= 128 ? ORDER_WAVES : 1u;
-    const size_t lds = sizeof(uint4) * 4 * (size_t)cap_ * ow;
-    if (lds > 64 * 1024)
-      GS_HIP(hipFuncSetAttribute((const void *)k_order, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds));
+    if (cap_ > 128) {
+      /* LDS for the largest guide of this pass (2 x the largest item count, as a power of two) */
+      uint32_t nmax = 256;
+      while (nmax < 2u * max_item && nmax < 2u * cap_) nmax <<= 1;
+      const size_t lds = sizeof(uint4) * (size_t)nmax;
+      if (lds > 64 * 1024)
+        GS_HIP(hipFuncSetAttribute((const void *)k_order_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      uint32_t grid = ng;
+      const uint32_t gmax = (uint32_t)cus * (uint32_t)(lds > 80 * 1024 ? 1 : lds > 40 * 1024 ? 3 : 6);
+      if (grid > gmax) grid = gmax;
+      if (grid == 0) grid = 1;
+      hipLaunchKernelGGL(k_order_wg, dim3(grid), dim3(256), lds, st, oa, nmax);
+      return GS_OK;
+    }
+    /* four waves per workgroup (4 KiB per wave at cap 64); eight workgroups per CU resident, twice
+     * that many launched so the tail balances */
+    const uint32_t ow = ORDER_WAVES;
+    const size_t lds = sizeof(uint4) * (2 * (size_t)cap_ + ORDER_SMALL) * ow;
     uint32_t grid = (ng + ow - 1) / ow;
     const uint32_t gmax = (uint32_t)cus * 16u;
     if (grid > gmax) grid = gmax;
@@ -1839,106 +2042,168 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_locate, dim3(ng), dim3(WAVE), lds, st, la);
   };
 
-  /* guides whose match count exceeds what k_order can sort in LDS */
-  std::vector<uint64_t> h_slot_off;
-  uint32_t h_n_uq = 0;
-  auto huge_redo = [&](uint32_t n_o) -> gs_status {
-    std::vector<uint32_t> c2(2 * (size_t)n_o);
-    GS_HIP(hipMemcpy(c2.data(), ix->w_counts2.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost));
-    h_slot_off.assign(2 * (size_t)n_o + 1, 0);
-    for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + c2[i];
-    const uint64_t T = h_slot_off.back();
-    if (T >= (1ull << 31)) {
-      gs_set_error("more than 2^31 match records in one batch of repeat-derived guides");
+  /* ---- guides whose match count exceeds what k_order sorts in LDS: `n_set`
+   * guides whose items' records lie in the main slot array (stride cap) or, for guides on the redo
+   * list, in the exact-size array slots2/slot_off2.  Leaves nmatch/nhits per set guide and the
+   * sorted arrays k_big_locate reads once the CSR offsets exist. */
+  uint64_t big_T = 0;
+  bool big_used = false;
+  auto big_order = [&](uint32_t n_set, const uint32_t *counts_main, uint32_t cap_, const uint32_t *redo_pos,
+                       const uint64_t *slot_off2, const uint32_t *counts2, uint32_t *nmatch_out,
+                       uint32_t *nhits_out) -> gs_status {
+    gs_status r2;
+    const uint32_t n_it = 2 * n_set;
+    if ((r2 = gs_reserve(ix->w_b_src, sizeof(gs_big_src) * ((size_t)n_it + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_cnt, 8 * ((size_t)n_it + 2))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_prefix, 8 * ((size_t)n_it + 2))) != GS_OK) return r2;
+    hipLaunchKernelGGL(k_big_sources, dim3((n_it + 255) / 256), dim3(256), 0, st, counts_main, redo_pos, slot_off2,
+                       counts2, n_it, cap_, (gs_big_src *)ix->w_b_src.p, (unsigned long long *)ix->w_b_cnt.p);
+    GS_HIP(hipMemsetAsync((unsigned long long *)ix->w_b_cnt.p + n_it, 0, 8, st));
+    size_t tb = 0;
+    GS_HIP(rocprim::exclusive_scan(nullptr, tb, (unsigned long long *)ix->w_b_cnt.p,
+                                   (unsigned long long *)ix->w_b_prefix.p, 0ull, (size_t)n_it + 1,
+                                   rocprim::plus<unsigned long long>(), st));
+    if ((r2 = gs_reserve(ix->w_h_tmp, tb + 16)) != GS_OK) return r2;
+    size_t tbs = ix->w_h_tmp.cap;
+    GS_HIP(rocprim::exclusive_scan(ix->w_h_tmp.p, tbs, (unsigned long long *)ix->w_b_cnt.p,
+                                   (unsigned long long *)ix->w_b_prefix.p, 0ull, (size_t)n_it + 1,
+                                   rocprim::plus<unsigned long long>(), st));
+    unsigned long long T = 0;
+    GS_HIP(hipMemcpyAsync(&T, (unsigned long long *)ix->w_b_prefix.p + n_it, 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (T >= (1ull << 32) - 2) {
+      gs_set_error("more than 2^32 match records in one batch: use smaller batches at this mismatch budget");
       return GS_ERR_UNSUPPORTED;
     }
-    gs_status rc2;
-    if ((rc2 = gs_reserve(ix->w_slots2, sizeof(uint4) * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_off, 8 * h_slot_off.size())) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_a, sizeof(gs_hrec) * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_b, sizeof(gs_hrec) * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_flag, 4 * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_pos, 4 * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_uq, sizeof(uint4) * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_uqg, 4 * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_cnt, 8 * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_scan, 8 * (T + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_nh, 8 * ((size_t)n_o + 1))) != GS_OK) return rc2;
-    if ((rc2 = gs_reserve(ix->w_h_first, 8 * ((size_t)n_o + 1))) != GS_OK) return rc2;
+    big_T = T;
+    big_used = true;
+    if ((r2 = gs_reserve(ix->w_b_recs, 16 * (T + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_w0, 8 * (T + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_w0b, 8 * (T + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_w1, 8 * (T + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_idx, 4 * (T + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_idxb, 4 * (T + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_keep, 4 * (T + 2))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_keeps, 4 * (T + 2))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_rows, 8 * (T + 2))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_b_rowss, 8 * (T + 2))) != GS_OK) return r2;
+    uint4 *recs = (uint4 *)ix->w_b_recs.p;
+    unsigned long long *w0 = (unsigned long long *)ix->w_b_w0.p, *w0b = (unsigned long long *)ix->w_b_w0b.p,
+                       *w1 = (unsigned long long *)ix->w_b_w1.p;
+    uint32_t *idx = (uint32_t *)ix->w_b_idx.p, *idxb = (uint32_t *)ix->w_b_idxb.p;
+    if (T) {
+      hipLaunchKernelGGL(k_big_compact, dim3(n_it), dim3(256), 0, st, (const uint4 *)ix->w_slots.p,
+                         (const uint4 *)ix->w_slots2.p, (const gs_big_src *)ix->w_b_src.p,
+                         (const unsigned long long *)ix->w_b_prefix.p, n_it, recs, w0, w1, idx);
+      /* (key bits 31:8, first row): 56 bits; then, stable, (guide, key bits 63:32) */
+      uint32_t gbits = 1;
+      while ((1ull << gbits) < n_set) gbits++;
+      size_t s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+      GS_HIP(rocprim::radix_sort_pairs(nullptr, s1, w0, w0b, idx, idxb, (size_t)T, 0, 56, st));
+      GS_HIP(rocprim::radix_sort_pairs(nullptr, s2, w0b, w0, idxb, idx, (size_t)T, 0, 32 + gbits, st));
+      GS_HIP(rocprim::exclusive_scan(nullptr, s3, (uint32_t *)ix->w_b_keep.p, (uint32_t *)ix->w_b_keeps.p, 0u,
+                                     (size_t)T + 1, rocprim::plus<uint32_t>(), st));
+      GS_HIP(rocprim::exclusive_scan(nullptr, s4, (unsigned long long *)ix->w_b_rows.p,
+                                     (unsigned long long *)ix->w_b_rowss.p, 0ull, (size_t)T + 1,
+                                     rocprim::plus<unsigned long long>(), st));
+      size_t need = s1 > s2 ? s1 : s2;
+      if (s3 > need) need = s3;
+      if (s4 > need) need = s4;
+      if ((r2 = gs_reserve(ix->w_h_tmp, need + 16)) != GS_OK) return r2;
+      tbs = ix->w_h_tmp.cap;
+      GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, w0, w0b, idx, idxb, (size_t)T, 0, 56, st));
+      const unsigned gT = (unsigned)((T + 255) / 256);
+      hipLaunchKernelGGL(k_big_gather_w1, dim3(gT), dim3(256), 0, st, (const unsigned long long *)w1,
+                         (const uint32_t *)idxb, T, w0b); /* w0b now holds w1 in the first sort's order */
+      tbs = ix->w_h_tmp.cap;
+      GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, w0b, w0, idxb, idx, (size_t)T, 0, 32 + gbits, st));
+      /* w0 = sorted (guide, key high), idx = final order */
+      hipLaunchKernelGGL(k_big_flags, dim3(gT), dim3(256), 0, st, (const uint4 *)recs, (const uint32_t *)idx,
+                         (const unsigned long long *)w0, T, (uint32_t *)ix->w_b_keep.p,
+                         (unsigned long long *)ix->w_b_rows.p);
+    }
+    GS_HIP(hipMemsetAsync((uint32_t *)ix->w_b_keep.p + T, 0, 4, st));
+    GS_HIP(hipMemsetAsync((unsigned long long *)ix->w_b_rows.p + T, 0, 8, st));
+    {
+      size_t s3 = 0, s4 = 0;
+      GS_HIP(rocprim::exclusive_scan(nullptr, s3, (uint32_t *)ix->w_b_keep.p, (uint32_t *)ix->w_b_keeps.p, 0u,
+                                     (size_t)T + 1, rocprim::plus<uint32_t>(), st));
+      GS_HIP(rocprim::exclusive_scan(nullptr, s4, (unsigned long long *)ix->w_b_rows.p,
+                                     (unsigned long long *)ix->w_b_rowss.p, 0ull, (size_t)T + 1,
+                                     rocprim::plus<unsigned long long>(), st));
+      if ((r2 = gs_reserve(ix->w_h_tmp, (s3 > s4 ? s3 : s4) + 16)) != GS_OK) return r2;
+      tbs = ix->w_h_tmp.cap;
+      GS_HIP(rocprim::exclusive_scan(ix->w_h_tmp.p, tbs, (uint32_t *)ix->w_b_keep.p, (uint32_t *)ix->w_b_keeps.p,
+                                     0u, (size_t)T + 1, rocprim::plus<uint32_t>(), st));
+      tbs = ix->w_h_tmp.cap;
+      GS_HIP(rocprim::exclusive_scan(ix->w_h_tmp.p, tbs, (unsigned long long *)ix->w_b_rows.p,
+                                     (unsigned long long *)ix->w_b_rowss.p, 0ull, (size_t)T + 1,
+                                     rocprim::plus<unsigned long long>(), st));
+    }
+    uint32_t *d_err = d_work + 3;
+    hipLaunchKernelGGL(k_big_totals, dim3((n_set + 255) / 256), dim3(256), 0, st,
+                       (const unsigned long long *)ix->w_b_prefix.p, (const uint32_t *)ix->w_b_keeps.p,
+                       (const unsigned long long *)ix->w_b_rowss.p, n_set, nmatch_out, nhits_out, d_err);
+    uint32_t h_err = 0, h_uq = 0;
+    GS_HIP(hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipMemcpyAsync(&h_uq, (uint32_t *)ix->w_b_keeps.p + T, 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if (h_err) {
+      gs_set_error("more than 2^32 hits for one guide");
+      return GS_ERR_UNSUPPORTED;
+    }
+    /* matches counter: these guides were skipped by (or never went through) k_order */
+    unsigned long long cur = 0;
+    GS_HIP(hipMemcpy(&cur, d_stats + 2, 8, hipMemcpyDeviceToHost));
+    cur += h_uq;
+    GS_HIP(hipMemcpy(d_stats + 2, &cur, 8, hipMemcpyHostToDevice));
+    return GS_OK;
+  };
+  auto big_locate = [&](const uint32_t *gmap) {
+    if (!big_T) return;
+    gs_blocate2_args la;
+    la.sd[0] = ix->strand[0].d;
+    la.sd[1] = ix->strand[1].d;
+    la.recs = (const uint4 *)ix->w_b_recs.p;
+    la.idx = (const uint32_t *)ix->w_b_idx.p;
+    la.w1s = (const unsigned long long *)ix->w_b_w0.p;
+    la.keep = (const uint32_t *)ix->w_b_keep.p;
+    la.row_scan = (const unsigned long long *)ix->w_b_rowss.p;
+    la.prefix = (const unsigned long long *)ix->w_b_prefix.p;
+    la.gmap = gmap;
+    la.offsets = (const uint64_t *)ix->w_offsets.p;
+    la.hits = (gs_hit *)ix->w_hits.p;
+    la.genome_length = ix->genome_length;
+    la.T = big_T;
+    la.v_rem = v_rem;
+    hipLaunchKernelGGL(k_big_locate, dim3((unsigned)((big_T + 255) / 256)), dim3(256), 0, st, la);
+  };
+  /* exact-size second pass of the guides on the redo list (their counts2 are exact) */
+  auto redo_exact = [&](uint32_t n_o) -> gs_status {
+    std::vector<uint32_t> c2(2 * (size_t)n_o);
+    GS_HIP(hipMemcpy(c2.data(), ix->w_counts2.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> h_slot_off(2 * (size_t)n_o + 1, 0);
+    for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + c2[i];
+    const uint64_t T = h_slot_off.back();
+    gs_status r2;
+    if ((r2 = gs_reserve(ix->w_slots2, sizeof(uint4) * (T + 1))) != GS_OK) return r2;
+    if ((r2 = gs_reserve(ix->w_h_off, 8 * h_slot_off.size())) != GS_OK) return r2;
     GS_HIP(hipMemcpyAsync(ix->w_h_off.p, h_slot_off.data(), 8 * h_slot_off.size(), hipMemcpyHostToDevice, st));
+    GS_HIP(hipStreamSynchronize(st)); /* h_slot_off is a local */
     unsigned long long h2[2] = {0, 0};
-    if ((rc2 = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
-                          (uint32_t *)ix->w_counts2.p, 0, h2, (const uint64_t *)ix->w_h_off.p)) != GS_OK)
-      return rc2;
+    if ((r2 = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
+                         (uint32_t *)ix->w_counts2.p, 0, h2, (const uint64_t *)ix->w_h_off.p)) != GS_OK)
+      return r2;
     if (h2[1] != 0) {
       gs_set_error("internal: exact-size redo overflowed");
       return GS_ERR_DEVICE;
     }
-    gs_hrec *ha = (gs_hrec *)ix->w_h_a.p, *hb = (gs_hrec *)ix->w_h_b.p;
-    hipLaunchKernelGGL(k_huge_tag, dim3(2 * n_o), dim3(256), 0, st, (const uint4 *)ix->w_slots2.p,
-                       (const uint64_t *)ix->w_h_off.p, 2 * n_o, ha);
-    size_t tb = 0;
-    GS_HIP(rocprim::merge_sort(nullptr, tb, ha, hb, (size_t)T, gs_hrec_less(), st));
-    size_t tb2 = 0, tb3 = 0;
-    GS_HIP(rocprim::exclusive_scan(nullptr, tb2, (uint32_t *)ix->w_h_flag.p, (uint32_t *)ix->w_h_pos.p, 0u,
-                                   (size_t)T, rocprim::plus<uint32_t>(), st));
-    GS_HIP(rocprim::exclusive_scan(nullptr, tb3, (unsigned long long *)ix->w_h_cnt.p,
-                                   (unsigned long long *)ix->w_h_scan.p, 0ull, (size_t)T,
-                                   rocprim::plus<unsigned long long>(), st));
-    if (tb2 > tb) tb = tb2;
-    if (tb3 > tb) tb = tb3;
-    if ((rc2 = gs_reserve(ix->w_h_tmp, tb + 16)) != GS_OK) return rc2;
-    size_t tbs = tb;
-    GS_HIP(rocprim::merge_sort(ix->w_h_tmp.p, tbs, ha, hb, (size_t)T, gs_hrec_less(), st));
-    const unsigned gT = (unsigned)((T + 255) / 256);
-    hipLaunchKernelGGL(k_huge_flags, dim3(gT), dim3(256), 0, st, (const gs_hrec *)hb, T,
-                       (uint32_t *)ix->w_h_flag.p);
-    tbs = tb;
-    GS_HIP(rocprim::exclusive_scan(ix->w_h_tmp.p, tbs, (uint32_t *)ix->w_h_flag.p, (uint32_t *)ix->w_h_pos.p,
-                                   0u, (size_t)T, rocprim::plus<uint32_t>(), st));
-    GS_HIP(hipMemsetAsync(ix->w_nmatch2.p, 0, 4 * (size_t)n_o, st));
-    GS_HIP(hipMemsetAsync(ix->w_h_nh.p, 0, 8 * (size_t)n_o, st));
-    GS_HIP(hipMemsetAsync(ix->w_h_cnt.p, 0, 8 * (T + 1), st));
-    hipLaunchKernelGGL(k_huge_compact, dim3(gT), dim3(256), 0, st, (const gs_hrec *)hb,
-                       (const uint32_t *)ix->w_h_flag.p, (const uint32_t *)ix->w_h_pos.p, T,
-                       (uint4 *)ix->w_h_uq.p, (uint32_t *)ix->w_h_uqg.p, (unsigned long long *)ix->w_h_cnt.p,
-                       (uint32_t *)ix->w_nmatch2.p, (unsigned long long *)ix->w_h_nh.p);
-    std::vector<uint32_t> nm(n_o);
-    std::vector<unsigned long long> nh(n_o);
-    GS_HIP(hipMemcpyAsync(nm.data(), ix->w_nmatch2.p, 4 * (size_t)n_o, hipMemcpyDeviceToHost, st));
-    GS_HIP(hipMemcpyAsync(nh.data(), ix->w_h_nh.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost, st));
-    GS_HIP(hipStreamSynchronize(st));
-    uint64_t nuq = 0;
-    std::vector<unsigned long long> first(n_o + 1, 0);
-    std::vector<uint32_t> nh32(n_o);
-    for (uint32_t i = 0; i < n_o; i++) {
-      if (nh[i] >= (1ull << 32)) {
-        gs_set_error("more than 2^32 hits for one guide");
-        return GS_ERR_UNSUPPORTED;
-      }
-      nh32[i] = (uint32_t)nh[i];
-      first[i + 1] = first[i] + nh[i]; /* unique records are grouped by guide in list order */
-      nuq += nm[i];
-    }
-    h_n_uq = (uint32_t)nuq;
-    tbs = tb;
-    GS_HIP(rocprim::exclusive_scan(ix->w_h_tmp.p, tbs, (unsigned long long *)ix->w_h_cnt.p,
-                                   (unsigned long long *)ix->w_h_scan.p, 0ull, (size_t)nuq + 1,
-                                   rocprim::plus<unsigned long long>(), st));
-    GS_HIP(hipMemcpyAsync(ix->w_h_first.p, first.data(), 8 * (size_t)n_o, hipMemcpyHostToDevice, st));
-    GS_HIP(hipMemcpyAsync(ix->w_nhits2.p, nh32.data(), 4 * (size_t)n_o, hipMemcpyHostToDevice, st));
-    unsigned long long tot_m = nuq;
-    (void)tot_m;
-    GS_HIP(hipStreamSynchronize(st));
-    /* matches counter: these guides were skipped by the main k_order */
-    unsigned long long cur = 0;
-    GS_HIP(hipMemcpy(&cur, d_stats + 2, 8, hipMemcpyDeviceToHost));
-    cur += nuq;
-    GS_HIP(hipMemcpy(d_stats + 2, &cur, 8, hipMemcpyHostToDevice));
     return GS_OK;
   };
 
   /* ---- main pass ---- */
+  const uint32_t LDS_CAP_MAX = 4096; /* k_order: 2 * cap records of 16 bytes in LDS */
+  const bool big_batch = cap > LDS_CAP_MAX; /* every guide through the device-wide sort */
   if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
   unsigned long long h_stats[2] = {0, 0};
   if ((rc = run_search((const gs_guide_rec *)ix->w_grec.p, n32, (uint4 *)ix->w_slots.p,
@@ -1946,12 +2211,25 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     return rc;
   if (stats) stats->n_ext = h_stats[0];
   GS_HIP(hipMemsetAsync(d_stats + 2, 0, 8, st)); /* match counter */
-  if ((rc = run_order((uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_counts.p,
-                      (uint32_t *)ix->w_nmatch.p, (uint32_t *)ix->w_nhits.p, n32, cap)) != GS_OK)
-    return rc;
+  unsigned long long h_cstat[2] = {0, 0}; /* sum and maximum of this batch's exact per-item counts */
+  {
+    GS_HIP(hipMemsetAsync(d_stats + 14, 0, 16, st));
+    hipLaunchKernelGGL(k_count_stats, dim3((2 * n32 + 255) / 256), dim3(256), 0, st, (const uint32_t *)ix->w_counts.p,
+                       2 * n32, d_stats + 14);
+    if (cap > 128) { /* sizes k_order_wg's LDS; the small-slot path does not wait for it */
+      GS_HIP(hipMemcpyAsync(h_cstat, d_stats + 14, 16, hipMemcpyDeviceToHost, st));
+      GS_HIP(hipStreamSynchronize(st));
+    }
+  }
+  if (!big_batch)
+    if ((rc = run_order((uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_counts.p,
+                        (uint32_t *)ix->w_nmatch.p, (uint32_t *)ix->w_nhits.p, n32, cap,
+                        (uint32_t)(h_cstat[1] < cap ? h_cstat[1] : cap))) != GS_OK)
+      return rc;
 
   /* ---- redo only the guides whose matches did not fit their slots ---- */
   uint32_t n_o = 0, cap2 = cap;
+  bool redo_big = false;
   if (h_stats[1] != 0) {
     if ((rc = gs_reserve(ix->w_ovf_list, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
     GS_HIP(hipMemsetAsync(d_nlist, 0, 4, st));
@@ -1966,40 +2244,64 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     hipLaunchKernelGGL(k_gather_guides, dim3((n_o + 255) / 256), dim3(256), 0, st,
                        (const gs_guide_rec *)ix->w_grec.p, (const uint32_t *)ix->w_ovf_list.p, n_o,
                        (gs_guide_rec *)ix->w_grec2.p);
-    bool huge = false, counted = false;
-    for (;;) {
-      cap2 = cap2 >= 1024 ? cap2 * 2 : cap2 * 4;
-      if (cap2 > 2048) {
-        huge = true; /* counts2 of the last pass are exact: size the slots from them */
-        break;
-      }
-      counted = true;
+    /* the main pass counted every item's matches exactly, also beyond its slots */
+    hipLaunchKernelGGL(k_gather_counts, dim3((n_o + 255) / 256), dim3(256), 0, st,
+                       (const uint32_t *)ix->w_counts.p, (const uint32_t *)ix->w_ovf_list.p, n_o,
+                       (uint32_t *)ix->w_counts2.p);
+    uint32_t need_cap = 0;
+    {
+      std::vector<uint32_t> c2(2 * (size_t)n_o);
+      GS_HIP(hipMemcpyAsync(c2.data(), ix->w_counts2.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost, st));
+      GS_HIP(hipStreamSynchronize(st));
+      for (uint32_t c : c2) need_cap = c > need_cap ? c : need_cap;
+    }
+    if (!big_batch && need_cap <= LDS_CAP_MAX) {
+      /* one more pass with slots every redo guide fits, ordered in LDS */
+      cap2 = 128;
+      while (cap2 < need_cap) cap2 <<= 1;
       if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (size_t)cap2 * 2 * n_o)) != GS_OK) return rc;
       unsigned long long h2[2] = {0, 0};
       if ((rc = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
                            (uint32_t *)ix->w_counts2.p, cap2, h2)) != GS_OK)
         return rc;
-      if (h2[1] == 0) break;
-    }
-    if (huge && !counted) {
-      /* the first capacity was already the largest an LDS sort takes (m >= 6): no pass has
-       * counted the redo list's matches yet - count them with zero-size slots */
-      if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4))) != GS_OK) return rc;
-      unsigned long long h2[2] = {0, 0};
-      if ((rc = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
-                           (uint32_t *)ix->w_counts2.p, 0, h2)) != GS_OK)
-        return rc;
-    }
-    if (!huge) {
+      if (h2[1] != 0) {
+        gs_set_error("internal: redo pass overflowed slots sized from exact counts");
+        return GS_ERR_DEVICE;
+      }
       if ((rc = run_order((uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_counts2.p,
-                          (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2)) != GS_OK)
+                          (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2, need_cap)) != GS_OK)
         return rc;
     } else {
-      if ((rc = huge_redo(n_o)) != GS_OK) return rc;
+      if ((rc = redo_exact(n_o)) != GS_OK) return rc;
+      redo_big = true;
+      if (!big_batch) {
+        /* the redo list alone goes through the device-wide sort */
+        if ((rc = big_order(n_o, nullptr, 0, nullptr, (const uint64_t *)ix->w_h_off.p,
+                            (const uint32_t *)ix->w_counts2.p, (uint32_t *)ix->w_nmatch2.p,
+                            (uint32_t *)ix->w_nhits2.p)) != GS_OK)
+          return rc;
+      }
     }
-    hipLaunchKernelGGL(k_patch_overflow, dim3((n_o + 255) / 256), dim3(256), 0, st,
-                       (const uint32_t *)ix->w_ovf_list.p, n_o, (const uint32_t *)ix->w_nhits2.p,
-                       (uint32_t *)ix->w_nhits.p);
+    if (!big_batch)
+      hipLaunchKernelGGL(k_patch_overflow, dim3((n_o + 255) / 256), dim3(256), 0, st,
+                         (const uint32_t *)ix->w_ovf_list.p, n_o, (const uint32_t *)ix->w_nhits2.p,
+                         (uint32_t *)ix->w_nhits.p);
+  }
+  if (big_batch) {
+    /* every guide: records from the main slots, or from the exact-size array for redo guides */
+    const uint32_t *redo_pos = nullptr;
+    if (n_o) {
+      if ((rc = gs_reserve(ix->w_b_redo_pos, 4 * ((size_t)n + 1))) != GS_OK) return rc;
+      hipLaunchKernelGGL(k_fill_u32, dim3((n32 + 255) / 256), dim3(256), 0, st, (uint32_t *)ix->w_b_redo_pos.p,
+                         0xFFFFFFFFu, n32);
+      hipLaunchKernelGGL(k_mark_redo, dim3((n_o + 255) / 256), dim3(256), 0, st, (const uint32_t *)ix->w_ovf_list.p,
+                         n_o, (uint32_t *)ix->w_b_redo_pos.p);
+      redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
+    }
+    if ((rc = big_order(n32, (const uint32_t *)ix->w_counts.p, cap, redo_pos, (const uint64_t *)ix->w_h_off.p,
+                        (const uint32_t *)ix->w_counts2.p, (uint32_t *)ix->w_nmatch.p,
+                        (uint32_t *)ix->w_nhits.p)) != GS_OK)
+      return rc;
   }
 
   hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_BLOCK), 0, st,
@@ -2013,34 +2315,29 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   GS_HIP(hipMemcpyAsync(&total, (uint64_t *)ix->w_offsets.p + n, 8, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   if ((rc = gs_reserve(ix->w_hits, sizeof(gs_hit) * (total + 1))) != GS_OK) return rc;
-  run_locate((const uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_nmatch.p, nullptr, n32, cap);
-  if (n_o && !h_n_uq)
-    run_locate((const uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_nmatch2.p,
-               (const uint32_t *)ix->w_ovf_list.p, n_o, cap2);
-  if (n_o && h_n_uq) {
-    gs_hlocate_args ha;
-    ha.sd[0] = ix->strand[0].d;
-    ha.sd[1] = ix->strand[1].d;
-    ha.uq = (const uint4 *)ix->w_h_uq.p;
-    ha.uq_g = (const uint32_t *)ix->w_h_uqg.p;
-    ha.hit_scan = (const unsigned long long *)ix->w_h_scan.p;
-    ha.guide_first = (const unsigned long long *)ix->w_h_first.p;
-    ha.list = (const uint32_t *)ix->w_ovf_list.p;
-    ha.offsets = (const uint64_t *)ix->w_offsets.p;
-    ha.hits = (gs_hit *)ix->w_hits.p;
-    ha.genome_length = ix->genome_length;
-    ha.n_uq = h_n_uq;
-    ha.v_rem = v_rem;
-    hipLaunchKernelGGL(k_huge_locate, dim3(h_n_uq), dim3(WAVE), 0, st, ha);
+  if (big_batch) {
+    big_locate(nullptr);
+  } else {
+    run_locate((const uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_nmatch.p, nullptr, n32, cap);
+    if (n_o && !redo_big)
+      run_locate((const uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_nmatch2.p,
+                 (const uint32_t *)ix->w_ovf_list.p, n_o, cap2);
+    if (n_o && redo_big) big_locate((const uint32_t *)ix->w_ovf_list.p);
   }
   GS_HIP(hipEventRecord(ix->ev[3], st));
   unsigned long long h_stats3[16] = {0};
   GS_HIP(hipMemcpyAsync(h_stats3, d_stats, sizeof(h_stats3), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   if (bidir && getenv("GS_DEBUG"))
-    fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu\n",
-            h_stats3[4], h_stats3[5]);
+    fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu; slots %u per item, "
+            "%u guides redone%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (device-wide ordering)" : "");
   memcpy(ix->last_counters, h_stats3, sizeof(h_stats3));
+  /* matches per item seen at this budget: sizes the slots of the next batch */
+  if (mismatches < 8 && n32) {
+    ix->seen_mean[mismatches] = (double)h_stats3[14] / (2.0 * n32);
+    ix->seen_max[mismatches] = (double)h_stats3[15];
+    ix->seen_key[mismatches] = ((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START);
+  }
   GS_HIP(hipGetLastError());
   if (d_offsets) *d_offsets = ix->w_offsets.p;
   if (d_hits) *d_hits = ix->w_hits.p;
