@@ -35,7 +35,19 @@ WORKLOADS = {
     "saccer3": ("SACCER3_LENGTHS", 1000, (0.31, 0.19, 0.19, 0.31)),
     "chr1": ("CHR1", 100_000, (0.29, 0.21, 0.21, 0.29)),
     "hg38": ("GRCH38_LENGTHS", 1_000_000, (0.29, 0.21, 0.21, 0.29)),
+    # the same sizes with 45 % of the bases overwritten by repeat families (synth.plant_repeats:
+    # ~1e6 SINE-like 300-mers at 10-15 %, ~1.6e5 LINE-like copies at 5 %, tandem arrays, 100-kb
+    # segmental duplications at 1 %, both strands); guides are sampled uniformly, so ~45 % of them
+    # lie inside repeats and have 10^3..10^5 hits: small batches
+    "chr1rep": ("CHR1", 20_000, (0.29, 0.21, 0.21, 0.29)),
+    "hg38rep": ("GRCH38_LENGTHS", 20_000, (0.29, 0.21, 0.21, 0.29)),
 }
+
+
+def make_workload_genome(synth, workload, lengths, probs, out=None):
+    if workload.endswith("rep"):
+        return synth.make_repeat_genome(lengths, seed=1, probs=probs, out=out)
+    return synth.make_genome(lengths, seed=1, probs=probs, out=out)
 
 
 def main():
@@ -216,7 +228,10 @@ def main():
                    "device_ms_total_per_step": ms_total / K, "index_build_s": t_index,
                    "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes,
                    "items_two_sided": req["items_two_sided"], "items_one_sided": req["items_one_sided"],
-                   "overflow_items_first_pass": req["overflow_items"]},
+                   "overflow_items_first_pass": req["overflow_items"], "guides_redone": req["guides_redone"],
+                   "slots_per_item": req["slots_per_item"], "matches_max_per_item": req["matches_max_per_item"],
+                   "ordered_device_wide": req["ordered_device_wide"],
+                   "redo_ordered_device_wide": req["redo_ordered_device_wide"]},
     }
 
     if rank == 0:
@@ -268,11 +283,11 @@ def shared_genome(synth, workload, lengths, probs, dist, local_rank):
         names, lengths = [f"chr{i + 1}" for i in range(len(lengths))], [int(x) for x in lengths]
         return text, names, lengths
     if dist is None or dist.get_world_size() == 1:
-        return synth.make_genome(lengths, seed=1, probs=probs)
+        return make_workload_genome(synth, workload, lengths, probs)
     path = genome_file(workload)
     if local_rank == 0:
         mm = np.lib.format.open_memmap(path + ".npy", mode="w+", dtype=np.uint8, shape=(total,))
-        synth.make_genome(lengths, seed=1, probs=probs, out=mm)
+        make_workload_genome(synth, workload, lengths, probs, out=mm)
         mm.flush()
         del mm
     dist.barrier()
@@ -304,7 +319,7 @@ def launch_ranks(args, extra_env=None, module="torch.distributed.run"):
         path = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp",
                             f"gs_bench_{args.workload}_{port}.u8")
         mm = np.memmap(path, dtype=np.uint8, mode="w+", shape=(int(sum(lengths)),))
-        synth.make_genome(lengths, seed=1, probs=probs, out=mm)
+        make_workload_genome(synth, args.workload, lengths, probs, out=mm)
         mm.flush()
         del mm
         env["GS_BENCH_TEXT"] = path

@@ -2331,6 +2331,9 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   if (bidir && getenv("GS_DEBUG"))
     fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu; slots %u per item, "
             "%u guides redone%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (device-wide ordering)" : "");
+  h_stats3[6] = n_o;
+  h_stats3[7] = (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u);
+  h_stats3[13] = cap;
   memcpy(ix->last_counters, h_stats3, sizeof(h_stats3));
   /* matches per item seen at this budget: sizes the slots of the next batch */
   if (mismatches < 8 && n32) {

@@ -79,6 +79,96 @@ def make_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), n_blocks=True, 
     return text, names, [int(x) for x in lengths]
 
 
+def _mutate(rng, block, div):
+    """substitute each base of uint8[n, w] independently with probability div (to one of the other three)"""
+    hit = rng.random(block.shape) < div
+    if hit.any():
+        code = np.searchsorted(_ACGT, block[hit])            # A,C,G,T -> 0..3 (sorted bytes)
+        block[hit] = _ACGT[(code + rng.integers(1, 4, size=code.shape[0])) & 3]
+    return block
+
+
+def plant_repeats(text, lengths, seed=1, fraction=0.45, chunk_bytes=1 << 28):
+    """Overwrite ~`fraction` of an i.i.d. genome with repeat families, both strands (a real assembly is
+    about half interspersed repeats; guides drawn from them have 10^4..10^5 near-copies):
+      SINE-like   : 300 bp unit, divergence 10-15 % from the unit per copy      (22 % of the repeat bases)
+      LINE-like   : 6 kb unit (copies 5'-truncated to 0.5-6 kb), divergence 5 %  (45 %)
+      tandem      : arrays of a 2-170 bp motif, 1-4 kb long, divergence 2 %       (8 %)
+      segmental   : duplications of 100 kb stretches of the genome itself at 1 %  (25 %)
+    At 3.09 Gbp and fraction 0.45 that is ~1.0e6 SINE-like and ~1.6e5 LINE-like copies.  Seeded;
+    copies may overlap (later ones win); N blocks are not written over."""
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    total = int(text.shape[0])
+    rep = fraction * total
+    ar = np.arange
+    keep_n = text == ord("N") if total < (1 << 28) else None   # small genomes: exact; large: N blocks re-applied by the caller
+
+    def place(unit, n_copies, div_lo, div_hi, min_len=None):
+        w = unit.shape[0]
+        per = max(1, chunk_bytes // w)
+        for c0 in range(0, n_copies, per):
+            n = min(per, n_copies - c0)
+            block = np.tile(unit, (n, 1))
+            div = rng.uniform(div_lo, div_hi, size=(n, 1))
+            block = _mutate(rng, block, div)
+            minus = rng.random(n) < 0.5
+            block[minus] = _COMP[block[minus][:, ::-1]]
+            starts = rng.integers(0, total - w, size=n)
+            if min_len is None:
+                text[starts[:, None] + ar(w)[None, :]] = block
+            else:   # truncated copies: keep the last `ln` bases of each
+                ln = rng.integers(min_len, w + 1, size=n)
+                cols = ar(w)[None, :]
+                m = cols >= (w - ln)[:, None]
+                idx = (starts[:, None] + cols)[m]
+                text[idx] = block[m]
+
+    sine = _ACGT[rng.integers(0, 4, size=300)]
+    place(sine, int(0.22 * rep / 300), 0.10, 0.15)
+    line = _ACGT[rng.integers(0, 4, size=6000)]
+    place(line, int(0.45 * rep / 3250), 0.05, 0.05, min_len=500)
+    n_tandem = int(0.08 * rep / 2500)
+    for _ in range(n_tandem):
+        motif = _ACGT[rng.integers(0, 4, size=int(rng.integers(2, 171)))]
+        ln = int(rng.integers(1000, 4001))
+        arr = np.tile(motif, ln // motif.shape[0] + 1)[:ln][None, :].copy()
+        arr = _mutate(rng, arr, 0.02)[0]
+        at = int(rng.integers(0, total - ln))
+        text[at:at + ln] = arr
+    n_seg = int(0.25 * rep / 100_000)
+    for _ in range(n_seg):
+        src = int(rng.integers(0, total - 100_000))
+        dup = _mutate(rng, text[src:src + 100_000][None, :].copy(), 0.01)[0]
+        ok = np.isin(dup, _ACGT)
+        dup[~ok] = _ACGT[rng.integers(0, 4, size=int((~ok).sum()))]   # a source stretch inside an N block
+        if rng.random() < 0.5:
+            dup = _COMP[dup[::-1]]
+        at = int(rng.integers(0, total - 100_000))
+        text[at:at + 100_000] = dup
+    if keep_n is not None:
+        text[keep_n] = ord("N")
+    return text
+
+
+def make_repeat_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), fraction=0.45, out=None):
+    """make_genome + plant_repeats, N blocks as make_genome lays them"""
+    text, names, lengths = make_genome(lengths, seed=seed, probs=probs, n_blocks=False, out=out)
+    if not text.flags.writeable:
+        text = text.copy()
+    plant_repeats(text, lengths, seed=seed, fraction=fraction)
+    off = 0
+    for ln in lengths:
+        if ln > 100_000:
+            tel = 10_000
+            text[off:off + tel] = ord("N")
+            text[off + ln - tel:off + ln] = ord("N")
+            cen = max(1000, int(ln * 0.012))
+            c0 = off + ln // 3
+            text[c0:c0 + cen] = ord("N")
+        off += ln
+    return text, names, lengths
+
+
 def sample_guides(text: np.ndarray, n: int, seed=7, L=20, pam=b"NGG", minus_fraction=0.5):
     """Sample on-target guides: + strand sites whose next P bases match `pam`
     (N = any of ACGT) and - strand sites (reverse complement), protospacer ACGT only.

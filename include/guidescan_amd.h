@@ -116,7 +116,10 @@ gs_status gs_sdsl_extract_text(const char *index_file, uint8_t **text, uint64_t 
 void gs_index_close(gs_index *ix);
 /* Work counters of the last gs_enumerate_device call on this handle: [0] extensions executed by the
  * Occ walk, [1] items whose matches overflowed their slots, [2] distinct matches, [4] items seeded
- * from both strands' tables, [5] items seeded one-sided although two-sided seeding was on; with
+ * from both strands' tables, [5] items seeded one-sided although two-sided seeding was on, [6] guides
+ * redone because their matches overflowed the first pass's slots, [7] bit 0: the whole batch was ordered
+ * device-wide, bit 1: the redone guides were, [13] slots per item of the first pass, [14] / [15] sum and
+ * maximum of the per-item match counts; with
  * GS_FLAG_COUNT_REQUESTS also the 64-byte lines requested by the search kernel: [8] prefix-table
  * lines, [9] 16-bit context lines, [10] 32-bit context words, [11] SA/ISA gathers of the search,
  * [12] Occ block lines.  (the bytes the roofline is priced on.) */
