@@ -35,7 +35,7 @@ class GsHit(C.Structure):
 
 
 HIT_DTYPE = np.dtype([("pos", "<i8"), ("key", "<u8")])
-HIT_EX_DTYPE = np.dtype([("pos", "<i8"), ("key_hi", "<u8"), ("key_lo", "<u8"), ("mismatches", "<u4"),
+HIT_EX_DTYPE = np.dtype([("pos", "<i8"), ("seq", "S32"), ("mismatches", "<u4"),
                          ("dna_bulges", "u1"), ("rna_bulges", "u1"), ("index", "u1"), ("seq_len", "u1")])
 
 
@@ -43,7 +43,8 @@ class GsResultView(C.Structure):
     _fields_ = [("n_guides", C.c_uint64), ("n_hits", C.c_uint64),
                 ("guide_offsets", C.POINTER(C.c_uint64)), ("hits", C.POINTER(GsHit)),
                 ("n_ext", C.c_uint64), ("n_matches", C.c_uint64),
-                ("ms_search", C.c_float), ("ms_total", C.c_float)]
+                ("ms_search", C.c_float), ("ms_total", C.c_float),
+                ("n_unsupported", C.c_uint64), ("guide_flags", C.POINTER(C.c_uint8))]
 
 
 class GsSaReport(C.Structure):
@@ -135,7 +136,12 @@ def lib():
     L.gs_result_ex_get.argtypes = [vp, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]
     L.gs_result_ex_free.argtypes = [vp]
     L.gs_decode_sequence_ex.restype = i32
-    L.gs_decode_sequence_ex.argtypes = [u64, u64, C.c_char_p]
+    L.gs_decode_sequence_ex.argtypes = [vp, C.c_char_p]
+    L.gs_enumerate_general.restype = i32
+    L.gs_enumerate_general.argtypes = [vp, vp, u64, u32, vp, u32, C.c_char_p, u32, u32, u32, u32, u32,
+                                       C.POINTER(vp)]
+    L.gs_index_last_guide_flags.restype = i32
+    L.gs_index_last_guide_flags.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.gs_format_guide_ex.restype = i32
     L.gs_format_guide_ex.argtypes = [C.POINTER(GsGenomeStructure), C.POINTER(GsKmer), vp, u64, u32, u32,
                                      C.c_int64, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -164,7 +170,8 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide", "gs_format_header", "gs_free", "gs_sdsl_extract_text",
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
-           "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters"]
+           "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
+           "gs_index_last_guide_flags"]
 
 
 def _check(rc):
@@ -272,10 +279,9 @@ def sdsl_extract_text(index_file) -> np.ndarray:
     return t
 
 
-def decode_sequence_ex(key_hi: int, key_lo: int) -> str:
-    buf = C.create_string_buffer(40)
-    _check(lib().gs_decode_sequence_ex(key_hi, key_lo, buf))
-    return buf.value.decode()
+def decode_sequence_ex(hit) -> str:
+    """match.sequence of one HIT_EX_DTYPE record"""
+    return bytes(hit["seq"])[:int(hit["seq_len"])].decode()
 
 
 def format_guide_ex(gs, gid, sequence, pam, sense_positive, hits, mismatches, sam=False, complete=True,
@@ -406,7 +412,9 @@ class GenomeIndex:
             else:
                 hits = np.empty(0, dtype=HIT_DTYPE)
             stats = dict(n_ext=int(v.n_ext), n_matches=int(v.n_matches), n_hits=int(v.n_hits),
-                         ms_search=float(v.ms_search), ms_total=float(v.ms_total))
+                         ms_search=float(v.ms_search), ms_total=float(v.ms_total),
+                         needs_general=(np.nonzero(np.ctypeslib.as_array(v.guide_flags, shape=(n,)) & 1)[0].tolist()
+                                        if v.n_unsupported and n else []))
         finally:
             lib().gs_result_free(r)
         return offsets, hits, stats
@@ -433,6 +441,11 @@ class GenomeIndex:
         _check(lib().gs_score_device(self._h, d_guides_ptr, n, L, P, flags, max_off_targets, C.byref(gs),
                                      d_offsets_ptr, d_hits_ptr, stream, d_cfd_ptr, d_spec_ptr))
 
+    def enumerate_general(self, seqs, pams, mismatches=3, rna_bulges=0, dna_bulges=0, alt_pams=(),
+                          start=False):
+        """the general path (any symbol, any number of PAMs, bulges) -> (offsets uint64[n+1], hits HIT_EX_DTYPE[])"""
+        return self.enumerate_bulges(seqs, pams, mismatches, rna_bulges, dna_bulges, alt_pams, start)
+
     def enumerate_bulges(self, seqs, pams, mismatches=3, rna_bulges=0, dna_bulges=0, alt_pams=(),
                          start=False):
         """bulge-aware search (index.hpp:250-375) -> (offsets uint64[n+1], hits HIT_EX_DTYPE[])"""
@@ -451,7 +464,7 @@ class GenomeIndex:
             _check(lib().gs_result_ex_get(r, C.byref(ng), C.byref(po), C.byref(ph)))
             offsets = np.frombuffer(C.string_at(po, 8 * (n + 1)), dtype=np.uint64).copy()
             nh = int(offsets[-1])
-            hits = (np.frombuffer(C.string_at(ph, 32 * nh), dtype=HIT_EX_DTYPE).copy() if nh
+            hits = (np.frombuffer(C.string_at(ph, 48 * nh), dtype=HIT_EX_DTYPE).copy() if nh
                     else np.empty(0, dtype=HIT_EX_DTYPE))
         finally:
             lib().gs_result_ex_free(r)

@@ -61,11 +61,20 @@ struct gs_strand_dev {
   const uint32_t *exc_row;
   const uint64_t *exc_sym;
   uint32_t n_exc;
+  /* every symbol outside A,C,G,T (the general path, gs_general.hip): maximal runs of equal such
+   * symbols in the BWT, grouped by symbol.  xr_seg[c] = {first run of symbol c, number of runs};
+   * xr_start[i] = first row of run i, xr_cum[i] = rows of the symbol in its earlier runs (one entry
+   * more per symbol: its total); C256[c] = csa.C[csa.char2comp[c]] for every byte present. */
+  const uint32_t *xr_start;
+  const uint32_t *xr_cum;
+  const uint2 *xr_seg;
+  const uint32_t *C256;
 };
 
 struct gs_strand {
   gs_strand_dev d{};
-  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ctx16 = nullptr, *ptab_rot = nullptr, *isa = nullptr, *exc_row = nullptr, *exc_sym = nullptr;
+  void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ctx16 = nullptr, *ptab_rot = nullptr, *isa = nullptr, *exc_row = nullptr, *exc_sym = nullptr, *xr_start = nullptr, *xr_cum = nullptr, *xr_seg = nullptr, *C256 = nullptr;
+  bool has_sym[256] = {false}; /* bytes present in this strand's text */
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;
@@ -91,7 +100,7 @@ struct gs_index {
   gs_strand strand[2];
   /* per-handle workspace, grown on demand, reused across calls */
   gs_buffer w_guides, w_slots, w_counts, w_nmatch, w_nhits, w_offsets, w_hits, w_misc, w_blocksums,
-      w_grec, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_tmp,
+      w_grec, w_flags, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_tmp,
       /* device-wide ordering of guides with more matches than an LDS sort holds (gs_search.hip) */
       w_b_src, w_b_cnt, w_b_prefix, w_b_recs, w_b_w0, w_b_w0b, w_b_w1, w_b_idx, w_b_idxb, w_b_keep, w_b_keeps,
       w_b_rows, w_b_rowss, w_b_redo_pos,
@@ -99,6 +108,7 @@ struct gs_index {
   /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
   double seen_mean[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
   double seen_max[8] = {0};
+  uint64_t last_unsupported = 0; /* guides of the last batch flagged GS_GUIDE_NEEDS_GENERAL (w_flags) */
   uint64_t seen_key[8] = {0};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   /* prefix-table seeding plan: position masks of every mismatch combination over the first

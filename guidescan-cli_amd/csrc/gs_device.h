@@ -74,6 +74,27 @@ __device__ __forceinline__ uint32_t occ_n(const gs_strand_dev &sd, uint32_t i) {
   return sd.run_cum[r] + (d < len ? d : len);
 }
 
+/* number of BWT rows < i holding symbol c, c outside A,C,G,T (general path: a literal query or PAM
+ * symbol, index.hpp:139-149, 218-228), from the per-symbol run lists */
+__device__ __forceinline__ uint32_t occ_sym(const gs_strand_dev &sd, uint32_t c, uint32_t i) {
+  const uint2 seg = sd.xr_seg[c & 255u];
+  if (!seg.y) return 0;
+  const uint32_t *st = sd.xr_start + seg.x, *cu = sd.xr_cum + seg.x;
+  uint32_t lo = 0, hi = seg.y; /* last run with start < i */
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (st[mid] < i)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo == 0) return 0;
+  const uint32_t r = lo - 1;
+  const uint32_t len = cu[r + 1] - cu[r];
+  const uint32_t d = i - st[r];
+  return cu[r] + (d < len ? d : len);
+}
+
 /* 16 bytes from a 2-byte aligned address (global memory takes unaligned dwordx4 loads) */
 typedef uint32_t gs_u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
 __device__ __forceinline__ uint4 load16_a2(const uint16_t *p) {
@@ -116,10 +137,13 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
 struct gs_prep_args {
   const uint8_t *guides;     /* n*L */
   const uint8_t *guide_pams; /* n*P */
-  uint8_t alt[4][8];         /* alt PAM patterns (ASCII) */
-  gs_guide_rec *out;
+  uint8_t alt[32][8];        /* alt PAM patterns (ASCII) */
+  gs_guide_rec *out;         /* records of this chunk of the PAM list */
   uint32_t *n_invalid;
+  uint8_t *flags;            /* per guide: GS_GUIDE_NEEDS_GENERAL (chunk 0 writes them) */
   uint32_t n, L, P, n_alt, start;
+  uint32_t chunk;            /* this launch packs patterns 4*chunk .. 4*chunk+3 of alt_pams ++ [k.pam] */
+  uint32_t force_invalid;    /* an alt PAM needs the general path: every guide does */
 };
 
 /* k_prepare (gs_search.hip): ASCII guides/PAMs -> packed records, process.hpp:51-63 */

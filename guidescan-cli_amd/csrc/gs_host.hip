@@ -30,6 +30,7 @@ extern "C" const char *gs_version(void) { return "guidescan-amd 0.1 (gfx950)"; }
 struct gs_result {
   std::vector<uint64_t> offsets;
   std::vector<gs_hit> hits;
+  std::vector<uint8_t> flags;
   gs_result_view view{};
 };
 
@@ -63,6 +64,13 @@ extern "C" gs_status gs_enumerate(gs_index *ix, const char *guides, uint64_t n, 
   r->view.n_guides = n;
   r->view.guide_offsets = r->offsets.data();
   r->view.hits = r->hits.data();
+  r->view.n_unsupported = ix->last_unsupported;
+  r->view.guide_flags = nullptr;
+  if (ix->last_unsupported) {
+    r->flags.resize(n);
+    GS_HIP(hipMemcpy(r->flags.data(), ix->w_flags.p, n, hipMemcpyDeviceToHost));
+    r->view.guide_flags = r->flags.data();
+  }
   *out = r;
   return GS_OK;
 }

@@ -88,24 +88,23 @@ __global__ void k_histogram(const uint8_t *text, uint64_t n, unsigned long long 
   for (int i = threadIdx.x; i < 256; i += blockDim.x)
     if (s[i]) atomicAdd(&hist[i], (unsigned long long)s[i]);
 }
-/* boundaries of maximal runs of 'N' in the BWT: starts and (exclusive) ends */
-__global__ void k_n_runs(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t *starts,
+/* boundaries of maximal runs of equal symbols outside A,C,G,T (and not the sentinel) in the BWT:
+ * starts as row << 8 | symbol, (exclusive) ends as rows */
+__global__ void k_x_runs(const uint8_t *text, const uint32_t *sa, uint64_t n, unsigned long long *starts,
                          uint32_t *ends, uint32_t *counters, uint32_t cap) {
   const uint64_t row = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= n) return;
-  const bool cur = bwt_at(text, sa, n, row) == 'N';
-  const bool prev = row > 0 && bwt_at(text, sa, n, row - 1) == 'N';
-  if (cur && !prev) {
+  const uint8_t cur = bwt_at(text, sa, n, row);
+  if (cur == 0 || sym_class(cur) < 4) return;
+  const bool first = row == 0 || bwt_at(text, sa, n, row - 1) != cur;
+  const bool last = row == n - 1 || bwt_at(text, sa, n, row + 1) != cur;
+  if (first) {
     const uint32_t k = atomicAdd(&counters[0], 1u);
-    if (k < cap) starts[k] = (uint32_t)row;
+    if (k < cap) starts[k] = ((unsigned long long)row << 8) | cur;
   }
-  if (!cur && prev) {
+  if (last) {
     const uint32_t k = atomicAdd(&counters[1], 1u);
-    if (k < cap) ends[k] = (uint32_t)row;
-  }
-  if (cur && row == n - 1) {
-    const uint32_t k = atomicAdd(&counters[1], 1u);
-    if (k < cap) ends[k] = (uint32_t)n;
+    if (k < cap) ends[k] = (uint32_t)(row + 1);
   }
 }
 __global__ void k_revcomp(const uint8_t *in, uint8_t *out, uint64_t len) {
@@ -140,6 +139,10 @@ void gs_strand_free(gs_strand *s) {
   if (s->isa) hipFree(s->isa);
   if (s->exc_row) hipFree(s->exc_row);
   if (s->exc_sym) hipFree(s->exc_sym);
+  if (s->xr_start) hipFree(s->xr_start);
+  if (s->xr_cum) hipFree(s->xr_cum);
+  if (s->xr_seg) hipFree(s->xr_seg);
+  if (s->C256) hipFree(s->C256);
   *s = gs_strand();
 }
 
@@ -195,25 +198,27 @@ gs_status gs_strand_from_device(const uint8_t *d_text, uint32_t *d_sa_owned, uin
   const char bases[5] = {'A', 'C', 'G', 'T', 'N'};
   for (int k = 0; k < 5; k++) out->C_acgtn[k] = hist[(uint8_t)bases[k]] ? Cc[(uint8_t)bases[k]] : 0;
 
-  /* runs of N in the BWT */
-  uint32_t *d_cnt = nullptr, *d_starts = nullptr, *d_ends = nullptr;
+  /* runs of the symbols outside A,C,G,T in the BWT */
+  uint32_t *d_cnt = nullptr, *d_ends = nullptr;
+  unsigned long long *d_starts = nullptr;
   uint32_t cap = 1u << 20;
-  std::vector<uint32_t> starts, ends;
+  std::vector<unsigned long long> xstarts;
+  std::vector<uint32_t> xends;
   for (;;) {
     GS_HIP(hipMalloc(&d_cnt, 8));
-    GS_HIP(hipMalloc(&d_starts, 4ull * cap));
+    GS_HIP(hipMalloc(&d_starts, 8ull * cap));
     GS_HIP(hipMalloc(&d_ends, 4ull * cap));
     GS_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
-    hipLaunchKernelGGL(k_n_runs, dim3(nblk(n, 256)), dim3(256), 0, st, d_text, d_sa_owned, n, d_starts,
+    hipLaunchKernelGGL(k_x_runs, dim3(nblk(n, 256)), dim3(256), 0, st, d_text, d_sa_owned, n, d_starts,
                        d_ends, d_cnt, cap);
     uint32_t hc[2];
     GS_HIP(hipMemcpyAsync(hc, d_cnt, 8, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     if (hc[0] <= cap && hc[1] <= cap) {
-      starts.resize(hc[0]);
-      ends.resize(hc[1]);
-      if (hc[0]) GS_HIP(hipMemcpy(starts.data(), d_starts, 4ull * hc[0], hipMemcpyDeviceToHost));
-      if (hc[1]) GS_HIP(hipMemcpy(ends.data(), d_ends, 4ull * hc[1], hipMemcpyDeviceToHost));
+      xstarts.resize(hc[0]);
+      xends.resize(hc[1]);
+      if (hc[0]) GS_HIP(hipMemcpy(xstarts.data(), d_starts, 8ull * hc[0], hipMemcpyDeviceToHost));
+      if (hc[1]) GS_HIP(hipMemcpy(xends.data(), d_ends, 4ull * hc[1], hipMemcpyDeviceToHost));
       hipFree(d_cnt);
       hipFree(d_starts);
       hipFree(d_ends);
@@ -224,14 +229,57 @@ gs_status gs_strand_from_device(const uint8_t *d_text, uint32_t *d_sa_owned, uin
     hipFree(d_starts);
     hipFree(d_ends);
   }
-  if (starts.size() != ends.size()) {
-    gs_set_error("internal: N run boundaries do not pair up");
+  if (xstarts.size() != xends.size()) {
+    gs_set_error("internal: run boundaries do not pair up");
     return GS_ERR_DEVICE;
   }
-  std::sort(starts.begin(), starts.end());
-  std::sort(ends.begin(), ends.end());
+  /* runs are disjoint: the i-th start and the i-th end, both in row order, belong together */
+  std::sort(xstarts.begin(), xstarts.end());
+  std::sort(xends.begin(), xends.end());
+  std::vector<uint32_t> starts, ends; /* the runs of 'N' (the fast path's literal-N rule) */
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> by_sym(256);
+  for (size_t r = 0; r < xstarts.size(); r++) {
+    const uint32_t row = (uint32_t)(xstarts[r] >> 8), sym = (uint32_t)(xstarts[r] & 255u);
+    by_sym[sym].push_back({row, xends[r]});
+    if (sym == 'N') {
+      starts.push_back(row);
+      ends.push_back(xends[r]);
+    }
+  }
   std::vector<uint32_t> cum(starts.size() + 1, 0);
   for (size_t r = 0; r < starts.size(); r++) cum[r + 1] = cum[r] + (ends[r] - starts[r]);
+  {
+    std::vector<uint32_t> xs, xc, c256(256, 0);
+    std::vector<uint2> seg(256, make_uint2(0u, 0u));
+    for (int c = 0; c < 256; c++) {
+      c256[c] = hist[c] ? (uint32_t)Cc[c] : 0u; /* char2comp of an absent byte is 0 and C[0] = 0 */
+      out->has_sym[c] = hist[c] != 0;
+      if (by_sym[c].empty()) continue;
+      seg[c] = make_uint2((uint32_t)xs.size(), (uint32_t)by_sym[c].size());
+      uint32_t acc = 0;
+      for (auto &pr : by_sym[c]) {
+        xs.push_back(pr.first);
+        xc.push_back(acc);
+        acc += pr.second - pr.first;
+      }
+      xs.push_back(0xFFFFFFFFu); /* keeps xr_cum[i + 1] valid for the symbol's last run */
+      xc.push_back(acc);
+    }
+    GS_HIP(hipMalloc(&out->xr_seg, sizeof(uint2) * 256));
+    GS_HIP(hipMalloc(&out->C256, 4 * 256));
+    GS_HIP(hipMemcpy(out->xr_seg, seg.data(), sizeof(uint2) * 256, hipMemcpyHostToDevice));
+    GS_HIP(hipMemcpy(out->C256, c256.data(), 4 * 256, hipMemcpyHostToDevice));
+    if (!xs.empty()) {
+      GS_HIP(hipMalloc(&out->xr_start, 4 * xs.size()));
+      GS_HIP(hipMalloc(&out->xr_cum, 4 * xc.size()));
+      GS_HIP(hipMemcpy(out->xr_start, xs.data(), 4 * xs.size(), hipMemcpyHostToDevice));
+      GS_HIP(hipMemcpy(out->xr_cum, xc.data(), 4 * xc.size(), hipMemcpyHostToDevice));
+    }
+    out->d.xr_start = (const uint32_t *)out->xr_start;
+    out->d.xr_cum = (const uint32_t *)out->xr_cum;
+    out->d.xr_seg = (const uint2 *)out->xr_seg;
+    out->d.C256 = (const uint32_t *)out->C256;
+  }
 
   out->blocks = blocks;
   out->sa = d_sa_owned;
@@ -711,7 +759,7 @@ extern "C" void gs_index_close(gs_index *ix) {
   gs_strand_free(&ix->strand[0]);
   gs_strand_free(&ix->strand[1]);
   gs_buffer *bufs[] = {&ix->w_guides, &ix->w_slots, &ix->w_counts, &ix->w_nmatch, &ix->w_nhits,
-                       &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec,
+                       &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec, &ix->w_flags,
                        &ix->w_ovf_list, &ix->w_grec2, &ix->w_slots2, &ix->w_counts2, &ix->w_nmatch2,
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_tmp, &ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix,
                        &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx, &ix->w_b_idxb,
@@ -723,6 +771,12 @@ extern "C" void gs_index_close(gs_index *ix) {
     if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
   if (ix->d_combo) hipFree(ix->d_combo);
   delete ix;
+}
+extern "C" gs_status gs_index_last_guide_flags(const gs_index *ix, const void **d_flags, uint64_t *n_unsupported) {
+  if (!ix) return GS_ERR_ARG;
+  if (d_flags) *d_flags = ix->w_flags.p;
+  if (n_unsupported) *n_unsupported = ix->last_unsupported;
+  return GS_OK;
 }
 extern "C" gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]) {
   if (!ix || !out) return GS_ERR_ARG;

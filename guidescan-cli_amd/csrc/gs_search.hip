@@ -72,6 +72,7 @@ struct gs_search_args {
    * guide (only the other strand's table, with the PAM).  A site with (a, o, b) substitutions in
    * (X, O, R) is found from THIS strand's table when a < astar(o) and from the OTHER strand's
    * table otherwise; astar holds 4 bits per o (15: this strand takes every a). */
+  uint32_t append; /* this pass adds to the matches an earlier pass (other PAM patterns) left in the slots */
   uint32_t bidir, astar;
   uint32_t planA_g, nclsA; /* this strand's filtered plan: word offset in combo[], classes */
   uint32_t planB_g, nclsB; /* other strand's plan: header of 4 words per class {mask offset, lane
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     uint4 *out = a.slots + (a.slot_off ? (size_t)a.slot_off[slot] : (size_t)slot * a.cap);
     const uint32_t item_cap = a.slot_off ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : a.cap;
     uint32_t n_match = 0;
+    if (a.append) n_match = __builtin_amdgcn_readfirstlane(a.counts[slot]);
     uint32_t xs = 0, gs = 0; /* sizes of the X and G stacks */
 
     /* is a node at step t2 with k2 mismatches (PAM pattern pamid) a single-symbol node? */
@@ -1004,7 +1006,7 @@ __global__ void k_prepare(gs_prep_args a) {
   if (g >= a.n) return;
   gs_guide_rec r;
   r.q = 0;
-  r.valid = 1;
+  r.valid = a.force_invalid ? 0u : 1u;
   r.npams = 0;
   for (int j = 0; j < 4; j++) r.pam[j] = 0;
   const uint8_t *s = a.guides + (size_t)g * a.L;
@@ -1021,9 +1023,11 @@ __global__ void k_prepare(gs_prep_args a) {
   }
   if (a.P > 0) {
     const uint8_t *own = a.guide_pams + (size_t)g * a.P;
-    /* pams = alt_pams ++ [k.pam] (process.hpp:51-56) */
+    /* pams = alt_pams ++ [k.pam] (process.hpp:51-56); this record holds four of them */
     const uint32_t np = a.n_alt + 1;
-    for (uint32_t j = 0; j < np; j++) {
+    for (uint32_t u = 0; u < a.P; u++) /* the guide's own PAM decides validity whatever the chunk */
+      if (own[u] != 'N' && base_code(own[u]) < 0) r.valid = 0;
+    for (uint32_t j = 4u * a.chunk; j < np && j < 4u * a.chunk + 4u; j++) {
       const uint8_t *p = j < a.n_alt ? a.alt[j] : own;
       uint32_t code = 0;
       for (uint32_t u = 0; u < a.P; u++) {
@@ -1033,22 +1037,22 @@ __global__ void k_prepare(gs_prep_args a) {
           c = 4;
         } else {
           c = base_code(ch);
-          if (c < 0) {
-            r.valid = 0;
-            c = 0;
-          } else if (!a.start) {
+          if (c < 0)
+            c = 0; /* the guide is invalid (own PAM); alt PAMs were checked on the host */
+          else if (!a.start)
             c = 3 - c;
-          }
         }
         code |= (uint32_t)c << (3 * u);
       }
-      r.pam[j] = code;
+      r.pam[r.npams++] = code;
     }
-    r.npams = np;
   } else {
     r.npams = 1;
   }
-  if (!r.valid) atomicAdd(a.n_invalid, 1u);
+  if (a.chunk == 0) {
+    if (!r.valid) atomicAdd(a.n_invalid, 1u);
+    if (a.flags) a.flags[g] = r.valid ? 0u : 1u;
+  }
   a.out[g] = r;
 }
 
@@ -1637,12 +1641,13 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   if (!ix || (!d_guides && n) || (P && !d_guide_pams && n) || (n_alt && !alt_pams))
     return GS_ERR_ARG;
   if (n >= (1ull << 31)) return GS_ERR_ARG;
-  if (L < 1 || L > 31 || P > 8 || 2 * L + 3 * P > 52 || mismatches > 7 || n_alt > 3) {
-    gs_set_error("device path supports 1<=L<=31, P<=8, 2L+3P<=52, mismatches<=7, <=3 alt PAMs");
+  if (L < 1 || L > 31 || P > 8 || 2 * L + 3 * P > 52 || mismatches > 7 || n_alt > 31) {
+    gs_set_error("device path supports 1<=L<=31, P<=8, 2L+3P<=52, mismatches<=7, <=31 alt PAMs");
     return GS_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
   GS_HIP(hipSetDevice(ix->device));
+  ix->last_unsupported = 0;
   for (int i = 0; i < 4; i++)
     if (!ix->ev[i]) GS_HIP(hipEventCreate(&ix->ev[i]));
 
@@ -1651,7 +1656,31 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   gs_status rc;
   /* misc: [0..15] uint64 stats ; then work counter / invalid counter */
   if ((rc = gs_reserve(ix->w_misc, 256)) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_grec, sizeof(gs_guide_rec) * (n + 1))) != GS_OK) return rc;
+  /* PAM list = alt PAMs ++ the guide's own (process.hpp:51-56).  An alt PAM with a symbol outside
+   * A,C,G,T,N is a literal (index.hpp:130-137): it can only match if the genome holds that symbol -
+   * then the whole batch belongs to the general path - and is dropped otherwise. */
+  std::string alt_kept;
+  bool force_general = false;
+  if (P)
+    for (uint32_t j = 0; j < n_alt; j++) {
+      bool plain = true, possible = true;
+      for (uint32_t u = 0; u < P; u++) {
+        const uint8_t c = (uint8_t)alt_pams[j * P + u];
+        if (c == 'A' || c == 'C' || c == 'G' || c == 'T' || c == 'N') continue;
+        plain = false;
+        if (!ix->strand[0].has_sym[c] && !ix->strand[1].has_sym[c]) possible = false;
+      }
+      if (plain)
+        alt_kept.append(alt_pams + j * P, P);
+      else if (possible)
+        force_general = true;
+    }
+  const uint32_t n_alt_f = P ? (uint32_t)(alt_kept.size() / P) : 0u; /* alt PAMs of the fast path */
+  /* a guide record holds four PAM patterns: longer lists are searched in chunks that append to the
+   * same match slots (k_order merges them and drops sequences found twice, as the std::set does) */
+  const uint32_t n_chunks = (n_alt_f + 1 + 3) / 4;
+  if ((rc = gs_reserve(ix->w_grec, sizeof(gs_guide_rec) * (n + 1) * n_chunks)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_flags, n + 16)) != GS_OK) return rc;
   if ((rc = gs_reserve(ix->w_counts, sizeof(uint32_t) * (2 * n + 2))) != GS_OK) return rc;
   if ((rc = gs_reserve(ix->w_nmatch, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
   if ((rc = gs_reserve(ix->w_nhits, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
@@ -1675,29 +1704,34 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     }
     return GS_OK;
   }
-  {
+  for (uint32_t c = 0; c < n_chunks; c++) {
     gs_prep_args pa;
     memset(&pa, 0, sizeof(pa));
     pa.guides = (const uint8_t *)d_guides;
     pa.guide_pams = (const uint8_t *)d_guide_pams;
-    for (uint32_t j = 0; j < n_alt; j++)
-      for (uint32_t u = 0; u < P; u++) pa.alt[j][u] = (uint8_t)alt_pams[j * P + u];
-    pa.out = (gs_guide_rec *)ix->w_grec.p;
+    for (uint32_t j = 0; j < n_alt_f; j++)
+      for (uint32_t u = 0; u < P; u++) pa.alt[j][u] = (uint8_t)alt_kept[j * P + u];
+    pa.out = (gs_guide_rec *)ix->w_grec.p + (size_t)c * n;
     pa.n_invalid = d_invalid;
+    pa.flags = (uint8_t *)ix->w_flags.p;
     pa.n = n32;
     pa.L = L;
     pa.P = P;
-    pa.n_alt = P ? n_alt : 0; /* empty guide PAM drops the alt PAMs: process.hpp:52-53 */
+    pa.n_alt = n_alt_f; /* empty guide PAM drops the alt PAMs: process.hpp:52-53 */
     pa.start = (flags & GS_FLAG_PAM_AT_START) ? 1 : 0;
+    pa.chunk = c;
+    pa.force_invalid = force_general ? 1u : 0u;
     hipLaunchKernelGGL(k_prepare, dim3((n32 + 255) / 256), dim3(256), 0, st, pa);
   }
+  /* guides the fast path does not encode get empty hit lists and a flag; the batch goes on */
   uint32_t h_invalid = 0;
   GS_HIP(hipMemcpyAsync(&h_invalid, d_invalid, 4, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
-  if (h_invalid) {
-    gs_set_error("guide or PAM contains a symbol outside A,C,G,T (PAM: +N): not implemented on the device path");
-    return GS_ERR_UNSUPPORTED;
-  }
+  ix->last_unsupported = h_invalid;
+  const uint32_t n_alt_given = n_alt;
+  (void)n_alt_given;
+  n_alt = n_alt_f;
+  alt_pams = alt_kept.data();
 
   const int cus = gs_num_cus(ix->device);
   float ms_search = 0.f;
@@ -1917,7 +1951,6 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     memset(&sa, 0, sizeof(sa));
     sa.sd[0] = ix->strand[0].d;
     sa.sd[1] = ix->strand[1].d;
-    sa.guides = guides;
     sa.slots = slots;
     sa.slot_off = slot_off;
     sa.counts = counts;
@@ -1976,10 +2009,15 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
               grid, WAVE * SEARCH_WAVES, sizeof(uint4) * WAVE_LDS_ENTRIES * SEARCH_WAVES, dyn, occ);
     }
     GS_HIP(hipEventRecord(ix->ev[1], st));
-    if (count_req)
-      hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
-    else
-      hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+    for (uint32_t c = 0; c < n_chunks; c++) { /* four PAM patterns per pass, appending to the same slots */
+      sa.guides = guides + (size_t)c * ng;
+      sa.append = c ? 1u : 0u;
+      if (c) GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
+      if (count_req)
+        hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+      else
+        hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+    }
     GS_HIP(hipEventRecord(ix->ev[2], st));
     GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
@@ -2237,13 +2275,14 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
                        (const uint32_t *)ix->w_counts.p, n32, cap, (uint32_t *)ix->w_ovf_list.p, d_nlist);
     GS_HIP(hipMemcpyAsync(&n_o, d_nlist, 4, hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
-    if ((rc = gs_reserve(ix->w_grec2, sizeof(gs_guide_rec) * (size_t)n_o)) != GS_OK) return rc;
+    if ((rc = gs_reserve(ix->w_grec2, sizeof(gs_guide_rec) * (size_t)n_o * n_chunks)) != GS_OK) return rc;
     if ((rc = gs_reserve(ix->w_counts2, sizeof(uint32_t) * 2 * (size_t)n_o)) != GS_OK) return rc;
     if ((rc = gs_reserve(ix->w_nmatch2, sizeof(uint32_t) * (size_t)n_o)) != GS_OK) return rc;
     if ((rc = gs_reserve(ix->w_nhits2, sizeof(uint32_t) * (size_t)n_o)) != GS_OK) return rc;
-    hipLaunchKernelGGL(k_gather_guides, dim3((n_o + 255) / 256), dim3(256), 0, st,
-                       (const gs_guide_rec *)ix->w_grec.p, (const uint32_t *)ix->w_ovf_list.p, n_o,
-                       (gs_guide_rec *)ix->w_grec2.p);
+    for (uint32_t c = 0; c < n_chunks; c++)
+      hipLaunchKernelGGL(k_gather_guides, dim3((n_o + 255) / 256), dim3(256), 0, st,
+                         (const gs_guide_rec *)ix->w_grec.p + (size_t)c * n, (const uint32_t *)ix->w_ovf_list.p, n_o,
+                         (gs_guide_rec *)ix->w_grec2.p + (size_t)c * n_o);
     /* the main pass counted every item's matches exactly, also beyond its slots */
     hipLaunchKernelGGL(k_gather_counts, dim3((n_o + 255) / 256), dim3(256), 0, st,
                        (const uint32_t *)ix->w_counts.p, (const uint32_t *)ix->w_ovf_list.p, n_o,

@@ -280,17 +280,10 @@ extern "C" gs_status gs_format_guide_scored(const gs_genome_structure *gs, const
                            &specificity);
 }
 
-extern "C" gs_status gs_decode_sequence_ex(uint64_t key_hi, uint64_t key_lo, char *out) {
-  if (!out) return GS_ERR_ARG;
-  static const char SYM[11] = {0, '.', 'A', 'C', 'G', 'N', 'T', 'a', 'c', 'g', 't'};
-  uint32_t n = 0;
-  for (uint32_t i = 0; i < 32; i++) {
-    const uint32_t c = (uint32_t)((i < 16 ? key_hi >> (60 - 4 * i) : key_lo >> (60 - 4 * (i - 16))) & 15u);
-    if (c == 0) break;
-    if (c > 10) return GS_ERR_ARG;
-    out[n++] = SYM[c];
-  }
-  out[n] = 0;
+extern "C" gs_status gs_decode_sequence_ex(const gs_hit_ex *hit, char *out) {
+  if (!hit || !out || hit->seq_len > 32) return GS_ERR_ARG;
+  memcpy(out, hit->seq, hit->seq_len);
+  out[hit->seq_len] = 0;
   return GS_OK;
 }
 
@@ -304,7 +297,7 @@ extern "C" gs_status gs_format_guide_ex(const gs_genome_structure *gs, const gs_
   char buf[40];
   for (uint64_t h = 0; h < n_hits; h++) {
     if (hits[h].mismatches > mismatches) return GS_ERR_ARG;
-    gs_status rc = gs_decode_sequence_ex(hits[h].key_hi, hits[h].key_lo, buf);
+    gs_status rc = gs_decode_sequence_ex(&hits[h], buf);
     if (rc != GS_OK) return rc;
     decoded_hit dh;
     dh.pos = hits[h].pos;

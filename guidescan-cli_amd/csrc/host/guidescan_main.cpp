@@ -9,7 +9,11 @@
  *       seq_io.cxx:57-63).  The FM-index itself is built on the GPU when `enumerate` starts
  *       (~25 s at hg38 size, about what the reference needs to load its index files).
  *   guidescan enumerate PREFIX -f KMERS.csv -o OUT [-m 3] [-a PAM ...] [--format csv|sam]
- *       [--mode succinct|complete] [--max-off-targets N] [--start] [--device D] [--batch-size B]
+ *       [--mode succinct|complete] [--max-off-targets N] [--start] [--device D] [--gpus N] [--batch-size B]
+ *       --gpus N: one index per device (devices D .. D+N-1), one host thread per device pulling batches
+ *       from a shared queue, output written in input order (src/guidescan.cxx:226-251 is the
+ *       reference's fan-out over threads).  On every device the search of batch i+1 overlaps the text
+ *       formatting of batch i.
  */
 #include <chrono>
 #include <cstdio>
@@ -17,7 +21,10 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -65,13 +72,22 @@ bool write_gs(const std::string &path, const genome_structure &gs) {
   for (size_t i = 0; i < gs.names.size(); i++) out << gs.names[i] << "\n" << gs.lengths[i] << "\n";
   return (bool)out;
 }
-bool read_gs(const std::string &path, genome_structure &gs) { /* seq_io.cxx:124-144 */
+bool read_gs(const std::string &path, genome_structure &gs, std::string &err) { /* seq_io.cxx:124-144 */
   std::ifstream in(path);
-  if (!in) return false;
+  if (!in) {
+    err = "No genome structure file " + path;
+    return false;
+  }
   std::string name, len;
   while (std::getline(in, name) && std::getline(in, len)) {
+    char *end = nullptr;
+    const unsigned long long v = strtoull(len.c_str(), &end, 10);
+    if (end == len.c_str() || (*end && *end != '\r')) {
+      err = "malformed genome structure file " + path + ": length '" + len + "' of " + name;
+      return false;
+    }
     gs.names.push_back(name);
-    gs.lengths.push_back(std::stoull(len));
+    gs.lengths.push_back(v);
   }
   return true;
 }
@@ -152,7 +168,8 @@ int usage() {
   std::cerr << "usage: guidescan index [--index PREFIX] GENOME.fa\n"
                "       guidescan enumerate PREFIX -f KMERS -o OUT [-m N] [-a PAM]... [--format csv|sam]\n"
                "                 [--mode succinct|complete] [--max-off-targets N] [--start]\n"
-               "                 [--device D] [--batch-size B]\n";
+               "                 [--rna-bulges N] [--dna-bulges N] [-t THRESHOLD] [-n FORMAT_THREADS]\n"
+               "                 [--device D] [--gpus N] [--batch-size B]\n";
   return 2;
 }
 
@@ -190,12 +207,187 @@ int do_index(int argc, char **argv) {
   return 0;
 }
 
+/* One batch of kmers with equal (L, P), as it moves through the pipeline: a device thread searches
+ * and scores it, a formatting task turns the hit lists into text, the main thread writes the text
+ * in input order. */
+struct batch {
+  size_t lo = 0, hi = 0;
+  std::string seqs, pams;
+  gs_result *res = nullptr;
+  gs_result_ex *resx = nullptr;       /* general path: every guide (bulges) or the flagged ones */
+  std::vector<uint32_t> gen_of;       /* guide -> its position in resx, or ~0u */
+  std::vector<float> spec;
+  std::vector<char> skip;
+  std::string text;
+  std::string error;
+  bool ready = false;
+};
+
+struct enumerate_job {
+  std::vector<kmer_row> kmers;
+  std::vector<batch> batches;
+  genome_structure gs;
+  gs_genome_structure cgs{};
+  std::vector<const char *> names;
+  std::string alts;
+  uint32_t n_alt = 0;
+  uint32_t mismatches = 3, rna = 0, dna = 0, tflags = 0, sflags = 0;
+  long long max_off = -1, threshold = -1;
+  unsigned fmt_threads = 1;
+  std::mutex mtx;
+  std::condition_variable cv;
+  size_t next_batch = 0;   /* work queue of the device threads */
+  size_t in_flight = 0;    /* searched but not yet written: bounds the host memory held by results */
+  size_t max_in_flight = 2;
+};
+
+/* text of one batch from its hit lists: contiguous guide ranges formatted in parallel */
+static void format_batch(enumerate_job &job, batch &b) {
+  const size_t n = b.hi - b.lo;
+  gs_result_view v;
+  memset(&v, 0, sizeof v);
+  if (b.res) gs_result_get(b.res, &v);
+  const uint64_t *xoff = nullptr;
+  const gs_hit_ex *xhits = nullptr;
+  if (b.resx) gs_result_ex_get(b.resx, nullptr, &xoff, &xhits);
+  unsigned nt = job.fmt_threads;
+  if (nt < 1) nt = 1;
+  if (nt > n) nt = (unsigned)n;
+  std::vector<std::string> parts(nt);
+  std::vector<gs_status> prc(nt, GS_OK);
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nt; t++) {
+    pool.emplace_back([&, t]() {
+      const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+      char *tx = nullptr;
+      size_t tl = 0;
+      for (size_t g = lo; g < hi; g++) {
+        if (!b.skip.empty() && b.skip[g]) continue;
+        const kmer_row &k = job.kmers[b.lo + g];
+        gs_kmer ck{k.id.c_str(), k.sequence.c_str(), k.pam.c_str(), k.sense == "+" ? 1 : 0};
+        gs_status r;
+        const uint32_t gx = b.gen_of.empty() ? ~0u : b.gen_of[g];
+        if (gx == ~0u) {
+          const uint64_t s0 = v.guide_offsets[g], s1 = v.guide_offsets[g + 1];
+          r = gs_format_guide_scored(&job.cgs, &ck, v.hits + s0, s1 - s0, job.mismatches, job.tflags | job.sflags,
+                                     job.max_off, b.spec[g], &tx, &tl);
+        } else {
+          const uint64_t s0 = xoff[gx], s1 = xoff[gx + 1];
+          r = gs_format_guide_ex(&job.cgs, &ck, xhits + s0, s1 - s0, job.mismatches, job.tflags | job.sflags,
+                                 job.max_off, &tx, &tl);
+        }
+        if (r != GS_OK) {
+          prc[t] = r;
+          return;
+        }
+        parts[t].append(tx, tl);
+        gs_free(tx);
+      }
+    });
+  }
+  for (auto &th : pool) th.join();
+  size_t total = 0;
+  for (unsigned t = 0; t < nt; t++) {
+    if (prc[t] != GS_OK && b.error.empty()) b.error = gs_status_string(prc[t]);
+    total += parts[t].size();
+  }
+  b.text.reserve(total);
+  for (unsigned t = 0; t < nt; t++) b.text += parts[t];
+  if (b.res) gs_result_free(b.res);
+  if (b.resx) gs_result_ex_free(b.resx);
+  b.res = nullptr;
+  b.resx = nullptr;
+  b.spec = std::vector<float>();
+}
+
+/* the device side of one batch: threshold filter, search (fast path; general path for the guides it
+ * flags, or for all of them with bulges), scoring */
+static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
+  const size_t n = b.hi - b.lo;
+  const uint32_t L = (uint32_t)job.kmers[b.lo].sequence.size(), P = (uint32_t)job.kmers[b.lo].pam.size();
+  const uint32_t n_alt = P ? job.n_alt : 0;
+  const bool bulges = job.rna > 0 || job.dna > 0;
+  gs_status rc;
+  /* --threshold t (process.hpp:66-76): a guide with more than one site within t mismatches (both
+   * indexes, bulges off) is dropped before the real search */
+  if (job.threshold > 0) {
+    gs_result *cres = nullptr;
+    rc = gs_enumerate(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), n_alt, (uint32_t)job.threshold,
+                      job.sflags, &cres);
+    if (rc != GS_OK) return gs_status_string(rc);
+    gs_result_view cv;
+    gs_result_get(cres, &cv);
+    b.skip.assign(n, 0);
+    for (size_t g = 0; g < n; g++) b.skip[g] = cv.guide_offsets[g + 1] - cv.guide_offsets[g] > 1;
+    /* guides the fast path cannot count: through the general path (rare, exact) */
+    if (cv.n_unsupported) {
+      std::string s2, p2;
+      std::vector<size_t> idx;
+      for (size_t g = 0; g < n; g++)
+        if (cv.guide_flags[g] & GS_GUIDE_NEEDS_GENERAL) {
+          idx.push_back(g);
+          s2.append(b.seqs, g * L, L);
+          p2.append(b.pams, g * P, P);
+        }
+      gs_result_ex *cx = nullptr;
+      rc = gs_enumerate_general(ix, s2.data(), idx.size(), L, p2.data(), P, job.alts.data(), n_alt,
+                                (uint32_t)job.threshold, 0, 0, job.sflags, &cx);
+      if (rc != GS_OK) {
+        gs_result_free(cres);
+        return gs_status_string(rc);
+      }
+      const uint64_t *xo = nullptr;
+      gs_result_ex_get(cx, nullptr, &xo, nullptr);
+      for (size_t j = 0; j < idx.size(); j++) b.skip[idx[j]] = xo[j + 1] - xo[j] > 1;
+      gs_result_ex_free(cx);
+    }
+    gs_result_free(cres);
+  }
+  if (bulges) {
+    /* bulge-aware search: index.hpp:250-375 behind gs_enumerate_general */
+    rc = gs_enumerate_general(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), n_alt, job.mismatches,
+                              job.rna, job.dna, job.sflags, &b.resx);
+    if (rc != GS_OK) return gs_status_string(rc);
+    b.gen_of.resize(n);
+    for (size_t g = 0; g < n; g++) b.gen_of[g] = (uint32_t)g;
+    return "";
+  }
+  rc = gs_enumerate(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), n_alt, job.mismatches, job.sflags,
+                    &b.res);
+  if (rc != GS_OK) return gs_status_string(rc);
+  gs_result_view v;
+  gs_result_get(b.res, &v);
+  if (v.n_unsupported) {
+    /* guides with symbols the fast path does not encode (index.hpp:218-247): the general path, for
+     * them alone; the rest of the batch is untouched */
+    std::string s2, p2;
+    b.gen_of.assign(n, ~0u);
+    uint32_t k = 0;
+    for (size_t g = 0; g < n; g++)
+      if (v.guide_flags[g] & GS_GUIDE_NEEDS_GENERAL) {
+        b.gen_of[g] = k++;
+        s2.append(b.seqs, g * L, L);
+        p2.append(b.pams, g * P, P);
+      }
+    rc = gs_enumerate_general(ix, s2.data(), k, L, p2.data(), P, job.alts.data(), n_alt, job.mismatches, 0, 0,
+                              job.sflags, &b.resx);
+    if (rc != GS_OK) return gs_status_string(rc);
+  }
+  /* specificity of every guide of the batch on the device (printer.hpp:98-170, 251-297 behind
+   * gs_score): the formatting threads only print */
+  b.spec.resize(n);
+  rc = gs_score(ix, b.seqs.data(), n, L, P, job.tflags | job.sflags, job.max_off, &job.cgs, v.guide_offsets, v.hits,
+                nullptr, b.spec.data());
+  if (rc != GS_OK) return gs_status_string(rc);
+  return "";
+}
+
 int do_enumerate(int argc, char **argv) {
   std::string prefix, kmers_file, output, format = "csv", mode = "complete";
   std::vector<std::string> alt_pams;
   long long mismatches = 3, max_off = -1, threshold = -1, rna = 0, dna = 0;
-  int device = 0;
-  size_t batch_size = 1u << 20;
+  int device = 0, gpus = 1;
+  size_t batch_size = 0;
   unsigned fmt_threads = 0;
   bool start = false;
   for (int i = 0; i < argc; i++) {
@@ -220,16 +412,18 @@ int do_enumerate(int argc, char **argv) {
     else if (a == "--mode") mode = need("--mode");
     else if (a == "--start") start = true;
     else if (a == "--device") device = atoi(need("--device"));
+    else if (a == "--gpus") gpus = atoi(need("--gpus"));
     else if (a == "--batch-size") batch_size = (size_t)atoll(need("--batch-size"));
     else if (!a.empty() && a[0] != '-' && prefix.empty()) prefix = a;
     else return usage();
   }
   if (prefix.empty() || kmers_file.empty() || output.empty()) return usage();
   if ((format != "csv" && format != "sam") || (mode != "succinct" && mode != "complete")) return usage();
-  const bool bulges = rna > 0 || dna > 0;
-  genome_structure gs;
-  if (!read_gs(prefix + ".gs", gs)) {
-    std::cerr << "error: No genome structure file " << prefix << ".gs\n";
+  if (gpus < 1 || mismatches < 0 || rna < 0 || dna < 0) return usage();
+  enumerate_job job;
+  std::string err;
+  if (!read_gs(prefix + ".gs", job.gs, err)) {
+    std::cerr << "error: " << err << "\n";
     return 1;
   }
   /* PREFIX.dna (this tool's `index`) or, for indices made by the reference, PREFIX.forward */
@@ -248,24 +442,36 @@ int do_enumerate(int argc, char **argv) {
       return 1;
     }
   }
-
-  std::vector<kmer_row> kmers;
-  std::string err;
-  if (!read_kmers(kmers_file, kmers, err)) {
+  if (!read_kmers(kmers_file, job.kmers, err)) {
     std::cerr << "error: " << err << "\n";
     return 1;
   }
-  std::cout << "Read in " << kmers.size() << " kmer(s).\n";
+  std::cout << "Read in " << job.kmers.size() << " kmer(s).\n";
 
+  /* one index per device, built side by side (src/guidescan.cxx:226-251 fans the guides out over
+   * threads that share one index; here every GPU holds its own copy in HBM) */
   auto t0 = std::chrono::steady_clock::now();
-  gs_index *ix = nullptr;
-  gs_status rc = from_sdsl ? gs_index_open_sdsl(prefix.c_str(), device, &ix)
-                           : gs_index_build((const uint8_t *)text.data(), text.size(), device, &ix);
-  if (rc != GS_OK) {
-    std::cerr << "error: " << gs_status_string(rc) << "\n";
-    return 1;
+  std::vector<gs_index *> ix((size_t)gpus, nullptr);
+  {
+    std::vector<gs_status> brc((size_t)gpus, GS_OK);
+    std::vector<std::string> bmsg((size_t)gpus);
+    std::vector<std::thread> bt;
+    for (int d = 0; d < gpus; d++)
+      bt.emplace_back([&, d]() {
+        brc[d] = from_sdsl ? gs_index_open_sdsl(prefix.c_str(), device + d, &ix[d])
+                           : gs_index_build((const uint8_t *)text.data(), text.size(), device + d, &ix[d]);
+        if (brc[d] != GS_OK) bmsg[d] = gs_status_string(brc[d]);
+      });
+    for (auto &th : bt) th.join();
+    for (int d = 0; d < gpus; d++)
+      if (brc[d] != GS_OK) {
+        std::cerr << "error: device " << device + d << ": " << bmsg[d] << "\n";
+        for (gs_index *p : ix) gs_index_close(p);
+        return 1;
+      }
   }
-  std::cout << "Built the forward and reverse index on device " << device << " in "
+  text = std::string();
+  std::cout << "Built the forward and reverse index on " << gpus << " device(s) from " << device << " in "
             << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << " s\n";
 
   std::ofstream out(output, std::ios::binary);
@@ -273,142 +479,112 @@ int do_enumerate(int argc, char **argv) {
     std::cerr << "error: cannot write " << output << "\n";
     return 1;
   }
-  std::vector<const char *> names;
-  for (auto &n : gs.names) names.push_back(n.c_str());
-  gs_genome_structure cgs{names.data(), gs.lengths.data(), (uint32_t)names.size()};
-  const uint32_t tflags = (format == "sam" ? GS_TEXT_SAM : 0u) | (mode == "complete" ? GS_TEXT_COMPLETE : 0u);
-  const uint32_t sflags = start ? GS_FLAG_PAM_AT_START : 0u;
+  for (auto &n : job.gs.names) job.names.push_back(n.c_str());
+  job.cgs = gs_genome_structure{job.names.data(), job.gs.lengths.data(), (uint32_t)job.names.size()};
+  job.tflags = (format == "sam" ? GS_TEXT_SAM : 0u) | (mode == "complete" ? GS_TEXT_COMPLETE : 0u);
+  job.sflags = start ? GS_FLAG_PAM_AT_START : 0u;
+  job.mismatches = (uint32_t)mismatches;
+  job.rna = (uint32_t)rna;
+  job.dna = (uint32_t)dna;
+  job.max_off = max_off;
+  job.threshold = threshold;
+  job.fmt_threads = fmt_threads ? fmt_threads : std::max(1u, std::thread::hardware_concurrency());
+  job.max_in_flight = 2 * (size_t)gpus;
   char *txt = nullptr;
   size_t len = 0;
-  gs_format_header(&cgs, tflags, &txt, &len);
+  gs_format_header(&job.cgs, job.tflags, &txt, &len);
   out.write(txt, (std::streamsize)len);
   gs_free(txt);
 
-  /* batches of equal (L, P) in input order: the device call takes fixed-width rows */
-  t0 = std::chrono::steady_clock::now();
-  size_t done = 0;
-  while (done < kmers.size()) {
-    const size_t L = kmers[done].sequence.size(), P = kmers[done].pam.size();
+  /* batches of equal (L, P) in input order: the device call takes fixed-width rows.  The hit lists
+   * of a batch live in HBM and on the host until it is written: ~13 hits per guide at <= 3
+   * mismatches, ~1.4e3 at 5, ~1.1e4 at 6 on a human-sized genome, so deeper searches take smaller batches */
+  if (!batch_size) batch_size = mismatches <= 3 ? (1u << 20) : mismatches == 4 ? (1u << 18) : mismatches == 5 ? (1u << 16) : (1u << 13);
+  for (size_t done = 0; done < job.kmers.size();) {
+    const size_t L = job.kmers[done].sequence.size(), P = job.kmers[done].pam.size();
+    batch b;
+    b.lo = done;
     size_t end = done;
-    std::string seqs, pams, alts;
-    while (end < kmers.size() && end - done < batch_size && kmers[end].sequence.size() == L &&
-           kmers[end].pam.size() == P) {
-      seqs += kmers[end].sequence;
-      pams += kmers[end].pam;
+    while (end < job.kmers.size() && end - done < batch_size && job.kmers[end].sequence.size() == L &&
+           job.kmers[end].pam.size() == P)
       end++;
-    }
-    uint32_t n_alt = 0;
-    if (P > 0)
-      for (auto &a : alt_pams) {
-        if (a.size() != P) {
-          std::cerr << "error: alt PAM " << a << " differs in length from the guides' PAM\n";
-          return 1;
-        }
-        alts += a;
-        n_alt++;
-      }
-    /* --threshold t (process.hpp:66-76): a guide with more than one site within t mismatches
-     * (both indexes, bulges off) is dropped before the real search */
-    std::vector<char> skip(end - done, 0);
-    if (threshold > 0) {
-      gs_result *cres = nullptr;
-      rc = gs_enumerate(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P, alts.data(),
-                        n_alt, (uint32_t)threshold, sflags, &cres);
-      if (rc != GS_OK) {
-        std::cerr << "error: " << gs_status_string(rc) << "\n";
-        return 1;
-      }
-      gs_result_view cv;
-      gs_result_get(cres, &cv);
-      for (size_t g = 0; g < end - done; g++)
-        skip[g] = cv.guide_offsets[g + 1] - cv.guide_offsets[g] > 1;
-      gs_result_free(cres);
-    }
-    gs_result *res = nullptr;
-    gs_result_ex *resx = nullptr;
-    gs_result_view v;
-    memset(&v, 0, sizeof v);
-    const uint64_t *xoff = nullptr;
-    const gs_hit_ex *xhits = nullptr;
-    if (!bulges) {
-      rc = gs_enumerate(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P, alts.data(),
-                        n_alt, (uint32_t)mismatches, sflags, &res);
-    } else {
-      /* bulge-aware search: index.hpp:250-375 behind gs_enumerate_bulges */
-      rc = gs_enumerate_bulges(ix, seqs.data(), end - done, (uint32_t)L, pams.data(), (uint32_t)P,
-                               alts.data(), n_alt, (uint32_t)mismatches, (uint32_t)rna, (uint32_t)dna,
-                               sflags, &resx);
-    }
-    if (rc != GS_OK) {
-      std::cerr << "error: " << gs_status_string(rc) << "\n";
-      return 1;
-    }
-    /* specificity of every guide of the batch on the device (printer.hpp:98-170, 251-297 behind
-     * gs_score): the formatting threads below only print */
-    std::vector<float> spec;
-    if (!bulges) {
-      gs_result_get(res, &v);
-      spec.resize(end - done);
-      rc = gs_score(ix, seqs.data(), end - done, (uint32_t)L, (uint32_t)P, tflags | sflags, max_off, &cgs,
-                    v.guide_offsets, v.hits, nullptr, spec.data());
-      if (rc != GS_OK) {
-        std::cerr << "error: " << gs_status_string(rc) << "\n";
-        return 1;
-      }
-    } else {
-      gs_result_ex_get(resx, nullptr, &xoff, &xhits);
-    }
-    /* format in parallel over contiguous guide ranges, write in input order (-n 1 order) */
-    unsigned nt = fmt_threads ? fmt_threads : std::thread::hardware_concurrency();
-    if (nt < 1) nt = 1;
-    if (nt > end - done) nt = (unsigned)(end - done);
-    std::vector<std::string> parts(nt);
-    std::vector<gs_status> prc(nt, GS_OK);
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nt; t++) {
-      pool.emplace_back([&, t]() {
-        const size_t lo = done + (end - done) * t / nt, hi = done + (end - done) * (t + 1) / nt;
-        char *tx = nullptr;
-        size_t tl = 0;
-        for (size_t g = lo; g < hi; g++) {
-          if (skip[g - done]) continue;
-          const kmer_row &k = kmers[g];
-          gs_kmer ck{k.id.c_str(), k.sequence.c_str(), k.pam.c_str(), k.sense == "+" ? 1 : 0};
-          gs_status r;
-          if (!bulges) {
-            const uint64_t b = v.guide_offsets[g - done], e = v.guide_offsets[g - done + 1];
-            r = gs_format_guide_scored(&cgs, &ck, v.hits + b, e - b, (uint32_t)mismatches, tflags | sflags,
-                                       max_off, spec[g - done], &tx, &tl);
-          } else {
-            const uint64_t b = xoff[g - done], e = xoff[g - done + 1];
-            r = gs_format_guide_ex(&cgs, &ck, xhits + b, e - b, (uint32_t)mismatches, tflags | sflags,
-                                   max_off, &tx, &tl);
-          }
-          if (r != GS_OK) {
-            prc[t] = r;
-            return;
-          }
-          parts[t].append(tx, tl);
-          gs_free(tx);
-        }
-      });
-    }
-    for (auto &th : pool) th.join();
-    for (unsigned t = 0; t < nt; t++) {
-      if (prc[t] != GS_OK) {
-        std::cerr << "error: " << gs_status_string(prc[t]) << "\n";
-        return 1;
-      }
-      out.write(parts[t].data(), (std::streamsize)parts[t].size());
-    }
-    if (res) gs_result_free(res);
-    if (resx) gs_result_ex_free(resx);
+    b.hi = end;
+    job.batches.push_back(std::move(b));
     done = end;
   }
+  /* alt PAMs shorter or longer than the guides' PAM can never complete a match of the same length
+   * class: the reference searches them all the same (process.hpp:51-56) and so does the general
+   * path; the fixed-width fast path takes the ones of the batch's PAM length */
+  size_t palen = 0;
+  for (auto &b : job.batches) palen = std::max(palen, job.kmers[b.lo].pam.size());
+  for (auto &a : alt_pams) {
+    if (a.size() != palen) {
+      std::cerr << "error: alt PAM " << a << " differs in length from the guides' PAM\n";
+      for (gs_index *p : ix) gs_index_close(p);
+      return 1;
+    }
+    job.alts += a;
+    job.n_alt++;
+  }
+
+  t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> formatters(job.batches.size());
+  std::vector<std::thread> devs;
+  for (int d = 0; d < gpus; d++)
+    devs.emplace_back([&, d]() {
+      for (;;) {
+        size_t bi;
+        {
+          std::unique_lock<std::mutex> lk(job.mtx);
+          job.cv.wait(lk, [&] { return job.in_flight < job.max_in_flight || job.next_batch >= job.batches.size(); });
+          if (job.next_batch >= job.batches.size()) return;
+          bi = job.next_batch++;
+          job.in_flight++;
+        }
+        batch &b = job.batches[bi];
+        for (size_t g = b.lo; g < b.hi; g++) {
+          b.seqs += job.kmers[g].sequence;
+          b.pams += job.kmers[g].pam;
+        }
+        b.error = search_batch(job, ix[d], b);
+        /* text formatting of this batch overlaps the device work of the next one */
+        formatters[bi] = std::thread([&job, &b]() {
+          if (b.error.empty()) format_batch(job, b);
+          std::lock_guard<std::mutex> lk(job.mtx);
+          b.ready = true;
+          job.cv.notify_all();
+        });
+      }
+    });
+  int rcode = 0;
+  for (size_t bi = 0; bi < job.batches.size(); bi++) {
+    batch &b = job.batches[bi];
+    {
+      std::unique_lock<std::mutex> lk(job.mtx);
+      job.cv.wait(lk, [&] { return b.ready; });
+    }
+    formatters[bi].join();
+    if (!b.error.empty()) {
+      if (!rcode) std::cerr << "error: " << b.error << "\n";
+      rcode = 1;
+    } else {
+      out.write(b.text.data(), (std::streamsize)b.text.size());
+    }
+    b.text = std::string();
+    b.seqs = std::string();
+    b.pams = std::string();
+    {
+      std::lock_guard<std::mutex> lk(job.mtx);
+      job.in_flight--;
+      if (rcode) job.next_batch = job.batches.size(); /* stop handing out work */
+      job.cv.notify_all();
+    }
+  }
+  for (auto &th : devs) th.join();
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  std::cout << "Processed " << kmers.size() << " kmers in " << secs << " seconds.\n";
-  gs_index_close(ix);
-  return out ? 0 : 1;
+  std::cout << "Processed " << job.kmers.size() << " kmers in " << secs << " seconds.\n";
+  for (gs_index *p : ix) gs_index_close(p);
+  return (out && !rcode) ? 0 : 1;
 }
 
 }  // namespace

@@ -86,7 +86,16 @@ typedef struct {
   /* device timing of the last call, milliseconds (HIP events on the call's stream) */
   float ms_search;  /* search kernel only */
   float ms_total;   /* prepare + search + order + locate, device side */
+  /* Guides outside what the fast path encodes (a guide symbol outside A,C,G,T; a symbol other than
+   * A,C,G,T,N in the guide's own PAM; an alt PAM with such a symbol that the genome contains): their
+   * hit lists are EMPTY here and guide_flags[i] has bit 0 set - enumerate exactly those guides with
+   * gs_enumerate_general (same arguments) and format them with gs_format_guide_ex.  The rest of the
+   * batch is unaffected.  guide_flags: n_guides bytes (host memory owned by the result), or NULL
+   * when n_unsupported == 0. */
+  uint64_t n_unsupported;
+  const uint8_t *guide_flags;
 } gs_result_view;
+#define GS_GUIDE_NEEDS_GENERAL 1u
 
 typedef struct gs_result gs_result;
 
@@ -151,6 +160,9 @@ gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uint64_t n, ui
                               uint32_t n_alt, uint32_t mismatches, uint32_t flags, void *stream,
                               const void **d_offsets, const void **d_hits, gs_result_view *stats);
 
+/* flags of the last gs_enumerate_device call on this handle (device memory, n bytes, valid until the
+ * next call) and how many guides carry GS_GUIDE_NEEDS_GENERAL */
+gs_status gs_index_last_guide_flags(const gs_index *ix, const void **d_flags, uint64_t *n_unsupported);
 gs_status gs_result_get(const gs_result *r, gs_result_view *view);
 void gs_result_free(gs_result *r);
 
@@ -228,26 +240,34 @@ gs_status gs_format_header(const gs_genome_structure *gs, uint32_t flags, char *
                            size_t *out_len);
 void gs_free(void *p);
 
-/* ---- bulge-aware search (include/genomics/index.hpp:250-375) ------------------------------ */
+/* ---- the general path: bulges, symbols outside A,C,G,T, any number of PAMs ---------------------- */
 
-/* One hit of the bulge-aware path, 32 bytes.  match.sequence can hold '.', lower-case bulge bases
- * and has no fixed length, so it travels as 4-bit codes, position 0 in the top nibble of key_hi:
- * 0 = end, 1 '.', 2 'A', 3 'C', 4 'G', 5 'N', 6 'T', 7 'a', 8 'c', 9 'g', 10 't'
- * (numeric order == ASCII order == the reference's std::set<match> order). */
+/* One hit of the general path, 48 bytes.  match.sequence can hold '.', lower-case bulge bases, any
+ * literal symbol of the guide or of a PAM pattern, and has no fixed length, so it travels as its
+ * bytes (byte order == the reference's std::set<match> order). */
 typedef struct {
   int64_t pos;
-  uint64_t key_hi, key_lo;
+  char seq[32];      /* match.sequence, seq_len bytes, NUL padded */
   uint32_t mismatches;
   uint8_t dna_bulges, rna_bulges;
   uint8_t index;   /* 0 forward index, 1 reverse index */
-  uint8_t seq_len; /* symbols in key_hi:key_lo */
+  uint8_t seq_len;
 } gs_hit_ex;
 
 typedef struct gs_result_ex gs_result_ex;
 
-/* gs_enumerate with --rna-bulges / --dna-bulges > 0: replaces genome_index::inexact_search's
- * bulge-aware branch (index.hpp:394-397 -> 250-375, max_bulge_size = 1 as process.hpp:82-83 calls
- * it) plus the same set ordering and resolve() expansion.  Hits per guide in canonical order. */
+/* Everything genome_index::inexact_search accepts, exactly: replaces both branches of the dispatcher
+ * (index.hpp:377-398) - the bulge-aware recursion (:250-375, max_bulge_size = 1 as process.hpp:82-83
+ * calls it) when rna_bulges/dna_bulges > 0, else the PAM-aware recursion (:182-248) - for inputs the
+ * fast path does not encode: guide symbols outside A,C,G,T (matched literally, else charged a
+ * mismatch, :218-247), PAM symbols other than 'N' as literals (:125-170), up to 31 alt PAMs
+ * (process.hpp:51-56).  Same set ordering and resolve() expansion; hits per guide in canonical order.
+ * A slow path (one node per lane, comparator sort): gs_enumerate reports which guides need it. */
+gs_status gs_enumerate_general(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
+                               const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,
+                               uint32_t mismatches, uint32_t rna_bulges, uint32_t dna_bulges,
+                               uint32_t flags, gs_result_ex **out);
+/* the same function under the name the bulge options were first served by */
 gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
                               const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,
                               uint32_t mismatches, uint32_t rna_bulges, uint32_t dna_bulges,
@@ -255,9 +275,9 @@ gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint64_t n, uint
 gs_status gs_result_ex_get(const gs_result_ex *r, uint64_t *n_guides, const uint64_t **guide_offsets,
                            const gs_hit_ex **hits);
 void gs_result_ex_free(gs_result_ex *r);
-/* match.sequence of a bulge-path hit; out needs 33 bytes */
-gs_status gs_decode_sequence_ex(uint64_t key_hi, uint64_t key_lo, char *out);
-/* gs_format_guide for bulge-path hits (rna_bulges / dna_bulges columns filled in) */
+/* match.sequence of a general-path hit as a C string; out needs 33 bytes */
+gs_status gs_decode_sequence_ex(const gs_hit_ex *hit, char *out);
+/* gs_format_guide for general-path hits (rna_bulges / dna_bulges columns filled in) */
 gs_status gs_format_guide_ex(const gs_genome_structure *gs, const gs_kmer *k, const gs_hit_ex *hits,
                              uint64_t n_hits, uint32_t mismatches, uint32_t flags,
                              int64_t max_off_targets, char **out_text, size_t *out_len);

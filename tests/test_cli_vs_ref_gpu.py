@@ -7,6 +7,8 @@ test_oracle_vs_ref_pipeline.py (mismatches 0..4, CSV/SAM, succinct, alt PAMs, --
 snapshot; nothing reads /root/reference here.  GPU only."""
 import subprocess
 
+import numpy as np
+
 import pytest
 
 import oracle_lib as ol
@@ -73,4 +75,39 @@ def test_cli_reading_reference_index_equals_compiled_reference(tmp_path):
         out = tmp_path / "got"
         subprocess.run([str(CLI), "enumerate", str(tmp_path / "r.idx"), "-f", str(kcsv), "-o", str(out), "-n", "1"]
                        + cli_args(**cfg), check=True, timeout=120)
+        assert out.read_bytes() == want, cfg
+
+
+def test_cli_accepts_what_the_reference_accepts(tmp_path):
+    """a kmers file holding guides with N / lower case / IUPAC symbols next to ordinary ones, five alt
+    PAMs (one of them with a literal the genome lacks), many small batches: the CLI answers every
+    row - the odd guides through the general path, the others through the fast path, four PAM
+    patterns per pass - and its files equal the compiled reference's byte for byte"""
+    text, names, lengths, rows = pipe.random_case(501)
+    t = text
+    isn = t == ord("N")
+    at = int(np.nonzero(isn)[0][0]) if isn.any() else 100
+    odd = ["ACGTNCGTACGTACGTACGT", "acgtACGTACGTACGTACGT", "ACGTACGTACGTACGTACGR",
+           t[at - 7:at + 13].tobytes().decode(), rows[0][1][:9] + "N" + rows[0][1][10:]]
+    L = len(rows[0][1])
+    odd = [g for g in odd if len(g) == L]
+    rows = rows[:10] + [(f"odd{i}", g, rows[0][2], "+") for i, g in enumerate(odd)] + rows[10:]
+    kcsv = tmp_path / "kmers.csv"
+    pipe.synth.write_kmers_csv(kcsv, [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows],
+                               [names[0]] * len(rows), [1] * len(rows), [r[3] for r in rows])
+    oidx = ol.OracleIndex(text)
+    try:
+        pipe.write_reference_index(oidx, text.shape[0] + 1, tmp_path / "r.idx", names, lengths)
+    finally:
+        oidx.close()
+    text.tofile(tmp_path / "g.dna")
+    (tmp_path / "g.gs").write_text("".join(f"{a}\n{b}\n" for a, b in zip(names, lengths)))
+    P = len(rows[0][2])
+    alts = [p for p in ("NAG", "NGA", "RGG", "NGT", "NCG") if len(p) == P]
+    for cfg in (dict(m=2, alt=tuple(alts)), dict(m=3, fmt="sam", alt=tuple(alts)), dict(m=1, start=True, alt=tuple(alts[:4])),
+                dict(m=2, thr=1, alt=("NAG",)), dict(m=2, maxo=2, complete=False)):
+        want = pipe.run_shim(tmp_path / "r.idx", kcsv, tmp_path / "want", **cfg)
+        out = tmp_path / "got"
+        subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(kcsv), "-o", str(out), "-n", "2",
+                        "--batch-size", "7"] + cli_args(**cfg), check=True, timeout=300)
         assert out.read_bytes() == want, cfg

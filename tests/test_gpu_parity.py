@@ -105,13 +105,103 @@ def test_toy_hit_sets_bit_exact(toy_gpu, cfg):
             assert stats["n_hits"] == offsets[-1]
 
 
-def test_unsupported_symbols_fail_loudly(toy_gpu):
+def general_hits_as_records(offsets, hits, i):
+    return [(int(x["pos"]), int(x["mismatches"]), int(x["index"]), api.decode_sequence_ex(x), int(x["dna_bulges"]),
+             int(x["rna_bulges"])) for x in hits[offsets[i]:offsets[i + 1]]]
+
+
+def oracle_general_records(oidx, seq, pam, opts):
+    _, ctr, raw = oidx.enumerate(seq, pam, opts)
+    out, n = raw
+    exp = [(out[j].pos, out[j].mismatches, out[j].index, out[j].sequence.decode(), out[j].dna_bulges,
+            out[j].rna_bulges) for j in range(n)]
+    ol.lib().gso_free(out)
+    return exp
+
+
+ODD_GUIDES = ["ACGTNCGTACGTACGTACGT", "acgtACGTACGTACGTACGT", "ACGTACGTACGTACGTACGR", "NNACGTACGTACGTACGTAC"]
+
+
+@pytest.mark.parametrize("cfg", [dict(m=2), dict(m=3, alt=("NAG", "NGA", "NGT", "NTG", "NCG")),
+                                 dict(m=1, alt=("NAG", "RGG", "nGG", "NGN", "NNG", "NGC"), start=True),
+                                 dict(m=2, alt=("NAG",), own="NRG")],
+                         ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_symbols_outside_acgt_and_long_pam_lists(toy_gpu, cfg):
+    """what the reference accepts, the product accepts (index.hpp:125-170, 218-247; process.hpp:51-56):
+    a guide with N / lower case / IUPAC symbols does not abort its batch - the fast path answers the
+    other guides (any number of alt PAMs, four per pass) and flags the odd ones, which the general
+    path then enumerates exactly; alt PAMs with literals the genome does not hold simply never match"""
     toy, oidx, gidx = toy_gpu
-    seqs = np.array([list(b"ACGTNCGTACGTACGTACGT")], dtype=np.uint8)
-    pams = np.array([list(b"NGG")], dtype=np.uint8)
-    with pytest.raises(api.GsError) as e:
-        gidx.enumerate(seqs, pams, mismatches=1)
-    assert e.value.status == 3
+    m, alt, start, own = cfg["m"], cfg.get("alt", ()), cfg.get("start", False), cfg.get("own", "NGG")
+    # take guides from the toy genome itself so that the odd ones sit next to real sites
+    normal = [k.sequence for k in toy["kmers"] if k.pam and len(k.sequence) == 20][:12]
+    t = toy["text"]
+    isn = t == ord("N")
+    lone = np.nonzero(isn[1:-1] & ~isn[:-2] & ~isn[2:])[0] + 1   # an isolated literal N of the genome
+    at = int(lone[0]) if lone.size else int(np.nonzero(isn)[0][0])
+    odd = list(ODD_GUIDES) + [t[at - 4:at + 16].tobytes().decode()]   # a site whose 5th base is that N
+    guides = normal[:6] + odd + normal[6:]
+    seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
+    pams = np.tile(np.frombuffer(own.encode(), np.uint8), (len(guides), 1))
+    opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
+    offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=start)
+    plain_own = all(c in "ACGTN" for c in own)
+    want_flagged = [i for i, g in enumerate(guides) if not plain_own or any(c not in "ACGT" for c in g)]
+    assert stats["needs_general"] == want_flagged
+    for i, g in enumerate(guides):
+        if i in want_flagged:
+            assert offsets[i + 1] == offsets[i]
+        else:
+            exp, _ = oracle_hits_as_records(oidx, g, own, opts, 3, start)
+            assert gpu_hits_as_records(offsets, hits, i, g, 3, start) == exp, (i, g, cfg)
+    # the general path: every guide of the batch, odd or not, equals the oracle
+    goff, ghits = gidx.enumerate_general(seqs, pams, mismatches=m, alt_pams=alt, start=start)
+    n_lit = 0
+    for i, g in enumerate(guides):
+        exp = oracle_general_records(oidx, g, own, opts)
+        got = general_hits_as_records(goff, ghits, i)
+        assert got == exp, (i, g, cfg)
+
+
+def test_literal_symbols_match_literally():
+    """a guide's N against a literal N of the genome is an exact match, against a base a mismatch
+    (index.hpp:218-247); an IUPAC letter in a PAM pattern matches only the same letter in the genome
+    (index.hpp:130-137): planted sites on both strands, general path vs oracle"""
+    rng = np.random.default_rng(3)
+    text = rng.choice(np.frombuffer(b"ACGT", np.uint8), 30_000)
+    site = np.frombuffer(b"ACGTNCGTACGATTGCATGC", np.uint8)
+    text[1000:1023] = np.concatenate([site, np.frombuffer(b"TGG", np.uint8)])                 # N under the guide's N
+    text[5000:5023] = synth.reverse_complement_bytes(np.concatenate([site, np.frombuffer(b"AGG", np.uint8)]))
+    plain = site.copy()
+    plain[4] = ord("A")
+    text[9000:9023] = np.concatenate([plain, np.frombuffer(b"CGG", np.uint8)])                # a base under the guide's N
+    text[12000:12023] = np.concatenate([plain, np.frombuffer(b"RGG", np.uint8)])              # literal R in the genome's PAM
+    text[15000:15023] = np.concatenate([plain, np.frombuffer(b"NGG", np.uint8)])              # literal N in the genome's PAM
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        guides = [site.tobytes().decode(), plain.tobytes().decode()]
+        seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
+        for own, alt in (("NGG", ()), ("NGG", ("RGG",)), ("RGG", ("NAG",))):
+            pams = np.tile(np.frombuffer(own.encode(), np.uint8), (2, 1))
+            opts = ol.make_opts(mismatches=2, alt_pams=alt)
+            goff, ghits = gidx.enumerate_general(seqs, pams, mismatches=2, alt_pams=alt)
+            seen = set()
+            for i, g in enumerate(guides):
+                exp = oracle_general_records(oidx, g, own, opts)
+                assert general_hits_as_records(goff, ghits, i) == exp, (i, own, alt)
+                seen |= {e[3] for e in exp}
+            if own == "NGG" and not alt:
+                assert any(sq[4] == "N" for sq in seen) and any(sq[4] in "acgt" for sq in seen) and \
+                    any(sq[20] == "N" for sq in seen)
+            else:
+                assert any("R" in sq[20:] for sq in seen)
+            # the fast path with an alt PAM whose literal the genome holds hands the whole batch over
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=2, alt_pams=alt)
+            assert stats["needs_general"] == ([0, 1] if (own != "NGG" or "RGG" in alt) else [0])
+    finally:
+        gidx.close()
+        oidx.close()
 
 
 def test_empty_batch(toy_gpu):
@@ -437,11 +527,7 @@ def test_bulge_aware_search_bit_exact(toy_gpu, cfg):
             exp = [(out[j].pos, out[j].mismatches, out[j].index, out[j].sequence.decode(),
                     out[j].dna_bulges, out[j].rna_bulges) for j in range(n)]
             ol.lib().gso_free(out)
-            h = hits[offsets[i]:offsets[i + 1]]
-            got = [(int(x["pos"]), int(x["mismatches"]), int(x["index"]),
-                    api.decode_sequence_ex(int(x["key_hi"]), int(x["key_lo"])), int(x["dna_bulges"]),
-                    int(x["rna_bulges"])) for x in h]
-            assert got == exp, (k.id, cfg)
+            assert general_hits_as_records(offsets, hits, i) == exp, (k.id, cfg)
 
 
 def test_repeat_family_genome_bit_exact(monkeypatch):
