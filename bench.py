@@ -584,12 +584,30 @@ def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample):
                             "csv", "complete", str(m), "0", "0", "-1", "-1", "0"], env=env, check=True,
                            timeout=3600, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
         dt = float(re.search(r"kmers in ([0-9.eE+-]+) s", r.stderr.decode()).group(1))
+        # the baseline's output doubles as a parity check at this size: its data lines (row order
+        # varies with the thread count, so as a sorted list) against the product's lines for the
+        # same guides - device search, device scoring, gs_format_guide_scored
+        with open(os.path.join(td, "o.csv")) as f:
+            want = sorted(f.read().splitlines()[1:])
+        api = import_module("guidescan-cli_amd.api")
+        gs = api.make_genome_structure(names, lengths)
+        off, hits, _ = gidx.enumerate(seqs[:sample], pams[:sample], mismatches=m)
+        _, spec = gidx.score(gs, seqs[:sample], pams.shape[1], off, hits, want_cfd=False)
+        got = []
+        for i in range(sample):
+            got += api.format_guide(gs, f"g{i}", seqs[i].tobytes().decode(), pams[i].tobytes().decode(), True,
+                                    hits[off[i]:off[i + 1]], m, specificity=spec[i]).splitlines()
+        got.sort()
+        parity = {"lines": len(want), "identical_to_product": got == want}
+        if got != want:
+            print(f"[bench] PARITY FAILURE: {len(want)} reference lines vs {len(got)} product lines", file=sys.stderr)
     finally:
         shutil.rmtree(td, ignore_errors=True)
     return {"value": sample / dt, "unit": "guides/s", "cores": cores, "kind": "reference",
             "sample": f"first {sample} guides of rank 0's batch through the compiled reference "
-                      f"(process_kmers_to_stream, CSV out), {cores} threads, {dt:.1f} s; "
-                      f"SDSL index files written in {t_files:.0f} s (untimed)"}
+                      f"(process_kmers_to_stream, CSV out, built -O3 -DNDEBUG as its Release build), {cores} threads, "
+                      f"{dt:.1f} s; SDSL index files written in {t_files:.0f} s (untimed)",
+            "parity": parity}
 
 
 if __name__ == "__main__":

@@ -90,6 +90,10 @@ def lib():
     L.gs_index_open_sdsl.argtypes = [C.c_char_p, i32, C.POINTER(vp)]
     L.gs_sdsl_extract_text.restype = i32
     L.gs_sdsl_extract_text.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u64)]
+    L.gs_index_save_sa.restype = i32
+    L.gs_index_save_sa.argtypes = [vp, vp, u64, C.c_char_p]
+    L.gs_index_open_sa.restype = i32
+    L.gs_index_open_sa.argtypes = [vp, u64, C.c_char_p, i32, C.POINTER(vp)]
     L.gs_index_close.argtypes = [vp]
     L.gs_index_genome_length.restype = u64
     L.gs_index_genome_length.argtypes = [vp]
@@ -171,7 +175,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
-           "gs_index_last_guide_flags"]
+           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa"]
 
 
 def _check(rc):
@@ -324,6 +328,19 @@ class GenomeIndex:
                                                 sa_rev.ctypes.data, device, C.byref(h)))
         else:
             _check(lib().gs_index_build(text.ctypes.data, text.shape[0], device, C.byref(h)))
+        return cls(h, device)
+
+    def save_sa(self, text, path):
+        """store both suffix arrays next to the text (gs_index_save_sa)"""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        _check(lib().gs_index_save_sa(self._h, text.ctypes.data, text.shape[0], str(path).encode()))
+
+    @classmethod
+    def open_sa(cls, text, path, device: int = 0):
+        """text + stored suffix arrays -> index without the suffix sort (gs_index_open_sa)"""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(lib().gs_index_open_sa(text.ctypes.data, text.shape[0], str(path).encode(), device, C.byref(h)))
         return cls(h, device)
 
     @classmethod

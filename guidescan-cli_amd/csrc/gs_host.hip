@@ -27,17 +27,66 @@ extern "C" const char *gs_status_string(gs_status s) {
 }
 extern "C" const char *gs_version(void) { return "guidescan-amd 0.1 (gfx950)"; }
 
+/* Page-locked host buffers for the results of the host-pointer entry point, kept in a small
+ * process-wide pool: a 1 M-guide batch returns ~215 MB of hits, and a fresh pageable buffer costs
+ * more (page faults, staged copy) than the copy itself.  Portable: any device may fill them. */
+struct gs_pinned {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+static std::mutex g_pin_mtx;
+static std::vector<gs_pinned> g_pin_free;
+static gs_pinned pin_acquire(size_t bytes) {
+  if (!bytes) bytes = 16;
+  {
+    std::lock_guard<std::mutex> lk(g_pin_mtx);
+    int best = -1;
+    for (size_t i = 0; i < g_pin_free.size(); i++)
+      if (g_pin_free[i].cap >= bytes && (best < 0 || g_pin_free[i].cap < g_pin_free[best].cap)) best = (int)i;
+    if (best >= 0) {
+      gs_pinned b = g_pin_free[best];
+      g_pin_free.erase(g_pin_free.begin() + best);
+      return b;
+    }
+  }
+  gs_pinned b;
+  const size_t want = bytes + bytes / 4 + 4096;
+  if (hipHostMalloc(&b.p, want, hipHostMallocPortable) == hipSuccess) {
+    b.cap = want;
+  } else {
+    (void)hipGetLastError();
+    b.p = nullptr;
+    if (hipHostMalloc(&b.p, bytes, hipHostMallocPortable) == hipSuccess) b.cap = bytes;
+    else (void)hipGetLastError();
+  }
+  return b;
+}
+static void pin_release(gs_pinned b) {
+  if (!b.p) return;
+  std::lock_guard<std::mutex> lk(g_pin_mtx);
+  g_pin_free.push_back(b);
+  while (g_pin_free.size() > 8) { /* keep the pool small: drop the smallest buffer */
+    size_t k = 0;
+    for (size_t i = 1; i < g_pin_free.size(); i++)
+      if (g_pin_free[i].cap < g_pin_free[k].cap) k = i;
+    hipHostFree(g_pin_free[k].p);
+    g_pin_free.erase(g_pin_free.begin() + k);
+  }
+}
+
 struct gs_result {
-  std::vector<uint64_t> offsets;
-  std::vector<gs_hit> hits;
-  std::vector<uint8_t> flags;
+  gs_pinned offsets, hits, flags;
   gs_result_view view{};
+  ~gs_result() {
+    pin_release(offsets);
+    pin_release(hits);
+    pin_release(flags);
+  }
 };
 
-extern "C" gs_status gs_enumerate(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
-                                  const char *guide_pams, uint32_t P, const char *alt_pams,
-                                  uint32_t n_alt, uint32_t mismatches, uint32_t flags,
-                                  gs_result **out) {
+static gs_status enumerate_host(gs_index *ix, const char *guides, uint64_t n, uint32_t L, const char *guide_pams,
+                                uint32_t P, const char *alt_pams, uint32_t n_alt, uint32_t mismatches, uint32_t flags,
+                                gs_result **out) {
   if (!ix || !out || (n && !guides) || (n && P && !guide_pams)) return GS_ERR_ARG;
   GS_HIP(hipSetDevice(ix->device));
   gs_status rc = gs_reserve(ix->w_guides, n * (size_t)(L + P) + 16);
@@ -50,29 +99,43 @@ extern "C" gs_status gs_enumerate(gs_index *ix, const char *guides, uint64_t n, 
   }
   const void *d_off = nullptr, *d_hits = nullptr;
   gs_result *r = new gs_result();
+  struct guard_t {
+    gs_result *p;
+    ~guard_t() { delete p; }
+  } guard{r};
   rc = gs_enumerate_device(ix, d_g, n, L, d_p, P, alt_pams, n_alt, mismatches, flags, nullptr, &d_off,
                            &d_hits, &r->view);
-  if (rc != GS_OK) {
-    delete r;
-    return rc;
-  }
-  r->offsets.resize(n + 1);
-  r->hits.resize(r->view.n_hits);
-  GS_HIP(hipMemcpy(r->offsets.data(), d_off, 8 * (n + 1), hipMemcpyDeviceToHost));
+  if (rc != GS_OK) return rc;
+  r->offsets = pin_acquire(8 * (n + 1));
+  r->hits = pin_acquire(sizeof(gs_hit) * r->view.n_hits);
+  if (!r->offsets.p || !r->hits.p) return GS_ERR_NOMEM;
+  GS_HIP(hipMemcpy(r->offsets.p, d_off, 8 * (n + 1), hipMemcpyDeviceToHost));
   if (r->view.n_hits)
-    GS_HIP(hipMemcpy(r->hits.data(), d_hits, sizeof(gs_hit) * r->view.n_hits, hipMemcpyDeviceToHost));
+    GS_HIP(hipMemcpy(r->hits.p, d_hits, sizeof(gs_hit) * r->view.n_hits, hipMemcpyDeviceToHost));
   r->view.n_guides = n;
-  r->view.guide_offsets = r->offsets.data();
-  r->view.hits = r->hits.data();
+  r->view.guide_offsets = (const uint64_t *)r->offsets.p;
+  r->view.hits = (const gs_hit *)r->hits.p;
   r->view.n_unsupported = ix->last_unsupported;
   r->view.guide_flags = nullptr;
   if (ix->last_unsupported) {
-    r->flags.resize(n);
-    GS_HIP(hipMemcpy(r->flags.data(), ix->w_flags.p, n, hipMemcpyDeviceToHost));
-    r->view.guide_flags = r->flags.data();
+    r->flags = pin_acquire(n);
+    if (!r->flags.p) return GS_ERR_NOMEM;
+    GS_HIP(hipMemcpy(r->flags.p, ix->w_flags.p, n, hipMemcpyDeviceToHost));
+    r->view.guide_flags = (const uint8_t *)r->flags.p;
   }
+  guard.p = nullptr;
   *out = r;
   return GS_OK;
+}
+extern "C" gs_status gs_enumerate(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
+                                  const char *guide_pams, uint32_t P, const char *alt_pams,
+                                  uint32_t n_alt, uint32_t mismatches, uint32_t flags,
+                                  gs_result **out) {
+  try { /* nothing may throw across the C boundary */
+    return enumerate_host(ix, guides, n, L, guide_pams, P, alt_pams, n_alt, mismatches, flags, out);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
 }
 
 extern "C" gs_status gs_result_get(const gs_result *r, gs_result_view *view) {

@@ -603,28 +603,36 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
     }
     s->bytes += 6 * s->n;
   }
+  /* optional structures, HBM capacity spent to cut random requests: the
+   * rotated table copies (k-1 tables: 56 GB per strand at k = 14) and the inverse suffix array
+   * (4n: what two-sided seeding needs).  GS_INDEX_BUDGET_GB caps the whole index (both strands):
+   * the copies go first, then the inverse suffix array; an allocation that fails is skipped too. */
+  double budget = 1e30;
+  if (const char *e = getenv("GS_INDEX_BUDGET_GB")) budget = atof(e) * 1e9 / 2.0; /* per strand */
+  const double base_bytes = (double)s->bytes + (double)bytes; /* blocks, SA, context arrays, table */
+  const uint32_t nrot = k >= 4 ? k - 1 : 0;
+  const double rot_bytes = (double)bytes * nrot, isa_bytes = 4.0 * (double)s->n;
+  uint32_t *isa = nullptr;
+  if (ctx && !getenv("GS_NO_BIDIR") && !getenv("GS_NO_ISA") && base_bytes + isa_bytes <= budget) {
+    if (hipMalloc(&isa, 4 * s->n) == hipSuccess) {
+      hipLaunchKernelGGL(k_isa_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, (const uint32_t *)s->sa, s->n, isa);
+      s->bytes += 4 * s->n;
+    } else {
+      isa = nullptr;
+      (void)hipGetLastError();
+    }
+  }
   uint4 *rot = nullptr;
-  if (ctx && k >= 4 && !getenv("GS_NO_ROT")) {
+  if (ctx && nrot && !getenv("GS_NO_ROT") && base_bytes + (isa ? isa_bytes : 0.0) + rot_bytes <= budget) {
     /* one copy per step 0..k-2: steps 0..k-3 serve the budget-0 variants (their last
      * substituted step), step k-2 the budget-1 variants (substitutions of the second-last
      * symbol next to each other) */
-    const uint32_t nrot = k - 1;
     if (hipMalloc(&rot, bytes * nrot) == hipSuccess) {
       for (uint32_t p = 0; p < nrot; p++)
         hipLaunchKernelGGL(k_rot_copy, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, rot, k, p);
       s->bytes += bytes * nrot;
     } else {
       rot = nullptr; /* not enough memory: the plain table serves every class */
-      (void)hipGetLastError();
-    }
-  }
-  uint32_t *isa = nullptr;
-  if (rot && !getenv("GS_NO_BIDIR")) {
-    if (hipMalloc(&isa, 4 * s->n) == hipSuccess) {
-      hipLaunchKernelGGL(k_isa_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, (const uint32_t *)s->sa, s->n, isa);
-      s->bytes += 4 * s->n;
-    } else {
-      isa = nullptr;
       (void)hipGetLastError();
     }
   }
@@ -705,11 +713,26 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
   }
   GS_HIP(hipSetDevice(device));
   const uint64_t n = len + 1;
-  gs_index *ix = new gs_index();
+  gs_index *ix = new (std::nothrow) gs_index();
+  if (!ix) return GS_ERR_NOMEM;
   ix->device = device;
   ix->genome_length = len;
   hipStream_t st = nullptr;
   uint8_t *d_fwd = nullptr, *d_rev = nullptr;
+  /* every early return below (GS_HIP) releases what was allocated so far */
+  struct cleanup_t {
+    gs_index *&ix;
+    uint8_t *&a, *&b;
+    uint32_t *sa = nullptr; /* a suffix array not yet owned by a strand */
+    bool armed = true;
+    ~cleanup_t() {
+      if (a) hipFree(a);
+      if (b) hipFree(b);
+      if (!armed) return;
+      if (sa) hipFree(sa);
+      if (ix) gs_index_close(ix);
+    }
+  } cleanup{ix, d_fwd, d_rev};
   GS_HIP(hipMalloc(&d_fwd, n));
   GS_HIP(hipMalloc(&d_rev, n));
   GS_HIP(hipMemcpy(d_fwd, text, len, hipMemcpyHostToDevice));
@@ -721,6 +744,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
   for (int s = 0; s < 2 && rc == GS_OK; s++) {
     uint32_t *d_sa = nullptr;
     GS_HIP(hipMalloc(&d_sa, 4 * n));
+    cleanup.sa = d_sa;
     const uint32_t *given = s == 0 ? sa_fwd : sa_rev;
     const uint8_t *d_t = s == 0 ? d_fwd : d_rev;
     if (given) {
@@ -729,28 +753,125 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
       rc = gs_device_suffix_array(d_t, n, d_sa, st);
     }
     if (rc == GS_OK) rc = gs_strand_from_device(d_t, d_sa, n, &ix->strand[s], st);
-    if (rc != GS_OK) hipFree(d_sa);
+    if (ix->strand[s].sa == d_sa) cleanup.sa = nullptr; /* the strand owns it now (also when it failed later) */
     if (rc == GS_OK) rc = build_ptab(d_t, &ix->strand[s], pk, st);
   }
   if (rc == GS_OK) rc = build_seed_plan(ix, pk);
   if (rc == GS_OK) scan_n_runs(text, len, ix->nruns_text);
-  hipFree(d_fwd);
-  hipFree(d_rev);
-  if (rc != GS_OK) {
-    gs_index_close(ix);
-    return rc;
-  }
+  if (rc != GS_OK) return rc; /* cleanup releases everything */
+  cleanup.armed = false;
   *out = ix;
   return GS_OK;
 }
 
 extern "C" gs_status gs_index_build(const uint8_t *text, uint64_t len, int device, gs_index **out) {
-  return build_common(text, len, nullptr, nullptr, device, out);
+  try {
+    return build_common(text, len, nullptr, nullptr, device, out);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
 }
 extern "C" gs_status gs_index_build_with_sa(const uint8_t *text, uint64_t len, const uint32_t *sa_fwd,
                                             const uint32_t *sa_rev, int device, gs_index **out) {
   if (!sa_fwd || !sa_rev) return GS_ERR_ARG;
-  return build_common(text, len, sa_fwd, sa_rev, device, out);
+  try {
+    return build_common(text, len, sa_fwd, sa_rev, device, out);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
+}
+
+/* ---- native index file: the two suffix arrays, kept next to the genome text ------------------
+ * `guidescan index` of the reference stores what `enumerate` loads (src/guidescan.cxx:168-175).
+ * The device layout is derived data (210 GB at hg38 size, rebuilt from text + suffix arrays in a few
+ * seconds); what is worth storing is the result of the sort: 4 bytes per row and strand. */
+struct gs_sa_header {
+  char magic[8]; /* "GSAMDSA1" */
+  uint64_t n;    /* rows per strand = text length + 1 */
+  uint64_t text_hash;
+  uint64_t reserved[5];
+};
+static uint64_t text_fingerprint(const uint8_t *text, uint64_t len) {
+  /* every byte of the text, eight at a time (a suffix array of another text would give wrong hits
+   * silently, so no sampling): ~0.5 s at 3.1 GB */
+  uint64_t h = 0x9E3779B97F4A7C15ull ^ len;
+  uint64_t i = 0;
+  for (; i + 8 <= len; i += 8) {
+    uint64_t w;
+    memcpy(&w, text + i, 8);
+    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+    h ^= h >> 32;
+  }
+  for (; i < len; i++) h = (h ^ text[i]) * 1099511628211ull;
+  return h;
+}
+extern "C" gs_status gs_index_save_sa(gs_index *ix, const uint8_t *text, uint64_t len, const char *path) {
+  if (!ix || !text || !path || len != ix->genome_length) return GS_ERR_ARG;
+  GS_HIP(hipSetDevice(ix->device));
+  FILE *f = fopen(path, "wb");
+  if (!f) {
+    gs_set_error(std::string("cannot write ") + path);
+    return GS_ERR_IO;
+  }
+  gs_sa_header h;
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "GSAMDSA1", 8);
+  h.n = ix->strand[0].n;
+  h.text_hash = text_fingerprint(text, len);
+  bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+  const size_t chunk = 64u << 20; /* entries per copy */
+  std::vector<uint32_t> buf;
+  try {
+    buf.resize(chunk);
+  } catch (const std::bad_alloc &) {
+    fclose(f);
+    return GS_ERR_NOMEM;
+  }
+  for (int s = 0; s < 2 && ok; s++)
+    for (uint64_t at = 0; at < h.n && ok; at += chunk) {
+      const size_t m = (size_t)std::min<uint64_t>(chunk, h.n - at);
+      if (hipMemcpy(buf.data(), (const uint32_t *)ix->strand[s].sa + at, 4 * m, hipMemcpyDeviceToHost) != hipSuccess) {
+        fclose(f);
+        gs_set_error("copying the suffix array back failed");
+        return GS_ERR_DEVICE;
+      }
+      ok = fwrite(buf.data(), 4, m, f) == m;
+    }
+  ok = fclose(f) == 0 && ok;
+  if (!ok) {
+    gs_set_error(std::string("short write to ") + path);
+    return GS_ERR_IO;
+  }
+  return GS_OK;
+}
+extern "C" gs_status gs_index_open_sa(const uint8_t *text, uint64_t len, const char *path, int device,
+                                      gs_index **out) {
+  if (!text || !path || !out || len < 1) return GS_ERR_ARG;
+  FILE *f = fopen(path, "rb");
+  if (!f) {
+    gs_set_error(std::string("cannot read ") + path);
+    return GS_ERR_IO;
+  }
+  gs_sa_header h;
+  const uint64_t n = len + 1;
+  bool ok = fread(&h, sizeof(h), 1, f) == 1 && !memcmp(h.magic, "GSAMDSA1", 8) && h.n == n &&
+            h.text_hash == text_fingerprint(text, len);
+  std::vector<uint32_t> sa[2];
+  try {
+    for (int s = 0; s < 2 && ok; s++) {
+      sa[s].resize(n);
+      ok = fread(sa[s].data(), 4, n, f) == n;
+    }
+  } catch (const std::bad_alloc &) {
+    fclose(f);
+    return GS_ERR_NOMEM;
+  }
+  fclose(f);
+  if (!ok) {
+    gs_set_error(std::string(path) + " is not the suffix-array file of this genome text");
+    return GS_ERR_FORMAT;
+  }
+  return build_common(text, len, sa[0].data(), sa[1].data(), device, out);
 }
 
 extern "C" void gs_index_close(gs_index *ix) {

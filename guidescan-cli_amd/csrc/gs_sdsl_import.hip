@@ -10,6 +10,9 @@
  */
 #include "gs_common.h"
 
+#include <new>
+#include <stdexcept>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -98,20 +101,39 @@ uint64_t rank1(const parsed &P, uint64_t i) { /* ones in bv[0,i) */
   return r;
 }
 
-/* the symbol sequence stored in node v (size symbols) */
-void expand(const parsed &P, uint16_t v, uint64_t size, std::vector<uint8_t> &out) {
+/* the symbol sequence stored in node v (size symbols).  The file is user input: every node and
+ * every bit range is checked before it is followed (validate_tree), so a foreign or damaged file
+ * ends in GS_ERR_FORMAT, not in an out-of-bounds read or an endless recursion. */
+bool validate_tree(const parsed &P) {
+  const size_t nn = P.nodes.size();
+  for (size_t v = 0; v < nn; v++) {
+    const wt_node &nd = P.nodes[v];
+    if (nd.child[0] == 0xFFFF || nd.child[1] == 0xFFFF) {
+      if (nd.child[0] != nd.child[1]) return false; /* a leaf has no child at all */
+      continue;
+    }
+    /* children come after their parent in the node array (BFS order): no cycles, depth <= nodes */
+    if (nd.child[0] >= nn || nd.child[1] >= nn || nd.child[0] <= v || nd.child[1] <= v) return false;
+    if (nd.bv_pos > P.bv.bits) return false;
+  }
+  return true;
+}
+bool expand(const parsed &P, uint16_t v, uint64_t size, std::vector<uint8_t> &out, uint32_t depth = 0) {
+  if (v >= P.nodes.size() || depth > 256) return false;
   const wt_node &nd = P.nodes[v];
   out.resize(size);
   if (nd.child[0] == 0xFFFF) { /* leaf: bv_pos_rank holds the symbol */
     std::fill(out.begin(), out.end(), (uint8_t)nd.bv_pos_rank);
-    return;
+    return true;
   }
+  if (nd.bv_pos > P.bv.bits || size > P.bv.bits - nd.bv_pos) return false; /* the node's bits lie inside bv */
   const uint64_t ones = rank1(P, nd.bv_pos + size) - rank1(P, nd.bv_pos);
   std::vector<uint8_t> left, right;
-  expand(P, nd.child[0], size - ones, left);
-  expand(P, nd.child[1], ones, right);
+  if (!expand(P, nd.child[0], size - ones, left, depth + 1) || !expand(P, nd.child[1], ones, right, depth + 1))
+    return false;
   uint64_t l = 0, r = 0;
   for (uint64_t j = 0; j < size; j++) out[j] = bit(P.bv, nd.bv_pos + j) ? right[r++] : left[l++];
+  return true;
 }
 
 }  // namespace
@@ -125,6 +147,11 @@ gs_status gs_sdsl_read_text(const char *path, std::vector<uint8_t> &text) {
   fseek(f, 0, SEEK_END);
   const long fsz = ftell(f);
   fseek(f, 0, SEEK_SET);
+  if (fsz < 0) {
+    fclose(f);
+    gs_set_error(std::string("cannot size ") + path);
+    return GS_ERR_IO;
+  }
   std::vector<uint8_t> buf((size_t)fsz);
   if (fread(buf.data(), 1, buf.size(), f) != buf.size()) {
     fclose(f);
@@ -185,7 +212,10 @@ gs_status gs_sdsl_read_text(const char *path, std::vector<uint8_t> &text) {
   P.ones_before[nw] = acc;
 
   std::vector<uint8_t> bwt;
-  expand(P, 0, n, bwt);
+  if (P.bv.bits > (uint64_t)buf.size() * 8 || !validate_tree(P) || !expand(P, 0, n, bwt)) {
+    gs_set_error("inconsistent wavelet tree (not a csa_wt<wt_huff<>,64,8192> file?)");
+    return GS_ERR_FORMAT;
+  }
 
   /* LF support: C[] and per-64-row checkpoints of the symbols present */
   uint64_t cnt[256] = {0};
@@ -259,23 +289,37 @@ gs_status gs_sdsl_read_text(const char *path, std::vector<uint8_t> &text) {
 
 extern "C" gs_status gs_sdsl_extract_text(const char *index_file, uint8_t **text, uint64_t *len) {
   if (!index_file || !text || !len) return GS_ERR_ARG;
-  std::vector<uint8_t> t;
-  gs_status rc = gs_sdsl_read_text(index_file, t);
-  if (rc != GS_OK) return rc;
-  uint8_t *p = (uint8_t *)malloc(t.size() ? t.size() : 1);
-  if (!p) return GS_ERR_NOMEM;
-  memcpy(p, t.data(), t.size());
-  *text = p;
-  *len = t.size();
-  return GS_OK;
+  try { /* the parser works in std containers sized by the file's own fields */
+    std::vector<uint8_t> t;
+    gs_status rc = gs_sdsl_read_text(index_file, t);
+    if (rc != GS_OK) return rc;
+    uint8_t *p = (uint8_t *)malloc(t.size() ? t.size() : 1);
+    if (!p) return GS_ERR_NOMEM;
+    memcpy(p, t.data(), t.size());
+    *text = p;
+    *len = t.size();
+    return GS_OK;
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  } catch (const std::length_error &) {
+    gs_set_error("index file declares an impossible size");
+    return GS_ERR_FORMAT;
+  }
 }
 
 extern "C" gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out) {
   if (!prefix || !out) return GS_ERR_ARG;
-  std::vector<uint8_t> fwd;
-  gs_status rc = gs_sdsl_read_text((std::string(prefix) + ".forward").c_str(), fwd);
-  if (rc != GS_OK) return rc;
-  /* the reverse index is the FM-index of reverse_complement(forward text)
-   * (src/guidescan.cxx:146-157); it is rebuilt from the text rather than imported */
-  return gs_index_build(fwd.data(), fwd.size(), device, out);
+  try {
+    std::vector<uint8_t> fwd;
+    gs_status rc = gs_sdsl_read_text((std::string(prefix) + ".forward").c_str(), fwd);
+    if (rc != GS_OK) return rc;
+    /* the reverse index is the FM-index of reverse_complement(forward text)
+     * (src/guidescan.cxx:146-157); it is rebuilt from the text rather than imported */
+    return gs_index_build(fwd.data(), fwd.size(), device, out);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  } catch (const std::length_error &) {
+    gs_set_error("index file declares an impossible size");
+    return GS_ERR_FORMAT;
+  }
 }

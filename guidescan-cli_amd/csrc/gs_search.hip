@@ -1633,11 +1633,28 @@ static void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, d
     if (astar[o] > astar[o - 1]) astar[o] = astar[o - 1];
 }
 
+static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,
+                                       const void *d_guide_pams, uint32_t P, const char *alt_pams,
+                                       uint32_t n_alt, uint32_t mismatches, uint32_t flags,
+                                       void *stream, const void **d_offsets, const void **d_hits,
+                                       gs_result_view *stats);
 extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,
                                          const void *d_guide_pams, uint32_t P, const char *alt_pams,
                                          uint32_t n_alt, uint32_t mismatches, uint32_t flags,
                                          void *stream, const void **d_offsets, const void **d_hits,
                                          gs_result_view *stats) {
+  try { /* the plans and lists built per batch live in std containers: nothing may throw across the C boundary */
+    return enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream,
+                                 d_offsets, d_hits, stats);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
+}
+static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,
+                                       const void *d_guide_pams, uint32_t P, const char *alt_pams,
+                                       uint32_t n_alt, uint32_t mismatches, uint32_t flags,
+                                       void *stream, const void **d_offsets, const void **d_hits,
+                                       gs_result_view *stats) {
   if (!ix || (!d_guides && n) || (P && !d_guide_pams && n) || (n_alt && !alt_pams))
     return GS_ERR_ARG;
   if (n >= (1ull << 31)) return GS_ERR_ARG;

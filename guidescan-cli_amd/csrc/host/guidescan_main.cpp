@@ -3,7 +3,7 @@
  * (src/guidescan.cxx:28-95, 316-358) and database output, and calls the MI355X path through the
  * C-ABI (include/guidescan_amd.h).  Control plane only: no search logic lives here.
  *
- *   guidescan index  [--index PREFIX] GENOME.fa
+ *   guidescan index  [--index PREFIX] [--store-sa] GENOME.fa
  *       writes PREFIX.gs (chromosome names/lengths, src/genomics/seq_io.cxx:112-122) and
  *       PREFIX.dna (= the reference's <fasta>.forward.dna: upper-cased concatenated sequence,
  *       seq_io.cxx:57-63).  The FM-index itself is built on the GPU when `enumerate` starts
@@ -165,7 +165,7 @@ bool read_kmers(const std::string &path, std::vector<kmer_row> &rows, std::strin
 }
 
 int usage() {
-  std::cerr << "usage: guidescan index [--index PREFIX] GENOME.fa\n"
+  std::cerr << "usage: guidescan index [--index PREFIX] [--store-sa [--device D]] GENOME.fa\n"
                "       guidescan enumerate PREFIX -f KMERS -o OUT [-m N] [-a PAM]... [--format csv|sam]\n"
                "                 [--mode succinct|complete] [--max-off-targets N] [--start]\n"
                "                 [--rna-bulges N] [--dna-bulges N] [-t THRESHOLD] [-n FORMAT_THREADS]\n"
@@ -175,10 +175,16 @@ int usage() {
 
 int do_index(int argc, char **argv) {
   std::string fasta, prefix;
+  bool store_sa = false;
+  int device = 0;
   for (int i = 0; i < argc; i++) {
     const std::string a = argv[i];
     if (a == "--index" && i + 1 < argc)
       prefix = argv[++i];
+    else if (a == "--store-sa")
+      store_sa = true;
+    else if (a == "--device" && i + 1 < argc)
+      device = atoi(argv[++i]);
     else if (!a.empty() && a[0] != '-')
       fasta = a;
     else
@@ -204,6 +210,19 @@ int do_index(int argc, char **argv) {
   }
   std::cout << "Wrote " << prefix << ".gs and " << prefix << ".dna (" << text.size() << " bases, "
             << gs.names.size() << " sequences)\n";
+  if (store_sa) {
+    /* the part of the index worth storing: both suffix arrays (built on the GPU now), so that
+     * `enumerate` skips the sort; 8 bytes per base on disk */
+    gs_index *ix = nullptr;
+    gs_status rc = gs_index_build((const uint8_t *)text.data(), text.size(), device, &ix);
+    if (rc == GS_OK) rc = gs_index_save_sa(ix, (const uint8_t *)text.data(), text.size(), (prefix + ".sa").c_str());
+    if (ix) gs_index_close(ix);
+    if (rc != GS_OK) {
+      std::cerr << "error: " << gs_status_string(rc) << "\n";
+      return 1;
+    }
+    std::cout << "Wrote " << prefix << ".sa\n";
+  }
   return 0;
 }
 
@@ -458,8 +477,17 @@ int do_enumerate(int argc, char **argv) {
     std::vector<std::thread> bt;
     for (int d = 0; d < gpus; d++)
       bt.emplace_back([&, d]() {
-        brc[d] = from_sdsl ? gs_index_open_sdsl(prefix.c_str(), device + d, &ix[d])
-                           : gs_index_build((const uint8_t *)text.data(), text.size(), device + d, &ix[d]);
+        if (from_sdsl) {
+          brc[d] = gs_index_open_sdsl(prefix.c_str(), device + d, &ix[d]);
+        } else {
+          /* stored suffix arrays (guidescan index --store-sa) skip the sort; a file that does not
+           * belong to this text is ignored */
+          brc[d] = GS_ERR_IO;
+          if (std::ifstream(prefix + ".sa"))
+            brc[d] = gs_index_open_sa((const uint8_t *)text.data(), text.size(), (prefix + ".sa").c_str(), device + d, &ix[d]);
+          if (brc[d] == GS_ERR_IO || brc[d] == GS_ERR_FORMAT)
+            brc[d] = gs_index_build((const uint8_t *)text.data(), text.size(), device + d, &ix[d]);
+        }
         if (brc[d] != GS_OK) bmsg[d] = gs_status_string(brc[d]);
       });
     for (auto &th : bt) th.join();

@@ -122,6 +122,14 @@ gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out);
  * gs_index_open_sdsl feeds to the GPU builder.  *text is malloc'ed: release with gs_free. */
 gs_status gs_sdsl_extract_text(const char *index_file, uint8_t **text, uint64_t *len);
 
+/* Native index file: both suffix arrays of a built index (4 bytes per row and strand, with the text's
+ * length and a fingerprint), so that a later gs_index_open_sa skips the suffix sort - the part of
+ * `guidescan index` worth storing (src/guidescan.cxx:168-175 stores the whole csa_wt; the device
+ * layout here is derived data rebuilt from text + suffix arrays in seconds).  `text` as given to
+ * gs_index_build.  gs_index_open_sa returns GS_ERR_FORMAT when the file belongs to another text. */
+gs_status gs_index_save_sa(gs_index *ix, const uint8_t *text, uint64_t len, const char *path);
+gs_status gs_index_open_sa(const uint8_t *text, uint64_t len, const char *path, int device, gs_index **out);
+
 void gs_index_close(gs_index *ix);
 /* Work counters of the last gs_enumerate_device call on this handle: [0] extensions executed by the
  * Occ walk, [1] items whose matches overflowed their slots, [2] distinct matches, [4] items seeded

@@ -264,3 +264,32 @@ def test_sdsl_importer_rejects_garbage(tmp_path):
     with pytest.raises(api.GsError) as e:
         api.sdsl_extract_text(p)
     assert e.value.status in (5, 6)
+
+
+def test_sdsl_importer_rejects_damaged_files(tmp_path):
+    ROOT = ol.ROOT
+    """the reference's index file is user input: truncations, garbage and a wavelet tree whose nodes
+    point outside the file must come back as GS_ERR_FORMAT / GS_ERR_IO, never as a crash (CPU only:
+    the parser runs on the host)"""
+    from importlib import import_module
+    api = import_module("guidescan-cli_amd.api")
+    good = (ROOT / "tests" / "golden" / "toy" / "toy.idx.forward").read_bytes()
+    assert api.sdsl_extract_text(ROOT / "tests" / "golden" / "toy" / "toy.idx.forward").shape[0] > 50_000
+    rng = np.random.default_rng(0)
+    cases = {"empty": b"", "short": good[:100], "half": good[:len(good) // 2], "garbage": rng.bytes(5000),
+             "tail": good + b"x"}
+    # flip bytes inside the node table (children / bit-vector offsets) and in the size fields
+    for i, at in enumerate([0, 8, 16, len(good) - 3000, len(good) - 2600, len(good) - 2400]):
+        b = bytearray(good)
+        for j in range(8):
+            b[at + j] ^= 0xFF
+        cases[f"flip{i}"] = bytes(b)
+    for name, data in cases.items():
+        f = tmp_path / (name + ".forward")
+        f.write_bytes(data)
+        try:
+            t = api.sdsl_extract_text(f)
+            assert name.startswith("flip"), name     # a flipped byte may leave a loadable (different) tree
+            assert t.shape[0] >= 1
+        except api.GsError as e:
+            assert e.status in (4, 5, 6), (name, e.status)

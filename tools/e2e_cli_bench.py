@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end timing of the C++ CLI (kmers CSV in -> CSV database out) on a synthetic genome:
 what SURVEY.md section 8d calls rate (iii), incl. index build, kmers parsing and the text writer.
-    python tools/e2e_cli_bench.py [workload=chr1] [n_guides=100000]"""
+    python tools/e2e_cli_bench.py [workload=chr1] [n_guides=100000] [extra CLI arguments ...]"""
 import subprocess
 import sys
 import time
@@ -31,7 +31,7 @@ def main():
             f.write(f"g{i},{seqs[i].tobytes().decode()},NGG,chr1,{int(pos[i]) + 1},{chr(strands[i])}\n")
     cli = ROOT / "guidescan-cli_amd" / "bin" / "guidescan"
     t0 = time.time()
-    r = subprocess.run([str(cli), "enumerate", str(d / "g"), "-f", str(d / "k.csv"), "-o", str(d / "o.csv"), "-m", "3"],
+    r = subprocess.run([str(cli), "enumerate", str(d / "g"), "-f", str(d / "k.csv"), "-o", str(d / "o.csv"), "-m", "3"] + sys.argv[3:],
                        capture_output=True, text=True, timeout=3000)
     dt = time.time() - t0
     print(r.stdout.strip())
