@@ -129,6 +129,9 @@ def lib():
     L.gs_format_guide_scored.restype = i32
     L.gs_format_guide_scored.argtypes = [C.POINTER(GsGenomeStructure), C.POINTER(GsKmer), vp, u64, u32, u32,
                                          C.c_int64, C.c_float, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.gs_format_guides_scored.restype = i32
+    L.gs_format_guides_scored.argtypes = [C.POINTER(GsGenomeStructure), vp, u64, vp, vp, vp, vp, u32, u32, C.c_int64,
+                                          C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.gs_format_header.restype = i32
     L.gs_format_header.argtypes = [C.POINTER(GsGenomeStructure), u32, C.POINTER(vp),
                                    C.POINTER(C.c_size_t)]
@@ -175,7 +178,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
-           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa"]
+           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored"]
 
 
 def _check(rc):
@@ -217,6 +220,28 @@ def format_guide(gs, gid, sequence, pam, sense_positive, hits, mismatches, sam=F
                                             mismatches, flags, max_off_targets, float(specificity),
                                             C.byref(out), C.byref(n)))
     s = C.string_at(out, n.value).decode()
+    lib().gs_free(out)
+    return s
+
+
+def format_guides(gs, ids, seqs, pams, senses_positive, offsets, hits, specificity, mismatches, sam=False,
+                  complete=True, start=False, max_off_targets=-1, skip=None) -> bytes:
+    """the lines of a whole batch in one call (gs_format_guides_scored)"""
+    n = len(ids)
+    arr = (GsKmer * n)(*[GsKmer(ids[i].encode(), seqs[i].encode(), pams[i].encode(), int(senses_positive[i]))
+                         for i in range(n)])
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    spec = np.ascontiguousarray(specificity, dtype=np.float32)
+    sk = None if skip is None else np.ascontiguousarray(skip, dtype=np.uint8)
+    out, ln = C.c_void_p(), C.c_size_t()
+    flags = ((GS_TEXT_SAM if sam else 0) | (GS_TEXT_COMPLETE if complete else 0) |
+             (GS_FLAG_PAM_AT_START if start else 0))
+    _check(lib().gs_format_guides_scored(C.byref(gs), arr, n, offsets.ctypes.data,
+                                         hits.ctypes.data if hits.shape[0] else None, spec.ctypes.data,
+                                         sk.ctypes.data if sk is not None else None, mismatches, flags,
+                                         max_off_targets, C.byref(out), C.byref(ln)))
+    s = C.string_at(out, ln.value)
     lib().gs_free(out)
     return s
 

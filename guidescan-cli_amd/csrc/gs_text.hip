@@ -280,6 +280,202 @@ extern "C" gs_status gs_format_guide_scored(const gs_genome_structure *gs, const
                            &specificity);
 }
 
+/* ---- the CSV rows of many guides in one buffer: what the writer of `guidescan enumerate` calls.
+ * Same bytes as gs_format_guide_scored guide after guide (get_csv_lines, printer.hpp:245-300), but
+ * no per-hit strings: the 13 M lines of a 1 M-guide batch are written straight into one growing
+ * buffer, the match sequence decoded from the hit key in place. */
+namespace {
+struct outbuf {
+  char *p = nullptr;
+  size_t len = 0, cap = 0;
+  bool ok = true;
+  bool need(size_t k) {
+    if (len + k <= cap) return true;
+    size_t nc = cap ? cap + cap / 2 : (1u << 16);
+    while (nc < len + k) nc += nc / 2;
+    char *q = (char *)realloc(p, nc);
+    if (!q) {
+      ok = false;
+      return false;
+    }
+    p = q;
+    cap = nc;
+    return true;
+  }
+  void put(const char *s, size_t k) {
+    memcpy(p + len, s, k);
+    len += k;
+  }
+  void ch(char c) { p[len++] = c; }
+  void u64(uint64_t v) {
+    char t[24];
+    int k = 0;
+    do {
+      t[k++] = (char)('0' + v % 10);
+      v /= 10;
+    } while (v);
+    while (k) p[len++] = t[--k];
+  }
+};
+}  // namespace
+
+static gs_status format_csv_fast(const gs_genome_structure *gs, const uint64_t *chr_end /* prefix sums */,
+                                 const gs_kmer *k, const gs_hit *hits, uint64_t n_hits, uint32_t mismatches,
+                                 uint32_t flags, int64_t max_off_targets, float spec, outbuf &o) {
+  const bool start = flags & GS_FLAG_PAM_AT_START, complete = flags & GS_TEXT_COMPLETE;
+  const size_t L = strlen(k->sequence), P = strlen(k->pam), idl = strlen(k->id);
+  if (L < 1 || 2 * L + 3 * P > 52) return GS_ERR_ARG;
+  if (!o.need(idl + L + P + 64)) return GS_ERR_NOMEM;
+  if (n_hits == 0) { /* printer.hpp:189-199 */
+    o.put(k->id, idl);
+    o.ch(',');
+    if (start) o.put(k->pam, P);
+    o.put(k->sequence, L);
+    if (!start) o.put(k->pam, P);
+    o.put(",NA,NA,NA,0", 11);
+    if (complete) o.put(",NA,NA,NA", 9);
+    o.put(",1.0\n", 5);
+    return GS_OK;
+  }
+  char sp[64];
+  const int spl = snprintf(sp, sizeof sp, "%f", (double)spec); /* std::to_string(float) */
+  static const char B[4] = {'A', 'C', 'G', 'T'};
+  static const char PBC[5] = {'T', 'G', 'C', 'N', 'A'}; /* complement of A,C,G,N,T */
+  uint32_t cur_d = 0xFFFFFFFFu;
+  int64_t idx_in_d = 0;
+  for (uint64_t h = 0; h < n_hits; h++) {
+    const uint64_t key = hits[h].key;
+    const uint32_t d = GS_KEY_MISMATCHES(key);
+    if (d > mismatches) return GS_ERR_ARG;
+    if (d != cur_d) {
+      cur_d = d;
+      idx_in_d = 0;
+    }
+    const int64_t i = idx_in_d++;
+    if (max_off_targets != -1 && i >= max_off_targets) continue; /* raw index, :259 (break of that distance) */
+    /* resolve_absolute, src/genomics/structures.cxx:7-52 */
+    int64_t abs = hits[h].pos;
+    char st = '+';
+    if (abs < 0) {
+      abs = -abs;
+      st = '-';
+    }
+    uint32_t lo = 0, hi = gs->n_chr; /* first chromosome whose end exceeds abs */
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if ((uint64_t)abs < chr_end[mid + 1])
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    if (lo >= gs->n_chr) continue;
+    const int64_t in_chr = abs - (int64_t)chr_end[lo];
+    int64_t s, e;
+    if (st == '+') {
+      e = in_chr + 1;
+      s = e - (int64_t)L - (int64_t)P + 1;
+    } else {
+      s = in_chr + 1;
+      e = s + (int64_t)L + (int64_t)P - 1;
+    }
+    if (s < 0 || e > (int64_t)gs->chr_lengths[lo]) continue; /* boundary sentinel: no row (:280-283) */
+    const size_t cl = strlen(gs->chr_names[lo]);
+    if (!o.need(idl + 2 * (L + P) + cl + spl + 64)) return GS_ERR_NOMEM;
+    o.put(k->id, idl);
+    o.ch(',');
+    if (start) o.put(k->pam, P);
+    o.put(k->sequence, L);
+    if (!start) o.put(k->pam, P);
+    o.ch(',');
+    o.put(gs->chr_names[lo], cl);
+    o.ch(',');
+    o.u64((uint64_t)s);
+    o.ch(',');
+    o.ch(st);
+    o.ch(',');
+    o.u64(d);
+    if (complete) {
+      o.ch(',');
+      /* complement(match.sequence), decoded from the key (gs_decode_sequence + printer.hpp:232,264) */
+      const uint64_t path = (key >> 8) & ((1ull << 52) - 1);
+      for (uint32_t t = 0; t < L; t++) {
+        const char gq = start ? k->sequence[L - 1 - t] : k->sequence[t]; /* guide base under this step */
+        const char qc = start ? gq : comp(gq);                            /* the query char (index.hpp:218) */
+        const uint32_t code = (uint32_t)(path >> (50 - 2 * t)) & 3u;
+        if (code == 0) {
+          o.ch(comp(qc));
+        } else {
+          const int q = qc == 'A' ? 0 : qc == 'C' ? 1 : qc == 'G' ? 2 : qc == 'T' ? 3 : -1;
+          if (q < 0) return GS_ERR_ARG;
+          int a = (int)code - 1;
+          if (a >= q) a++;
+          o.ch((char)(comp(B[a]) | 0x20)); /* lower case marks the mismatch (index.hpp:243) */
+        }
+      }
+      for (uint32_t u = 0; u < P; u++) {
+        const uint32_t code = (uint32_t)(path >> (49 - 2 * L - 3 * u)) & 7u;
+        if (code > 4) return GS_ERR_ARG;
+        o.ch(PBC[code]);
+      }
+      o.put(",0,0", 4); /* rna_bulges, dna_bulges */
+    }
+    o.ch(',');
+    o.put(sp, (size_t)spl);
+    o.ch('\n');
+  }
+  return GS_OK;
+}
+
+extern "C" gs_status gs_format_guides_scored(const gs_genome_structure *gs, const gs_kmer *kmers, uint64_t n,
+                                             const uint64_t *offsets, const gs_hit *hits, const float *specificity,
+                                             const uint8_t *skip, uint32_t mismatches, uint32_t flags,
+                                             int64_t max_off_targets, char **out_text, size_t *out_len) {
+  if (!gs || (n && (!kmers || !offsets || !specificity)) || !out_text) return GS_ERR_ARG;
+  try {
+    std::vector<uint64_t> chr_end(gs->n_chr + 1, 0);
+    for (uint32_t i = 0; i < gs->n_chr; i++) chr_end[i + 1] = chr_end[i] + gs->chr_lengths[i];
+    outbuf o;
+    if (!o.need(n ? (size_t)((offsets[n] - offsets[0]) * 96 + n * 16 + 64) : 64)) return GS_ERR_NOMEM;
+    for (uint64_t g = 0; g < n; g++) {
+      if (skip && skip[g]) continue;
+      const gs_kmer *k = kmers + g;
+      if (!k->id || !k->sequence || !k->pam) {
+        free(o.p);
+        return GS_ERR_ARG;
+      }
+      const uint64_t b = offsets[g], e = offsets[g + 1];
+      gs_status rc;
+      if (flags & GS_TEXT_SAM) { /* the SAM writer keeps the general encoder */
+        char *tx = nullptr;
+        size_t tl = 0;
+        rc = format_guide_impl(gs, k, hits + b, e - b, mismatches, flags, max_off_targets, &tx, &tl, &specificity[g]);
+        if (rc == GS_OK) {
+          if (o.need(tl + 1)) o.put(tx, tl);
+          else rc = GS_ERR_NOMEM;
+          free(tx);
+        }
+      } else {
+        rc = format_csv_fast(gs, chr_end.data(), k, hits + b, e - b, mismatches, flags, max_off_targets,
+                             specificity[g], o);
+      }
+      if (rc != GS_OK) {
+        free(o.p);
+        return rc;
+      }
+    }
+    if (!o.need(1)) {
+      free(o.p);
+      return GS_ERR_NOMEM;
+    }
+    o.p[o.len] = 0;
+    *out_text = o.p;
+    if (out_len) *out_len = o.len;
+    return GS_OK;
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
+}
+
 extern "C" gs_status gs_decode_sequence_ex(const gs_hit_ex *hit, char *out) {
   if (!hit || !out || hit->seq_len > 32) return GS_ERR_ARG;
   memcpy(out, hit->seq, hit->seq_len);

@@ -243,6 +243,13 @@ gs_status gs_format_guide_scored(const gs_genome_structure *gs, const gs_kmer *k
                                  uint64_t n_hits, uint32_t mismatches, uint32_t flags,
                                  int64_t max_off_targets, float specificity, char **out_text,
                                  size_t *out_len);
+/* The lines of guides [0, n) of one enumerate result in ONE buffer (same bytes as
+ * gs_format_guide_scored guide after guide; rows of guides with skip[g] != 0 left out): what a
+ * writer thread calls per contiguous range of a batch.  offsets: n+1 positions into `hits`. */
+gs_status gs_format_guides_scored(const gs_genome_structure *gs, const gs_kmer *kmers, uint64_t n,
+                                  const uint64_t *offsets, const gs_hit *hits, const float *specificity,
+                                  const uint8_t *skip, uint32_t mismatches, uint32_t flags,
+                                  int64_t max_off_targets, char **out_text, size_t *out_len);
 /* write_sam_header / write_csv_header (include/genomics/printer.hpp:173-187) */
 gs_status gs_format_header(const gs_genome_structure *gs, uint32_t flags, char **out_text,
                            size_t *out_len);

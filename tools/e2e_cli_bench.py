@@ -19,7 +19,8 @@ def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "chr1"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
     lengths = {"chr1": [synth.CHR1_LENGTH], "hg38": synth.GRCH38_LENGTHS, "saccer3": synth.SACCER3_LENGTHS}[workload]
-    d = Path("/tmp/gs_e2e")
+    import os
+    d = Path(os.environ.get("GS_E2E_DIR", "/tmp/gs_e2e"))
     d.mkdir(exist_ok=True)
     text, names, lengths = synth.make_genome(lengths, seed=1)
     text.tofile(d / "g.dna")
