@@ -314,7 +314,21 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
           okm[jj] = on ? (((2u << (m - kkv[jj])) - 1u) & ~((1u << lo8) - 1u)) : 0u;
           wq[jj] = make_uint4(0u, 0u, 0u, 0u);
           if (on) wq[jj] = load16_a2(sv.ctx16 + row0[jj]);
-          count_lines(c_c16, on, sv.ctx16 + row0[jj]);
+        }
+        if constexpr (CNT) {
+          /* distinct lines of the pass: the lanes' groups in order (2l, 2l+1), a group counted when
+           * its first or its last byte lies in a line the group before it did not reach */
+          const bool on0 = nrow[0] != 0u, on1 = nrow[1] != 0u;
+          const uint32_t f0 = (uint32_t)((uintptr_t)(sv.ctx16 + row0[0]) >> 6), l0 = (uint32_t)(((uintptr_t)(sv.ctx16 + row0[0]) + 15u) >> 6);
+          const uint32_t f1 = (uint32_t)((uintptr_t)(sv.ctx16 + row0[1]) >> 6), l1 = (uint32_t)(((uintptr_t)(sv.ctx16 + row0[1]) + 15u) >> 6);
+          const uint32_t mylast = on1 ? l1 : l0;
+          const uint32_t prev = (uint32_t)__shfl_up((int)mylast, 1);
+          const int pact = __shfl_up((int)(on0 || on1), 1);
+          uint32_t add = 0;
+          if (on0) add += ((lane == 0u || !pact || prev != f0) ? 1u : 0u) + (l0 != f0 ? 1u : 0u);
+          if (on1) add += ((!on0 || l0 != f1) ? 1u : 0u) + (l1 != f1 ? 1u : 0u);
+          for (int o = 32; o > 0; o >>= 1) add += (uint32_t)__shfl_xor((int)add, o);
+          c_c16 += add;
         }
         uint32_t cm = 0u; /* candidate rows of this lane: bit 8*jj + r */
 #pragma unroll
