@@ -25,7 +25,7 @@ extern "C" const char *gs_status_string(gs_status s) {
   }
   return "unknown";
 }
-extern "C" const char *gs_version(void) { return "guidescan-amd 0.1 (gfx950)"; }
+extern "C" const char *gs_version(void) { return "guidescan-amd 0.2 (gfx950)"; }
 
 /* Page-locked host buffers for the results of the host-pointer entry point, kept in a small
  * process-wide pool: a 1 M-guide batch returns ~215 MB of hits, and a fresh pageable buffer costs
