@@ -37,8 +37,15 @@ struct gs_strand_dev {
    * a (k-2)-mer are contiguous.  Entry = {sp, cnt | flag<<31, mask_lo, mask_hi}:
    * cnt==0: k-mer absent; flag: some row of the interval has a non-ACGT symbol (or the text
    * start) within the 16 symbols preceding its suffix, so it must take the Occ walk;
-   * mask bit t (t = 3 symbols, 2 bits each, nearest first): some row is preceded by triple t. */
+   * mask (64 bits in z, w): four 16-bit sets; bit 16j + v: some row of the interval is preceded by
+   * the symbol pair v (two symbols, 2 bits each, nearest first) at distances mask_off[j],
+   * mask_off[j]+1 (0 = the symbol right before the suffix).  The offsets are 0, 2, 4 and - so that
+   * for 20-mers with a 3-symbol PAM whose first symbol is a wildcard the fourth pair is the PAM's two
+   * fixed symbols - 21-k (7 at k = 14); any offsets are correct, they only set the filter's power.  A site with at
+   * most b substitutions among the symbols a seed still has to match leaves at least (pairs - b)
+   * of its query pairs intact, so a seed whose interval shows fewer of them cannot reach a hit. */
   const uint4 *ptab;
+  uint32_t mask_off; /* 4 bits per pair position */
   /* rotated copies of the table: copy p (p < k-2) has the symbol of
    * consumption step p moved to the lowest index bits, so the three substitutions at step p
    * of an otherwise fixed k-mer are neighbours in one 64-byte line.  k-2 tables back to back. */

@@ -487,7 +487,7 @@ __global__ void k_ptab_finish(uint4 *tab, uint64_t entries) {
  * non-ACGT symbol or runs off the text start flag their k-mer's table entry */
 __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n, uint32_t k,
                             uint32_t *ctx, uint16_t *ctx16, uint4 *tab, uint32_t *exc_count,
-                            uint32_t *exc_row, uint64_t *exc_sym, uint32_t exc_cap) {
+                            uint32_t *exc_row, uint64_t *exc_sym, uint32_t exc_cap, uint32_t mask_off) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= n) return;
   const uint64_t p = sa[r];
@@ -517,9 +517,11 @@ __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n,
           exc_sym[at] = nib;
         }
       }
-      /* which 3-symbol left contexts occur in this k-mer's interval */
-      const uint32_t t = w & 63u;
-      atomicOr(t < 32u ? &tab[c].z : &tab[c].w, 1u << (t & 31u));
+      /* which symbol pairs occur to the left of this k-mer's rows: four 16-bit sets, pair j =
+       * the symbols 2j and 2j+1 before the suffix (nearest first), bit = 4 bits of the pair */
+      const uint32_t o0 = mask_off & 15u, o1 = (mask_off >> 4) & 15u, o2 = (mask_off >> 8) & 15u, o3 = (mask_off >> 12) & 15u;
+      atomicOr(&tab[c].z, (1u << ((w >> (2u * o0)) & 15u)) | (1u << (16u + ((w >> (2u * o1)) & 15u))));
+      atomicOr(&tab[c].w, (1u << ((w >> (2u * o2)) & 15u)) | (1u << (16u + ((w >> (2u * o3)) & 15u))));
     }
   }
 }
@@ -554,6 +556,20 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   if (!getenv("GS_NO_CTX")) {
     GS_HIP(hipMalloc(&ctx, 4 * s->n + 16));
     GS_HIP(hipMalloc(&ctx16, 2 * s->n + 32)); /* one row group of padding (k_search reads groups of eight) */
+    /* pair positions of the context mask (gs_strand_dev::mask_off) */
+    uint32_t off3 = k < 21 ? 21u - k : 6u;
+    if (off3 < 6) off3 = 6;
+    if (off3 > 14) off3 = 14;
+    uint32_t mask_off = 0u | (2u << 4) | (4u << 8) | (off3 << 12);
+    if (const char *e = getenv("GS_MASK_OFFSETS")) { /* experiments: "0,2,4,7" */
+      mask_off = 0;
+      for (uint32_t j = 0; j < 4 && *e; j++) {
+        const unsigned long v = strtoul(e, (char **)&e, 10);
+        mask_off |= (uint32_t)(v > 14 ? 14 : v) << (4 * j);
+        if (*e == ',') e++;
+      }
+    }
+    s->d.mask_off = mask_off;
     /* exception rows: counted in a first pass when the first guess is too small */
     uint32_t *d_cnt = nullptr, *d_er = nullptr;
     uint64_t *d_es = nullptr;
@@ -564,7 +580,7 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
       GS_HIP(hipMalloc(&d_es, 8 * (size_t)cap));
       GS_HIP(hipMemsetAsync(d_cnt, 0, 4, st));
       hipLaunchKernelGGL(k_ctx_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, d_text,
-                         (const uint32_t *)s->sa, s->n, k, ctx, ctx16, tab, d_cnt, d_er, d_es, cap);
+                         (const uint32_t *)s->sa, s->n, k, ctx, ctx16, tab, d_cnt, d_er, d_es, cap, mask_off);
       GS_HIP(hipMemcpyAsync(&h_cnt, d_cnt, 4, hipMemcpyDeviceToHost, st));
       GS_HIP(hipStreamSynchronize(st));
       if (h_cnt <= cap) break;

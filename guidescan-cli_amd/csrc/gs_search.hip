@@ -104,15 +104,18 @@ struct gs_search_args {
  * CNT: count the distinct 64-byte lines every load instruction asks for (bench.py's algorithmic
  * bytes of THIS algorithm); the timed kernel is the CNT = false instantiation. */
 #ifndef GS_WAVES_EU
-#define GS_WAVES_EU 6 /* 80 VGPRs: measured best of 4..8 (two-sided seeding, hg38-sized) */
+#define GS_WAVES_EU 6 /* the walking variant: 80 VGPRs, measured best of 4..8 in round 1 */
 #endif
-template <bool CNT>
-__global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(GS_WAVES_EU, GS_WAVES_EU))) void k_search(gs_search_args a) {
-  __shared__ uint4 s_stack[SEARCH_WAVES][WAVE_LDS_ENTRIES];
-  extern __shared__ uint32_t s_plan[]; /* seeding plan: one LDS read instead of a global one */
-  const uint32_t wave = threadIdx.x / WAVE;
+#ifndef GS_WAVES_EU_FAST
+#define GS_WAVES_EU_FAST 8 /* the table-only variants carry no X/G stack code: <= 64 VGPRs */
+#endif
+/* WALK: the Occ walk (X/G stacks, G fan-out) is compiled in - the reference-order walk from the root
+ * and inputs whose remainder does not fit ctx[].  The table-only variant (every interval resolved
+ * against the context arrays) needs neither the 3.5 KiB stack array per wave nor that code. */
+template <bool CNT, bool WALK>
+__device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk, uint32_t *s_plan) {
+  constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
   const uint32_t lane = lane_id();
-  uint4 *stk = s_stack[wave];
   if (a.plan_lds) {
     for (uint32_t i = threadIdx.x; i < a.plan_words; i += WAVE * SEARCH_WAVES) s_plan[i] = a.combo[a.plan_src + i];
     __syncthreads();
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
   /* a seeding step pushes at most 64 nodes: it runs only while that keeps the stacks within
    * `limit`, so the single-pop DFS of the G iterations always finds its reserve */
   const uint32_t seed_low = limit > WAVE ? (limit - WAVE < SEED_LOW_MAX ? limit - WAVE : SEED_LOW_MAX) : 0u;
-  uint4 *vq = stk + STACK_ENTRIES;             /* queued seed descriptors */
+  uint4 *vq = stk + STK;                       /* queued seed descriptors */
   uint2 *own2 = (uint2 *)(vq + VQ_CAP);        /* owner markers of a pass, two per lane */
   uint32_t *own = (uint32_t *)own2;
 
@@ -190,20 +193,24 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     /* route a live child: emit (terminal), push on X or on G */
     auto route = [&](bool live, bool term, bool single, uint32_t csp, uint32_t cep, uint64_t cmeta,
                      uint32_t vflag = 0u) __attribute__((always_inline)) {
-      const bool px = live && !term && single;
-      const bool pg = live && !term && !single;
       const bool em = live && term;
-      const uint64_t bx = __ballot(px);
-      if (bx) {
-        if (px) stk[xs + lanes_below(bx)] = make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
-        xs += __popcll(bx);
-      }
-      const uint64_t bg = __ballot(pg);
-      if (bg) {
-        if (pg)
-          stk[STACK_ENTRIES - 1u - (gs + lanes_below(bg))] =
-              make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
-        gs += __popcll(bg);
+      if constexpr (WALK) {
+        const bool px = live && !term && single;
+        const bool pg = live && !term && !single;
+        const uint64_t bx = __ballot(px);
+        if (bx) {
+          if (px) stk[xs + lanes_below(bx)] = make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+          xs += __popcll(bx);
+        }
+        const uint64_t bg = __ballot(pg);
+        if (bg) {
+          if (pg)
+            stk[STACK_ENTRIES - 1u - (gs + lanes_below(bg))] =
+                make_uint4(csp, cep, (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+          gs += __popcll(bg);
+        }
+      } else {
+        (void)single;
       }
       const uint64_t be = __ballot(em);
       if (be) {
@@ -446,20 +453,36 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     const bool seeding = a.pt_k != 0;
     bool seeds_left = seeding;
     uint32_t pidx0 = 0; /* table index of the exact k-prefix of the query */
-    uint64_t allow3[3] = {0ull, 0ull, 0ull}; /* triples within 0,1,2 substitutions of the next 3 symbols */
-    const bool use_mask3 = seeding && a.pt_k + 3u <= L; /* the next three steps are guide steps */
+    /* context mask of this strand's seeds (gs_strand_dev::ptab): the query's symbol pairs at the four
+     * pair positions after the table depth.  A pair of two guide steps may be broken by a
+     * substitution (each substitution breaks at most one pair); a pair of two PAM steps must occur
+     * as one of the pairs the PAM patterns allow; a pair straddling guide and PAM is not tested. */
+    uint32_t qpairs = 0;      /* 4 bits per pair position: the query's pair */
+    uint32_t g_pairs = 0;     /* bit j: pair position j lies inside the guide */
+    uint32_t n_gpairs = 0;
+    uint32_t pam_pairs = 0;   /* bit j: pair position j lies inside the PAM */
+    uint32_t pam16[4] = {0u, 0u, 0u, 0u}; /* PAM pair positions: the 16-bit set of pairs some pattern allows */
+    const bool use_mask = seeding;
     if (seeding) {
       for (uint32_t t = 0; t < a.pt_k; ++t)
         pidx0 |= ((uint32_t)(gr_q >> (2u * t)) & 3u) << (2u * (a.pt_k - 1u - t));
-      const uint32_t q3 = (uint32_t)(gr_q >> (2u * a.pt_k)) & 63u;
-      for (uint32_t t3 = 0; t3 < 64u; ++t3) {
-        const uint32_t x = t3 ^ q3;
-        const uint32_t d = ((x & 3u) != 0u) + (((x >> 2) & 3u) != 0u) + (((x >> 4) & 3u) != 0u);
-        if (d <= 0u) allow3[0] |= 1ull << t3;
-        if (d <= 1u) allow3[1] |= 1ull << t3;
-        if (d <= 2u) allow3[2] |= 1ull << t3;
+      for (uint32_t j = 0; j < 4u; ++j) {
+        const uint32_t s0 = a.pt_k + ((sd.mask_off >> (4u * j)) & 15u), s1 = s0 + 1u;
+        if (s1 < L) {
+          qpairs |= ((uint32_t)(gr_q >> (2u * s0)) & 15u) << (4u * j);
+          g_pairs |= 1u << j;
+          n_gpairs++;
+        } else if (s0 >= L && s1 < T_end) {
+          pam_pairs |= 1u << j;
+          for (uint32_t pj = 0; pj < npams; ++pj) {
+            const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+            const uint32_t c0 = (pw >> (3u * (s0 - L))) & 7u, c1 = (pw >> (3u * (s1 - L))) & 7u;
+            for (uint32_t v = 0; v < 16u; ++v)
+              if ((c0 == 4u || (v & 3u) == c0) && (c1 == 4u || (v >> 2) == c1)) pam16[j] |= 1u << v;
+          }
+        }
       }
-    } else {
+    } else if constexpr (WALK) {
       /* root: whole SA range, nothing consumed (index.hpp:388-391) */
       if (is_single(0, 0, 0)) {
         xs = 1;
@@ -536,19 +559,18 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
             route(ok, true, false, rowA, rowA, ((uint64_t)tot << 56) | gpath | ppath, 0u);
           }
         }
-        /* context masks for the other strand's seeds: the triples within 0, 1, 2 substitutions of
-         * the three symbols it consumes next - the complemented X symbols, last first */
-        uint64_t allow_b[3] = {~0ull, ~0ull, ~0ull};
-        if (sx >= 3u) {
-          uint32_t q3b = 0;
-          for (uint32_t j = 0; j < 3u; ++j) q3b |= (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - j))) & 3u)) << (2u * j);
-          allow_b[0] = allow_b[1] = allow_b[2] = 0ull;
-          for (uint32_t t3 = 0; t3 < 64u; ++t3) {
-            const uint32_t x = t3 ^ q3b;
-            const uint32_t d = ((x & 3u) != 0u) + (((x >> 2) & 3u) != 0u) + (((x >> 4) & 3u) != 0u);
-            if (d <= 0u) allow_b[0] |= 1ull << t3;
-            if (d <= 1u) allow_b[1] |= 1ull << t3;
-            if (d <= 2u) allow_b[2] |= 1ull << t3;
+        /* context mask for the other strand's seeds: the symbols it consumes next are the complemented
+         * X symbols, last first - all guide symbols: up to four pairs, each broken by at most one
+         * of the substitutions the seed's budget leaves for X */
+        uint32_t qpairs_b = 0, b_pairs = 0, n_bpairs = 0;
+        for (uint32_t j = 0; j < 4u; ++j) {
+          const uint32_t o = (sb.mask_off >> (4u * j)) & 15u;
+          if (o + 1u < sx) { /* both symbols inside X */
+            const uint32_t v = (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - o))) & 3u)) |
+                               ((3u - ((uint32_t)(gr_q >> (2u * (sx - 2u - o))) & 3u)) << 2);
+            qpairs_b |= v << (4u * j);
+            b_pairs |= 1u << j;
+            n_bpairs++;
           }
         }
         const bool plb_lds = a.plan_lds != 0u;
@@ -633,8 +655,14 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
               bool live = act && ecnt != 0u && !(a.dbg_skip & 2u);
               /* no row of the interval has a left context within the budget left for X */
               const uint32_t bl = m - jb;
-              const uint64_t am = bl == 0u ? allow_b[0] : bl == 1u ? allow_b[1] : bl == 2u ? allow_b[2] : ~0ull;
-              if (!eflag && ((((uint64_t)ent.w << 32) | ent.z) & am) == 0ull) live = false;
+              if (!eflag) {
+                const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
+                uint32_t intact = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j)
+                  if ((b_pairs >> j) & 1u) intact += (em[j] >> ((qpairs_b >> (4u * j)) & 15u)) & 1u;
+                if (intact + bl < n_bpairs) live = false;
+              }
               const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)jb << 56) | path;
               /* the queue is empty here (one-sided seeding has not started); intervals larger than a
                * descriptor holds are verified piece by piece */
@@ -779,9 +807,17 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         /* context mask: drop the seed when none of the 3-symbol left contexts present in its
          * interval is within the remaining budget of the next three query symbols */
         const uint32_t bl = m - (sj + mm); /* budget left (>= 0 by construction) */
-        const uint64_t amask = bl == 0u ? allow3[0] : bl == 1u ? allow3[1] : bl == 2u ? allow3[2] : ~0ull;
-        const uint64_t emask = ((uint64_t)ent.w << 32) | ent.z;
-        const bool hopeless = use_mask3 && eflag == 0u && (emask & amask) == 0ull;
+        bool hopeless = false;
+        if (use_mask && eflag == 0u) {
+          const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
+          uint32_t intact = 0;
+#pragma unroll
+          for (uint32_t j = 0; j < 4u; ++j) {
+            if ((g_pairs >> j) & 1u) intact += (em[j] >> ((qpairs >> (4u * j)) & 15u)) & 1u;
+            if (((pam_pairs >> j) & 1u) && (em[j] & pam16[j]) == 0u) hopeless = true;
+          }
+          hopeless = hopeless || intact + bl < n_gpairs;
+        }
         const bool live = act && ecnt != 0u && !hopeless && !(a.dbg_skip & 2u);
         const uint32_t c2 = s2 == q2 ? 0u : 1u + s2 - (s2 > q2 ? 1u : 0u);
         const uint32_t c1 = s1 == q1 ? 0u : 1u + s1 - (s1 > q1 ? 1u : 0u);
@@ -792,8 +828,8 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         /* every interval is resolved right here against ctx[] (exception rows included, large
          * ones in pieces); without the context arrays the seeds continue as ordinary nodes
          * (k < L: never terminal) */
-        const bool ver = live && a.v_rem != 0u;
-        route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
+        const bool ver = live && (!WALK || a.v_rem != 0u);
+        if constexpr (WALK) route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
         /* advance the (class, position) cursor */
         spos += WAVE;
         if (spos >= span) {
@@ -834,6 +870,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         continue;
       }
       if (total == 0) break;
+      if constexpr (WALK) {
       const uint32_t room = total < limit ? limit - total : 0u;
 
       if (xs > 0 && (xs >= WAVE || gs == 0 || room < (MAX_FANOUT - 1) * WAVE)) {
@@ -984,6 +1021,7 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
         route(live, cterm, single, csp, cep, cmeta);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      } /* WALK */
     }
     if (lane == 0) a.counts[slot] = n_match;
     if (n_match > item_cap) n_ovf++;
@@ -1002,6 +1040,17 @@ __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per
     }
   }
 }
+
+#define GS_DEF_SEARCH(NAME, CNT, WALK, WEU)                                                                          \
+  __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(WEU, WEU))) void NAME(          \
+      gs_search_args a) {                                                                                             \
+    __shared__ uint4 s_stack[SEARCH_WAVES][((WALK) ? STACK_ENTRIES : 0) + VQ_CAP + 32];                                \
+    extern __shared__ uint32_t s_plan[]; /* seeding plan: one LDS read instead of a global one */                     \
+    k_search_body<CNT, WALK>(a, s_stack[threadIdx.x / WAVE], s_plan);                                                  \
+  }
+GS_DEF_SEARCH(k_search_walk, false, true, GS_WAVES_EU)       /* reference-order walk; remainders beyond ctx[] */
+GS_DEF_SEARCH(k_search_fast, false, false, GS_WAVES_EU_FAST) /* the timed kernel */
+GS_DEF_SEARCH(k_search_count, true, false, GS_WAVES_EU_FAST) /* the same with the request tally (bench.py) */
 
 /* ---- prepare: ASCII -> packed records (process.hpp:51-63) ------------------ */
 __device__ __forceinline__ int base_code(uint8_t c) {
@@ -2027,27 +2076,35 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       }
       sa.plan_lds = sa.plan_words <= (getenv("GS_PLAN_LDS") ? (uint32_t)atol(getenv("GS_PLAN_LDS")) : 1024u) ? 1u : 0u;
     }
-    /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as
-     * their LDS (stacks + verification queue: 6 KiB per wave, + the plan) allows */
+    /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as their
+     * LDS (verification queue 2.5 KiB per wave, + 3.5 KiB of stacks in the walking variant, + the
+     * plan) and the registers (8 waves per SIMD = 8 workgroups per CU) allow */
+    const bool walk = sa.pt_k == 0 || sa.v_rem == 0;
     const size_t dyn = sa.plan_lds ? 4 * (size_t)sa.plan_words : 0;
-    uint32_t grid = (uint32_t)cus * (uint32_t)(160u * 1024u / (WAVE_LDS_ENTRIES * 16u * SEARCH_WAVES + dyn));
+    const size_t lds_wg = sizeof(uint4) * ((walk ? STACK_ENTRIES : 0) + VQ_CAP + 32) * SEARCH_WAVES + dyn;
+    uint32_t per_cu = (uint32_t)(160u * 1024u / lds_wg);
+    const uint32_t weu = walk ? GS_WAVES_EU : GS_WAVES_EU_FAST;
+    if (per_cu > weu) per_cu = weu; /* 4 SIMDs x weu waves = weu four-wave workgroups per CU */
+    uint32_t grid = (uint32_t)cus * per_cu;
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
     if (getenv("GS_DEBUG")) {
       int occ = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search<false>, WAVE * SEARCH_WAVES, dyn);
-      fprintf(stderr, "[gs] k_search: grid %u x %u threads, LDS %zu + %zu B per workgroup, %d workgroups per CU resident\n",
-              grid, WAVE * SEARCH_WAVES, sizeof(uint4) * WAVE_LDS_ENTRIES * SEARCH_WAVES, dyn, occ);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, walk ? k_search_walk : k_search_fast, WAVE * SEARCH_WAVES, dyn);
+      fprintf(stderr, "[gs] k_search (%s): grid %u x %u threads, LDS %zu B per workgroup, %d workgroups per CU resident\n",
+              walk ? "walk" : "table", grid, WAVE * SEARCH_WAVES, lds_wg, occ);
     }
     GS_HIP(hipEventRecord(ix->ev[1], st));
     for (uint32_t c = 0; c < n_chunks; c++) { /* four PAM patterns per pass, appending to the same slots */
       sa.guides = guides + (size_t)c * ng;
       sa.append = c ? 1u : 0u;
       if (c) GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
-      if (count_req)
-        hipLaunchKernelGGL(k_search<true>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+      if (walk)
+        hipLaunchKernelGGL(k_search_walk, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+      else if (count_req)
+        hipLaunchKernelGGL(k_search_count, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else
-        hipLaunchKernelGGL(k_search<false>, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+        hipLaunchKernelGGL(k_search_fast, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
     }
     GS_HIP(hipEventRecord(ix->ev[2], st));
     GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
