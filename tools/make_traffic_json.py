@@ -7,8 +7,8 @@ FETCH_SIZE / WRITE_SIZE bytes of the timed k_search dispatch and a hash of the k
 
 FETCH.json / WRITE.json are tools/pmc_summary.py outputs of `rocprofv3 --pmc FETCH_SIZE` /
 `--pmc WRITE_SIZE` passes of `bench.py --steps 1 --warmup 0 --cpu-sample 0` (tools/profile_round.sh);
-the k_search dispatches there are: the reference-order walk sample, the counting pass
-(k_search<true>), the timed step, side steps - the first k_search<false> dispatch after the counting
+the search dispatches there are: the reference-order walk sample (k_search_walk), the counting pass
+(k_search_count), the timed step, side steps - the first k_search_fast dispatch after the counting
 pass is the timed step.  Counters are in KB."""
 import json
 import sys
@@ -23,11 +23,11 @@ def main():
     tag, workload, batch, m, ffile, wfile = sys.argv[1:7]
 
     def pick(path, counter):
-        """the timed step = the first k_search<false> dispatch after the counting pass (k_search<true>)"""
+        """the timed step = the first k_search_fast dispatch after the counting pass (k_search_count)"""
         d = json.loads(Path(path).read_text())
-        counting = d.get("k_search<true>", [])
+        counting = d.get("k_search_count", [])
         after = max((e["dispatch_id"] for e in counting), default=-1)
-        rows = [e for e in d["k_search<false>"] if e["dispatch_id"] > after]
+        rows = [e for e in d["k_search_fast"] if e["dispatch_id"] > after]
         return rows[0][counter] * 1024.0, rows[0]["duration_ms"]
     fetch, dur_f = pick(ffile, "FETCH_SIZE")
     write, dur_w = pick(wfile, "WRITE_SIZE")
@@ -39,7 +39,7 @@ def main():
                  "kernel_sha": bench.kernel_stamp(),
                  "source": f"profiles/{tag}_pmc_fetch_size.json + {tag}_pmc_write_size.json: rocprofv3 --pmc FETCH_SIZE / "
                            f"WRITE_SIZE (separate passes, tools/profile_round.sh) of `bench.py --steps 1 --warmup 0 "
-                           f"--cpu-sample 0`, the timed k_search<false> dispatch (the first after the counting pass)"})
+                           f"--cpu-sample 0`, the timed k_search_fast dispatch (the first after the counting pass k_search_count)"})
     out.write_text(json.dumps(recs, indent=1))
     print(json.dumps(recs[-1]))
 
