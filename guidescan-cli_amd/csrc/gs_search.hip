@@ -580,102 +580,139 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         };
         const uint32_t nclsB = a.nclsB;
         const uint32_t nlanes = nclsB ? PLB(4u * (nclsB - 1u) + 1u) : 0u;
-        for (uint32_t pj = 0; pj < npams; ++pj) {
-          const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-          uint32_t nn = 0;
-          for (uint32_t u = 0; u < P; ++u) nn += ((pw >> (3u * u)) & 7u) == 4u;
-          for (uint32_t e = 0; e < (1u << (2u * nn)); ++e) {
-            /* the k-mer of the other strand: step P-1-u holds the complement of PAM symbol u, step
-             * P+y the complement of guide symbol L-1-y */
-            uint32_t pidxb = 0, ee = e;
-            uint64_t ppath = 0;
-            for (uint32_t u = 0; u < P; ++u) {
-              const uint32_t pc = (pw >> (3u * u)) & 7u;
-              uint32_t base = pc;
-              if (pc == 4u) {
-                base = ee & 3u;
-                ee >>= 2;
+        /* the guide part of the other strand's k-mer: step P+y holds the complement of guide symbol L-1-y */
+        uint32_t pidxg = 0;
+        for (uint32_t y = 0; y < nY; ++y)
+          pidxg |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (k - 1u - P - y));
+        /* steps over (PAM pattern bpj, expansion be of its N's, 64 lanes from bc0 of the plan's lane
+         * space), then one last round that only drains the queue: written as one loop so that the
+         * verification is instantiated once */
+        uint32_t bpj = 0, be = 0, bc0 = 0, bnn = 0, pidxb = 0;
+        uint64_t ppath = 0;
+        bool bfinal = nlanes == 0u;
+        for (;;) {
+          uint32_t rem = 0, first = 0, jb = 0, lo = 0, eflag = 0;
+          uint64_t cmeta = 0;
+          if (!bfinal) {
+            if (bc0 == 0u) {
+              /* the PAM part: step P-1-u holds the complement of PAM symbol u ('N': the expansion's base) */
+              const uint32_t pw = bpj == 0 ? gr_pam0 : bpj == 1 ? gr_pam1 : bpj == 2 ? gr_pam2 : gr_pam3;
+              bnn = 0;
+              for (uint32_t u = 0; u < P; ++u) bnn += ((pw >> (3u * u)) & 7u) == 4u;
+              uint32_t ee = be;
+              pidxb = pidxg;
+              ppath = 0;
+              for (uint32_t u = 0; u < P; ++u) {
+                const uint32_t pc = (pw >> (3u * u)) & 7u;
+                uint32_t base = pc;
+                if (pc == 4u) {
+                  base = ee & 3u;
+                  ee >>= 2;
+                }
+                ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
+                pidxb |= (3u - base) << (2u * (k - P + u));
               }
-              ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
-              pidxb |= (3u - base) << (2u * (k - P + u));
             }
-            for (uint32_t y = 0; y < nY; ++y)
-              pidxb |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (k - 1u - P - y));
             /* lane space of one expansion: the plan's classes one after the other; inside a class
              * (position mask ci) x (3^jb digit combinations), the digit of the last consumed
              * substituted symbol running fastest, so the three lanes that differ only there share
              * one 64-byte line of that step's rotated copy (or of the plain table when it is the
              * k-mer's last step) */
-            for (uint32_t c0 = 0; c0 < nlanes; c0 += WAVE) {
-              const uint32_t idx = c0 + lane;
-              const bool act = idx < nlanes;
-              uint32_t cls = 0, cbase = 0;
-              for (uint32_t c = 0; c + 1u < nclsB; ++c) {
-                const uint32_t ce = PLB(4u * c + 1u);
-                if (idx >= ce) {
-                  cls = c + 1u;
-                  cbase = ce;
-                }
+            const uint32_t idx = bc0 + lane;
+            const bool act = idx < nlanes;
+            uint32_t cls = 0, cbase = 0;
+            for (uint32_t c = 0; c + 1u < nclsB; ++c) {
+              const uint32_t ce = PLB(4u * c + 1u);
+              if (idx >= ce) {
+                cls = c + 1u;
+                cbase = ce;
               }
-              const uint32_t cmw = PLB(4u * cls + 2u);
-              const uint32_t jb = cmw & 15u, lo = (cmw >> 4) & 15u, pw3 = cmw >> 8;
-              const uint32_t i2 = idx - cbase;
-              const uint32_t ci = jb ? __umulhi(i2, PLB(4u * cls + 3u)) : i2;
-              uint32_t dg = i2 - ci * pw3;
-              uint32_t mk = act ? PLB(PLB(4u * cls) + ci) : 0u;
-              uint32_t pidx = pidxb;
-              uint64_t path = ppath;
-              uint32_t slast = 0xFFFFFFFFu;
-              if (mk) slast = P + (31u - (uint32_t)__clz((int)mk));
-              while (mk) {
-                const uint32_t y = 31u - (uint32_t)__clz((int)mk);
-                mk &= ~(1u << y);
-                const uint32_t third = __umul24(dg, 43691u) >> 17;
-                const uint32_t d = dg - 3u * third;
-                dg = third;
-                const uint32_t t = L - 1u - y;
-                const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
-                const uint32_t sym = (qc + 1u + d) & 3u;
-                path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
-                pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
+            }
+            const uint32_t cmw = PLB(4u * cls + 2u);
+            const uint32_t pw3 = cmw >> 8;
+            jb = cmw & 15u;
+            lo = (cmw >> 4) & 15u;
+            const uint32_t i2 = idx - cbase;
+            const uint32_t ci = jb ? __umulhi(i2, PLB(4u * cls + 3u)) : i2;
+            uint32_t dg = i2 - ci * pw3;
+            uint32_t mk = act ? PLB(PLB(4u * cls) + ci) : 0u;
+            uint32_t pidx = pidxb;
+            uint64_t path = ppath;
+            uint32_t slast = 0xFFFFFFFFu;
+            if (mk) slast = P + (31u - (uint32_t)__clz((int)mk));
+            while (mk) {
+              const uint32_t y = 31u - (uint32_t)__clz((int)mk);
+              mk &= ~(1u << y);
+              const uint32_t third = __umul24(dg, 43691u) >> 17;
+              const uint32_t d = dg - 3u * third;
+              dg = third;
+              const uint32_t t = L - 1u - y;
+              const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+              const uint32_t sym = (qc + 1u + d) & 3u;
+              path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
+              pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
+            }
+            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+            {
+              const uint4 *ep = sb.ptab + pidx;
+              if (slast <= k - 2u && sb.ptab_rot != nullptr) {
+                const uint32_t sh = 2u * (k - 1u - slast);
+                const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
+                                      ((pidx >> sh) & 3u);
+                ep = sb.ptab_rot + (((size_t)slast << (2u * k)) + ridx);
               }
-              uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-              {
-                const uint4 *ep = sb.ptab + pidx;
-                if (slast <= k - 2u && sb.ptab_rot != nullptr) {
-                  const uint32_t sh = 2u * (k - 1u - slast);
-                  const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
-                                        ((pidx >> sh) & 3u);
-                  ep = sb.ptab_rot + (((size_t)slast << (2u * k)) + ridx);
-                }
-                if (act) ent = *ep;
-                count_lines(c_tab, act, ep);
-              }
-              const uint32_t ecnt = ent.y & 0x7FFFFFFFu, eflag = ent.y >> 31;
-              bool live = act && ecnt != 0u && !(a.dbg_skip & 2u);
-              /* no row of the interval has a left context within the budget left for X */
-              const uint32_t bl = m - jb;
-              if (!eflag) {
-                const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
-                uint32_t intact = 0;
+              if (act) ent = *ep;
+              count_lines(c_tab, act, ep);
+            }
+            const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
+            eflag = ent.y >> 31;
+            bool live = act && ecnt != 0u && !(a.dbg_skip & 2u);
+            /* fewer of the query's pairs to the left of the interval's rows than the budget left for
+             * X can break: no row can match */
+            const uint32_t bl = m - jb;
+            if (!eflag) {
+              const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
+              uint32_t intact = 0;
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j)
-                  if ((b_pairs >> j) & 1u) intact += (em[j] >> ((qpairs_b >> (4u * j)) & 15u)) & 1u;
-                if (intact + bl < n_bpairs) live = false;
-              }
-              const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)jb << 56) | path;
-              /* the queue is empty here (one-sided seeding has not started); intervals larger than a
-               * descriptor holds are verified piece by piece */
-              uint32_t rem = (live && !(a.dbg_skip & 1u)) ? ecnt : 0u, first = ent.x;
-              do {
-                const uint32_t rows = rem < a.v_max ? rem : a.v_max;
-                vq[lane] = make_uint4(first, (jb << 14) | (rows << 17) | (lo << DSC_LO) | (eflag << DSC_EXC),
-                                      (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                verify(true, WAVE, vq);
-                first += rows;
-                rem -= rows;
-              } while (__ballot(rem != 0u));
+              for (uint32_t j = 0; j < 4u; ++j)
+                if ((b_pairs >> j) & 1u) intact += (em[j] >> ((qpairs_b >> (4u * j)) & 15u)) & 1u;
+              if (intact + bl < n_bpairs) live = false;
+            }
+            cmeta = ((uint64_t)k << 59) | ((uint64_t)jb << 56) | path;
+            rem = (live && !(a.dbg_skip & 1u)) ? ecnt : 0u;
+            first = ent.x;
+          }
+          /* the surviving seeds wait in the queue (it is this phase's alone: one-sided seeding has not
+           * started) until a pass can be filled - a pass costs the same instructions for 10 seeds as
+           * for 64; intervals larger than a descriptor holds are queued piece by piece */
+          for (;;) {
+            const uint64_t bq = __ballot(rem != 0u);
+            if (bq && qn + WAVE <= VQ_CAP) {
+              const uint32_t rows = rem < a.v_max ? rem : a.v_max;
+              if (rem != 0u)
+                vq[qn + lanes_below(bq)] = make_uint4(first, (jb << 14) | (rows << 17) | (lo << DSC_LO) | (eflag << DSC_EXC),
+                                                      (uint32_t)cmeta, (uint32_t)(cmeta >> 32));
+              qn += __popcll(bq);
+              first += rows;
+              rem -= rows;
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              continue;
+            }
+            if (qn >= VQ_DRAIN || (bq && qn != 0u) || (bfinal && qn != 0u)) {
+              const uint32_t take = qn < WAVE ? qn : WAVE;
+              qn -= take;
+              verify(true, take, vq + qn);
+              continue;
+            }
+            break;
+          }
+          if (bfinal) break;
+          bc0 += WAVE;
+          if (bc0 >= nlanes) {
+            bc0 = 0;
+            if (++be >= (1u << (2u * bnn))) {
+              be = 0;
+              if (++bpj >= npams) bfinal = true;
             }
           }
         }
