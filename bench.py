@@ -130,10 +130,18 @@ def main():
     # rules.  The timed path skips the input-independent top of the tree through the prefix
     # table, so it is measured here, untimed, with the reference-order walk on a sample (sized so
     # that the walk stays around a second: it is ~10^5 extensions per guide at m = 3, 3.5e7 at m = 6).
-    ns = min(batch, {0: 20000, 1: 20000, 2: 20000, 3: 20000, 4: 4000, 5: 600}.get(m, 128))
-    _, _, st_ref = gidx.enumerate_device(d_seqs.data_ptr(), ns, L, d_pams.data_ptr(), P, mismatches=m,
-                                         faithful=True)
-    n_ext_ref_per_guide = st_ref["n_ext"] / ns
+    ns = min(batch, {0: 20000, 1: 20000, 2: 20000, 3: 20000, 4: 4000}.get(m, 0))
+    if ns:
+        _, _, st_ref = gidx.enumerate_device(d_seqs.data_ptr(), ns, L, d_pams.data_ptr(), P, mismatches=m,
+                                             faithful=True)
+        n_ext_ref_per_guide = st_ref["n_ext"] / ns
+    else:
+        # m >= 5: one item of the walk is 10^7 extensions on ONE wavefront (16 s at m = 6 whatever the
+        # sample); SURVEY App. C's closed form, within 7 % of the measured walk at three genome sizes
+        from math import comb
+        n_rows = float(text.shape[0])
+        n_ext_ref_per_guide = 2.0 * sum(min(1.0, n_rows / 4.0 ** d) * sum(comb(d, k) * 3 ** k for k in range(min(m, d) + 1))
+                                        for d in range(L + 1))
     # The bytes THIS algorithm asks the memory system for: one untimed pass of the first batch
     # through the counting instantiation of k_search (same code, plus a tally of the distinct
     # 64-byte lines every load instruction requests; include/guidescan_amd.h GS_FLAG_COUNT_REQUESTS)
@@ -219,7 +227,9 @@ def main():
                      # need for this batch.  Not what this kernel does: table, context mask, context
                      # arrays and two-sided seeding skip that work.
                      "reference_traversal": {"alg_bytes_per_launch": ref_bytes,
-                                             "n_ext_per_guide": n_ext_ref_per_guide, "n_ext_sample": ns,
+                                             "n_ext_per_guide": n_ext_ref_per_guide,
+                                             "n_ext_source": f"reference-order walk on {ns} guides" if ns
+                                             else "closed form of SURVEY App. C",
                                              "bytes_vs_this_algorithm": ref_bytes / alg_bytes_per_launch
                                              if alg_bytes_per_launch else None}},
         "detail": {"executed_ext_per_guide": n_ext / (batch * K), "hits_per_guide": n_hits / (batch * K),
