@@ -375,10 +375,13 @@ def stub_main(args):
 
 
 def kernel_stamp():
-    """sha256 of the sources that decide k_search's memory traffic"""
+    """sha256 of the sources that decide k_search's memory traffic: the kernel itself (gs_search.hip from
+    its argument struct to the end of its wrappers), the device helpers, the index layout and builder"""
     import hashlib
     h = hashlib.sha256()
-    for f in ("gs_search.hip", "gs_device.h", "gs_common.h", "gs_index.hip"):
+    src = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_search.hip").read_text()
+    h.update(src[src.index("struct gs_search_args {"):src.index("/* ---- prepare: ASCII")].encode())
+    for f in ("gs_device.h", "gs_common.h", "gs_index.hip"):
         h.update((ROOT / "guidescan-cli_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
