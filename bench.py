@@ -376,12 +376,15 @@ def stub_main(args):
 
 def kernel_stamp():
     """sha256 of the sources that decide k_search's memory traffic: the kernel itself (gs_search.hip from
-    its argument struct to the end of its wrappers), the device helpers, the index layout and builder"""
+    its argument struct to the end of its wrappers), the device helpers, the device layout of the index
+    (struct gs_strand_dev) and its builder"""
     import hashlib
     h = hashlib.sha256()
     src = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_search.hip").read_text()
     h.update(src[src.index("struct gs_search_args {"):src.index("/* ---- prepare: ASCII")].encode())
-    for f in ("gs_device.h", "gs_common.h", "gs_index.hip"):
+    com = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_common.h").read_text()
+    h.update(com[com.index("struct gs_strand_dev {"):com.index("struct gs_strand {")].encode())  # the device layout
+    for f in ("gs_device.h", "gs_index.hip"):
         h.update((ROOT / "guidescan-cli_amd" / "csrc" / f).read_bytes())
     return h.hexdigest()[:16]
 
