@@ -384,8 +384,9 @@ def kernel_stamp():
     h.update(src[src.index("struct gs_search_args {"):src.index("/* ---- prepare: ASCII")].encode())
     com = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_common.h").read_text()
     h.update(com[com.index("struct gs_strand_dev {"):com.index("struct gs_strand {")].encode())  # the device layout
-    for f in ("gs_device.h", "gs_index.hip"):
-        h.update((ROOT / "guidescan-cli_amd" / "csrc" / f).read_bytes())
+    h.update((ROOT / "guidescan-cli_amd" / "csrc" / "gs_device.h").read_bytes())
+    bld = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_index.hip").read_text()
+    h.update(bld[:bld.index("C-ABI: index lifecycle")].encode())  # the builder kernels, not the handle bookkeeping
     return h.hexdigest()[:16]
 
 

@@ -22,6 +22,7 @@ LIB_PATH = Path(os.environ.get("GS_LIB_PATH", str(PKG / "libgsamd.so")))
 GS_FLAG_PAM_AT_START = 1
 GS_FLAG_FAITHFUL_WALK = 2
 GS_FLAG_COUNT_REQUESTS = 4
+GS_FLAG_RAW_COUNTS = 8
 
 
 class GsError(RuntimeError):
@@ -44,7 +45,8 @@ class GsResultView(C.Structure):
                 ("guide_offsets", C.POINTER(C.c_uint64)), ("hits", C.POINTER(GsHit)),
                 ("n_ext", C.c_uint64), ("n_matches", C.c_uint64),
                 ("ms_search", C.c_float), ("ms_total", C.c_float),
-                ("n_unsupported", C.c_uint64), ("guide_flags", C.POINTER(C.c_uint8))]
+                ("n_unsupported", C.c_uint64), ("guide_flags", C.POINTER(C.c_uint8)),
+                ("raw_hits", C.POINTER(C.c_uint32))]
 
 
 class GsSaReport(C.Structure):
@@ -142,6 +144,8 @@ def lib():
     L.gs_result_ex_get.restype = i32
     L.gs_result_ex_get.argtypes = [vp, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]
     L.gs_result_ex_free.argtypes = [vp]
+    L.gs_result_ex_raw_hits.restype = i32
+    L.gs_result_ex_raw_hits.argtypes = [vp, C.POINTER(vp)]
     L.gs_decode_sequence_ex.restype = i32
     L.gs_decode_sequence_ex.argtypes = [vp, C.c_char_p]
     L.gs_enumerate_general.restype = i32
@@ -178,7 +182,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
-           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored"]
+           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits"]
 
 
 def _check(rc):
@@ -427,7 +431,7 @@ class GenomeIndex:
         return {k: int(getattr(rep, k)) for k, _ in GsSaReport._fields_}
 
     def enumerate(self, seqs: np.ndarray, pams: np.ndarray, mismatches=3, alt_pams=(), start=False,
-                  faithful=False):
+                  faithful=False, raw_counts=False):
         """seqs uint8[n,L], pams uint8[n,P] -> (offsets uint64[n+1], hits HIT_DTYPE[], stats dict).
         Hits of guide i are hits[offsets[i]:offsets[i+1]] in the reference's canonical order."""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
@@ -440,7 +444,8 @@ class GenomeIndex:
             if len(p) != P:
                 raise ValueError("alt PAM length differs from the guides' PAM length")
         r = C.c_void_p()
-        flags = (GS_FLAG_PAM_AT_START if start else 0) | (GS_FLAG_FAITHFUL_WALK if faithful else 0)
+        flags = ((GS_FLAG_PAM_AT_START if start else 0) | (GS_FLAG_FAITHFUL_WALK if faithful else 0) |
+                 (GS_FLAG_RAW_COUNTS if raw_counts else 0))
         _check(lib().gs_enumerate(self._h, seqs.ctypes.data, n, L, pams.ctypes.data if P else None, P,
                                   alt if alt_pams else None, len(alt_pams), mismatches, flags,
                                   C.byref(r)))
@@ -455,6 +460,8 @@ class GenomeIndex:
                 hits = np.empty(0, dtype=HIT_DTYPE)
             stats = dict(n_ext=int(v.n_ext), n_matches=int(v.n_matches), n_hits=int(v.n_hits),
                          ms_search=float(v.ms_search), ms_total=float(v.ms_total),
+                         raw_hits=(np.ctypeslib.as_array(v.raw_hits, shape=(n,)).copy() if raw_counts and n and v.raw_hits
+                                   else None),
                          needs_general=(np.nonzero(np.ctypeslib.as_array(v.guide_flags, shape=(n,)) & 1)[0].tolist()
                                         if v.n_unsupported and n else []))
         finally:

@@ -107,7 +107,7 @@ struct gs_index {
   gs_strand strand[2];
   /* per-handle workspace, grown on demand, reused across calls */
   gs_buffer w_guides, w_slots, w_counts, w_nmatch, w_nhits, w_offsets, w_hits, w_misc, w_blocksums,
-      w_grec, w_flags, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_tmp,
+      w_grec, w_flags, w_raw, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_tmp,
       /* device-wide ordering of guides with more matches than an LDS sort holds (gs_search.hip) */
       w_b_src, w_b_cnt, w_b_prefix, w_b_recs, w_b_w0, w_b_w0b, w_b_w1, w_b_idx, w_b_idxb, w_b_keep, w_b_keeps,
       w_b_rows, w_b_rowss, w_b_redo_pos,
@@ -115,6 +115,7 @@ struct gs_index {
   /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
   double seen_mean[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
   double seen_max[8] = {0};
+  bool last_raw_valid = false;   /* w_raw holds the raw hit counts of the last batch (GS_FLAG_RAW_COUNTS) */
   uint64_t last_unsupported = 0; /* guides of the last batch flagged GS_GUIDE_NEEDS_GENERAL (w_flags) */
   uint64_t seen_key[8] = {0};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -330,9 +330,16 @@ __global__ void k_gen_first(const unsigned long long *hit_scan, const uint64_t *
   if (g < n) guide_first[g] = hit_scan[first_rec[g]];
 }
 
+/* hits per guide before the sets drop duplicate sequences (off_target_counter, process.hpp:25-27) */
+__global__ void k_gen_raw(const gs_grec *recs, uint64_t T, unsigned long long *raw) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < T) atomicAdd(&raw[recs[r].g], (unsigned long long)(recs[r].ep - recs[r].sp + 1u));
+}
+
 struct gs_result_ex {
   std::vector<uint64_t> offsets;
   std::vector<gs_hit_ex> hits;
+  std::vector<uint32_t> raw;
 };
 
 #define GS_TRY(expr)                 \
@@ -382,6 +389,7 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
     ~res_guard() { delete p; }
   } guard{res};
   res->offsets.assign(n + 1, 0);
+  res->raw.assign(n, 0);
   if (n == 0) {
     guard.p = nullptr;
     *out = res;
@@ -470,6 +478,16 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
   sa.recs = (gs_grec *)d_a.p;
   sa.slot_off = (const uint64_t *)d_off.p;
   hipLaunchKernelGGL(k_search_general, dim3(grid), dim3(WAVE), 0, st, sa);
+  {
+    dbuf d_raw;
+    GS_TRY(d_raw.get(8 * n));
+    GS_HIP(hipMemsetAsync(d_raw.p, 0, 8 * n, st));
+    hipLaunchKernelGGL(k_gen_raw, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, st, (const gs_grec *)d_a.p, T,
+                       (unsigned long long *)d_raw.p);
+    std::vector<unsigned long long> hr(n);
+    GS_HIP(hipMemcpy(hr.data(), d_raw.p, 8 * n, hipMemcpyDeviceToHost));
+    for (uint64_t g = 0; g < n; g++) res->raw[g] = hr[g] > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)hr[g];
+  }
   /* canonical order: (guide, distance, index, sequence, row) */
   size_t tb = 0, tb2 = 0, tb3 = 0;
   GS_TRY(d_flag.get(4 * T));
@@ -570,6 +588,11 @@ extern "C" gs_status gs_result_ex_get(const gs_result_ex *r, uint64_t *n_guides,
   if (n_guides) *n_guides = r->offsets.size() - 1;
   if (offsets) *offsets = r->offsets.data();
   if (hits) *hits = r->hits.data();
+  return GS_OK;
+}
+extern "C" gs_status gs_result_ex_raw_hits(const gs_result_ex *r, const uint32_t **raw_hits) {
+  if (!r || !raw_hits) return GS_ERR_ARG;
+  *raw_hits = r->raw.data();
   return GS_OK;
 }
 extern "C" void gs_result_ex_free(gs_result_ex *r) { delete r; }

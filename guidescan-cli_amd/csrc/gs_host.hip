@@ -75,12 +75,13 @@ static void pin_release(gs_pinned b) {
 }
 
 struct gs_result {
-  gs_pinned offsets, hits, flags;
+  gs_pinned offsets, hits, flags, raw;
   gs_result_view view{};
   ~gs_result() {
     pin_release(offsets);
     pin_release(hits);
     pin_release(flags);
+    pin_release(raw);
   }
 };
 
@@ -122,6 +123,13 @@ static gs_status enumerate_host(gs_index *ix, const char *guides, uint64_t n, ui
     if (!r->flags.p) return GS_ERR_NOMEM;
     GS_HIP(hipMemcpy(r->flags.p, ix->w_flags.p, n, hipMemcpyDeviceToHost));
     r->view.guide_flags = (const uint8_t *)r->flags.p;
+  }
+  r->view.raw_hits = nullptr;
+  if ((flags & GS_FLAG_RAW_COUNTS) && ix->last_raw_valid && n) {
+    r->raw = pin_acquire(4 * n);
+    if (!r->raw.p) return GS_ERR_NOMEM;
+    GS_HIP(hipMemcpy(r->raw.p, ix->w_raw.p, 4 * n, hipMemcpyDeviceToHost));
+    r->view.raw_hits = (const uint32_t *)r->raw.p;
   }
   guard.p = nullptr;
   *out = r;

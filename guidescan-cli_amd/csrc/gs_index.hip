@@ -896,7 +896,7 @@ extern "C" void gs_index_close(gs_index *ix) {
   gs_strand_free(&ix->strand[0]);
   gs_strand_free(&ix->strand[1]);
   gs_buffer *bufs[] = {&ix->w_guides, &ix->w_slots, &ix->w_counts, &ix->w_nmatch, &ix->w_nhits,
-                       &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec, &ix->w_flags,
+                       &ix->w_offsets, &ix->w_hits, &ix->w_misc, &ix->w_blocksums, &ix->w_grec, &ix->w_flags, &ix->w_raw,
                        &ix->w_ovf_list, &ix->w_grec2, &ix->w_slots2, &ix->w_counts2, &ix->w_nmatch2,
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_tmp, &ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix,
                        &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx, &ix->w_b_idxb,

@@ -1633,6 +1633,26 @@ __global__ void k_mark_redo(const uint32_t *list, uint32_t n_o, uint32_t *redo_p
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_o) redo_pos[list[i]] = i;
 }
+/* hits of a guide BEFORE the per-distance sets drop duplicate sequences: what the reference's
+ * threshold filter counts (off_target_counter, process.hpp:25-27: ep - sp + 1 per callback, one
+ * callback per PAM pattern that matches).  One wavefront per guide over its raw match records;
+ * a guide whose matches overflowed its slots has far more than the filter's bound: saturated. */
+__global__ __launch_bounds__(256) void k_raw_counts(const uint4 *slots, const uint32_t *counts, uint32_t n, uint32_t cap,
+                                                    uint32_t *raw) {
+  const uint32_t g = blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE, lane = lane_id();
+  if (g >= n) return;
+  const uint32_t c0 = counts[2 * g], c1 = counts[2 * g + 1];
+  unsigned long long s = 0;
+  if (c0 > cap || c1 > cap) {
+    s = 0xFFFFFFFFull;
+  } else {
+    const uint4 *base = slots + (size_t)g * 2 * cap;
+    for (uint32_t i = lane; i < c0; i += WAVE) s += base[i].w - base[i].z + 1u;
+    for (uint32_t i = lane; i < c1; i += WAVE) s += base[cap + i].w - base[cap + i].z + 1u;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  }
+  if (lane == 0) raw[g] = s > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)s;
+}
 /* sum and maximum of the per-item match counts (slot sizing of the next batch) */
 __global__ void k_count_stats(const uint32_t *counts, uint32_t n_items, unsigned long long *out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2383,6 +2403,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       GS_HIP(hipMemcpyAsync(h_cstat, d_stats + 14, 16, hipMemcpyDeviceToHost, st));
       GS_HIP(hipStreamSynchronize(st));
     }
+  }
+  ix->last_raw_valid = false;
+  if (flags & GS_FLAG_RAW_COUNTS) { /* before k_order replaces the raw records by the unique ones */
+    if ((rc = gs_reserve(ix->w_raw, 4 * ((size_t)n + 1))) != GS_OK) return rc;
+    hipLaunchKernelGGL(k_raw_counts, dim3((n32 + 3) / 4), dim3(256), 0, st, (const uint4 *)ix->w_slots.p,
+                       (const uint32_t *)ix->w_counts.p, n32, cap, (uint32_t *)ix->w_raw.p);
+    ix->last_raw_valid = true;
   }
   if (!big_batch)
     if ((rc = run_order((uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_counts.p,

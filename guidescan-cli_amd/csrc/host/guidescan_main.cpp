@@ -344,17 +344,19 @@ static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
   const uint32_t n_alt = P ? job.n_alt : 0;
   const bool bulges = job.rna > 0 || job.dna > 0;
   gs_status rc;
-  /* --threshold t (process.hpp:66-76): a guide with more than one site within t mismatches (both
-   * indexes, bulges off) is dropped before the real search */
+  /* --threshold t (process.hpp:66-76): a guide with more than one hit within t mismatches (both
+   * indexes, bulges off; counted per PAM pattern, before duplicate sequences collapse) is dropped
+   * before the real search */
   if (job.threshold > 0) {
     gs_result *cres = nullptr;
     rc = gs_enumerate(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), n_alt, (uint32_t)job.threshold,
-                      job.sflags, &cres);
+                      job.sflags | GS_FLAG_RAW_COUNTS, &cres);
     if (rc != GS_OK) return gs_status_string(rc);
     gs_result_view cv;
     gs_result_get(cres, &cv);
     b.skip.assign(n, 0);
-    for (size_t g = 0; g < n; g++) b.skip[g] = cv.guide_offsets[g + 1] - cv.guide_offsets[g] > 1;
+    /* raw counts: a site that two PAM patterns of the list match counts twice, as off_target_counter does */
+    for (size_t g = 0; g < n; g++) b.skip[g] = cv.raw_hits[g] > 1;
     /* guides the fast path cannot count: through the general path (rare, exact) */
     if (cv.n_unsupported) {
       std::string s2, p2;
@@ -372,9 +374,9 @@ static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
         gs_result_free(cres);
         return gs_status_string(rc);
       }
-      const uint64_t *xo = nullptr;
-      gs_result_ex_get(cx, nullptr, &xo, nullptr);
-      for (size_t j = 0; j < idx.size(); j++) b.skip[idx[j]] = xo[j + 1] - xo[j] > 1;
+      const uint32_t *xraw = nullptr;
+      gs_result_ex_raw_hits(cx, &xraw);
+      for (size_t j = 0; j < idx.size(); j++) b.skip[idx[j]] = xraw[j] > 1;
       gs_result_ex_free(cx);
     }
     gs_result_free(cres);

@@ -73,6 +73,11 @@ typedef struct {
  * 64-byte lines each of its load instructions asks for (gs_index_last_counters).  Same results,
  * slower; never set in a timed call. */
 #define GS_FLAG_COUNT_REQUESTS 4u
+/* Also return, per guide, the number of hits BEFORE duplicate sequences are dropped
+ * (gs_result_view.raw_hits): the quantity the reference's --threshold filter compares with 1
+ * (off_target_counter, process.hpp:25-27 and 66-76 - one count per PAM pattern that matches, so a
+ * site two patterns of the list match counts twice).  Saturates at 2^32-1. */
+#define GS_FLAG_RAW_COUNTS 8u
 
 typedef struct {
   uint64_t n_guides;
@@ -94,6 +99,7 @@ typedef struct {
    * when n_unsupported == 0. */
   uint64_t n_unsupported;
   const uint8_t *guide_flags;
+  const uint32_t *raw_hits; /* n_guides entries with GS_FLAG_RAW_COUNTS, else NULL */
 } gs_result_view;
 #define GS_GUIDE_NEEDS_GENERAL 1u
 
@@ -289,6 +295,8 @@ gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint64_t n, uint
                               uint32_t flags, gs_result_ex **out);
 gs_status gs_result_ex_get(const gs_result_ex *r, uint64_t *n_guides, const uint64_t **guide_offsets,
                            const gs_hit_ex **hits);
+/* per guide: hits before duplicate sequences are dropped (what --threshold compares, process.hpp:25-27) */
+gs_status gs_result_ex_raw_hits(const gs_result_ex *r, const uint32_t **raw_hits);
 void gs_result_ex_free(gs_result_ex *r);
 /* match.sequence of a general-path hit as a C string; out needs 33 bytes */
 gs_status gs_decode_sequence_ex(const gs_hit_ex *hit, char *out);

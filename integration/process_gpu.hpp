@@ -49,10 +49,11 @@ namespace genomics {
     if (opts.threshold > 0) {
       gs_result* cres = nullptr;
       gs_status rc = gs_enumerate(gpu, seqs.data(), kmers.size(), L, pams.data(), P, alts.data(), n_alt,
-                                  opts.threshold, flags, &cres);
+                                  opts.threshold, flags | GS_FLAG_RAW_COUNTS, &cres);
       if (rc != GS_OK) throw std::runtime_error(std::string("threshold pass: ") + gs_status_string(rc));
       gs_result_view cv; gs_result_get(cres, &cv);
-      for (size_t g = 0; g < kmers.size(); g++) skip[g] = cv.guide_offsets[g + 1] - cv.guide_offsets[g] > 1;
+      // off_target_counter (process.hpp:25-27) counts per PAM pattern, before the sets drop duplicates
+      for (size_t g = 0; g < kmers.size(); g++) skip[g] = cv.raw_hits[g] > 1;
       gs_result_free(cres);
     }
 

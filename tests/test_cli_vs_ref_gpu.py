@@ -105,7 +105,10 @@ def test_cli_accepts_what_the_reference_accepts(tmp_path):
     P = len(rows[0][2])
     alts = [p for p in ("NAG", "NGA", "RGG", "NGT", "NCG") if len(p) == P]
     for cfg in (dict(m=2, alt=tuple(alts)), dict(m=3, fmt="sam", alt=tuple(alts)), dict(m=1, start=True, alt=tuple(alts[:4])),
-                dict(m=2, thr=1, alt=("NAG",)), dict(m=2, maxo=2, complete=False)):
+                dict(m=2, thr=1, alt=("NAG",)), dict(m=2, maxo=2, complete=False),
+                # the threshold filter counts per PAM pattern (process.hpp:25-27): with the guides' own
+                # pattern given again as an alt PAM every site counts twice and every guide is dropped
+                dict(m=2, thr=1, alt=("NGG",)), dict(m=3, thr=2, alt=("NGG", "NAG"), fmt="sam")):
         want = pipe.run_shim(tmp_path / "r.idx", kcsv, tmp_path / "want", **cfg)
         out = tmp_path / "got"
         subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(kcsv), "-o", str(out), "-n", "2",

@@ -554,3 +554,18 @@ def test_repeat_family_genome_bit_exact(monkeypatch):
     finally:
         gidx.close()
         oidx.close()
+
+
+def test_raw_hit_counts_before_dedupe(toy_gpu):
+    """GS_FLAG_RAW_COUNTS: hits per guide before duplicate sequences collapse - with the guides' own PAM
+    pattern listed again as an alt PAM every hit counts twice (off_target_counter, process.hpp:25-27)"""
+    toy, oidx, gidx = toy_gpu
+    group = [k for k in toy["kmers"] if k.pam][:24]
+    seqs = np.array([list(k.sequence.encode()) for k in group], dtype=np.uint8)
+    pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8)
+    off1, hits1, st1 = gidx.enumerate(seqs, pams, mismatches=2, raw_counts=True)
+    assert np.array_equal(st1["raw_hits"], np.diff(off1).astype(np.uint32))
+    off2, hits2, st2 = gidx.enumerate(seqs, pams, mismatches=2, alt_pams=("NGG",), raw_counts=True)
+    assert np.array_equal(off2, off1) and hits2.tobytes() == hits1.tobytes()      # the sets drop the duplicates
+    assert np.array_equal(st2["raw_hits"], 2 * st1["raw_hits"])                   # the counter does not
+    assert st1["raw_hits"].sum() > 0
