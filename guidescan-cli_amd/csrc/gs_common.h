@@ -22,6 +22,20 @@
 #define GS_BLOCK_ROWS 128u
 #define GS_BLOCK_SHIFT 7u
 
+/* A PAM-pair table (gs_pairtab.hip): the depth-k prefix table restricted to the rows whose left context
+ * has the pair `code` (two 2-bit symbols) at offsets v_rem-2, v_rem-1 and only A,C,G,T nearer than
+ * that.  Entry = {first of its rows in the table's own row arrays, rows, z, w}: with one row z is
+ * that row's context word and w its row in the strand's suffix array; with more z, w are the
+ * strand table's pair masks over these rows only. */
+struct gs_pairtab_dev {
+  const uint4 *tab;
+  const uint4 *rot;      /* rotated copies of consumption steps rot_first .. k-2 */
+  const uint16_t *c16;   /* per row of the table: nearest eight context symbols */
+  const uint32_t *ctx;   /* all sixteen */
+  const uint32_t *rowid; /* its row in the strand's suffix array */
+  uint32_t rot_first;
+  uint32_t code;
+};
 struct gs_strand_dev {
   const uint4 *blocks;       /* (n >> 7) + 1 blocks of 4 x uint4 */
   const uint32_t *sa;        /* full suffix array, n entries */
@@ -101,6 +115,14 @@ struct gs_buffer {
   size_t cap = 0;
 };
 
+struct gs_pairtab_host {
+  bool valid = false;
+  uint32_t v_rem = 0, code = 0, rot_first = 31;
+  gs_pairtab_dev d[2]{};
+  void *mem[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+  uint64_t bytes = 0, used = 0;
+};
+
 struct gs_index {
   int device = 0;
   uint64_t genome_length = 0;
@@ -130,7 +152,20 @@ struct gs_index {
   unsigned long long last_counters[16] = {0}; /* k_search's stats array of the last gs_enumerate_device call */
   std::vector<gs_nrun> nruns_text; /* 'N' runs of the forward text */
   gs_buffer w_cand;                /* per-batch literal-N candidate windows (device) */
+  gs_buffer w_rec;                 /* seed recipes of the last (budget, geometry, thresholds): full | a | b */
+  uint64_t rec_key[2] = {0, 0};
+  bool rec_valid = false;
+  uint32_t n_rec_full = 0, n_rec_a = 0, n_rec_b = 0;
+  uint32_t rec_a_rot_first = 31;   /* lowest consumption step whose rotated copy rec_a reads (31: none) */
+  /* PAM-pair tables (gs_pairtab.hip), built on first use for the pairs a batch's patterns end in */
+  gs_pairtab_host pairtab[2];
+  uint64_t pair_clock = 0;
 };
+
+/* make sure slot `slot` holds the tables of pair `code` at context depth v_rem with rotated copies from
+ * step rot_first on (fewer when memory is short); valid stays false when they do not fit */
+gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, hipStream_t st);
+void gs_pairtab_free(gs_index *ix, uint32_t slot);
 
 #define GS_HIP(expr)                                                              \
   do {                                                                            \

@@ -144,6 +144,8 @@ struct gs_prep_args {
   uint32_t n, L, P, n_alt, start;
   uint32_t chunk;            /* this launch packs patterns 4*chunk .. 4*chunk+3 of alt_pams ++ [k.pam] */
   uint32_t force_invalid;    /* an alt PAM needs the general path: every guide does */
+  uint32_t *pair_hist;       /* or nullptr: [17] patterns of valid guides by the pair of bases they end in (consumption
+                                order; code = first | second << 2), [16] = patterns that end in an 'N' */
 };
 
 /* k_prepare (gs_search.hip): ASCII guides/PAMs -> packed records, process.hpp:51-63 */

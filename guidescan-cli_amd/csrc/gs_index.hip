@@ -901,12 +901,14 @@ extern "C" void gs_index_close(gs_index *ix) {
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_tmp, &ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix,
                        &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx, &ix->w_b_idxb,
                        &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_redo_pos,
-                       &ix->w_cand, &ix->w_score, &ix->w_score_io};
+                       &ix->w_cand, &ix->w_rec, &ix->w_score, &ix->w_score_io};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)
     if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
   if (ix->d_combo) hipFree(ix->d_combo);
+  gs_pairtab_free(ix, 0);
+  gs_pairtab_free(ix, 1);
   delete ix;
 }
 extern "C" gs_status gs_index_last_guide_flags(const gs_index *ix, const void **d_flags, uint64_t *n_unsupported) {
@@ -922,7 +924,7 @@ extern "C" gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]
 }
 extern "C" uint64_t gs_index_genome_length(const gs_index *ix) { return ix ? ix->genome_length : 0; }
 extern "C" uint64_t gs_index_device_bytes(const gs_index *ix) {
-  return ix ? ix->strand[0].bytes + ix->strand[1].bytes : 0;
+  return ix ? ix->strand[0].bytes + ix->strand[1].bytes + ix->pairtab[0].bytes + ix->pairtab[1].bytes : 0;
 }
 extern "C" gs_status gs_index_meta(const gs_index *ix, int strand, uint64_t C_acgtn[5],
                                    uint64_t *size) {

@@ -1,0 +1,243 @@
+/*
+ * gs_pairtab.hip -- PAM-pair tables: the depth-k prefix table of a strand restricted to the rows that
+ * can host a site of a PAM ending in a given pair of bases.
+ *
+ * This strand's seeds of k_search (gs_search.hip) are depth-k intervals of all rows whose suffix starts
+ * with a variant of the guide's first k consumed symbols; what decides a row is the v_rem symbols to
+ * its left: the rest of the guide, then the PAM (index.hpp:182-248 walk the same symbols one by
+ * one).  The last two consumed PAM symbols of NGG, NAG, TTTN (--start) ... are concrete bases, so
+ * only the rows with exactly that pair at context offsets v_rem-2, v_rem-1 can hold a site: one row in
+ * sixteen.  Collecting those rows per k-mer gives a table of the same shape whose intervals hold
+ * 0.7 rows instead of 11.5 at hg38 size: half the entries are empty (the seed dies with the table
+ * read), a third hold one row whose context word sits in the entry itself (no second read), the
+ * rest are filtered by pair masks over their few rows.  Rows with a symbol outside A,C,G,T among
+ * the nearest v_rem are left out: k_search reports those sites from the literal-N window list.
+ * Derived data, built on the device from the strand's table and ctx[] on first use (~0.1 s at hg38
+ * size), 4.3 GB per table copy + 10 bytes per selected row.
+ */
+#include "gs_common.h"
+
+#include <rocprim/rocprim.hpp>
+
+struct pt_args {
+  const uint4 *tab;
+  const uint32_t *ctx;
+  const uint32_t *exc_row;
+  const uint64_t *exc_sym;
+  uint32_t n_exc;
+  uint32_t v_rem, code, mask_off;
+  uint64_t entries;
+  /* outputs */
+  uint32_t *count;       /* per k-mer: selected rows */
+  const uint32_t *start; /* exclusive sums of count[] */
+  uint4 *out;
+  uint16_t *c16;
+  uint32_t *octx, *rowid;
+};
+
+/* does row r (context word w) belong to the pair's table? */
+__device__ __forceinline__ bool pt_selected(const pt_args &a, uint32_t r, uint32_t w, bool flagged) {
+  if (((w >> (2u * (a.v_rem - 2u))) & 15u) != a.code) return false;
+  if (flagged) { /* the k-mer has exception rows: is this one, and is the symbol near enough to matter? */
+    uint32_t lo = 0, hi = a.n_exc;
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a.exc_row[mid] < r)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (lo < a.n_exc && a.exc_row[lo] == r) {
+      const uint64_t nb = a.exc_sym[lo];
+      for (uint32_t j = 0; j < a.v_rem; j++)
+        if (((nb >> (4u * j)) & 15u) > 3u) return false;
+    }
+  }
+  return true;
+}
+
+__global__ void k_pt_count(pt_args a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.entries) return;
+  const uint4 e = a.tab[i];
+  const uint32_t cnt = e.y & 0x7FFFFFFFu;
+  const bool flagged = (e.y >> 31) != 0u;
+  uint32_t c = 0;
+  for (uint32_t j = 0; j < cnt; j++) c += pt_selected(a, e.x + j, a.ctx[e.x + j], flagged) ? 1u : 0u;
+  a.count[i] = c;
+}
+
+__global__ void k_pt_fill(pt_args a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.entries) return;
+  const uint32_t mine = a.count[i];
+  const uint32_t at = a.start[i];
+  uint4 o = make_uint4(at, mine, 0u, 0u);
+  if (mine) {
+    const uint4 e = a.tab[i];
+    const uint32_t cnt = e.y & 0x7FFFFFFFu;
+    const bool flagged = (e.y >> 31) != 0u;
+    const uint32_t o0 = a.mask_off & 15u, o1 = (a.mask_off >> 4) & 15u, o2 = (a.mask_off >> 8) & 15u, o3 = (a.mask_off >> 12) & 15u;
+    uint32_t c = 0, mz = 0, mw = 0, lw = 0, lr = 0;
+    for (uint32_t j = 0; j < cnt && c < mine; j++) {
+      const uint32_t r = e.x + j, w = a.ctx[r];
+      if (!pt_selected(a, r, w, flagged)) continue;
+      a.c16[at + c] = (uint16_t)w;
+      a.octx[at + c] = w;
+      a.rowid[at + c] = r;
+      mz |= (1u << ((w >> (2u * o0)) & 15u)) | (1u << (16u + ((w >> (2u * o1)) & 15u)));
+      mw |= (1u << ((w >> (2u * o2)) & 15u)) | (1u << (16u + ((w >> (2u * o3)) & 15u)));
+      lw = w;
+      lr = r;
+      c++;
+    }
+    o.z = mine == 1u ? lw : mz;
+    o.w = mine == 1u ? lr : mw;
+  }
+  a.out[i] = o;
+}
+
+/* rot[slot][perm_p(i)] = tab[i]: the field of consumption step p moves to bits 1:0 (gs_index.hip k_rot_copy) */
+__global__ void k_pt_rot(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p, uint32_t slot) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >> (2 * k)) return;
+  const uint32_t sh = 2u * (k - 1u - p);
+  const uint64_t hi = i >> (sh + 2u), lo = i & ((1ull << sh) - 1ull), f = (i >> sh) & 3ull;
+  rot[((uint64_t)slot << (2 * k)) + ((hi << (sh + 2u)) | (lo << 2) | f)] = tab[i];
+}
+
+void gs_pairtab_free(gs_index *ix, uint32_t slot) {
+  gs_pairtab_host &p = ix->pairtab[slot];
+  for (int s = 0; s < 2; s++)
+    for (int j = 0; j < 5; j++) {
+      if (p.mem[s][j]) hipFree(p.mem[s][j]);
+      p.mem[s][j] = nullptr;
+    }
+  p.valid = false;
+  p.bytes = 0;
+}
+
+static gs_status build_one(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, uint32_t rot_from, hipStream_t st) {
+  const gs_strand &S = ix->strand[s];
+  const uint64_t entries = 1ull << (2 * k);
+  pt_args a;
+  memset(&a, 0, sizeof(a));
+  a.tab = (const uint4 *)S.ptab;
+  a.ctx = (const uint32_t *)S.ctx;
+  a.exc_row = S.d.exc_row;
+  a.exc_sym = S.d.exc_sym;
+  a.n_exc = S.d.n_exc;
+  a.v_rem = p.v_rem;
+  a.code = p.code;
+  a.mask_off = S.d.mask_off;
+  a.entries = entries;
+  uint32_t *d_count = nullptr, *d_start = nullptr;
+  void *d_tmp = nullptr;
+  struct cleanup_t {
+    uint32_t *&c, *&s;
+    void *&t;
+    ~cleanup_t() {
+      if (c) hipFree(c);
+      if (s) hipFree(s);
+      if (t) hipFree(t);
+    }
+  } cleanup{d_count, d_start, d_tmp};
+  if (hipMalloc(&d_count, 4 * entries) != hipSuccess || hipMalloc(&d_start, 4 * entries) != hipSuccess) {
+    (void)hipGetLastError();
+    return GS_ERR_NOMEM;
+  }
+  a.count = d_count;
+  const uint32_t nb = (uint32_t)((entries + 255) / 256);
+  hipLaunchKernelGGL(k_pt_count, dim3(nb), dim3(256), 0, st, a);
+  size_t tmp_bytes = 0;
+  GS_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, d_count, d_start, 0u, entries, rocprim::plus<uint32_t>(), st));
+  if (hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 16) != hipSuccess) {
+    (void)hipGetLastError();
+    return GS_ERR_NOMEM;
+  }
+  GS_HIP(rocprim::exclusive_scan(d_tmp, tmp_bytes, d_count, d_start, 0u, entries, rocprim::plus<uint32_t>(), st));
+  uint32_t last_start = 0, last_count = 0;
+  GS_HIP(hipMemcpyAsync(&last_start, d_start + entries - 1, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&last_count, d_count + entries - 1, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  const uint64_t rows = (uint64_t)last_start + last_count;
+  void **m = p.mem[s];
+  const uint32_t nrot = rot_from + 1 < k ? k - 1 - rot_from : 0; /* steps rot_from .. k-2 */
+  if (hipMalloc(&m[0], sizeof(uint4) * entries) != hipSuccess || hipMalloc(&m[2], 2 * rows + 64) != hipSuccess ||
+      hipMalloc(&m[3], 4 * rows + 16) != hipSuccess || hipMalloc(&m[4], 4 * rows + 16) != hipSuccess ||
+      (nrot && hipMalloc(&m[1], sizeof(uint4) * entries * nrot) != hipSuccess)) {
+    (void)hipGetLastError();
+    return GS_ERR_NOMEM;
+  }
+  GS_HIP(hipMemsetAsync(m[2], 0, 2 * rows + 64, st)); /* k_search reads whole groups of eight */
+  a.start = d_start;
+  a.out = (uint4 *)m[0];
+  a.c16 = (uint16_t *)m[2];
+  a.octx = (uint32_t *)m[3];
+  a.rowid = (uint32_t *)m[4];
+  hipLaunchKernelGGL(k_pt_fill, dim3(nb), dim3(256), 0, st, a);
+  for (uint32_t j = 0; j < nrot; j++)
+    hipLaunchKernelGGL(k_pt_rot, dim3(nb), dim3(256), 0, st, (const uint4 *)m[0], (uint4 *)m[1], k, rot_from + j, j);
+  GS_HIP(hipStreamSynchronize(st));
+  GS_HIP(hipGetLastError());
+  gs_pairtab_dev &d = p.d[s];
+  d.tab = (const uint4 *)m[0];
+  d.rot = (const uint4 *)m[1];
+  d.c16 = (const uint16_t *)m[2];
+  d.ctx = (const uint32_t *)m[3];
+  d.rowid = (const uint32_t *)m[4];
+  d.rot_first = nrot ? rot_from : 31u;
+  d.code = p.code;
+  p.bytes += sizeof(uint4) * entries * (1 + nrot) + 10 * rows;
+  if (getenv("GS_DEBUG"))
+    fprintf(stderr, "[gs] PAM-pair table: strand %d, pair %u at context depth %u: %llu of %llu rows, %u rotated copies, %.2f GB\n",
+            s, p.code, p.v_rem, (unsigned long long)rows, (unsigned long long)S.n, nrot,
+            1e-9 * (double)(sizeof(uint4) * entries * (1 + nrot) + 10 * rows));
+  return GS_OK;
+}
+
+gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, hipStream_t st) {
+  gs_pairtab_host &p = ix->pairtab[slot];
+  const uint32_t k = ix->pt_k;
+  if (rot_first > 31) rot_first = 31;
+  if (!ix->strand[0].ptab_rot || !ix->strand[1].ptab_rot) rot_first = 31; /* the recipes read no copies then */
+  const uint32_t rot_wanted = rot_first;
+  if (p.valid && p.v_rem == v_rem && p.code == code && p.rot_first <= rot_wanted) return GS_OK;
+  gs_pairtab_free(ix, slot);
+  if (!k || v_rem < 2 || v_rem > 16 || !ix->strand[0].ctx || !ix->strand[1].ctx) return GS_OK;
+  /* fit into what is free, keeping room for the batch workspace: drop rotated copies first */
+  size_t free_b = 0, total_b = 0;
+  GS_HIP(hipMemGetInfo(&free_b, &total_b));
+  const double entry_bytes = 16.0 * (double)(1ull << (2 * k));
+  double reserve = 24e9;
+  if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
+  if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
+  const double rows_bytes = 10.0 * ((double)ix->strand[0].n + (double)ix->strand[1].n) / 16.0 * 1.5;
+  const double tmp_bytes = 8.0 * (double)(1ull << (2 * k)) + 64e6;
+  for (;;) {
+    const uint32_t nrot = rot_first + 1 < k ? k - 1 - rot_first : 0;
+    const double need = 2.0 * entry_bytes * (1 + nrot) + rows_bytes + tmp_bytes;
+    if (need + reserve <= (double)free_b) break;
+    if (nrot == 0) {
+      if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] PAM-pair table %u: not enough free memory (%.1f GB), skipped\n", code, 1e-9 * (double)free_b);
+      return GS_OK;
+    }
+    rot_first = nrot == 1 ? 31 : rot_first + 1;
+  }
+  p.v_rem = v_rem;
+  p.code = code;
+  p.rot_first = rot_wanted;
+  for (int s = 0; s < 2; s++) {
+    const gs_status rc = build_one(ix, p, s, k, rot_first, st);
+    if (rc == GS_ERR_NOMEM) { /* the estimate was off: go on without this table */
+      gs_pairtab_free(ix, slot);
+      return GS_OK;
+    }
+    if (rc != GS_OK) {
+      gs_pairtab_free(ix, slot);
+      return rc;
+    }
+  }
+  p.valid = true;
+  return GS_OK;
+}

@@ -31,7 +31,8 @@
 #ifndef VQ_DRAIN
 #define VQ_DRAIN 64 /* verify as soon as this many seeds wait (a seeding step adds at most 64) */
 #endif
-#define WAVE_LDS_ENTRIES (STACK_ENTRIES + VQ_CAP + 32) /* 6 KiB per wave -> 6 workgroups per CU */
+#define WAVE_LDS_FAST (VQ_CAP + 32 + DTAB) /* 16-byte entries per wave of the table-only variant: 3.9 KiB */
+#define WAVE_LDS_ENTRIES (STACK_ENTRIES + WAVE_LDS_FAST) /* the walking variant adds the X/G stacks: 8 KiB */
 #define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
 
 /* node meta (64 bit):  [63:59] t  [58:56] k  [55] -  [54] fan  [53:52] pam id  [51:0] path */
@@ -51,18 +52,24 @@ struct gs_search_args {
   uint32_t *work;        /* work-queue head */
   unsigned long long *stats; /* [0] n_ext, [1] overflow items, [4] two-sided items, [5] one-sided, [8..] request counters */
   uint32_t n_items, L, P, m, cap;
-  /* prefix-table seeding (pt_k = 0: walk from the root).  Seeding plans live in combo[]: the full
-   * plan at word 0 (one class per substitution count j over the first pt_k-2 steps), and - per
-   * batch, with two-sided seeding - this strand's filtered plan at planA_g followed by the other
-   * strand's plan at planB_g.  Plan of this strand: header [c] offset of class c's masks, [32+c]
-   * their count, [64+c] meta = j | eb << 4: j substitutions per mask, eb = how many more the
-   * two-symbol extension may add (15: the whole remaining budget m-j).  plan_lds != 0: the batch
-   * plans (or, one-sided, the full plan) are copied to LDS once per workgroup (plan_words words
-   * from combo + plan_src). */
-  const uint32_t *combo;
-  uint32_t plan_words, plan_src, plan_lds;
+  /* prefix-table seeding (pt_k = 0: walk from the root).  The seeds of an item are listed in
+   * RECIPES that do not depend on the guide (gs_build_recipes_*): a recipe is the set of
+   * substitutions (consumption step, which of the three other bases) that turns the guide's own
+   * k-mer into the seed's, plus the table copy to read it from.  64 bits: [2:0] substitutions n,
+   * [5:3] lower bound on the substitutions in X (other strand's seeds), [7:6] 1 = read the rotated
+   * copy of step [11:8], then n 7-bit fields 3*step + digit from bit 12.  Lane l of a seeding step
+   * takes recipe pos+l: consecutive recipes are laid out so that neighbours share table lines.
+   *   rec_full : every depth-k node within m substitutions (one-sided seeding)
+   *   rec_a    : this strand's share under two-sided seeding (a < astar(o))
+   *   rec_b    : the other strand's share, steps counted as y = guide symbol L-1-y */
+  const uint2 *rec_full, *rec_a, *rec_b;
+  uint32_t n_rec_full, n_rec_a, n_rec_b;
+  /* PAM-pair tables (gs_pairtab.hip): this strand's seeds of an item whose PAM patterns all end (in
+   * consumption order) in one of these pairs of concrete bases are looked up among the rows that
+   * have that pair in place - a sixteenth of the genome's rows - instead of all of them */
+  gs_pairtab_dev pt[2][2]; /* [slot][strand] */
+  uint32_t n_pt;           /* slots in use */
   uint32_t pt_k; /* table depth k; seeds are the depth-k nodes */
-  uint32_t ncls; /* classes of the full plan */
   /* context verification: L+P-pt_k (<= 16) symbols remain after the table depth; 0 = disabled */
   uint32_t v_rem;
   uint32_t v_max; /* rows per queued descriptor (<= 1023): larger intervals are verified in pieces */
@@ -74,10 +81,6 @@ struct gs_search_args {
    * table otherwise; astar holds 4 bits per o (15: this strand takes every a). */
   uint32_t append; /* this pass adds to the matches an earlier pass (other PAM patterns) left in the slots */
   uint32_t bidir, astar;
-  uint32_t planA_g, nclsA; /* this strand's filtered plan: word offset in combo[], classes */
-  uint32_t planB_g, nclsB; /* other strand's plan: header of 4 words per class {mask offset, lane
-                              prefix end, jb | lo << 4 | 3^jb << 8, magic for /3^jb}, then masks
-                              (bit y = guide symbol L-1-y) */
   /* windows of this strand's text where a literal 'N' lies under the PAM (index.hpp:139-149) and
    * the guide part is plain A,C,G,T: {q lo, q hi, PAM symbols (3 bits each: 0..3, 4 = N), text
    * position of the site}.  The other strand's table cannot see them: its share of them is
@@ -89,9 +92,8 @@ struct gs_search_args {
 #define DSC_EXC 30u /* descriptor.y bit 30: the interval holds exception rows (gs_strand_dev::exc_row) */
 
 #define VERIFY_MAX_DEFAULT 1023u
-#define GS_PLAN_CLASSES 32u
-#define GS_PLAN_HEADER (3u * GS_PLAN_CLASSES)
-#define GS_PLAN_LDS_MAX 3072u /* words of plan kept in LDS; larger plans are read from global memory */
+#define DTAB 88u /* per-item substitution table: 4 entries per step of this strand's k-mer (k <= 16) or per
+                    guide symbol of the other strand's (k - P <= 21); the two sides seed one after the other */
 
 #define SEED_LOW_MAX 128 /* refill the stacks from the prefix table when they hold this few nodes */
 
@@ -104,7 +106,7 @@ struct gs_search_args {
  * CNT: count the distinct 64-byte lines every load instruction asks for (bench.py's algorithmic
  * bytes of THIS algorithm); the timed kernel is the CNT = false instantiation. */
 #ifndef GS_WAVES_EU
-#define GS_WAVES_EU 6 /* the walking variant: 80 VGPRs, measured best of 4..8 in round 1 */
+#define GS_WAVES_EU 5 /* the walking variant: 88 VGPRs */
 #endif
 #ifndef GS_WAVES_EU_FAST
 #define GS_WAVES_EU_FAST 8 /* the table-only variants carry no X/G stack code: <= 64 VGPRs */
@@ -113,17 +115,13 @@ struct gs_search_args {
  * and inputs whose remainder does not fit ctx[].  The table-only variant (every interval resolved
  * against the context arrays) needs neither the 3.5 KiB stack array per wave nor that code. */
 template <bool CNT, bool WALK>
-__device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk, uint32_t *s_plan) {
+__device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk) {
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
   const uint32_t lane = lane_id();
-  if (a.plan_lds) {
-    for (uint32_t i = threadIdx.x; i < a.plan_words; i += WAVE * SEARCH_WAVES) s_plan[i] = a.combo[a.plan_src + i];
-    __syncthreads();
-  }
   unsigned long long n_ext = 0, n_ovf = 0;
-  uint32_t n_two = 0, n_fb = 0; /* items seeded from both strands / one-sided although two-sided seeding is on */
+  uint32_t n_two = 0, n_fb = 0, n_pair = 0; /* items seeded from both strands / one-sided although two-sided seeding is on */
   /* request counters (CNT): table lines, ctx16 lines, ctx words, SA/ISA gathers of the search, Occ lines */
-  uint32_t c_tab = 0, c_c16 = 0, c_ctx = 0, c_isa = 0, c_occ = 0;
+  uint32_t c_tab = 0, c_c16 = 0, c_ctx = 0, c_isa = 0, c_occ = 0, c_rec = 0;
   /* distinct 64-byte lines one load instruction asks for: lanes whose line differs from the
    * previous active lane's (the access patterns here are runs of neighbouring lanes) */
   auto count_lines = [&](uint32_t &acc, bool act, const void *p) __attribute__((always_inline)) {
@@ -145,6 +143,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   uint4 *vq = stk + STK;                       /* queued seed descriptors */
   uint2 *own2 = (uint2 *)(vq + VQ_CAP);        /* owner markers of a pass, two per lane */
   uint32_t *own = (uint32_t *)own2;
+  uint4 *dtab = vq + VQ_CAP + 32;              /* substitution table of the item: {index xor, path lo, path hi, -} */
 
   for (;;) {
     uint32_t item = 0;
@@ -181,6 +180,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     uint32_t n_match = 0;
     if (a.append) n_match = __builtin_amdgcn_readfirstlane(a.counts[slot]);
     uint32_t xs = 0, gs = 0; /* sizes of the X and G stacks */
+    /* what this strand's seeds are looked up in and verified against: the strand's own table and
+     * context arrays, or (set per item, below) a PAM-pair table and its rows */
+    const uint4 *atab = sd.ptab, *arot = sd.ptab_rot;
+    uint32_t arot_first = 0;
+    const uint16_t *a16 = sd.ctx16;
+    const uint32_t *actx = sd.ctx, *arow = nullptr;
 
     /* is a node at step t2 with k2 mismatches (PAM pattern pamid) a single-symbol node? */
     auto is_single = [&](uint32_t t2, uint32_t k2, uint32_t pamid) __attribute__((always_inline)) -> bool {
@@ -257,6 +262,9 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     auto verify = [&](const bool modeB, const uint32_t take, uint4 *dsrc) __attribute__((always_inline)) {
       const uint32_t k = a.pt_k;
       const gs_strand_dev &sv = modeB ? a.sd[strand ^ 1u] : sd;
+      /* the context arrays the rows live in: the other strand's, this strand's, or the rows of a PAM-pair table */
+      const uint16_t *const v16 = modeB ? sv.ctx16 : a16;
+      const uint32_t *const vctx = modeB ? sv.ctx : actx;
       /* lane l < take brings seed descriptor dsrc[l] = {first row, mismatches so far << 14 |
        * rows << 17 | lower bound << 27 | exceptions << 30, path lo, path hi}; the first group of
        * each seed is added to .y here */
@@ -320,14 +328,14 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint32_t lo8 = lo > g - g8 ? lo - (g - g8) : 0u;
           okm[jj] = on ? (((2u << (m - kkv[jj])) - 1u) & ~((1u << lo8) - 1u)) : 0u;
           wq[jj] = make_uint4(0u, 0u, 0u, 0u);
-          if (on) wq[jj] = load16_a2(sv.ctx16 + row0[jj]);
+          if (on) wq[jj] = load16_a2(v16 + row0[jj]);
         }
         if constexpr (CNT) {
           /* distinct lines of the pass: the lanes' groups in order (2l, 2l+1), a group counted when
            * its first or its last byte lies in a line the group before it did not reach */
           const bool on0 = nrow[0] != 0u, on1 = nrow[1] != 0u;
-          const uint32_t f0 = (uint32_t)((uintptr_t)(sv.ctx16 + row0[0]) >> 6), l0 = (uint32_t)(((uintptr_t)(sv.ctx16 + row0[0]) + 15u) >> 6);
-          const uint32_t f1 = (uint32_t)((uintptr_t)(sv.ctx16 + row0[1]) >> 6), l1 = (uint32_t)(((uintptr_t)(sv.ctx16 + row0[1]) + 15u) >> 6);
+          const uint32_t f0 = (uint32_t)((uintptr_t)(v16 + row0[0]) >> 6), l0 = (uint32_t)(((uintptr_t)(v16 + row0[0]) + 15u) >> 6);
+          const uint32_t f1 = (uint32_t)((uintptr_t)(v16 + row0[1]) >> 6), l1 = (uint32_t)(((uintptr_t)(v16 + row0[1]) + 15u) >> 6);
           const uint32_t mylast = on1 ? l1 : l0;
           const uint32_t prev = (uint32_t)__shfl_up((int)mylast, 1);
           const int pact = __shfl_up((int)(on0 || on1), 1);
@@ -361,7 +369,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint32_t row = (hi ? row0[1] : row0[0]) + (pick & 7u);
           const uint32_t kv = hi ? kkv[1] : kkv[0];
           uint32_t w = 0u;
-          if (has) w = sv.ctx[row];
+          if (has) w = vctx[row];
           if constexpr (CNT) c_ctx += (uint32_t)__popcll(__ballot(has));
           /* exception rows: the true symbols decide.  Under a guide symbol nothing outside
            * A,C,G,T can match or be substituted (index.hpp:31,230-247); under a PAM 'N' a literal
@@ -420,6 +428,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             route(gok, true, false, rowA, rowA, mmeta, 0u);
             continue;
           }
+          uint32_t orow = row; /* the row as the strand's suffix array numbers it */
+          if (arow != nullptr) {
+            if (gok) orow = arow[row];
+            if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(gok));
+          }
           for (uint32_t pj = 0; pj < npams; ++pj) {
             const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
             bool ok = gok;
@@ -440,18 +453,62 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               gpath |= (uint64_t)code << (50u - 2u * (k + v));
             }
             const uint64_t mmeta = ((uint64_t)(kv + mmv) << 56) | spath | gpath | ppath;
-            route(ok, true, false, row, row, mmeta, 1u);
+            route(ok, true, false, orow, orow, mmeta, 1u);
           }
         }
       }
     };
 
-    /* seeding state (all wave-uniform): class of the plan, lane position inside the class */
-    uint32_t sc = 0, spos = 0;
-    uint32_t ncls = a.ncls;
+    /* seeding state (wave-uniform): position in the recipe list this strand's seeding reads */
+    uint32_t spos = 0;
+    const uint2 *rec = a.rec_full;
+    uint32_t nrec = a.n_rec_full;
     uint32_t qn = 0; /* seeds waiting in the verification queue */
     const bool seeding = a.pt_k != 0;
     bool seeds_left = seeding;
+    /* the substitution table of the item: entry 4 * step + digit = what substituting the digit-th
+     * other base at that step does to the k-mer's table index and to the path; digit 3 = nothing */
+    auto fill_dtab = [&](const bool sideB) __attribute__((always_inline)) {
+      const uint32_t k = a.pt_k, nst = sideB ? k - P : k;
+      for (uint32_t e = lane; e < 4u * nst; e += WAVE) {
+        const uint32_t s = e >> 2, d = e & 3u;
+        const uint32_t t = sideB ? L - 1u - s : s; /* guide symbol the step consumes */
+        const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
+        const uint32_t sym = (qc + 1u + d) & 3u;               /* one of the three other bases */
+        const uint32_t code = 1u + sym - (sym > qc ? 1u : 0u); /* its rank among them, A<C<G<T */
+        const uint64_t pb = (uint64_t)code << (50u - 2u * t);
+        /* the other strand's k-mer holds the complements: complementing both keeps the xor */
+        const uint32_t sh = 2u * (sideB ? k - 1u - P - s : k - 1u - s);
+        dtab[e] = d == 3u ? make_uint4(0u, 0u, 0u, 0u) : make_uint4((qc ^ sym) << sh, (uint32_t)pb, (uint32_t)(pb >> 32), 0u);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    /* a recipe applied to the exact k-mer index `pidx` / path `path`; returns the entry's address */
+    auto apply_recipe = [&](const uint2 rc, const uint4 *tab, const uint4 *rot, const uint32_t rot_first, uint32_t &pidx,
+                            uint64_t &path) __attribute__((always_inline)) -> const uint4 * {
+      const uint32_t k = a.pt_k, n = rc.x & 7u;
+      uint64_t f = (((uint64_t)rc.y << 32) | rc.x) >> 12;
+      uint32_t plo = (uint32_t)path, phi = (uint32_t)(path >> 32);
+      for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
+        const uint4 e = dtab[(uint32_t)f & 127u];
+        f >>= 7;
+        pidx ^= e.x;
+        plo |= e.y;
+        phi |= e.z;
+      }
+      path = ((uint64_t)phi << 32) | plo;
+      const uint4 *ep = tab + pidx;
+      const uint32_t rs = (rc.x >> 7) & 31u;
+      if ((rc.x & 64u) != 0u && rs >= rot_first) {
+        /* the copy rotated at step rs: that step's symbol and everything after it swap places, so the
+         * recipes that differ only at step rs are neighbours in one 64-byte line */
+        const uint32_t sh = 2u * (k - 1u - rs);
+        const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) | ((pidx >> sh) & 3u);
+        ep = rot + (((size_t)(rs - rot_first) << (2u * k)) + ridx);
+      }
+      return ep;
+    };
     uint32_t pidx0 = 0; /* table index of the exact k-prefix of the query */
     /* context mask of this strand's seeds (gs_strand_dev::ptab): the query's symbol pairs at the four
      * pair positions after the table depth.  A pair of two guide steps may be broken by a
@@ -494,16 +551,6 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-    /* the plan this strand's seeding reads: the full plan (one-sided) or the batch's filtered plan;
-     * from LDS when it was copied there, else from global memory (L2-resident, a few KiB) */
-    uint32_t pl_g = 0;        /* word offset in combo[] */
-    uint32_t pl_l = 0;        /* word offset in s_plan[] */
-    bool pl_lds = a.plan_lds != 0u && !a.bidir; /* one-sided: LDS holds the full plan */
-    uint32_t astar_item = 0xFFFFFFFFu; /* one-sided: this strand takes every site */
-    auto PL = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
-      return pl_lds ? s_plan[pl_l + i] : a.combo[pl_g + i];
-    };
-
     /* ---- two-sided seeding: a site with many substitutions among the first v_rem consumed
      * guide symbols (set X) has few in the rest, so it is cheap to enumerate from the other end:
      * on the other strand the same site reads reversed and complemented, and a backward search
@@ -513,6 +560,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
      * a >= astar(o) against the other strand's ctx[].  What it cannot see - a literal N under
      * the PAM - is reported from the batch's window list; a PAM pattern with more than two N
      * makes the item one-sided with the full plan. */
+    uint32_t pslots = 0; /* PAM-pair tables still to go through (bit per slot) */
     if (a.bidir && seeding) {
       bool fallback = false;
       const gs_strand_dev &sb = a.sd[strand ^ 1u];
@@ -523,8 +571,28 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         for (uint32_t u = 0; u < P; ++u) nn += ((pw >> (3u * u)) & 7u) == 4u;
         if (nn > 2u) fallback = true;
       }
+      /* PAM-pair tables: when every pattern of the item ends in a pair of concrete bases that has a
+       * table, this strand's seeds go through those tables (one pass of the recipes per table) */
+      if (!fallback && a.n_pt != 0u && P >= 2u) {
+        bool all = true;
+        for (uint32_t pj = 0; pj < npams; ++pj) {
+          const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+          const uint32_t c0 = (pw >> (3u * (P - 2u))) & 7u, c1 = (pw >> (3u * (P - 1u))) & 7u;
+          const uint32_t code = c0 | (c1 << 2);
+          if (c0 > 3u || c1 > 3u)
+            all = false;
+          else if (code == a.pt[0][strand].code)
+            pslots |= 1u;
+          else if (a.n_pt > 1u && code == a.pt[1][strand].code)
+            pslots |= 2u;
+          else
+            all = false;
+        }
+        if (!all) pslots = 0u;
+      }
       if (!fallback) {
-        /* literal-N windows within reach whose (a, o) belongs to the other side */
+        /* literal-N windows within reach whose (a, o) belongs to the other side - or all of them:
+         * the PAM-pair tables hold no row with a symbol outside A,C,G,T next to it */
         const uint32_t ncand = a.n_cand[strand];
         const uint64_t lmask = (1ull << (2u * L)) - 1ull;
         const uint64_t xmask = (1ull << (2u * sx)) - 1ull, komask = (1ull << (2u * k)) - 1ull;
@@ -536,7 +604,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint64_t x = cq ^ gr_q;
           const uint64_t nz = (x | (x >> 1)) & 0x5555555555555555ull & lmask;
           const uint32_t tot = __popcll(nz), jx = __popcll(nz & xmask), jo = __popcll(nz & komask & ~xmask);
-          const bool mine = in && tot <= m && jx >= ((a.astar >> (4u * (jo < 7u ? jo : 7u))) & 15u);
+          const bool mine = in && tot <= m && (pslots != 0u || jx >= ((a.astar >> (4u * (jo < 7u ? jo : 7u))) & 15u));
           if (!__ballot(mine)) continue;
           uint64_t gpath = 0;
           for (uint32_t t = 0; t < L; ++t) {
@@ -573,13 +641,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             n_bpairs++;
           }
         }
-        const bool plb_lds = a.plan_lds != 0u;
-        const uint32_t plb_l = a.planB_g - a.plan_src; /* the batch plans are copied as one piece */
-        auto PLB = [&](uint32_t i) __attribute__((always_inline)) -> uint32_t {
-          return plb_lds ? s_plan[plb_l + i] : a.combo[a.planB_g + i];
-        };
-        const uint32_t nclsB = a.nclsB;
-        const uint32_t nlanes = nclsB ? PLB(4u * (nclsB - 1u) + 1u) : 0u;
+        const uint32_t nlanes = a.n_rec_b;
+        fill_dtab(true);
         /* the guide part of the other strand's k-mer: step P+y holds the complement of guide symbol L-1-y */
         uint32_t pidxg = 0;
         for (uint32_t y = 0; y < nY; ++y)
@@ -613,54 +676,23 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
                 pidxb |= (3u - base) << (2u * (k - P + u));
               }
             }
-            /* lane space of one expansion: the plan's classes one after the other; inside a class
-             * (position mask ci) x (3^jb digit combinations), the digit of the last consumed
+            /* one expansion = the whole recipe list rec_b: classes (o, b) one after the other; inside a
+             * class (position mask) x (3^jb digit combinations), the digit of the last consumed
              * substituted symbol running fastest, so the three lanes that differ only there share
              * one 64-byte line of that step's rotated copy (or of the plain table when it is the
              * k-mer's last step) */
             const uint32_t idx = bc0 + lane;
             const bool act = idx < nlanes;
-            uint32_t cls = 0, cbase = 0;
-            for (uint32_t c = 0; c + 1u < nclsB; ++c) {
-              const uint32_t ce = PLB(4u * c + 1u);
-              if (idx >= ce) {
-                cls = c + 1u;
-                cbase = ce;
-              }
-            }
-            const uint32_t cmw = PLB(4u * cls + 2u);
-            const uint32_t pw3 = cmw >> 8;
-            jb = cmw & 15u;
-            lo = (cmw >> 4) & 15u;
-            const uint32_t i2 = idx - cbase;
-            const uint32_t ci = jb ? __umulhi(i2, PLB(4u * cls + 3u)) : i2;
-            uint32_t dg = i2 - ci * pw3;
-            uint32_t mk = act ? PLB(PLB(4u * cls) + ci) : 0u;
+            uint2 rc = make_uint2(0u, 0u);
+            if (act) rc = a.rec_b[idx];
+            count_lines(c_rec, act, a.rec_b + idx);
+            jb = rc.x & 7u;
+            lo = (rc.x >> 3) & 7u;
             uint32_t pidx = pidxb;
             uint64_t path = ppath;
-            uint32_t slast = 0xFFFFFFFFu;
-            if (mk) slast = P + (31u - (uint32_t)__clz((int)mk));
-            while (mk) {
-              const uint32_t y = 31u - (uint32_t)__clz((int)mk);
-              mk &= ~(1u << y);
-              const uint32_t third = __umul24(dg, 43691u) >> 17;
-              const uint32_t d = dg - 3u * third;
-              dg = third;
-              const uint32_t t = L - 1u - y;
-              const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
-              const uint32_t sym = (qc + 1u + d) & 3u;
-              path |= (uint64_t)(1u + sym - (sym > qc ? 1u : 0u)) << (50u - 2u * t);
-              pidx ^= (qc ^ sym) << (2u * (k - 1u - P - y)); /* complementing both keeps the xor */
-            }
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
             {
-              const uint4 *ep = sb.ptab + pidx;
-              if (slast <= k - 2u && sb.ptab_rot != nullptr) {
-                const uint32_t sh = 2u * (k - 1u - slast);
-                const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
-                                      ((pidx >> sh) & 3u);
-                ep = sb.ptab_rot + (((size_t)slast << (2u * k)) + ridx);
-              }
+              const uint4 *ep = apply_recipe(rc, sb.ptab, sb.ptab_rot, 0u, pidx, path);
               if (act) ent = *ep;
               count_lines(c_tab, act, ep);
             }
@@ -718,18 +750,32 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         }
       }
       if (fallback) {
-        n_fb++;
-        pl_g = 0; /* the full plan, from global memory */
-        pl_lds = false;
+        n_fb++; /* every seed from this strand */
       } else {
         n_two++;
-        astar_item = a.astar;
-        pl_g = a.planA_g;
-        pl_l = a.planA_g - a.plan_src;
-        pl_lds = a.plan_lds != 0u;
-        ncls = a.nclsA;
-        if (ncls == 0u) seeds_left = false;
+        rec = a.rec_a;
+        nrec = a.n_rec_a;
+        if (pslots) n_pair++;
       }
+    }
+    auto next_pairtab = [&]() __attribute__((always_inline)) {
+      const uint32_t s = (pslots & 1u) ? 0u : 1u;
+      pslots &= ~(1u << s);
+      const gs_pairtab_dev &p = a.pt[s][strand];
+      atab = p.tab;
+      arot = p.rot;
+      arot_first = p.rot_first;
+      a16 = p.c16;
+      actx = p.ctx;
+      arow = p.rowid;
+    };
+    if (pslots) next_pairtab();
+    /* the guide symbols this strand's seeds leave to the context check */
+    const uint32_t gA = L - a.pt_k, gmaskA = gA >= 16u ? 0xFFFFFFFFu : ((1u << (2u * gA)) - 1u);
+    const uint32_t qremA = seeding ? (uint32_t)(gr_q >> (2u * a.pt_k)) & gmaskA : 0u;
+    if (seeding) {
+      fill_dtab(false);
+      if (nrec == 0u) seeds_left = false;
     }
 
     for (;;) {
@@ -740,112 +786,37 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
          * instead of walking it, enumerate every variant of the first k-2 query symbols with
          * j <= m substitutions and, one table entry per lane, the two-symbol extensions the
          * remaining budget allows.  Same node set at depth k as the walk (index.hpp:182-248). */
-        const uint32_t k = a.pt_k, kp = k - 2u;
-        const uint32_t cmeta_w = PL(2u * GS_PLAN_CLASSES + sc);
-        const uint32_t sj = cmeta_w & 15u;
-        const uint32_t bud = (cmeta_w >> 4) == 15u ? m - sj : (cmeta_w >> 4); /* extension budget */
-        uint32_t spow = 1u;
-        for (uint32_t i = 0; i < sj; ++i) spow *= 3u;
-        /* budget-0 variants with >= 1 substitution use the rotated table of their LAST
-         * substituted step: the three substitutions there sit in neighbouring lanes and in one
-         * 64-byte line, so three variants cost one request.  Budget-1 variants take 8 lanes:
-         * four with the second-last symbol exact (one line of the plain table: the last symbol
-         * runs) and four with the last symbol exact (one line of the rotated copy of step k-2:
-         * the second-last symbol runs; the all-exact entry there is a duplicate and idles). */
-        const bool rot = sd.ptab_rot != nullptr && bud == 0u && sj >= 1u;
-        const bool rot2 = sd.ptab_rot != nullptr && bud == 1u;
-        const uint32_t E = bud >= 2u ? 16u : bud == 1u ? (rot2 ? 8u : 7u) : 1u;
-        /* The class's lane space is (position mask ci, digit combination, lane of the variant u),
-         * u fastest: a step takes the next 64 lanes of it, whatever variants they belong to, so
-         * small classes (one mask x 27 digit combinations x 3 lanes) do not cost a step per
-         * digit combination.  nsub = 3^sj digit combinations, a third of that when the last
-         * digit runs over the lanes. */
-        const uint32_t lanes_per = rot ? 3u : E;
-        const uint32_t nsub = rot ? spow / 3u : spow;
-        const uint32_t span = PL(GS_PLAN_CLASSES + sc) * nsub * lanes_per;
+        const uint32_t k = a.pt_k;
+        /* Seeds = the recipes of the list, 64 per step whatever classes they belong to.  Their order
+         * (gs_build_recipes_a) keeps table lines shared: the 16 two-symbol extensions of a variant of
+         * the first k-2 symbols are 4 lines of the plain table; with one substitution left 4 + 3
+         * recipes read one line of the plain table (last symbol runs) and one of the copy rotated at
+         * step k-2 (second-last runs); with none left the three recipes that differ in the digit of
+         * their last substituted step read one line of that step's rotated copy. */
         const uint32_t l = spos + lane;
-        bool act = l < span;
-        const uint32_t tv = rot ? l / 3u : E == 16u ? l >> 4 : E == 8u ? l >> 3 : E == 7u ? l / 7u : l;
-        const uint32_t u = l - tv * lanes_per;
-        uint32_t ci; /* tv = ci * nsub + digit combination; nsub is wave-uniform: constant divisors */
-        switch (nsub) {
-          case 1u: ci = tv; break;
-          case 3u: ci = tv / 3u; break;
-          case 9u: ci = tv / 9u; break;
-          case 27u: ci = tv / 27u; break;
-          case 81u: ci = tv / 81u; break;
-          case 243u: ci = tv / 243u; break;
-          case 729u: ci = tv / 729u; break;
-          default: ci = tv / nsub; break;
-        }
-        uint32_t mask = act ? PL(PL(sc) + ci) : 0u;
-        /* substitutions inside X (the first v_rem consumed symbols); the others lie in O */
-        const uint32_t ax = __popc(mask & ((1u << a.v_rem) - 1u));
+        const bool act = l < nrec;
+        uint2 rc = make_uint2(0u, 0u);
+        if (act) rc = rec[l];
+        count_lines(c_rec, act, rec + l);
+        const uint32_t kk = rc.x & 7u;
         uint32_t pidx = pidx0;
         uint64_t path = 0;
-        uint32_t sub = tv - ci * nsub; /* < 3^7: thirds through a full-rate 24-bit multiply */
-        uint32_t plast = 0;
-        for (uint32_t i = 0; i < sj; ++i) { /* sj substitutions at the set bits of mask */
-          const uint32_t third = __umul24(sub, 43691u) >> 17; /* exact for sub < 2^17 */
-          uint32_t d = sub - 3u * third;
-          sub = third;
-          if (rot && i + 1u == sj) d = u; /* the last step's digit runs over the lanes */
-          const uint32_t t = mask ? (uint32_t)__builtin_ctz(mask) : 0u;
-          mask &= mask - 1u;
-          plast = t;
-          const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
-          const uint32_t sym = (qc + 1u + d) & 3u;               /* one of the three other bases */
-          const uint32_t code = 1u + sym - (sym > qc ? 1u : 0u); /* its rank among them, A<C<G<T */
-          pidx ^= (qc ^ sym) << (2u * (k - 1u - t));
-          path |= (uint64_t)code << (50u - 2u * t);
-        }
-        const uint32_t q2 = (uint32_t)(gr_q >> (2u * kp)) & 3u;        /* query symbol of step k-2 */
-        const uint32_t q1 = (uint32_t)(gr_q >> (2u * (kp + 1u))) & 3u; /* and of step k-1 */
-        uint32_t s2 = q2, s1 = q1;
-        if (rot) {
-          /* exact last two symbols; u was the substitution digit */
-        } else if (E == 16u) {
-          s2 = u >> 2;
-          s1 = u & 3u;
-        } else if (E == 8u) {
-          if (u < 4u) {
-            s1 = u;
-          } else {
-            s2 = u - 4u;
-            act = act && s2 != q2;
-          }
-        } else if (E == 7u) {
-          if (u >= 1u && u <= 3u) s2 = (q2 + u) & 3u;
-          if (u >= 4u) s1 = (q1 + u - 3u) & 3u;
-        }
-        const uint32_t mm = (s2 != q2) + (s1 != q1);
-        pidx ^= ((q2 ^ s2) << 2) | (q1 ^ s1);
-        /* two-sided: with a substitutions in X and o in O the site is this strand's only when
-         * a < astar(o); the others come from the other strand's table (or its window list) */
-        const uint32_t otot = sj - ax + mm;
-        if (ax >= ((astar_item >> (4u * (otot < 7u ? otot : 7u))) & 15u) || sj + mm > m) act = false;
         uint4 ent = make_uint4(0u, 0u, 0u, 0u);
         {
-          const uint4 *ep = sd.ptab + pidx;
-          if (rot) {
-            const uint32_t sh = 2u * (k - 1u - plast);
-            const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) |
-                                  ((pidx >> sh) & 3u);
-            ep = sd.ptab_rot + (((size_t)plast << (2u * k)) + ridx);
-          } else if (rot2 && u >= 4u) {
-            /* copy of step k-2: its symbol (bits 3:2 of pidx) and the last one swap places */
-            const uint32_t ridx = (pidx & ~15u) | ((pidx & 3u) << 2) | ((pidx >> 2) & 3u);
-            ep = sd.ptab_rot + (((size_t)kp << (2u * k)) + ridx);
-          }
+          const uint4 *ep = apply_recipe(rc, atab, arot, arot_first, pidx, path);
           if (act) ent = *ep;
           count_lines(c_tab, act, ep);
         }
         const uint32_t ecnt = ent.y & 0x7FFFFFFFu, eflag = ent.y >> 31;
-        /* context mask: drop the seed when none of the 3-symbol left contexts present in its
-         * interval is within the remaining budget of the next three query symbols */
-        const uint32_t bl = m - (sj + mm); /* budget left (>= 0 by construction) */
+        /* context mask: drop the seed when fewer of the query's symbol pairs occur to the left of its
+         * interval's rows than the remaining budget can break, or none of the PAM's pairs does */
+        const uint32_t bl = m - kk; /* budget left (>= 0 by construction) */
         bool hopeless = false;
-        if (use_mask && eflag == 0u) {
+        if (arow != nullptr && ecnt == 1u) {
+          /* a PAM-pair table's entry with one row carries that row's context word */
+          const uint32_t xf = (ent.z ^ qremA) & gmaskA;
+          hopeless = (uint32_t)__popc((xf | (xf >> 1)) & 0x55555555u) > bl;
+        } else if (use_mask && eflag == 0u) {
           const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
           uint32_t intact = 0;
 #pragma unroll
@@ -856,26 +827,14 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           hopeless = hopeless || intact + bl < n_gpairs;
         }
         const bool live = act && ecnt != 0u && !hopeless && !(a.dbg_skip & 2u);
-        const uint32_t c2 = s2 == q2 ? 0u : 1u + s2 - (s2 > q2 ? 1u : 0u);
-        const uint32_t c1 = s1 == q1 ? 0u : 1u + s1 - (s1 > q1 ? 1u : 0u);
-        const uint32_t kk = sj + mm;
-        const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path |
-                               ((uint64_t)c2 << (50u - 2u * kp)) |
-                               ((uint64_t)c1 << (50u - 2u * (kp + 1u)));
+        const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
         /* every interval is resolved right here against ctx[] (exception rows included, large
          * ones in pieces); without the context arrays the seeds continue as ordinary nodes
          * (k < L: never terminal) */
         const bool ver = live && (!WALK || a.v_rem != 0u);
         if constexpr (WALK) route(live && !ver, false, kk == m, ent.x, ent.x + ecnt - 1u, cmeta);
-        /* advance the (class, position) cursor */
         spos += WAVE;
-        if (spos >= span) {
-          spos = 0;
-          do {
-            ++sc;
-          } while (sc < ncls && PL(GS_PLAN_CLASSES + sc) == 0u);
-          if (sc >= ncls) seeds_left = false;
-        }
+        const bool pass_end = spos >= nrec; /* of the recipes through one table */
         /* The verifying seeds wait in the queue until a pass can be filled: about a quarter of
          * a step's 64 lanes survive the context mask, and a pass (prefix sums, owner lookup,
          * row groups) costs the same instructions for 16 seeds as for 64.  Drain from the tail
@@ -895,13 +854,21 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             continue;
           }
-          if (qn >= VQ_DRAIN || (bq && qn != 0u) || (!seeds_left && qn != 0u)) {
+          if (qn >= VQ_DRAIN || (bq && qn != 0u) || (pass_end && qn != 0u)) {
             const uint32_t take = qn < WAVE ? qn : WAVE;
             qn -= take;
             verify(false, take, vq + qn);
             continue;
           }
           break;
+        }
+        if (pass_end) {
+          if (pslots) { /* the queue is empty: the same recipes through the next PAM-pair table */
+            next_pairtab();
+            spos = 0;
+          } else {
+            seeds_left = false;
+          }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         continue;
@@ -1068,12 +1035,14 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     if (n_ovf) atomicAdd(&a.stats[1], n_ovf);
     if (n_two) atomicAdd(&a.stats[4], (unsigned long long)n_two);
     if (n_fb) atomicAdd(&a.stats[5], (unsigned long long)n_fb);
+    if (n_pair) atomicAdd(&a.stats[7], (unsigned long long)n_pair);
     if constexpr (CNT) {
       atomicAdd(&a.stats[8], (unsigned long long)c_tab);
       atomicAdd(&a.stats[9], (unsigned long long)c_c16);
       atomicAdd(&a.stats[10], (unsigned long long)c_ctx);
       atomicAdd(&a.stats[11], (unsigned long long)c_isa);
       atomicAdd(&a.stats[12], (unsigned long long)c_occ);
+      atomicAdd(&a.stats[3], (unsigned long long)c_rec);
     }
   }
 }
@@ -1081,9 +1050,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
 #define GS_DEF_SEARCH(NAME, CNT, WALK, WEU)                                                                          \
   __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(WEU, WEU))) void NAME(          \
       gs_search_args a) {                                                                                             \
-    __shared__ uint4 s_stack[SEARCH_WAVES][((WALK) ? STACK_ENTRIES : 0) + VQ_CAP + 32];                                \
-    extern __shared__ uint32_t s_plan[]; /* seeding plan: one LDS read instead of a global one */                     \
-    k_search_body<CNT, WALK>(a, s_stack[threadIdx.x / WAVE], s_plan);                                                  \
+    __shared__ uint4 s_stack[SEARCH_WAVES][(WALK) ? WAVE_LDS_ENTRIES : WAVE_LDS_FAST];                                 \
+    k_search_body<CNT, WALK>(a, s_stack[threadIdx.x / WAVE]);                                                          \
   }
 GS_DEF_SEARCH(k_search_walk, false, true, GS_WAVES_EU)       /* reference-order walk; remainders beyond ctx[] */
 GS_DEF_SEARCH(k_search_fast, false, false, GS_WAVES_EU_FAST) /* the timed kernel */
@@ -1148,6 +1116,22 @@ __global__ void k_prepare(gs_prep_args a) {
     }
   } else {
     r.npams = 1;
+  }
+  if (a.pair_hist != nullptr && a.P >= 2u) {
+    /* which PAM-pair tables would serve this batch: one atomic per wave and distinct pair */
+    for (uint32_t j = 0; j < 4u; j++) {
+      const bool has = r.valid && j < r.npams;
+      const uint32_t c0 = (r.pam[j] >> (3u * (a.P - 2u))) & 7u, c1 = (r.pam[j] >> (3u * (a.P - 1u))) & 7u;
+      const uint32_t code = (c0 > 3u || c1 > 3u) ? 16u : (c0 | (c1 << 2));
+      uint64_t todo = __ballot(has);
+      while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        const uint32_t c = (uint32_t)__shfl((int)code, l);
+        const uint64_t same = __ballot(has && code == c);
+        if ((int)lane_id() == l) atomicAdd(&a.pair_hist[c], (uint32_t)__popcll(same));
+        todo &= ~same;
+      }
+    }
   }
   if (a.chunk == 0) {
     if (!r.valid) atomicAdd(a.n_invalid, 1u);
@@ -1753,6 +1737,138 @@ static void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, d
     if (astar[o] > astar[o - 1]) astar[o] = astar[o - 1];
 }
 
+/* ---- seed recipes (gs_search_args::rec_*) -------------------------------------------------------
+ * The depth-k seeds of an item are the same set of substitution patterns for every guide: which
+ * steps are substituted, by which of the three other bases (a digit relative to the guide's own
+ * symbol), read from which copy of the table.  The lists are written once per (budget, geometry,
+ * thresholds) and kept on the handle; a seeding step of k_search hands recipe pos + lane to lane. */
+static inline uint64_t recipe_word(uint32_t n, uint32_t lo, bool rot, uint32_t rs, const uint32_t *fields) {
+  uint64_t w = (uint64_t)n | ((uint64_t)lo << 3) | (rot ? (1ull << 6) | ((uint64_t)rs << 7) : 0ull);
+  for (uint32_t i = 0; i < 7; i++) w |= (uint64_t)(i < n ? fields[i] : 3u) << (12 + 7 * i);
+  return w;
+}
+/* this strand's seeds: variants of the first k-2 steps with j substitutions (ax of them among the first
+ * nX steps, set X) x the two-symbol extensions the budget allows; two-sided (astar != nullptr): only
+ * what has ax < astar[substitutions outside X] */
+static void build_recipes_a(std::vector<uint64_t> &out, uint32_t k, uint32_t m, uint32_t nX, const uint32_t *astar, bool rot) {
+  const uint32_t kp = k - 2, xmask = nX >= 32 ? 0xFFFFFFFFu : (1u << nX) - 1u;
+  auto mine = [&](uint32_t ax, uint32_t o) { return !astar || (o < 8 && ax < astar[o]); };
+  const uint32_t jmax = std::min(std::min(m, kp), 7u);
+  for (uint32_t j = 0; j <= jmax; j++)
+    for (uint32_t mk = 0; mk < (1u << kp); mk++) {
+      if ((uint32_t)__builtin_popcount(mk) != j) continue;
+      const uint32_t ax = (uint32_t)__builtin_popcount(mk & xmask), o0 = j - ax;
+      if (!mine(ax, o0)) continue;
+      uint32_t eb = 0; /* substitutions the extension may add */
+      while (eb < 2 && j + eb + 1 <= m && mine(ax, o0 + eb + 1)) eb++;
+      uint32_t steps[8], ns = 0, plast = 0;
+      for (uint32_t t = 0; t < kp; t++)
+        if ((mk >> t) & 1u) steps[ns++] = plast = t;
+      uint32_t ndig = 1;
+      for (uint32_t i = 0; i < j; i++) ndig *= 3;
+      for (uint32_t dc = 0; dc < ndig; dc++) {
+        uint32_t f[8], x = dc;
+        for (uint32_t i = j; i-- > 0;) { /* the last substituted step's digit runs fastest */
+          f[i] = (steps[i] << 2) | (x % 3);
+          x /= 3;
+        }
+        auto emit = [&](uint32_t e2, uint32_t e1, bool r, uint32_t rs) {
+          uint32_t n = j;
+          if (e2) f[n++] = ((k - 2) << 2) | (e2 - 1);
+          if (e1) f[n++] = ((k - 1) << 2) | (e1 - 1);
+          if (n > m || n > 7 || !mine(ax, o0 + (n - j))) return;
+          out.push_back(recipe_word(n, 0, r, rs, f));
+        };
+        if (eb >= 2) { /* 16 neighbours of the plain table: 4 lines */
+          for (uint32_t e2 = 0; e2 < 4; e2++)
+            for (uint32_t e1 = 0; e1 < 4; e1++) emit(e2, e1, false, 0);
+        } else if (eb == 1) { /* one line of the plain table + one of the copy rotated at step k-2 */
+          for (uint32_t e1 = 0; e1 < 4; e1++) emit(0, e1, false, 0);
+          for (uint32_t e2 = 1; e2 < 4; e2++) emit(e2, 0, rot, k - 2);
+        } else {
+          emit(0, 0, rot && j >= 1, plast);
+        }
+      }
+    }
+}
+/* the other strand's seeds under two-sided seeding: classes (o substitutions in O, b in R) with
+ * astar[o] + o + b <= m; step y consumes guide symbol L-1-y: R = y in [0, L-k), O = y in [L-k, k-P).
+ * The recipe carries lo = astar[o], the least number of substitutions its rows need inside X. */
+static void build_recipes_b(std::vector<uint64_t> &out, uint32_t k, uint32_t L, uint32_t P, uint32_t m, uint32_t nX,
+                            const uint32_t *astar, bool rot) {
+  const uint32_t nO = k - nX, nR = L - k, ylo = L - k;
+  for (uint32_t o = 0; o <= m && o <= nO && o < 8; o++)
+    for (uint32_t b = 0; b <= nR && astar[o] + o + b <= m; b++) {
+      if (astar[o] > nX || o + b > 7) continue;
+      const uint32_t jb = o + b;
+      uint32_t ndig = 1;
+      for (uint32_t i = 0; i < jb; i++) ndig *= 3;
+      for (uint32_t mo = 0; mo < (1u << nO); mo++) {
+        if ((uint32_t)__builtin_popcount(mo) != o) continue;
+        for (uint32_t mr = 0; mr < (1u << nR); mr++) {
+          if ((uint32_t)__builtin_popcount(mr) != b) continue;
+          const uint32_t mk = (mo << ylo) | mr;
+          uint32_t ys[8], ns = 0, ymax = 0;
+          for (uint32_t y = 0; y < k - P; y++)
+            if ((mk >> y) & 1u) ys[ns++] = ymax = y;
+          const uint32_t slast = P + ymax; /* consumption step of the last substituted symbol */
+          const bool r = rot && jb >= 1 && slast + 2 <= k;
+          for (uint32_t dc = 0; dc < ndig; dc++) {
+            uint32_t f[8], x = dc;
+            for (uint32_t i = jb; i-- > 0;) {
+              f[i] = (ys[i] << 2) | (x % 3);
+              x /= 3;
+            }
+            out.push_back(recipe_word(jb, astar[o] > 7 ? 7u : astar[o], r, slast, f));
+          }
+        }
+      }
+    }
+}
+static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m, uint32_t v_rem, const uint32_t *astar,
+                                hipStream_t st) {
+  const uint32_t k = ix->pt_k;
+  const bool rot = ix->strand[0].ptab_rot != nullptr && ix->strand[1].ptab_rot != nullptr;
+  uint64_t key[2] = {((uint64_t)L << 48) | ((uint64_t)P << 40) | ((uint64_t)m << 32) | ((uint64_t)k << 24) |
+                         ((uint64_t)v_rem << 16) | (rot ? 2u : 0u) | (astar ? 1u : 0u),
+                     0};
+  if (astar)
+    for (uint32_t o = 0; o < 8; o++) key[1] |= (uint64_t)(astar[o] > 15 ? 15u : astar[o]) << (4 * o);
+  if (ix->rec_valid && ix->rec_key[0] == key[0] && ix->rec_key[1] == key[1]) return GS_OK;
+  std::vector<uint64_t> all;
+  build_recipes_a(all, k, m, v_rem, nullptr, rot);
+  const size_t n_full = all.size();
+  size_t n_a = 0, n_b = 0;
+  if (astar) {
+    build_recipes_a(all, k, m, v_rem, astar, rot);
+    n_a = all.size() - n_full;
+    build_recipes_b(all, k, L, P, m, v_rem, astar, rot);
+    n_b = all.size() - n_full - n_a;
+  }
+  if (all.size() >= (1ull << 31)) {
+    gs_set_error("seed plan too large for this mismatch budget");
+    return GS_ERR_UNSUPPORTED;
+  }
+  ix->rec_valid = false;
+  gs_status rc = gs_reserve(ix->w_rec, 8 * all.size() + 64);
+  if (rc != GS_OK) return rc;
+  GS_HIP(hipMemcpyAsync(ix->w_rec.p, all.data(), 8 * all.size(), hipMemcpyHostToDevice, st));
+  GS_HIP(hipStreamSynchronize(st)); /* `all` is a local */
+  ix->n_rec_full = (uint32_t)n_full;
+  ix->n_rec_a = (uint32_t)n_a;
+  ix->n_rec_b = (uint32_t)n_b;
+  ix->rec_a_rot_first = 31;
+  for (size_t i = n_full; i < n_full + n_a; i++)
+    if (all[i] & 64u) ix->rec_a_rot_first = std::min(ix->rec_a_rot_first, (uint32_t)(all[i] >> 7) & 31u);
+  ix->rec_key[0] = key[0];
+  ix->rec_key[1] = key[1];
+  ix->rec_valid = true;
+  if (getenv("GS_DEBUG"))
+    fprintf(stderr, "[gs] seed recipes: %zu one-sided, %zu + %zu two-sided (%.1f MB)\n", n_full, n_a, n_b, 8e-6 * all.size());
+  return GS_OK;
+}
+
+
 static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,
                                        const void *d_guide_pams, uint32_t P, const char *alt_pams,
                                        uint32_t n_alt, uint32_t mismatches, uint32_t flags,
@@ -1792,7 +1908,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   uint32_t cap = choose_cap(ix, mismatches, L, P, P ? n_alt : 0, flags);
   gs_status rc;
   /* misc: [0..15] uint64 stats ; then work counter / invalid counter */
-  if ((rc = gs_reserve(ix->w_misc, 256)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_misc, 512)) != GS_OK) return rc;
   /* PAM list = alt PAMs ++ the guide's own (process.hpp:51-56).  An alt PAM with a symbol outside
    * A,C,G,T,N is a literal (index.hpp:130-137): it can only match if the genome holds that symbol -
    * then the whole batch belongs to the general path - and is dropped otherwise. */
@@ -1830,7 +1946,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   uint32_t *d_invalid = d_work + 1;
 
   GS_HIP(hipEventRecord(ix->ev[0], st));
-  GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 256, st));
+  GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 512, st));
   if (n == 0) {
     GS_HIP(hipMemsetAsync(ix->w_offsets.p, 0, sizeof(uint64_t), st));
     GS_HIP(hipStreamSynchronize(st));
@@ -1858,11 +1974,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     pa.start = (flags & GS_FLAG_PAM_AT_START) ? 1 : 0;
     pa.chunk = c;
     pa.force_invalid = force_general ? 1u : 0u;
+    pa.pair_hist = (uint32_t *)((char *)ix->w_misc.p + 256);
     hipLaunchKernelGGL(k_prepare, dim3((n32 + 255) / 256), dim3(256), 0, st, pa);
   }
   /* guides the fast path does not encode get empty hit lists and a flag; the batch goes on */
-  uint32_t h_invalid = 0;
+  uint32_t h_invalid = 0, h_pairs[17] = {0};
   GS_HIP(hipMemcpyAsync(&h_invalid, d_invalid, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(h_pairs, (char *)ix->w_misc.p + 256, sizeof(h_pairs), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   ix->last_unsupported = h_invalid;
   const uint32_t n_alt_given = n_alt;
@@ -1884,12 +2002,11 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
    * arrays exist */
   bool bidir = false;
   uint32_t astar_packed = 0xFFFFFFFFu, astar[8] = {15, 15, 15, 15, 15, 15, 15, 15};
-  uint32_t planA_g = 0, planB_g = 0, nclsA = 0, nclsB = 0, plan2_words = 0;
   uint32_t n_cand[2] = {0, 0};
   const uint4 *d_cand[2] = {nullptr, nullptr};
   if (v_rem != 0 && mismatches >= 1 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
       L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !getenv("GS_NO_BIDIR")) {
-    const uint32_t k = ix->pt_k, kp = k - 2, m = mismatches;
+    const uint32_t k = ix->pt_k, m = mismatches;
     const uint32_t nX = v_rem, nO = k - v_rem, nR = L - k; /* |X|, |O|, |R| */
     /* PAM expansions the other strand enumerates per item (its table holds concrete bases only) */
     double epam = 0;
@@ -1918,87 +2035,6 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       bidir = true;
       astar_packed = 0;
       for (uint32_t o = 0; o < 8; o++) astar_packed |= (astar[o] > 15 ? 15u : astar[o]) << (4 * o);
-      /* this strand's filtered plan: one class per (j substitutions in the first k-2 steps, ax of
-       * them inside X), kept when ax < astar(j - ax); its two-symbol extension (both symbols lie
-       * in O) may add as many substitutions as astar still allows */
-      const uint32_t xmask = (1u << nX) - 1u;
-      std::vector<uint32_t> planA(GS_PLAN_HEADER, 0u);
-      const uint32_t jmax = m < kp ? m : kp;
-      for (uint32_t j = 0; j <= jmax && bidir; j++)
-        for (uint32_t ax = 0; ax <= j && ax <= nX; ax++) {
-          const uint32_t o0 = j - ax;
-          if (o0 >= 8 || ax >= astar[o0]) continue;
-          uint32_t eb = 0;
-          while (eb < 2 && j + eb + 1 <= m && o0 + eb + 1 < 8 && ax < astar[o0 + eb + 1]) eb++;
-          if (nclsA >= GS_PLAN_CLASSES) {
-            bidir = false;
-            break;
-          }
-          const uint32_t c = nclsA;
-          planA[c] = (uint32_t)planA.size();
-          uint32_t cnt = 0;
-          for (uint32_t mk = 0; mk < (1u << kp); mk++) {
-            if ((uint32_t)__builtin_popcount(mk) != j || (uint32_t)__builtin_popcount(mk & xmask) != ax) continue;
-            planA.push_back(mk);
-            cnt++;
-          }
-          if (!cnt) continue;
-          planA[GS_PLAN_CLASSES + c] = cnt;
-          planA[2 * GS_PLAN_CLASSES + c] = j | (eb << 4);
-          nclsA++;
-        }
-      /* the other strand's plan: classes (o, b) with astar(o) + o + b <= m; bit y of a mask = guide
-       * symbol L-1-y; O = y in [L-k, k-P-1], R = y in [0, L-k-1] */
-      std::vector<uint32_t> planB;
-      {
-        struct cls {
-          uint32_t o, b;
-        };
-        std::vector<cls> cl;
-        for (uint32_t o = 0; o <= m && o <= nO && o < 8; o++)
-          for (uint32_t b = 0; b <= nR && astar[o] + o + b <= m; b++)
-            if (astar[o] <= nX) cl.push_back({o, b});
-        nclsB = (uint32_t)cl.size();
-        if (nclsB > 32) bidir = false;
-        planB.assign(4 * (size_t)nclsB, 0u);
-        const uint32_t ylo = L - k;
-        uint32_t lanes = 0;
-        for (uint32_t c = 0; c < nclsB && bidir; c++) {
-          const uint32_t o = cl[c].o, b = cl[c].b, jb = o + b;
-          uint32_t pw3 = 1;
-          for (uint32_t i = 0; i < jb; i++) pw3 *= 3;
-          planB[4 * c] = (uint32_t)planB.size();
-          uint32_t cnt = 0;
-          for (uint32_t mo = 0; mo < (1u << nO); mo++) {
-            if ((uint32_t)__builtin_popcount(mo) != o) continue;
-            for (uint32_t mr = 0; mr < (1u << nR); mr++) {
-              if ((uint32_t)__builtin_popcount(mr) != b) continue;
-              planB.push_back((mo << ylo) | mr);
-              cnt++;
-            }
-          }
-          const uint64_t span = (uint64_t)cnt * pw3;
-          if (span + lanes >= (1u << 20)) { /* the lane arithmetic of k_search is exact below 2^20 */
-            bidir = false;
-            break;
-          }
-          lanes += (uint32_t)span;
-          planB[4 * c + 1] = lanes;
-          planB[4 * c + 2] = jb | (astar[o] << 4) | (pw3 << 8);
-          planB[4 * c + 3] = jb ? (uint32_t)((0x100000000ull + pw3 - 1) / pw3) : 0u;
-        }
-      }
-      plan2_words = (uint32_t)(planA.size() + planB.size());
-      if (bidir && ix->combo_words + plan2_words > ix->combo_cap) bidir = false;
-      if (bidir) {
-        planA_g = ix->combo_words;
-        planB_g = ix->combo_words + (uint32_t)planA.size();
-        std::vector<uint32_t> both(planA);
-        both.insert(both.end(), planB.begin(), planB.end());
-        GS_HIP(hipMemcpyAsync((uint32_t *)ix->d_combo + ix->combo_words, both.data(), 4 * both.size(),
-                              hipMemcpyHostToDevice, st));
-        GS_HIP(hipStreamSynchronize(st)); /* `both` is a local */
-      }
     }
   }
   if (bidir) {
@@ -2073,9 +2109,59 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       d_cand[1] = dc + n_cand[0];
     }
     if (getenv("GS_DEBUG"))
-      fprintf(stderr, "[gs] two-sided seeding: astar %u,%u,%u,%u,%u,%u,%u,%u over |X|=%u |O|=%u |R|=%u, %u + %u classes, "
-              "plan %u words, literal-N windows %u + %u\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
-              astar[6], astar[7], v_rem, ix->pt_k - v_rem, L - ix->pt_k, nclsA, nclsB, plan2_words, n_cand[0], n_cand[1]);
+      fprintf(stderr, "[gs] two-sided seeding: astar %u,%u,%u,%u,%u,%u,%u,%u over |X|=%u |O|=%u |R|=%u, "
+              "literal-N windows %u + %u\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
+              astar[6], astar[7], v_rem, ix->pt_k - v_rem, L - ix->pt_k, n_cand[0], n_cand[1]);
+  }
+
+  /* the seed recipes of this (budget, geometry, thresholds): built once per handle and kept */
+  const bool table_seeding = ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK);
+  if (table_seeding) {
+    if (mismatches > 7) {
+      gs_set_error("more than 7 mismatches");
+      return GS_ERR_UNSUPPORTED;
+    }
+    if ((rc = gs_recipes_for(ix, L, P, mismatches, v_rem, bidir ? astar : nullptr, st)) != GS_OK) return rc;
+  }
+  /* PAM-pair tables for the (at most two) pairs of bases most patterns of this batch end in */
+  uint32_t n_pt = 0, pt_slot[2] = {0, 0};
+  if (bidir && P >= 2 && v_rem >= 2 && !getenv("GS_NO_PAIRTAB")) {
+    uint32_t want[2] = {16, 16};
+    for (uint32_t c = 0; c < 16; c++) {
+      if (!h_pairs[c]) continue;
+      if (want[0] == 16 || h_pairs[c] > h_pairs[want[0]]) {
+        want[1] = want[0];
+        want[0] = c;
+      } else if (want[1] == 16 || h_pairs[c] > h_pairs[want[1]]) {
+        want[1] = c;
+      }
+    }
+    const uint32_t max_pt = getenv("GS_PAIRTABS") ? (uint32_t)atol(getenv("GS_PAIRTABS")) : 2u;
+    bool taken[2] = {false, false};
+    for (uint32_t i = 0; i < 2 && i < max_pt; i++) { /* a slot that already holds the pair stays */
+      if (want[i] == 16) continue;
+      for (uint32_t s = 0; s < 2; s++)
+        if (!taken[s] && ix->pairtab[s].valid && ix->pairtab[s].code == want[i] && ix->pairtab[s].v_rem == v_rem) {
+          taken[s] = true;
+          break;
+        }
+    }
+    for (uint32_t i = 0; i < 2 && i < max_pt; i++) {
+      if (want[i] == 16) continue;
+      uint32_t s = 2;
+      for (uint32_t j = 0; j < 2; j++)
+        if (ix->pairtab[j].valid && ix->pairtab[j].code == want[i] && ix->pairtab[j].v_rem == v_rem) s = j;
+      if (s == 2)
+        for (uint32_t j = 0; j < 2; j++)
+          if (!taken[j]) {
+            s = j;
+            taken[j] = true;
+            break;
+          }
+      if (s == 2) continue;
+      if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], ix->rec_a_rot_first, st)) != GS_OK) return rc;
+      if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
+    }
   }
 
   const bool count_req = (flags & GS_FLAG_COUNT_REQUESTS) != 0;
@@ -2098,7 +2184,6 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     sa.P = P;
     sa.m = mismatches;
     sa.cap = cap_;
-    sa.combo = (const uint32_t *)ix->d_combo;
     sa.v_max = VERIFY_MAX_DEFAULT;
     if (const char *e = getenv("GS_VERIFY_MAX")) {
       const long v = atol(e);
@@ -2110,35 +2195,33 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
        * substitutions x the two-symbol extensions the remaining budget allows */
       sa.pt_k = ix->pt_k;
-      const uint32_t kp = ix->pt_k - 2;
-      uint32_t jmax = mismatches < kp ? mismatches : kp;
-      if (jmax > 7) jmax = 7;
-      sa.ncls = jmax + 1;
       sa.v_rem = v_rem;
-      sa.plan_words = ix->combo_off[jmax] + ix->combo_cnt[jmax];
-      sa.plan_src = 0;
+      sa.rec_full = (const uint2 *)ix->w_rec.p;
+      sa.n_rec_full = ix->n_rec_full;
       if (bidir) {
         sa.bidir = 1;
         sa.astar = astar_packed;
-        sa.planA_g = planA_g;
-        sa.nclsA = nclsA;
-        sa.planB_g = planB_g;
-        sa.nclsB = nclsB;
-        sa.plan_words = plan2_words;
-        sa.plan_src = ix->combo_words;
+        sa.rec_a = sa.rec_full + ix->n_rec_full;
+        sa.n_rec_a = ix->n_rec_a;
+        sa.rec_b = sa.rec_a + ix->n_rec_a;
+        sa.n_rec_b = ix->n_rec_b;
+        sa.n_pt = n_pt;
+        for (uint32_t i = 0; i < n_pt; i++) {
+          sa.pt[i][0] = ix->pairtab[pt_slot[i]].d[0];
+          sa.pt[i][1] = ix->pairtab[pt_slot[i]].d[1];
+        }
         sa.cand[0] = d_cand[0];
         sa.cand[1] = d_cand[1];
         sa.n_cand[0] = n_cand[0];
         sa.n_cand[1] = n_cand[1];
       }
-      sa.plan_lds = sa.plan_words <= (getenv("GS_PLAN_LDS") ? (uint32_t)atol(getenv("GS_PLAN_LDS")) : 1024u) ? 1u : 0u;
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as their
-     * LDS (verification queue 2.5 KiB per wave, + 3.5 KiB of stacks in the walking variant, + the
-     * plan) and the registers (8 waves per SIMD = 8 workgroups per CU) allow */
+     * LDS (verification queue 2.5 KiB + substitution table 1.4 KiB per wave, + 3.5 KiB of stacks in
+     * the walking variant) and the registers (8 waves per SIMD = 8 workgroups per CU) allow */
     const bool walk = sa.pt_k == 0 || sa.v_rem == 0;
-    const size_t dyn = sa.plan_lds ? 4 * (size_t)sa.plan_words : 0;
-    const size_t lds_wg = sizeof(uint4) * ((walk ? STACK_ENTRIES : 0) + VQ_CAP + 32) * SEARCH_WAVES + dyn;
+    const size_t dyn = 0;
+    const size_t lds_wg = sizeof(uint4) * (walk ? WAVE_LDS_ENTRIES : WAVE_LDS_FAST) * SEARCH_WAVES;
     uint32_t per_cu = (uint32_t)(160u * 1024u / lds_wg);
     const uint32_t weu = walk ? GS_WAVES_EU : GS_WAVES_EU_FAST;
     if (per_cu > weu) per_cu = weu; /* 4 SIMDs x weu waves = weu four-wave workgroups per CU */
@@ -2523,7 +2606,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu; slots %u per item, "
             "%u guides redone%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (device-wide ordering)" : "");
   h_stats3[6] = n_o;
-  h_stats3[7] = (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u);
+  h_stats3[7] = (h_stats3[7] << 8) | (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u); /* items through PAM-pair tables above the flags */
   h_stats3[13] = cap;
   memcpy(ix->last_counters, h_stats3, sizeof(h_stats3));
   /* matches per item seen at this budget: sizes the slots of the next batch */

@@ -145,7 +145,8 @@ void gs_index_close(gs_index *ix);
  * maximum of the per-item match counts; with
  * GS_FLAG_COUNT_REQUESTS also the 64-byte lines requested by the search kernel: [8] prefix-table
  * lines, [9] 16-bit context lines, [10] 32-bit context words, [11] SA/ISA gathers of the search,
- * [12] Occ block lines.  (the bytes the roofline is priced on.) */
+ * [12] Occ block lines, [3] lines of the seed recipe lists.  (the bytes the
+ * roofline is priced on.)  [7] >> 8: items whose seeds went through PAM-pair tables. */
 gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]);
 uint64_t gs_index_genome_length(const gs_index *ix); /* sum of chromosome lengths (no sentinel) */
 uint64_t gs_index_device_bytes(const gs_index *ix);

@@ -428,20 +428,34 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
         guides = [fam.tobytes().decode(), synth.reverse_complement_bytes(fam).tobytes().decode()]
         guides += [sampled[i].tobytes().decode() for i in range(sampled.shape[0])]
         seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
-        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (len(guides), 1))
         for cfg in (dict(m=3), dict(m=2), dict(m=4), dict(m=3, alt=("NAG",)), dict(m=3, start=True),
-                    dict(m=5, alt=("NAG", "NGA")), dict(m=6), dict(m=1), dict(m=4, alt=("NGN",))):
-            m, alt, start = cfg["m"], cfg.get("alt", ()), cfg.get("start", False)
+                    dict(m=5, alt=("NAG", "NGA")), dict(m=6), dict(m=1), dict(m=4, alt=("NGN",)),
+                    dict(m=3, start=True, pam="TTN"), dict(m=3, pam="NAG", alt=("NGG",)), dict(m=3, one_table=True, alt=("NAG",)),
+                    dict(m=4, no_tables=True)):
+            m, alt, start, own = cfg["m"], cfg.get("alt", ()), cfg.get("start", False), cfg.get("pam", "NGG")
+            pams = np.tile(np.frombuffer(own.encode(), np.uint8), (len(guides), 1))
             opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
+            if cfg.get("one_table"):
+                monkeypatch.setenv("GS_PAIRTABS", "1")
+            if cfg.get("no_tables"):
+                monkeypatch.setenv("GS_NO_PAIRTAB", "1")
             capfd.readouterr()
             offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=start)
+            monkeypatch.delenv("GS_PAIRTABS", raising=False)
+            monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
             assert "two-sided seeding" in capfd.readouterr().err, cfg
+            # PAM-pair tables serve the items whose patterns all end in (at most two) pairs of concrete bases
+            cnt = gidx.last_counters()
+            pairs = {p[-2:] if not start else p[:2][::-1] for p in (own,) + tuple(alt)}
+            concrete = all("N" not in p for p in pairs)
+            want_tables = concrete and len(pairs) <= (1 if cfg.get("one_table") else 2) and not cfg.get("no_tables")
+            assert (cnt["items_pair_tables"] > 0) == want_tables, (cfg, cnt)
             total = 0
             for i, g in enumerate(guides):
-                exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3, start)
+                exp, _ = oracle_hits_as_records(oidx, g, own, opts, 3, start)
                 assert gpu_hits_as_records(offsets, hits, i, g, 3, start) == exp, (i, cfg, pk)
                 total += len(exp)
-            assert total > 100 or start or m < 2
+            assert total > 100 or start or m < 2 or own != "NGG"
     finally:
         gidx.close()
         oidx.close()
