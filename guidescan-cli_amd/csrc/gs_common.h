@@ -62,8 +62,11 @@ struct gs_strand_dev {
   uint32_t mask_off; /* 4 bits per pair position */
   /* rotated copies of the table: copy p (p < k-2) has the symbol of
    * consumption step p moved to the lowest index bits, so the three substitutions at step p
-   * of an otherwise fixed k-mer are neighbours in one 64-byte line.  k-2 tables back to back. */
+   * of an otherwise fixed k-mer are neighbours in one 64-byte line.  Steps rot_first .. k-2, back to back. */
   const uint4 *ptab_rot;
+  uint32_t rot_first; /* first consumption step that has a copy (31: none).  The lowest steps are the
+                         other strand's PAM steps, never substituted, and the last substituted step of
+                         few one-sided seeds: their copies (4.3 GB each at hg38 size) are not built */
   /* preceding context: ctx[r] = the 16 text symbols before suffix SA[r],
    * nearest first, 2 bits each (A,C,G,T = 0..3).  Lets a small interval at depth k be resolved
    * against the rest of the pattern with one 4-byte read per row instead of an Occ walk. */
@@ -141,14 +144,7 @@ struct gs_index {
   uint64_t last_unsupported = 0; /* guides of the last batch flagged GS_GUIDE_NEEDS_GENERAL (w_flags) */
   uint64_t seen_key[8] = {0};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  /* prefix-table seeding plan: position masks of every mismatch combination over the first
-   * pt_k-2 query symbols, grouped by mismatch count j (gs_index.hip: build_seed_plan) */
-  uint32_t pt_k = 0;
-  void *d_combo = nullptr;         /* uint32 masks, all j concatenated */
-  uint32_t combo_off[10] = {0};    /* start of the masks with j mismatches */
-  uint32_t combo_cnt[10] = {0};    /* C(pt_k-2, j) */
-  uint32_t combo_words = 0;        /* words of the full plan */
-  uint32_t combo_cap = 0;          /* words d_combo holds: the per-batch plans of two-sided seeding follow the full plan */
+  uint32_t pt_k = 0; /* depth of the prefix interval tables (0: none) */
   unsigned long long last_counters[16] = {0}; /* k_search's stats array of the last gs_enumerate_device call */
   std::vector<gs_nrun> nruns_text; /* 'N' runs of the forward text */
   gs_buffer w_cand;                /* per-batch literal-N candidate windows (device) */
@@ -159,7 +155,7 @@ struct gs_index {
   uint32_t rec_a_rot_first = 31;   /* lowest consumption step whose rotated copy rec_a reads (31: none) */
   /* PAM-pair tables (gs_pairtab.hip), built on first use for the pairs a batch's patterns end in */
   gs_pairtab_host pairtab[2];
-  uint64_t pair_clock = 0;
+  bool pairtab_off = false; /* a batch ran out of memory next to them: not built again on this handle */
 };
 
 /* make sure slot `slot` holds the tables of pair `code` at context depth v_rem with rotated copies from

@@ -526,14 +526,14 @@ __global__ void k_ctx_build(const uint8_t *text, const uint32_t *sa, uint64_t n,
   }
 }
 
-/* rot[p][perm_p(i)] = tab[i]: the field of consumption step p (bits 2(k-1-p)) moves to bits 1:0 */
-__global__ void k_rot_copy(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p) {
+/* rot[slot][perm_p(i)] = tab[i]: the field of consumption step p (bits 2(k-1-p)) moves to bits 1:0 */
+__global__ void k_rot_copy(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p, uint32_t slot) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> (2 * k)) return;
   const uint32_t sh = 2u * (k - 1u - p);
   const uint64_t hi = i >> (sh + 2u), lo = i & ((1ull << sh) - 1ull), f = (i >> sh) & 3ull;
   const uint64_t j = (hi << (sh + 2u)) | (lo << 2) | f;
-  rot[((uint64_t)p << (2 * k)) + j] = tab[i];
+  rot[((uint64_t)slot << (2 * k)) + j] = tab[i];
 }
 
 __global__ void k_isa_build(const uint32_t *sa, uint64_t n, uint32_t *isa) {
@@ -626,7 +626,9 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   double budget = 1e30;
   if (const char *e = getenv("GS_INDEX_BUDGET_GB")) budget = atof(e) * 1e9 / 2.0; /* per strand */
   const double base_bytes = (double)s->bytes + (double)bytes; /* blocks, SA, context arrays, table */
-  const uint32_t nrot = k >= 4 ? k - 1 : 0;
+  uint32_t rot_first = 3; /* see gs_strand_dev::rot_first */
+  if (const char *e = getenv("GS_ROT_FIRST")) rot_first = (uint32_t)atoi(e);
+  const uint32_t nrot = k >= 4 && rot_first + 1 < k ? k - 1 - rot_first : 0;
   const double rot_bytes = (double)bytes * nrot, isa_bytes = 4.0 * (double)s->n;
   uint32_t *isa = nullptr;
   if (ctx && !getenv("GS_NO_BIDIR") && !getenv("GS_NO_ISA") && base_bytes + isa_bytes <= budget) {
@@ -640,12 +642,12 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   }
   uint4 *rot = nullptr;
   if (ctx && nrot && !getenv("GS_NO_ROT") && base_bytes + (isa ? isa_bytes : 0.0) + rot_bytes <= budget) {
-    /* one copy per step 0..k-2: steps 0..k-3 serve the budget-0 variants (their last
+    /* one copy per step rot_first..k-2: steps up to k-3 serve the budget-0 variants (their last
      * substituted step), step k-2 the budget-1 variants (substitutions of the second-last
      * symbol next to each other) */
     if (hipMalloc(&rot, bytes * nrot) == hipSuccess) {
       for (uint32_t p = 0; p < nrot; p++)
-        hipLaunchKernelGGL(k_rot_copy, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, rot, k, p);
+        hipLaunchKernelGGL(k_rot_copy, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, rot, k, rot_first + p, p);
       s->bytes += bytes * nrot;
     } else {
       rot = nullptr; /* not enough memory: the plain table serves every class */
@@ -657,6 +659,7 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   s->d.isa = isa;
   s->ptab_rot = rot;
   s->d.ptab_rot = rot;
+  s->d.rot_first = rot ? rot_first : 31u;
   s->ptab = tab;
   s->d.ptab = tab;
   s->ctx = ctx;
@@ -664,36 +667,6 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   s->ctx16 = ctx16;
   s->d.ctx16 = ctx16;
   s->bytes += bytes;
-  return GS_OK;
-}
-
-/* all position masks with j bits over kp positions, j = 0..min(kp,7), in a fixed order */
-static gs_status build_seed_plan(gs_index *ix, uint32_t k) {
-  ix->pt_k = k;
-  if (!k) return GS_OK;
-  const uint32_t kp = k - 2;
-  /* header (k_search, gs_search_args::combo): [c] offset, [32+c] count, [64+c] meta of class c; the
-   * full plan has one class per substitution count j, extension budget "all that is left" */
-  std::vector<uint32_t> masks(96, 0u);
-  for (uint32_t j = 0; j <= 7; j++) {
-    masks[j] = (uint32_t)masks.size();
-    uint32_t cnt = 0;
-    if (j <= kp)
-      for (uint32_t m = 0; m < (1u << kp); m++)
-        if ((uint32_t)__builtin_popcount(m) == j) {
-          masks.push_back(m);
-          cnt++;
-        }
-    masks[32 + j] = cnt;
-    masks[64 + j] = j | (15u << 4);
-    ix->combo_off[j] = masks[j];
-    ix->combo_cnt[j] = cnt;
-  }
-  /* room for a second, filtered plan written per batch (two-sided seeding) */
-  ix->combo_words = (uint32_t)masks.size();
-  ix->combo_cap = 2 * ix->combo_words + (1u << 15) + 1024u;
-  GS_HIP(hipMalloc(&ix->d_combo, 4 * (size_t)ix->combo_cap));
-  GS_HIP(hipMemcpy(ix->d_combo, masks.data(), 4 * masks.size(), hipMemcpyHostToDevice));
   return GS_OK;
 }
 
@@ -772,7 +745,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
     if (ix->strand[s].sa == d_sa) cleanup.sa = nullptr; /* the strand owns it now (also when it failed later) */
     if (rc == GS_OK) rc = build_ptab(d_t, &ix->strand[s], pk, st);
   }
-  if (rc == GS_OK) rc = build_seed_plan(ix, pk);
+  if (rc == GS_OK) ix->pt_k = pk; /* depth of the prefix interval tables; the seed recipes are written per batch shape (gs_search.hip) */
   if (rc == GS_OK) scan_n_runs(text, len, ix->nruns_text);
   if (rc != GS_OK) return rc; /* cleanup releases everything */
   cleanup.armed = false;
@@ -906,7 +879,6 @@ extern "C" void gs_index_close(gs_index *ix) {
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)
     if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
-  if (ix->d_combo) hipFree(ix->d_combo);
   gs_pairtab_free(ix, 0);
   gs_pairtab_free(ix, 1);
   delete ix;
@@ -948,7 +920,10 @@ gs_status gs_reserve(gs_buffer &b, size_t bytes) {
   b.cap = 0;
   size_t want = bytes + bytes / 4 + 256;
   if (hipMalloc(&b.p, want) != hipSuccess) {
+    (void)hipGetLastError(); /* or the next call that reports the last error (rocPRIM does) fails with this one */
     if (hipMalloc(&b.p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
       gs_set_error("out of device memory");
       return GS_ERR_NOMEM;
     }

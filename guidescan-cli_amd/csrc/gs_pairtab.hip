@@ -200,7 +200,6 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
   gs_pairtab_host &p = ix->pairtab[slot];
   const uint32_t k = ix->pt_k;
   if (rot_first > 31) rot_first = 31;
-  if (!ix->strand[0].ptab_rot || !ix->strand[1].ptab_rot) rot_first = 31; /* the recipes read no copies then */
   const uint32_t rot_wanted = rot_first;
   if (p.valid && p.v_rem == v_rem && p.code == code && p.rot_first <= rot_wanted) return GS_OK;
   gs_pairtab_free(ix, slot);
@@ -209,7 +208,7 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
   size_t free_b = 0, total_b = 0;
   GS_HIP(hipMemGetInfo(&free_b, &total_b));
   const double entry_bytes = 16.0 * (double)(1ull << (2 * k));
-  double reserve = 24e9;
+  double reserve = 64e9; /* slots, sort buffers and hits of a large batch at a high budget */
   if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
   if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
   const double rows_bytes = 10.0 * ((double)ix->strand[0].n + (double)ix->strand[1].n) / 16.0 * 1.5;

@@ -183,7 +183,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     /* what this strand's seeds are looked up in and verified against: the strand's own table and
      * context arrays, or (set per item, below) a PAM-pair table and its rows */
     const uint4 *atab = sd.ptab, *arot = sd.ptab_rot;
-    uint32_t arot_first = 0;
+    uint32_t arot_first = sd.rot_first;
     const uint16_t *a16 = sd.ctx16;
     const uint32_t *actx = sd.ctx, *arow = nullptr;
 
@@ -692,7 +692,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             uint64_t path = ppath;
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
             {
-              const uint4 *ep = apply_recipe(rc, sb.ptab, sb.ptab_rot, 0u, pidx, path);
+              const uint4 *ep = apply_recipe(rc, sb.ptab, sb.ptab_rot, sb.rot_first, pidx, path);
               if (act) ent = *ep;
               count_lines(c_tab, act, ep);
             }
@@ -1828,7 +1828,7 @@ static void build_recipes_b(std::vector<uint64_t> &out, uint32_t k, uint32_t L, 
 static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m, uint32_t v_rem, const uint32_t *astar,
                                 hipStream_t st) {
   const uint32_t k = ix->pt_k;
-  const bool rot = ix->strand[0].ptab_rot != nullptr && ix->strand[1].ptab_rot != nullptr;
+  const bool rot = true; /* the recipes name the copy that would share lines; a table without it reads its plain copy */
   uint64_t key[2] = {((uint64_t)L << 48) | ((uint64_t)P << 40) | ((uint64_t)m << 32) | ((uint64_t)k << 24) |
                          ((uint64_t)v_rem << 16) | (rot ? 2u : 0u) | (astar ? 1u : 0u),
                      0};
@@ -1880,8 +1880,19 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
                                          void *stream, const void **d_offsets, const void **d_hits,
                                          gs_result_view *stats) {
   try { /* the plans and lists built per batch live in std containers: nothing may throw across the C boundary */
-    return enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream,
-                                 d_offsets, d_hits, stats);
+    gs_status rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream,
+                                         d_offsets, d_hits, stats);
+    if (rc == GS_ERR_NOMEM && ix && (ix->pairtab[0].valid || ix->pairtab[1].valid)) {
+      /* the batch's workspace did not fit next to the PAM-pair tables: they are derived data and go first */
+      (void)hipGetLastError();
+      gs_pairtab_free(ix, 0);
+      gs_pairtab_free(ix, 1);
+      ix->pairtab_off = true;
+      if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: PAM-pair tables dropped, batch redone without them\n");
+      rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets,
+                                 d_hits, stats);
+    }
+    return rc;
   } catch (const std::bad_alloc &) {
     return GS_ERR_NOMEM;
   }
@@ -2125,7 +2136,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   }
   /* PAM-pair tables for the (at most two) pairs of bases most patterns of this batch end in */
   uint32_t n_pt = 0, pt_slot[2] = {0, 0};
-  if (bidir && P >= 2 && v_rem >= 2 && !getenv("GS_NO_PAIRTAB")) {
+  if (bidir && P >= 2 && v_rem >= 2 && !ix->pairtab_off && !getenv("GS_NO_PAIRTAB")) {
     uint32_t want[2] = {16, 16};
     for (uint32_t c = 0; c < 16; c++) {
       if (!h_pairs[c]) continue;
