@@ -35,6 +35,8 @@ struct gs_pairtab_dev {
   const uint32_t *rowid; /* its row in the strand's suffix array */
   uint32_t rot_first;
   uint32_t code;
+  /* the deep table of the strand seen from the other strand's items (gs_pairtab.hip), or nullptr */
+  const uint4 *deep;
 };
 struct gs_strand_dev {
   const uint4 *blocks;       /* (n >> 7) + 1 blocks of 4 x uint4 */
@@ -122,7 +124,9 @@ struct gs_pairtab_host {
   bool valid = false;
   uint32_t v_rem = 0, code = 0, rot_first = 31;
   gs_pairtab_dev d[2]{};
-  void *mem[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+  void *mem[2][8] = {{nullptr}, {nullptr}};
+  bool deep = false;               /* both strands' deep tables exist (PAM length deep_P) */
+  uint32_t deep_P = 0;
   uint64_t bytes = 0, used = 0;
 };
 
@@ -161,6 +165,8 @@ struct gs_index {
 /* make sure slot `slot` holds the tables of pair `code` at context depth v_rem with rotated copies from
  * step rot_first on (fewer when memory is short); valid stays false when they do not fit */
 gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, hipStream_t st);
+/* add the deep tables (the other strand's side, PAM of three symbols) to a valid slot; p.deep stays false when they do not fit */
+gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, hipStream_t st);
 void gs_pairtab_free(gs_index *ix, uint32_t slot);
 
 #define GS_HIP(expr)                                                              \

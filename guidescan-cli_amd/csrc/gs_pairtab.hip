@@ -15,8 +15,9 @@
  * Derived data, built on the device from the strand's table and ctx[] on first use (~0.1 s at hg38
  * size), 4.3 GB per table copy + 10 bytes per selected row.
  */
-#include "gs_common.h"
+#include "gs_device.h"
 
+#include <algorithm>
 #include <rocprim/rocprim.hpp>
 
 struct pt_args {
@@ -106,14 +107,68 @@ __global__ void k_pt_rot(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p, u
   rot[((uint64_t)slot << (2 * k)) + ((hi << (sh + 2u)) | (lo << 2) | f)] = tab[i];
 }
 
+/* ---- the other strand's side: tables deeper by the PAM's free symbol ----------------------------------
+ * Under two-sided seeding the sites with many substitutions among a guide's first consumed symbols
+ * come from the OTHER strand's table, whose backward search consumes the PAM first: k-mer = P PAM
+ * symbols + k-P guide symbols, one lookup per base a PAM 'N' can stand for.  For a PAM of three symbols
+ * that ends (as this strand consumes it) in the pair `code`, the deep table is indexed by k-2 guide
+ * symbols and, in the lowest two bits, the base under the N: entry = the interval of the rows that
+ * start with those k+1 symbols - a quarter of the rows of a depth-k interval - in the strand table's
+ * own format {first row, rows | flag << 31, pair masks over these rows (context offsets 0, 2, 4, 6)}.
+ * The four entries of one (k-2)-mer are one 64-byte line; with 2.9 rows behind a mask instead of
+ * 11.5 few seeds survive it.  The rows are rows of the strand's own suffix array: verification reads
+ * the strand's ctx16[] / ctx[] as before.  4^(k-2) x 64 bytes: 1.07 GB per strand at k = 14. */
+struct pb_args {
+  gs_strand_dev sd;
+  uint32_t k, P, code; /* code as this strand's consumption sees the pair: first | second << 2 */
+  uint64_t entries;    /* 4^(k-2) */
+  uint4 *out;          /* 4 per entry */
+};
+
+__global__ void k_pb_build(pb_args a) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.entries) return;
+  const uint32_t k = a.k, P = a.P, kb = k - 2u;
+  /* the first k consumed symbols: the pair (second consumed PAM symbol of this strand first), the base
+   * under the N, then the k-P leading symbols of the entry */
+  const uint32_t c0 = a.code & 3u, c1 = (a.code >> 2) & 3u;
+  uint32_t head = ((3u - c1) << (2u * (k - 1u))) | ((3u - c0) << (2u * (k - 2u)));
+  for (uint32_t y = 0; y < k - P; y++) head |= (uint32_t)((i >> (2u * (kb - 1u - y))) & 3u) << (2u * (k - 1u - P - y));
+  for (uint32_t x = 0; x < 4u; x++) {
+    const uint4 e = a.sd.ptab[head | (x << (2u * (k - 3u)))];
+    uint32_t lo = e.x, cnt = e.y & 0x7FFFFFFFu;
+    bool blind = (e.y >> 31) != 0u; /* exception rows somewhere in the depth-k interval: verify, do not filter */
+    for (uint32_t y = k - P; y < kb && cnt; y++) { /* the symbols the depth-k table does not reach */
+      const uint32_t c = (uint32_t)((i >> (2u * (kb - 1u - y))) & 3u);
+      const uint32_t hi = lo + cnt - 1u;
+      const uint32_t oa = occ1(a.sd.blocks, lo >> GS_BLOCK_SHIFT, lo & (GS_BLOCK_ROWS - 1u), c);
+      const uint32_t ob = occ1(a.sd.blocks, hi >> GS_BLOCK_SHIFT, (hi & (GS_BLOCK_ROWS - 1u)) + 1u, c);
+      lo = a.sd.C[c] + oa;
+      cnt = ob - oa;
+    }
+    if (cnt > 4096u) blind = true; /* too many rows to scan here */
+    uint32_t mz = 0, mw = 0;
+    if (cnt && !blind)
+      for (uint32_t j = 0; j < cnt; j++) {
+        const uint32_t w = a.sd.ctx[lo + j];
+        mz |= (1u << (w & 15u)) | (1u << (16u + ((w >> 4) & 15u)));
+        mw |= (1u << ((w >> 8) & 15u)) | (1u << (16u + ((w >> 12) & 15u)));
+      }
+    a.out[4 * i + x] = make_uint4(lo, cnt | (blind && cnt ? 0x80000000u : 0u), mz, mw);
+  }
+}
+
 void gs_pairtab_free(gs_index *ix, uint32_t slot) {
   gs_pairtab_host &p = ix->pairtab[slot];
   for (int s = 0; s < 2; s++)
-    for (int j = 0; j < 5; j++) {
+    for (int j = 0; j < 8; j++) {
       if (p.mem[s][j]) hipFree(p.mem[s][j]);
       p.mem[s][j] = nullptr;
     }
   p.valid = false;
+  p.deep = false;
+  p.d[0] = gs_pairtab_dev{};
+  p.d[1] = gs_pairtab_dev{};
   p.bytes = 0;
 }
 
@@ -196,6 +251,34 @@ static gs_status build_one(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, 
   return GS_OK;
 }
 
+/* the deep table of strand s for the pair (built after the pair table proper; optional) */
+static gs_status build_deep(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, uint32_t P, hipStream_t st) {
+  const gs_strand &S = ix->strand[s];
+  const uint64_t entries = 1ull << (2 * (k - 2));
+  void **m = p.mem[s];
+  if (hipMalloc(&m[5], 64 * entries) != hipSuccess) {
+    (void)hipGetLastError();
+    return GS_ERR_NOMEM;
+  }
+  pb_args a;
+  memset(&a, 0, sizeof(a));
+  a.sd = S.d;
+  a.k = k;
+  a.P = P;
+  a.code = p.code;
+  a.entries = entries;
+  a.out = (uint4 *)m[5];
+  hipLaunchKernelGGL(k_pb_build, dim3((uint32_t)((entries + 255) / 256)), dim3(256), 0, st, a);
+  GS_HIP(hipStreamSynchronize(st));
+  GS_HIP(hipGetLastError());
+  p.d[s].deep = (const uint4 *)m[5];
+  p.bytes += 64 * entries;
+  if (getenv("GS_DEBUG"))
+    fprintf(stderr, "[gs] deep table: strand %d, pair %u: %llu lines of four entries, %.2f GB\n", s, p.code,
+            (unsigned long long)entries, 1e-9 * (double)(64 * entries));
+  return GS_OK;
+}
+
 gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, hipStream_t st) {
   gs_pairtab_host &p = ix->pairtab[slot];
   const uint32_t k = ix->pt_k;
@@ -238,5 +321,37 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
     }
   }
   p.valid = true;
+  return GS_OK;
+}
+
+gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, hipStream_t st) {
+  gs_pairtab_host &p = ix->pairtab[slot];
+  const uint32_t k = ix->pt_k;
+  if (!p.valid || P != 3 || k < 6) return GS_OK;
+  if (p.deep && p.deep_P == P) return GS_OK;
+  auto drop = [&]() {
+    for (int s = 0; s < 2; s++) {
+      if (p.mem[s][5]) hipFree(p.mem[s][5]);
+      p.mem[s][5] = nullptr;
+      p.d[s].deep = nullptr;
+    }
+    p.deep = false;
+  };
+  drop();
+  size_t free_b = 0, total_b = 0;
+  GS_HIP(hipMemGetInfo(&free_b, &total_b));
+  double reserve = 56e9;
+  if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
+  if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
+  if (2.0 * 64.0 * (double)(1ull << (2 * (k - 2))) + reserve > (double)free_b) return GS_OK;
+  for (int s = 0; s < 2; s++) {
+    const gs_status rc = build_deep(ix, p, s, k, P, st);
+    if (rc != GS_OK) {
+      drop();
+      return rc == GS_ERR_NOMEM ? GS_OK : rc;
+    }
+  }
+  p.deep = true;
+  p.deep_P = P;
   return GS_OK;
 }

@@ -69,6 +69,10 @@ struct gs_search_args {
    * have that pair in place - a sixteenth of the genome's rows - instead of all of them */
   gs_pairtab_dev pt[2][2]; /* [slot][strand] */
   uint32_t n_pt;           /* slots in use */
+  /* bdeep: every pattern of the batch has a PAM-pair table with a deep table (PAM of three symbols): the
+   * other strand's seeds are entries of those - k-2 guide symbols deep, the base under the PAM's N
+   * folded in - and X shrinks to the first x_len = L-k+2 guide symbols (else x_len = v_rem) */
+  uint32_t bdeep, x_len;
   uint32_t pt_k; /* table depth k; seeds are the depth-k nodes */
   /* context verification: L+P-pt_k (<= 16) symbols remain after the table depth; 0 = disabled */
   uint32_t v_rem;
@@ -279,7 +283,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t excl = incl - vgrp;
       /* descriptor.y = first group (14 bits) | mismatches so far << 14 | rows << 17 | ... */
       if (lane < take) dsrc[lane].y = mine.y | excl;
-      const uint32_t g = modeB ? a.v_rem : L - k; /* guide symbols among the remaining ones */
+      const uint32_t g = modeB ? a.x_len : L - k; /* guide symbols among the remaining ones */
       const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
       uint32_t qrem;
       if (modeB) {
@@ -469,7 +473,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     /* the substitution table of the item: entry 4 * step + digit = what substituting the digit-th
      * other base at that step does to the k-mer's table index and to the path; digit 3 = nothing */
     auto fill_dtab = [&](const bool sideB) __attribute__((always_inline)) {
-      const uint32_t k = a.pt_k, nst = sideB ? k - P : k;
+      const uint32_t k = a.pt_k, nYb = a.bdeep ? k - 2u : k - P, nst = sideB ? nYb : k;
       for (uint32_t e = lane; e < 4u * nst; e += WAVE) {
         const uint32_t s = e >> 2, d = e & 3u;
         const uint32_t t = sideB ? L - 1u - s : s; /* guide symbol the step consumes */
@@ -478,16 +482,17 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         const uint32_t code = 1u + sym - (sym > qc ? 1u : 0u); /* its rank among them, A<C<G<T */
         const uint64_t pb = (uint64_t)code << (50u - 2u * t);
         /* the other strand's k-mer holds the complements: complementing both keeps the xor */
-        const uint32_t sh = 2u * (sideB ? k - 1u - P - s : k - 1u - s);
+        const uint32_t sh = 2u * (sideB ? nYb - 1u - s : k - 1u - s);
         dtab[e] = d == 3u ? make_uint4(0u, 0u, 0u, 0u) : make_uint4((qc ^ sym) << sh, (uint32_t)pb, (uint32_t)(pb >> 32), 0u);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     /* a recipe applied to the exact k-mer index `pidx` / path `path`; returns the entry's address */
-    auto apply_recipe = [&](const uint2 rc, const uint4 *tab, const uint4 *rot, const uint32_t rot_first, uint32_t &pidx,
-                            uint64_t &path) __attribute__((always_inline)) -> const uint4 * {
-      const uint32_t k = a.pt_k, n = rc.x & 7u;
+    /* kd = symbols the table is indexed by, dbl = log2 of the uint4 per index */
+    auto apply_recipe = [&](const uint2 rc, const uint4 *tab, const uint4 *rot, const uint32_t rot_first, const uint32_t kd,
+                            const uint32_t dbl, uint32_t &pidx, uint64_t &path) __attribute__((always_inline)) -> const uint4 * {
+      const uint32_t k = kd, n = rc.x & 7u;
       uint64_t f = (((uint64_t)rc.y << 32) | rc.x) >> 12;
       uint32_t plo = (uint32_t)path, phi = (uint32_t)(path >> 32);
       for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
@@ -498,14 +503,14 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         phi |= e.z;
       }
       path = ((uint64_t)phi << 32) | plo;
-      const uint4 *ep = tab + pidx;
+      const uint4 *ep = tab + ((size_t)pidx << dbl);
       const uint32_t rs = (rc.x >> 7) & 31u;
       if ((rc.x & 64u) != 0u && rs >= rot_first) {
         /* the copy rotated at step rs: that step's symbol and everything after it swap places, so the
          * recipes that differ only at step rs are neighbours in one 64-byte line */
         const uint32_t sh = 2u * (k - 1u - rs);
         const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) | ((pidx >> sh) & 3u);
-        ep = rot + (((size_t)(rs - rot_first) << (2u * k)) + ridx);
+        ep = rot + ((((size_t)(rs - rot_first) << (2u * k)) + ridx) << dbl);
       }
       return ep;
     };
@@ -564,7 +569,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     if (a.bidir && seeding) {
       bool fallback = false;
       const gs_strand_dev &sb = a.sd[strand ^ 1u];
-      const uint32_t k = a.pt_k, sx = a.v_rem, nY = k - P;
+      const uint32_t k = a.pt_k, sx = a.x_len, nY = k - P;
       for (uint32_t pj = 0; pj < npams; ++pj) {
         const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
         uint32_t nn = 0;
@@ -630,9 +635,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         /* context mask for the other strand's seeds: the symbols it consumes next are the complemented
          * X symbols, last first - all guide symbols: up to four pairs, each broken by at most one
          * of the substitutions the seed's budget leaves for X */
+        const uint32_t deep = a.bdeep;
+        const uint32_t boffs = deep ? 0x6420u : sb.mask_off; /* the deep tables' masks: pairs at 0, 2, 4, 6 */
         uint32_t qpairs_b = 0, b_pairs = 0, n_bpairs = 0;
         for (uint32_t j = 0; j < 4u; ++j) {
-          const uint32_t o = (sb.mask_off >> (4u * j)) & 15u;
+          const uint32_t o = (boffs >> (4u * j)) & 15u;
           if (o + 1u < sx) { /* both symbols inside X */
             const uint32_t v = (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - o))) & 3u)) |
                                ((3u - ((uint32_t)(gr_q >> (2u * (sx - 2u - o))) & 3u)) << 2);
@@ -641,16 +648,18 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             n_bpairs++;
           }
         }
-        const uint32_t nlanes = a.n_rec_b;
+        /* lanes of one pass over the recipes: one per recipe, or - deep tables - four, one per base under the N */
+        const uint32_t nlanes = deep ? 4u * a.n_rec_b : a.n_rec_b;
         fill_dtab(true);
         /* the guide part of the other strand's k-mer: step P+y holds the complement of guide symbol L-1-y */
+        const uint32_t nYb = deep ? k - 2u : nY;
         uint32_t pidxg = 0;
-        for (uint32_t y = 0; y < nY; ++y)
-          pidxg |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (k - 1u - P - y));
-        /* steps over (PAM pattern bpj, expansion be of its N's, 64 lanes from bc0 of the plan's lane
+        for (uint32_t y = 0; y < nYb; ++y)
+          pidxg |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (nYb - 1u - y));
+        /* steps over (PAM pattern bpj, expansion be of its N's, 64 lanes from bc0 of the recipes' lane
          * space), then one last round that only drains the queue: written as one loop so that the
          * verification is instantiated once */
-        uint32_t bpj = 0, be = 0, bc0 = 0, bnn = 0, pidxb = 0;
+        uint32_t bpj = 0, be = 0, bc0 = 0, bnn = 0, pidxb = 0, bxset = 0, bslot = 0;
         uint64_t ppath = 0;
         bool bfinal = nlanes == 0u;
         for (;;) {
@@ -665,15 +674,25 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               uint32_t ee = be;
               pidxb = pidxg;
               ppath = 0;
-              for (uint32_t u = 0; u < P; ++u) {
-                const uint32_t pc = (pw >> (3u * u)) & 7u;
-                uint32_t base = pc;
-                if (pc == 4u) {
-                  base = ee & 3u;
-                  ee >>= 2;
+              if (deep) {
+                /* the table of the pattern's pair; its first symbol picks the bases to take (bit 3 - base) */
+                const uint32_t c0 = (pw >> (3u * (P - 2u))) & 7u, c1 = (pw >> (3u * (P - 1u))) & 7u, cn = pw & 7u;
+                bslot = (a.n_pt > 1u && (c0 | (c1 << 2)) == a.pt[1][strand].code) ? 1u : 0u;
+                bxset = cn == 4u ? 15u : 1u << (3u - cn);
+                bnn = 0;
+                for (uint32_t u = 1; u < P; ++u)
+                  ppath |= (uint64_t)(((pw >> (3u * u)) & 7u) < 3u ? ((pw >> (3u * u)) & 7u) : 4u) << (49u - 2u * L - 3u * u);
+              } else {
+                for (uint32_t u = 0; u < P; ++u) {
+                  const uint32_t pc = (pw >> (3u * u)) & 7u;
+                  uint32_t base = pc;
+                  if (pc == 4u) {
+                    base = ee & 3u;
+                    ee >>= 2;
+                  }
+                  ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
+                  pidxb |= (3u - base) << (2u * (k - P + u));
                 }
-                ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
-                pidxb |= (3u - base) << (2u * (k - P + u));
               }
             }
             /* one expansion = the whole recipe list rec_b: classes (o, b) one after the other; inside a
@@ -682,28 +701,35 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
              * one 64-byte line of that step's rotated copy (or of the plain table when it is the
              * k-mer's last step) */
             const uint32_t idx = bc0 + lane;
-            const bool act = idx < nlanes;
+            const uint32_t ri = deep ? idx >> 2 : idx, bx = idx & 3u;
+            bool act = idx < nlanes;
             uint2 rc = make_uint2(0u, 0u);
-            if (act) rc = a.rec_b[idx];
-            count_lines(c_rec, act, a.rec_b + idx);
+            if (act) rc = a.rec_b[ri];
+            count_lines(c_rec, act, a.rec_b + ri);
             jb = rc.x & 7u;
             lo = (rc.x >> 3) & 7u;
             uint32_t pidx = pidxb;
             uint64_t path = ppath;
-            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-            {
-              const uint4 *ep = apply_recipe(rc, sb.ptab, sb.ptab_rot, sb.rot_first, pidx, path);
-              if (act) ent = *ep;
-              count_lines(c_tab, act, ep);
+            /* deep tables: the line of the recipe's (k-2)-mer holds one entry per base under the N */
+            const uint4 *ep = apply_recipe(rc, deep ? a.pt[bslot][strand ^ 1u].deep : sb.ptab, sb.ptab_rot,
+                                           deep ? 31u : sb.rot_first, deep ? nYb : k, deep ? 2u : 0u, pidx, path);
+            if (deep) {
+              ep += bx;
+              act = act && ((bxset >> bx) & 1u) != 0u;
+              path |= (uint64_t)(bx != 0u ? 3u - bx : 4u) << (49u - 2u * L); /* that base: 3 - bx (T = 3 is coded 4) */
             }
-            const uint32_t ecnt = ent.y & 0x7FFFFFFFu;
+            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+            if (act) ent = *ep;
+            count_lines(c_tab, act, ep);
+            const uint32_t ecnt = ent.y & 0x7FFFFFFFu, mz = ent.z, mw = ent.w;
             eflag = ent.y >> 31;
+            first = ent.x;
             bool live = act && ecnt != 0u && !(a.dbg_skip & 2u);
             /* fewer of the query's pairs to the left of the interval's rows than the budget left for
              * X can break: no row can match */
             const uint32_t bl = m - jb;
             if (!eflag) {
-              const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
+              const uint32_t em[4] = {mz & 0xFFFFu, mz >> 16, mw & 0xFFFFu, mw >> 16};
               uint32_t intact = 0;
 #pragma unroll
               for (uint32_t j = 0; j < 4u; ++j)
@@ -712,7 +738,6 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             }
             cmeta = ((uint64_t)k << 59) | ((uint64_t)jb << 56) | path;
             rem = (live && !(a.dbg_skip & 1u)) ? ecnt : 0u;
-            first = ent.x;
           }
           /* the surviving seeds wait in the queue (it is this phase's alone: one-sided seeding has not
            * started) until a pass can be filled - a pass costs the same instructions for 10 seeds as
@@ -803,7 +828,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         uint64_t path = 0;
         uint4 ent = make_uint4(0u, 0u, 0u, 0u);
         {
-          const uint4 *ep = apply_recipe(rc, atab, arot, arot_first, pidx, path);
+          const uint4 *ep = apply_recipe(rc, atab, arot, arot_first, a.pt_k, 0u, pidx, path);
           if (act) ent = *ep;
           count_lines(c_tab, act, ep);
         }
@@ -1701,8 +1726,10 @@ int gs_num_cus(int device) {
  * must each be covered by row a or by column b; the staircase shape makes every minimal cover
  * "rows a < a*, columns b <= m - o - a*", so the plan is one threshold a*(o) per o.
  * Cost of a class = its seeds x (table line share + chance to survive the context mask x a
- * verification pass), the chances being those of an hg38-sized table (11.5 rows per k-mer). */
-static void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, double epam, uint32_t astar[8]) {
+ * verification pass), the chances being those of an hg38-sized table (11.5 rows per k-mer); through a
+ * PAM-pair table (gs_pairtab.hip) a seed of this strand rarely verifies at all (verify_a ~ 0.2). */
+static void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, double epam, uint32_t astar[8],
+                            double verify_a = 1.5, double verify_b = 1.9) {
   auto binom3 = [](uint32_t n, uint32_t j) -> double { /* C(n, j) 3^j */
     if (j > n) return 0.0;
     double v = 1;
@@ -1720,10 +1747,10 @@ static void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, d
     double best = -1;
     for (uint32_t as = 0; as <= M + 1; as++) {
       double c = 0;
-      for (uint32_t a = 0; a < as && a <= M; a++) c += binom3(nX, a) * seed_cost(M - a, 1.5);
+      for (uint32_t a = 0; a < as && a <= M; a++) c += binom3(nX, a) * seed_cost(M - a, verify_a);
       if (as <= M) {
         if (as > nX) continue; /* the other side would need more substitutions in X than X holds */
-        for (uint32_t b = 0; b + as <= M; b++) c += epam * binom3(nR, b) * seed_cost(M - b, 1.9);
+        for (uint32_t b = 0; b + as <= M; b++) c += epam * binom3(nR, b) * seed_cost(M - b, verify_b);
       }
       if (best < 0 || c < best) {
         best = c;
@@ -1795,8 +1822,9 @@ static void build_recipes_a(std::vector<uint64_t> &out, uint32_t k, uint32_t m, 
  * astar[o] + o + b <= m; step y consumes guide symbol L-1-y: R = y in [0, L-k), O = y in [L-k, k-P).
  * The recipe carries lo = astar[o], the least number of substitutions its rows need inside X. */
 static void build_recipes_b(std::vector<uint64_t> &out, uint32_t k, uint32_t L, uint32_t P, uint32_t m, uint32_t nX,
-                            const uint32_t *astar, bool rot) {
-  const uint32_t nO = k - nX, nR = L - k, ylo = L - k;
+                            const uint32_t *astar, bool rot, bool deep) {
+  /* deep tables (gs_pairtab.hip): k-2 guide symbols index the table, the copies are numbered by guide symbol */
+  const uint32_t nO = k - nX, nR = L - k, ylo = L - k, nY = L - nX, step0 = deep ? 0 : P, kd = deep ? nY : k;
   for (uint32_t o = 0; o <= m && o <= nO && o < 8; o++)
     for (uint32_t b = 0; b <= nR && astar[o] + o + b <= m; b++) {
       if (astar[o] > nX || o + b > 7) continue;
@@ -1809,10 +1837,10 @@ static void build_recipes_b(std::vector<uint64_t> &out, uint32_t k, uint32_t L, 
           if ((uint32_t)__builtin_popcount(mr) != b) continue;
           const uint32_t mk = (mo << ylo) | mr;
           uint32_t ys[8], ns = 0, ymax = 0;
-          for (uint32_t y = 0; y < k - P; y++)
+          for (uint32_t y = 0; y < nY; y++)
             if ((mk >> y) & 1u) ys[ns++] = ymax = y;
-          const uint32_t slast = P + ymax; /* consumption step of the last substituted symbol */
-          const bool r = rot && jb >= 1 && slast + 2 <= k;
+          const uint32_t slast = step0 + ymax; /* consumption step of the last substituted symbol */
+          const bool r = rot && !deep && jb >= 1 && slast + 2 <= kd; /* a deep table's line is one index */
           for (uint32_t dc = 0; dc < ndig; dc++) {
             uint32_t f[8], x = dc;
             for (uint32_t i = jb; i-- > 0;) {
@@ -1826,11 +1854,11 @@ static void build_recipes_b(std::vector<uint64_t> &out, uint32_t k, uint32_t L, 
     }
 }
 static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m, uint32_t v_rem, const uint32_t *astar,
-                                hipStream_t st) {
+                                bool deep, hipStream_t st) {
   const uint32_t k = ix->pt_k;
   const bool rot = true; /* the recipes name the copy that would share lines; a table without it reads its plain copy */
   uint64_t key[2] = {((uint64_t)L << 48) | ((uint64_t)P << 40) | ((uint64_t)m << 32) | ((uint64_t)k << 24) |
-                         ((uint64_t)v_rem << 16) | (rot ? 2u : 0u) | (astar ? 1u : 0u),
+                         ((uint64_t)v_rem << 16) | (deep ? 4u : 0u) | (rot ? 2u : 0u) | (astar ? 1u : 0u),
                      0};
   if (astar)
     for (uint32_t o = 0; o < 8; o++) key[1] |= (uint64_t)(astar[o] > 15 ? 15u : astar[o]) << (4 * o);
@@ -1842,7 +1870,7 @@ static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m
   if (astar) {
     build_recipes_a(all, k, m, v_rem, astar, rot);
     n_a = all.size() - n_full;
-    build_recipes_b(all, k, L, P, m, v_rem, astar, rot);
+    build_recipes_b(all, k, L, P, m, v_rem, astar, rot, deep);
     n_b = all.size() - n_full - n_a;
   }
   if (all.size() >= (1ull << 31)) {
@@ -2008,45 +2036,114 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     v_rem = L + P - ix->pt_k;
   uint32_t *d_nlist = d_work + 2;
 
-  /* two-sided seeding (k_search): possible when set X (the first v_rem consumed guide symbols)
-   * lies inside the plan's positions, the PAM fits the table depth and both inverse suffix
-   * arrays exist */
-  bool bidir = false;
+  /* two-sided seeding (k_search): possible when set X (the first consumed guide symbols, which only
+   * this strand's table covers) lies inside the recipes' positions, the PAM fits the table depth and
+   * both inverse suffix arrays exist */
+  bool bidir = false, deep = false;
   uint32_t astar_packed = 0xFFFFFFFFu, astar[8] = {15, 15, 15, 15, 15, 15, 15, 15};
   uint32_t n_cand[2] = {0, 0};
   const uint4 *d_cand[2] = {nullptr, nullptr};
-  if (v_rem != 0 && mismatches >= 1 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
-      L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !getenv("GS_NO_BIDIR")) {
-    const uint32_t k = ix->pt_k, m = mismatches;
-    const uint32_t nX = v_rem, nO = k - v_rem, nR = L - k; /* |X|, |O|, |R| */
-    /* PAM expansions the other strand enumerates per item (its table holds concrete bases only) */
-    double epam = 0;
-    {
-      const uint32_t np = P ? n_alt + 1 : 1;
-      for (uint32_t j = 0; j < np; j++) {
-        double e = 1;
-        for (uint32_t u = 0; u < P; u++) {
-          const char c = j < n_alt ? alt_pams[j * P + u] : 'N'; /* the guides' own PAM: taken as one wildcard pattern */
-          if (c == 'N' && (j < n_alt || u == 0)) e *= 4;
+  uint32_t x_len = v_rem;
+  uint32_t n_pt = 0, pt_slot[2] = {0, 0};
+  const bool table_seeding = ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK);
+  if (table_seeding && mismatches > 7) {
+    gs_set_error("more than 7 mismatches");
+    return GS_ERR_UNSUPPORTED;
+  }
+  const bool two_ok = v_rem != 0 && mismatches >= 1 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
+                      L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !getenv("GS_NO_BIDIR");
+  /* the pairs of bases the batch's patterns end in (k_prepare's tally), most frequent first */
+  uint32_t want[2] = {16, 16}, n_codes = 0;
+  for (uint32_t c = 0; c < 16; c++) {
+    if (!h_pairs[c]) continue;
+    n_codes++;
+    if (want[0] == 16 || h_pairs[c] > h_pairs[want[0]]) {
+      want[1] = want[0];
+      want[0] = c;
+    } else if (want[1] == 16 || h_pairs[c] > h_pairs[want[1]]) {
+      want[1] = c;
+    }
+  }
+  const uint32_t max_pt = getenv("GS_PAIRTABS") ? std::min(2u, (uint32_t)atol(getenv("GS_PAIRTABS"))) : 2u;
+  const bool pairable = two_ok && P >= 2 && v_rem >= 2 && n_codes >= 1 && !ix->pairtab_off && !getenv("GS_NO_PAIRTAB");
+  /* deep tables for the other strand's side: every pattern of the batch must have its PAM-pair table */
+  bool try_deep = pairable && P == 3 && h_pairs[16] == 0 && n_codes <= max_pt && L >= ix->pt_k && L + 4 <= 2 * ix->pt_k &&
+                  !getenv("GS_NO_DEEP");
+  for (int attempt = 0; attempt < 2; attempt++) {
+    deep = try_deep;
+    bidir = false;
+    n_pt = 0;
+    x_len = deep ? L - ix->pt_k + 2 : v_rem;
+    if (two_ok) {
+      const uint32_t k = ix->pt_k, m = mismatches;
+      const uint32_t nX = x_len, nO = k - x_len, nR = L - k; /* |X|, |O|, |R| */
+      /* PAM expansions the other strand enumerates per item (its table holds concrete bases only;
+       * a deep table folds the N in: one pass per pattern) */
+      double epam = 0;
+      {
+        const uint32_t np = P ? n_alt + 1 : 1;
+        for (uint32_t j = 0; j < np; j++) {
+          double e = 1;
+          for (uint32_t u = 0; u < P && !deep; u++) {
+            const char c = j < n_alt ? alt_pams[j * P + u] : 'N'; /* the guides' own PAM: taken as one wildcard pattern */
+            if (c == 'N' && (j < n_alt || u == 0)) e *= 4;
+          }
+          epam += e;
         }
-        epam += e;
+      }
+      gs_choose_astar(m, nX, nO, nR, epam, astar, pairable ? 0.4 : 1.5, deep ? 1.6 : 1.9);
+      if (const char *e = getenv("GS_ASTAR")) { /* experiments: "2,2,1,1" */
+        uint32_t o = 0;
+        for (const char *p = e; *p && o < 8; o++) {
+          astar[o] = (uint32_t)strtoul(p, (char **)&p, 10);
+          if (*p == ',') p++;
+        }
+      }
+      bool any_b = false;
+      for (uint32_t o = 0; o <= m && o <= nO && o < 8; o++) any_b = any_b || astar[o] + o <= m;
+      if (any_b) {
+        bidir = true;
+        astar_packed = 0;
+        for (uint32_t o = 0; o < 8; o++) astar_packed |= (astar[o] > 15 ? 15u : astar[o]) << (4 * o);
       }
     }
-    gs_choose_astar(m, nX, nO, nR, epam, astar);
-    if (const char *e = getenv("GS_ASTAR")) { /* experiments: "2,2,1,1" */
-      uint32_t o = 0;
-      for (const char *p = e; *p && o < 8; o++) {
-        astar[o] = (uint32_t)strtoul(p, (char **)&p, 10);
-        if (*p == ',') p++;
+    deep = deep && bidir;
+    /* the seed recipes of this (budget, geometry, thresholds): built once per handle and kept */
+    if (table_seeding && (rc = gs_recipes_for(ix, L, P, mismatches, x_len, bidir ? astar : nullptr, deep, st)) != GS_OK) return rc;
+    /* PAM-pair tables for the (at most two) pairs of bases most patterns of this batch end in */
+    if (bidir && pairable) {
+      bool taken[2] = {false, false};
+      for (uint32_t i = 0; i < max_pt; i++) { /* a slot that already holds the pair stays */
+        if (want[i] == 16) continue;
+        for (uint32_t s = 0; s < 2; s++)
+          if (!taken[s] && ix->pairtab[s].valid && ix->pairtab[s].code == want[i] && ix->pairtab[s].v_rem == v_rem) {
+            taken[s] = true;
+            break;
+          }
+      }
+      for (uint32_t i = 0; i < max_pt; i++) {
+        if (want[i] == 16) continue;
+        uint32_t s = 2;
+        for (uint32_t j = 0; j < 2; j++)
+          if (ix->pairtab[j].valid && ix->pairtab[j].code == want[i] && ix->pairtab[j].v_rem == v_rem) s = j;
+        if (s == 2)
+          for (uint32_t j = 0; j < 2; j++)
+            if (!taken[j]) {
+              s = j;
+              taken[j] = true;
+              break;
+            }
+        if (s == 2) continue;
+        if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], ix->rec_a_rot_first, st)) != GS_OK) return rc;
+        if (ix->pairtab[s].valid && deep && (rc = gs_pairtab_ensure_deep(ix, s, P, st)) != GS_OK) return rc;
+        if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
       }
     }
-    bool any_b = false;
-    for (uint32_t o = 0; o <= m && o <= nO && o < 8; o++) any_b = any_b || astar[o] + o <= m;
-    if (any_b) {
-      bidir = true;
-      astar_packed = 0;
-      for (uint32_t o = 0; o < 8; o++) astar_packed |= (astar[o] > 15 ? 15u : astar[o]) << (4 * o);
-    }
+    if (!try_deep) break;
+    bool all_deep = deep && n_pt == n_codes;
+    for (uint32_t i = 0; i < n_pt; i++) all_deep = all_deep && ix->pairtab[pt_slot[i]].deep;
+    if (all_deep) break;
+    try_deep = false; /* not every pattern has its deep table: plan again with the strand tables on that side */
   }
   if (bidir) {
     /* windows where a literal 'N' of the genome lies under the PAM (index.hpp:139-149) and the
@@ -2121,59 +2218,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     if (getenv("GS_DEBUG"))
       fprintf(stderr, "[gs] two-sided seeding: astar %u,%u,%u,%u,%u,%u,%u,%u over |X|=%u |O|=%u |R|=%u, "
-              "literal-N windows %u + %u\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
-              astar[6], astar[7], v_rem, ix->pt_k - v_rem, L - ix->pt_k, n_cand[0], n_cand[1]);
+              "literal-N windows %u + %u, PAM-pair tables %u%s\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
+              astar[6], astar[7], x_len, ix->pt_k - x_len, L - ix->pt_k, n_cand[0], n_cand[1], n_pt, deep ? " with deep tables" : "");
   }
 
-  /* the seed recipes of this (budget, geometry, thresholds): built once per handle and kept */
-  const bool table_seeding = ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK);
-  if (table_seeding) {
-    if (mismatches > 7) {
-      gs_set_error("more than 7 mismatches");
-      return GS_ERR_UNSUPPORTED;
-    }
-    if ((rc = gs_recipes_for(ix, L, P, mismatches, v_rem, bidir ? astar : nullptr, st)) != GS_OK) return rc;
-  }
-  /* PAM-pair tables for the (at most two) pairs of bases most patterns of this batch end in */
-  uint32_t n_pt = 0, pt_slot[2] = {0, 0};
-  if (bidir && P >= 2 && v_rem >= 2 && !ix->pairtab_off && !getenv("GS_NO_PAIRTAB")) {
-    uint32_t want[2] = {16, 16};
-    for (uint32_t c = 0; c < 16; c++) {
-      if (!h_pairs[c]) continue;
-      if (want[0] == 16 || h_pairs[c] > h_pairs[want[0]]) {
-        want[1] = want[0];
-        want[0] = c;
-      } else if (want[1] == 16 || h_pairs[c] > h_pairs[want[1]]) {
-        want[1] = c;
-      }
-    }
-    const uint32_t max_pt = getenv("GS_PAIRTABS") ? (uint32_t)atol(getenv("GS_PAIRTABS")) : 2u;
-    bool taken[2] = {false, false};
-    for (uint32_t i = 0; i < 2 && i < max_pt; i++) { /* a slot that already holds the pair stays */
-      if (want[i] == 16) continue;
-      for (uint32_t s = 0; s < 2; s++)
-        if (!taken[s] && ix->pairtab[s].valid && ix->pairtab[s].code == want[i] && ix->pairtab[s].v_rem == v_rem) {
-          taken[s] = true;
-          break;
-        }
-    }
-    for (uint32_t i = 0; i < 2 && i < max_pt; i++) {
-      if (want[i] == 16) continue;
-      uint32_t s = 2;
-      for (uint32_t j = 0; j < 2; j++)
-        if (ix->pairtab[j].valid && ix->pairtab[j].code == want[i] && ix->pairtab[j].v_rem == v_rem) s = j;
-      if (s == 2)
-        for (uint32_t j = 0; j < 2; j++)
-          if (!taken[j]) {
-            s = j;
-            taken[j] = true;
-            break;
-          }
-      if (s == 2) continue;
-      if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], ix->rec_a_rot_first, st)) != GS_OK) return rc;
-      if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
-    }
-  }
 
   const bool count_req = (flags & GS_FLAG_COUNT_REQUESTS) != 0;
   auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
@@ -2207,6 +2255,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
        * substitutions x the two-symbol extensions the remaining budget allows */
       sa.pt_k = ix->pt_k;
       sa.v_rem = v_rem;
+      sa.x_len = x_len;
+      sa.bdeep = deep ? 1u : 0u;
       sa.rec_full = (const uint2 *)ix->w_rec.p;
       sa.n_rec_full = ix->n_rec_full;
       if (bidir) {

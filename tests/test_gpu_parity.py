@@ -443,13 +443,16 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
             offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=start)
             monkeypatch.delenv("GS_PAIRTABS", raising=False)
             monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
-            assert "two-sided seeding" in capfd.readouterr().err, cfg
+            err = capfd.readouterr().err
+            assert "two-sided seeding" in err, cfg
             # PAM-pair tables serve the items whose patterns all end in (at most two) pairs of concrete bases
             cnt = gidx.last_counters()
             pairs = {p[-2:] if not start else p[:2][::-1] for p in (own,) + tuple(alt)}
             concrete = all("N" not in p for p in pairs)
             want_tables = concrete and len(pairs) <= (1 if cfg.get("one_table") else 2) and not cfg.get("no_tables")
             assert (cnt["items_pair_tables"] > 0) == want_tables, (cfg, cnt)
+            # ... and when every pattern of the batch has one (3-symbol PAMs), the other strand's side uses the deep tables
+            assert ("with deep tables" in err) == want_tables, (cfg, err)
             total = 0
             for i, g in enumerate(guides):
                 exp, _ = oracle_hits_as_records(oidx, g, own, opts, 3, start)
