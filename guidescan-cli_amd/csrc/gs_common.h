@@ -126,7 +126,7 @@ struct gs_pairtab_host {
   gs_pairtab_dev d[2]{};
   void *mem[2][8] = {{nullptr}, {nullptr}};
   bool deep = false;               /* both strands' deep tables exist (PAM length deep_P) */
-  uint32_t deep_P = 0;
+  uint32_t deep_P = 0, deep_kb = 0;
   uint64_t bytes = 0, used = 0;
 };
 
@@ -166,7 +166,7 @@ struct gs_index {
  * step rot_first on (fewer when memory is short); valid stays false when they do not fit */
 gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, hipStream_t st);
 /* add the deep tables (the other strand's side, PAM of three symbols) to a valid slot; p.deep stays false when they do not fit */
-gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, hipStream_t st);
+gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, uint32_t kb, hipStream_t st);
 void gs_pairtab_free(gs_index *ix, uint32_t slot);
 
 #define GS_HIP(expr)                                                              \

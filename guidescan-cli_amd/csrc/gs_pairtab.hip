@@ -121,14 +121,15 @@ __global__ void k_pt_rot(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p, u
 struct pb_args {
   gs_strand_dev sd;
   uint32_t k, P, code; /* code as this strand's consumption sees the pair: first | second << 2 */
-  uint64_t entries;    /* 4^(k-2) */
+  uint32_t kb;         /* guide symbols of the index: k-P .. 14 */
+  uint64_t entries;    /* 4^kb */
   uint4 *out;          /* 4 per entry */
 };
 
 __global__ void k_pb_build(pb_args a) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.entries) return;
-  const uint32_t k = a.k, P = a.P, kb = k - 2u;
+  const uint32_t k = a.k, P = a.P, kb = a.kb;
   /* the first k consumed symbols: the pair (second consumed PAM symbol of this strand first), the base
    * under the N, then the k-P leading symbols of the entry */
   const uint32_t c0 = a.code & 3u, c1 = (a.code >> 2) & 3u;
@@ -252,9 +253,9 @@ static gs_status build_one(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, 
 }
 
 /* the deep table of strand s for the pair (built after the pair table proper; optional) */
-static gs_status build_deep(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, uint32_t P, hipStream_t st) {
+static gs_status build_deep(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, uint32_t P, uint32_t kb, hipStream_t st) {
   const gs_strand &S = ix->strand[s];
-  const uint64_t entries = 1ull << (2 * (k - 2));
+  const uint64_t entries = 1ull << (2 * kb);
   void **m = p.mem[s];
   if (hipMalloc(&m[5], 64 * entries) != hipSuccess) {
     (void)hipGetLastError();
@@ -265,6 +266,7 @@ static gs_status build_deep(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k,
   a.sd = S.d;
   a.k = k;
   a.P = P;
+  a.kb = kb;
   a.code = p.code;
   a.entries = entries;
   a.out = (uint4 *)m[5];
@@ -324,11 +326,11 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
   return GS_OK;
 }
 
-gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, hipStream_t st) {
+gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, uint32_t kb, hipStream_t st) {
   gs_pairtab_host &p = ix->pairtab[slot];
   const uint32_t k = ix->pt_k;
-  if (!p.valid || P != 3 || k < 6) return GS_OK;
-  if (p.deep && p.deep_P == P) return GS_OK;
+  if (!p.valid || P != 3 || k < 6 || kb + P < k || kb > 14) return GS_OK;
+  if (p.deep && p.deep_P == P && p.deep_kb == kb) return GS_OK;
   auto drop = [&]() {
     for (int s = 0; s < 2; s++) {
       if (p.mem[s][5]) hipFree(p.mem[s][5]);
@@ -343,9 +345,9 @@ gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, hipStr
   double reserve = 56e9;
   if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
   if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
-  if (2.0 * 64.0 * (double)(1ull << (2 * (k - 2))) + reserve > (double)free_b) return GS_OK;
+  if (2.0 * 64.0 * (double)(1ull << (2 * kb)) + reserve > (double)free_b) return GS_OK;
   for (int s = 0; s < 2; s++) {
-    const gs_status rc = build_deep(ix, p, s, k, P, st);
+    const gs_status rc = build_deep(ix, p, s, k, P, kb, st);
     if (rc != GS_OK) {
       drop();
       return rc == GS_ERR_NOMEM ? GS_OK : rc;
@@ -353,5 +355,6 @@ gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, hipStr
   }
   p.deep = true;
   p.deep_P = P;
+  p.deep_kb = kb;
   return GS_OK;
 }

@@ -473,7 +473,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     /* the substitution table of the item: entry 4 * step + digit = what substituting the digit-th
      * other base at that step does to the k-mer's table index and to the path; digit 3 = nothing */
     auto fill_dtab = [&](const bool sideB) __attribute__((always_inline)) {
-      const uint32_t k = a.pt_k, nYb = a.bdeep ? k - 2u : k - P, nst = sideB ? nYb : k;
+      const uint32_t k = a.pt_k, nYb = a.bdeep ? L - a.x_len : k - P, nst = sideB ? nYb : k;
       for (uint32_t e = lane; e < 4u * nst; e += WAVE) {
         const uint32_t s = e >> 2, d = e & 3u;
         const uint32_t t = sideB ? L - 1u - s : s; /* guide symbol the step consumes */
@@ -652,7 +652,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         const uint32_t nlanes = deep ? 4u * a.n_rec_b : a.n_rec_b;
         fill_dtab(true);
         /* the guide part of the other strand's k-mer: step P+y holds the complement of guide symbol L-1-y */
-        const uint32_t nYb = deep ? k - 2u : nY;
+        const uint32_t nYb = deep ? L - sx : nY;
         uint32_t pidxg = 0;
         for (uint32_t y = 0; y < nYb; ++y)
           pidxg |= (3u - ((uint32_t)(gr_q >> (2u * (L - 1u - y))) & 3u)) << (2u * (nYb - 1u - y));
@@ -2067,13 +2067,15 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   const uint32_t max_pt = getenv("GS_PAIRTABS") ? std::min(2u, (uint32_t)atol(getenv("GS_PAIRTABS"))) : 2u;
   const bool pairable = two_ok && P >= 2 && v_rem >= 2 && n_codes >= 1 && !ix->pairtab_off && !getenv("GS_NO_PAIRTAB");
   /* deep tables for the other strand's side: every pattern of the batch must have its PAM-pair table */
-  bool try_deep = pairable && P == 3 && h_pairs[16] == 0 && n_codes <= max_pt && L >= ix->pt_k && L + 4 <= 2 * ix->pt_k &&
-                  !getenv("GS_NO_DEEP");
+  uint32_t deep_kb = ix->pt_k - 2; /* guide symbols a deep table is indexed by */
+  if (const char *e = getenv("GS_DEEP_SYMBOLS")) deep_kb = (uint32_t)atoi(e);
+  bool try_deep = pairable && P == 3 && h_pairs[16] == 0 && n_codes <= max_pt && deep_kb + P >= ix->pt_k && deep_kb <= 14 &&
+                  deep_kb + 2 <= L && L <= deep_kb + 16 && L - deep_kb + 2 <= ix->pt_k && !getenv("GS_NO_DEEP");
   for (int attempt = 0; attempt < 2; attempt++) {
     deep = try_deep;
     bidir = false;
     n_pt = 0;
-    x_len = deep ? L - ix->pt_k + 2 : v_rem;
+    x_len = deep ? L - deep_kb : v_rem;
     if (two_ok) {
       const uint32_t k = ix->pt_k, m = mismatches;
       const uint32_t nX = x_len, nO = k - x_len, nR = L - k; /* |X|, |O|, |R| */
@@ -2135,7 +2137,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
             }
         if (s == 2) continue;
         if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], ix->rec_a_rot_first, st)) != GS_OK) return rc;
-        if (ix->pairtab[s].valid && deep && (rc = gs_pairtab_ensure_deep(ix, s, P, st)) != GS_OK) return rc;
+        if (ix->pairtab[s].valid && deep && (rc = gs_pairtab_ensure_deep(ix, s, P, deep_kb, st)) != GS_OK) return rc;
         if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
       }
     }
