@@ -388,7 +388,8 @@ def kernel_stamp():
     h.update((ROOT / "guidescan-cli_amd" / "csrc" / "gs_device.h").read_bytes())
     bld = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_index.hip").read_text()
     h.update(bld[:bld.index("C-ABI: index lifecycle")].encode())  # the builder kernels, not the handle bookkeeping
-    h.update((ROOT / "guidescan-cli_amd" / "csrc" / "gs_pairtab.hip").read_bytes())  # the PAM-pair tables
+    ptb = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_pairtab.hip").read_text()
+    h.update(ptb[:ptb.index("void gs_pairtab_free(")].encode())  # the PAM-pair / deep table kernels, not the memory policy
     return h.hexdigest()[:16]
 
 

@@ -163,8 +163,10 @@ struct gs_index {
 };
 
 /* make sure slot `slot` holds the tables of pair `code` at context depth v_rem with rotated copies from
- * step rot_first on (fewer when memory is short); valid stays false when they do not fit */
-gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, hipStream_t st);
+ * step rot_first on (fewer when memory is short: they may take `share` of what is free beyond the
+ * reserve); valid stays false when they do not fit */
+gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, double share,
+                            hipStream_t st);
 /* add the deep tables (the other strand's side, PAM of three symbols) to a valid slot; p.deep stays false when they do not fit */
 gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, uint32_t kb, hipStream_t st);
 void gs_pairtab_free(gs_index *ix, uint32_t slot);

@@ -281,7 +281,8 @@ static gs_status build_deep(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k,
   return GS_OK;
 }
 
-gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, hipStream_t st) {
+gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_t code, uint32_t rot_first, double share,
+                            hipStream_t st) {
   gs_pairtab_host &p = ix->pairtab[slot];
   const uint32_t k = ix->pt_k;
   if (rot_first > 31) rot_first = 31;
@@ -301,7 +302,7 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
   for (;;) {
     const uint32_t nrot = rot_first + 1 < k ? k - 1 - rot_first : 0;
     const double need = 2.0 * entry_bytes * (1 + nrot) + rows_bytes + tmp_bytes;
-    if (need + reserve <= (double)free_b) break;
+    if (need <= ((double)free_b - reserve) * share) break; /* share < 1: another pair's tables are still to come */
     if (nrot == 0) {
       if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] PAM-pair table %u: not enough free memory (%.1f GB), skipped\n", code, 1e-9 * (double)free_b);
       return GS_OK;

@@ -2114,31 +2114,55 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (table_seeding && (rc = gs_recipes_for(ix, L, P, mismatches, x_len, bidir ? astar : nullptr, deep, st)) != GS_OK) return rc;
     /* PAM-pair tables for the (at most two) pairs of bases most patterns of this batch end in */
     if (bidir && pairable) {
-      bool taken[2] = {false, false};
-      for (uint32_t i = 0; i < max_pt; i++) { /* a slot that already holds the pair stays */
-        if (want[i] == 16) continue;
-        for (uint32_t s = 0; s < 2; s++)
-          if (!taken[s] && ix->pairtab[s].valid && ix->pairtab[s].code == want[i] && ix->pairtab[s].v_rem == v_rem) {
-            taken[s] = true;
-            break;
-          }
-      }
-      for (uint32_t i = 0; i < max_pt; i++) {
-        if (want[i] == 16) continue;
-        uint32_t s = 2;
-        for (uint32_t j = 0; j < 2; j++)
-          if (ix->pairtab[j].valid && ix->pairtab[j].code == want[i] && ix->pairtab[j].v_rem == v_rem) s = j;
-        if (s == 2)
-          for (uint32_t j = 0; j < 2; j++)
-            if (!taken[j]) {
-              s = j;
-              taken[j] = true;
+      const uint32_t n_want = (want[0] < 16 ? 1u : 0u) + (max_pt > 1 && want[1] < 16 ? 1u : 0u);
+      for (int round = 0; round < 2; round++) {
+        /* round 0: a slot that already holds a pair stays, a missing one takes what is free; when the
+         * second pair does not fit next to a first one built with all its copies, round 1 frees both
+         * and gives each half of the room (fewer rotated copies each, but both patterns served) */
+        n_pt = 0;
+        bool taken[2] = {false, false};
+        for (uint32_t i = 0; i < max_pt; i++) {
+          if (want[i] == 16) continue;
+          for (uint32_t s = 0; s < 2; s++)
+            if (!taken[s] && ix->pairtab[s].valid && ix->pairtab[s].code == want[i] && ix->pairtab[s].v_rem == v_rem) {
+              taken[s] = true;
               break;
             }
-        if (s == 2) continue;
-        if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], ix->rec_a_rot_first, st)) != GS_OK) return rc;
-        if (ix->pairtab[s].valid && deep && (rc = gs_pairtab_ensure_deep(ix, s, P, deep_kb, st)) != GS_OK) return rc;
-        if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
+        }
+        uint32_t to_build = 0;
+        for (uint32_t i = 0; i < max_pt; i++) {
+          if (want[i] == 16) continue;
+          bool have = false;
+          for (uint32_t j = 0; j < 2; j++)
+            have = have || (ix->pairtab[j].valid && ix->pairtab[j].code == want[i] && ix->pairtab[j].v_rem == v_rem);
+          to_build += have ? 0u : 1u;
+        }
+        for (uint32_t i = 0; i < max_pt; i++) {
+          if (want[i] == 16) continue;
+          uint32_t s = 2;
+          bool have = false;
+          for (uint32_t j = 0; j < 2; j++)
+            if (ix->pairtab[j].valid && ix->pairtab[j].code == want[i] && ix->pairtab[j].v_rem == v_rem) {
+              s = j;
+              have = true;
+            }
+          if (s == 2)
+            for (uint32_t j = 0; j < 2; j++)
+              if (!taken[j]) {
+                s = j;
+                taken[j] = true;
+                break;
+              }
+          if (s == 2) continue;
+          if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], ix->rec_a_rot_first, have ? 1.0 : 1.0 / (double)to_build, st)) != GS_OK)
+            return rc;
+          if (!have && to_build) to_build--;
+          if (ix->pairtab[s].valid && deep && (rc = gs_pairtab_ensure_deep(ix, s, P, deep_kb, st)) != GS_OK) return rc;
+          if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
+        }
+        if (n_pt == n_want || n_want < 2 || round == 1) break;
+        gs_pairtab_free(ix, 0);
+        gs_pairtab_free(ix, 1);
       }
     }
     if (!try_deep) break;

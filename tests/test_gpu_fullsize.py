@@ -198,25 +198,25 @@ class Hg38:
         assert not self.ref_err, self.ref_err
         return os.path.join(self.dir, "g")
 
-    def run_reference(self, tag, ids, seqs, m, threads):
+    def run_reference(self, tag, ids, seqs, m, threads, alt=()):
         """kmers CSV -> the compiled reference (CSV, complete) -> sorted data lines"""
         prefix = self.reference_prefix()
         kcsv, out = os.path.join(self.dir, tag + ".kmers.csv"), os.path.join(self.dir, tag + ".out.csv")
         synth.write_kmers_csv(kcsv, ids, [s.tobytes().decode() for s in seqs], ["NGG"] * len(ids),
                               [self.names[0]] * len(ids), [1] * len(ids), ["+"] * len(ids))
         env = dict(os.environ, GS_REF_THREADS=str(threads))
-        subprocess.run([str(SHIM), prefix, kcsv, out, "csv", "complete", str(m), "0", "0", "-1", "-1", "0"],
+        subprocess.run([str(SHIM), prefix, kcsv, out, "csv", "complete", str(m), "0", "0", "-1", "-1", "0"] + list(alt),
                        env=env, check=True, timeout=1500, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         with open(out) as f:
             lines = f.read().splitlines()
         os.unlink(out)
         return lines[0], sorted(lines[1:])
 
-    def product_lines(self, ids, seqs, m):
+    def product_lines(self, ids, seqs, m, alt=()):
         """the same guides through the product: search, device scoring, text lines -> sorted data lines"""
         n = len(ids)
         pams = np.tile(NGG, (n, 1))
-        off, hits, st = self.gidx.enumerate(seqs, pams, mismatches=m)
+        off, hits, st = self.gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt)
         _, spec = self.gidx.score(self.gs, seqs, 3, off, hits, want_cfd=False)
         out = []
         for i in range(n):
@@ -317,4 +317,18 @@ def test_config5_hg38_depth_m6_lines_equal_the_compiled_reference(hg38):
     assert n_hits > 64 * 5000
     header, want = hg38.run_reference("m6", ids, seqs, 6, 64)
     assert len(got) == len(want)
+    assert got == want
+
+
+def test_hg38_alt_pam_through_two_pair_tables_equals_the_compiled_reference(hg38):
+    """`-a NAG` at hg38 size: the guides' own NGG and the alt pattern end in different pairs of bases, so
+    the batch needs two PAM-pair tables (with their deep tables) next to the 184 GB of strand tables -
+    they share what is free; every CSV line equals the reference's"""
+    seqs, _, _, _ = synth.sample_guides(hg38.text, 1024, seed=1002)
+    ids = [f"a{i}" for i in range(1024)]
+    got, n_hits = hg38.product_lines(ids, seqs, 3, alt=("NAG",))
+    cnt = hg38.gidx.last_counters()
+    assert cnt["items_pair_tables"] >= 2 * 1024, cnt   # every (guide, strand) item went through the tables
+    header, want = hg38.run_reference("m3nag", ids, seqs, 3, os.cpu_count() or 8, alt=("NAG",))
+    assert len(want) >= len(ids) and len(got) == len(want)
     assert got == want
