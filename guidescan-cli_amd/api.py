@@ -23,6 +23,7 @@ GS_FLAG_PAM_AT_START = 1
 GS_FLAG_FAITHFUL_WALK = 2
 GS_FLAG_COUNT_REQUESTS = 4
 GS_FLAG_RAW_COUNTS = 8
+GS_FLAG_NO_NEW_TABLES = 16
 
 
 class GsError(RuntimeError):
@@ -182,12 +183,41 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
-           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits"]
+           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
+           "gs_debug_seed_recipes", "gs_debug_choose_thresholds"]
 
 
 def _check(rc):
     if rc != 0:
         raise GsError(rc, lib().gs_status_string(rc).decode())
+
+
+def seed_recipes(k, L, P, m, n_x, astar=None, deep=False):
+    """the seed plan of k_search for a batch shape (gs_debug_seed_recipes; host only):
+    (one-sided, this strand's share, the other strand's share) as uint64 arrays"""
+    L_ = lib()
+    L_.gs_debug_seed_recipes.restype = C.c_int
+    L_.gs_debug_seed_recipes.argtypes = [C.c_uint32] * 5 + [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
+    a = None
+    if astar is not None:
+        a = (C.c_uint32 * 8)(*(list(astar) + [15] * 8)[:8])
+    counts = (C.c_uint64 * 3)()
+    _check(L_.gs_debug_seed_recipes(k, L, P, m, n_x, a, 1 if deep else 0, None, 0, counts))
+    n = sum(counts)
+    out = np.zeros(n, dtype=np.uint64)
+    _check(L_.gs_debug_seed_recipes(k, L, P, m, n_x, a, 1 if deep else 0, out.ctypes.data, n, counts))
+    c0, c1 = int(counts[0]), int(counts[1])
+    return out[:c0], out[c0:c0 + c1], out[c0 + c1:]
+
+
+def choose_thresholds(m, n_x, n_o, n_r, pam_expansions=4.0, verify_a=1.5, verify_b=1.9):
+    """the cost model's thresholds a*(o) (gs_debug_choose_thresholds)"""
+    L_ = lib()
+    L_.gs_debug_choose_thresholds.restype = None
+    L_.gs_debug_choose_thresholds.argtypes = [C.c_uint32] * 4 + [C.c_double] * 3 + [C.c_void_p]
+    out = (C.c_uint32 * 8)()
+    L_.gs_debug_choose_thresholds(m, n_x, n_o, n_r, pam_expansions, verify_a, verify_b, out)
+    return list(out)
 
 
 def make_genome_structure(names, lengths):
@@ -431,7 +461,7 @@ class GenomeIndex:
         return {k: int(getattr(rep, k)) for k, _ in GsSaReport._fields_}
 
     def enumerate(self, seqs: np.ndarray, pams: np.ndarray, mismatches=3, alt_pams=(), start=False,
-                  faithful=False, raw_counts=False):
+                  faithful=False, raw_counts=False, no_new_tables=False):
         """seqs uint8[n,L], pams uint8[n,P] -> (offsets uint64[n+1], hits HIT_DTYPE[], stats dict).
         Hits of guide i are hits[offsets[i]:offsets[i+1]] in the reference's canonical order."""
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
@@ -445,7 +475,7 @@ class GenomeIndex:
                 raise ValueError("alt PAM length differs from the guides' PAM length")
         r = C.c_void_p()
         flags = ((GS_FLAG_PAM_AT_START if start else 0) | (GS_FLAG_FAITHFUL_WALK if faithful else 0) |
-                 (GS_FLAG_RAW_COUNTS if raw_counts else 0))
+                 (GS_FLAG_RAW_COUNTS if raw_counts else 0) | (GS_FLAG_NO_NEW_TABLES if no_new_tables else 0))
         _check(lib().gs_enumerate(self._h, seqs.ctypes.data, n, L, pams.ctypes.data if P else None, P,
                                   alt if alt_pams else None, len(alt_pams), mismatches, flags,
                                   C.byref(r)))

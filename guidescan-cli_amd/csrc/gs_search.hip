@@ -1853,6 +1853,32 @@ static void build_recipes_b(std::vector<uint64_t> &out, uint32_t k, uint32_t L, 
       }
     }
 }
+extern "C" gs_status gs_debug_seed_recipes(uint32_t k, uint32_t L, uint32_t P, uint32_t m, uint32_t n_x,
+                                           const uint32_t *astar, uint32_t deep, uint64_t *out, uint64_t cap,
+                                           uint64_t counts[3]) {
+  if (k < 4 || k > 16 || L < k || L > 31 || m > 7 || n_x + 2 > k || !counts) return GS_ERR_ARG;
+  try {
+    std::vector<uint64_t> all;
+    build_recipes_a(all, k, m, n_x, nullptr, true);
+    counts[0] = all.size();
+    counts[1] = counts[2] = 0;
+    if (astar) {
+      build_recipes_a(all, k, m, n_x, astar, true);
+      counts[1] = all.size() - counts[0];
+      build_recipes_b(all, k, L, P, m, n_x, astar, true, deep != 0);
+      counts[2] = all.size() - counts[0] - counts[1];
+    }
+    for (uint64_t i = 0; i < all.size() && i < cap && out; i++) out[i] = all[i];
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
+  return GS_OK;
+}
+extern "C" void gs_debug_choose_thresholds(uint32_t m, uint32_t n_x, uint32_t n_o, uint32_t n_r, double pam_expansions,
+                                           double verify_a, double verify_b, uint32_t astar[8]) {
+  gs_choose_astar(m, n_x, n_o, n_r, pam_expansions, astar, verify_a, verify_b);
+}
+
 static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m, uint32_t v_rem, const uint32_t *astar,
                                 bool deep, hipStream_t st) {
   const uint32_t k = ix->pt_k;
@@ -2154,13 +2180,18 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
                 break;
               }
           if (s == 2) continue;
-          if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], ix->rec_a_rot_first, have ? 1.0 : 1.0 / (double)to_build, st)) != GS_OK)
+          const bool frozen = (flags & GS_FLAG_NO_NEW_TABLES) != 0; /* use what the handle holds, build nothing */
+          if (!have && frozen) continue;
+          if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], frozen ? 31u : ix->rec_a_rot_first,
+                                      have ? 1.0 : 1.0 / (double)to_build, st)) != GS_OK)
             return rc;
           if (!have && to_build) to_build--;
-          if (ix->pairtab[s].valid && deep && (rc = gs_pairtab_ensure_deep(ix, s, P, deep_kb, st)) != GS_OK) return rc;
+          if (ix->pairtab[s].valid && deep && !(frozen && !ix->pairtab[s].deep) &&
+              (rc = gs_pairtab_ensure_deep(ix, s, P, deep_kb, st)) != GS_OK)
+            return rc;
           if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
         }
-        if (n_pt == n_want || n_want < 2 || round == 1) break;
+        if (n_pt == n_want || n_want < 2 || round == 1 || (flags & GS_FLAG_NO_NEW_TABLES)) break;
         gs_pairtab_free(ix, 0);
         gs_pairtab_free(ix, 1);
       }

@@ -78,6 +78,11 @@ typedef struct {
  * (off_target_counter, process.hpp:25-27 and 66-76 - one count per PAM pattern that matches, so a
  * site two patterns of the list match counts twice).  Saturates at 2^32-1. */
 #define GS_FLAG_RAW_COUNTS 8u
+/* Do not build new derived tables for this call (the PAM-pair and deep tables, DESIGN.md 4.9-4.10: about
+ * 0.3 s and tens of GB at hg38 size, kept on the handle); tables the handle already holds are used.
+ * For short jobs: the tables pay for themselves after ~5 guides per 1,000 genome bases (15 M guides
+ * at hg38 size).  Same results either way. */
+#define GS_FLAG_NO_NEW_TABLES 16u
 
 typedef struct {
   uint64_t n_guides;
@@ -197,6 +202,19 @@ gs_status gs_resolve(gs_index *ix, int strand, const uint64_t *rows, uint64_t n,
 gs_status gs_index_meta(const gs_index *ix, int strand, uint64_t C_acgtn[5], uint64_t *size);
 /* copy the device-resident suffix array back (n = size entries) */
 gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out);
+/* The seed plan of k_search as data (host only, no device needed): which depth-k nodes of the
+ * reference's search tree (index.hpp:182-248: the variants of a guide's first k consumed symbols with
+ * at most m substitutions) a batch shape looks up, and from which strand's table.  Writes the 64-bit
+ * recipes (one-sided list | this strand's share | the other strand's share) to out[0..cap) and their
+ * counts to counts[3]; astar = NULL: one-sided only.  Recipe: bits 2:0 substitutions n, 5:3 lower bound
+ * the other strand's verification applies, 6 reads a rotated copy, 11:7 of which step, then n fields of 7
+ * bits from bit 12: step * 4 + digit (the digit-th other base).  n_x = |X|: the leading steps only this
+ * strand's table covers; deep: the other strand's recipes index a deep table (steps = guide symbols).
+ * gs_debug_choose_thresholds: the cost model's a*(o) for that shape (tests pin both). */
+gs_status gs_debug_seed_recipes(uint32_t k, uint32_t L, uint32_t P, uint32_t m, uint32_t n_x, const uint32_t *astar,
+                                uint32_t deep, uint64_t *out, uint64_t cap, uint64_t counts[3]);
+void gs_debug_choose_thresholds(uint32_t m, uint32_t n_x, uint32_t n_o, uint32_t n_r, double pam_expansions,
+                                double verify_a, double verify_b, uint32_t astar[8]);
 
 /* Self-check of a resident index from the genome text alone (no suffix-array builder involved):
  * the suffix array of `strand` is a permutation of [0, n) (all rows), n_samples evenly spread

@@ -431,7 +431,7 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
         for cfg in (dict(m=3), dict(m=2), dict(m=4), dict(m=3, alt=("NAG",)), dict(m=3, start=True),
                     dict(m=5, alt=("NAG", "NGA")), dict(m=6), dict(m=1), dict(m=4, alt=("NGN",)),
                     dict(m=3, start=True, pam="TTN"), dict(m=3, pam="NAG", alt=("NGG",)), dict(m=3, one_table=True, alt=("NAG",)),
-                    dict(m=4, no_tables=True)):
+                    dict(m=4, no_tables=True), dict(m=3), dict(m=3, pam="NCG", frozen=True), dict(m=2, frozen=True)):
             m, alt, start, own = cfg["m"], cfg.get("alt", ()), cfg.get("start", False), cfg.get("pam", "NGG")
             pams = np.tile(np.frombuffer(own.encode(), np.uint8), (len(guides), 1))
             opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
@@ -440,7 +440,9 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
             if cfg.get("no_tables"):
                 monkeypatch.setenv("GS_NO_PAIRTAB", "1")
             capfd.readouterr()
-            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=start)
+            # frozen: GS_FLAG_NO_NEW_TABLES - a pair the handle has no table for (NCG) goes without, one it has (NGG) uses it
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=start,
+                                                  no_new_tables=cfg.get("frozen", False))
             monkeypatch.delenv("GS_PAIRTABS", raising=False)
             monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
             err = capfd.readouterr().err
@@ -449,7 +451,8 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
             cnt = gidx.last_counters()
             pairs = {p[-2:] if not start else p[:2][::-1] for p in (own,) + tuple(alt)}
             concrete = all("N" not in p for p in pairs)
-            want_tables = concrete and len(pairs) <= (1 if cfg.get("one_table") else 2) and not cfg.get("no_tables")
+            want_tables = (concrete and len(pairs) <= (1 if cfg.get("one_table") else 2) and not cfg.get("no_tables")
+                           and not (cfg.get("frozen") and own != "NGG"))
             assert (cnt["items_pair_tables"] > 0) == want_tables, (cfg, cnt)
             # ... and when every pattern of the batch has one (3-symbol PAMs), the other strand's side uses the deep tables
             assert ("with deep tables" in err) == want_tables, (cfg, err)
