@@ -431,7 +431,9 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
         for cfg in (dict(m=3), dict(m=2), dict(m=4), dict(m=3, alt=("NAG",)), dict(m=3, start=True),
                     dict(m=5, alt=("NAG", "NGA")), dict(m=6), dict(m=1), dict(m=4, alt=("NGN",)),
                     dict(m=3, start=True, pam="TTN"), dict(m=3, pam="NAG", alt=("NGG",)), dict(m=3, one_table=True, alt=("NAG",)),
-                    dict(m=4, no_tables=True), dict(m=3), dict(m=3, pam="NCG", frozen=True), dict(m=2, frozen=True)):
+                    dict(m=4, no_tables=True), dict(m=3), dict(m=3, pam="NCG", frozen=True), dict(m=2, frozen=True),
+                    # six patterns = two passes of the kernel, two pairs; concrete first symbols pick one of a deep line's entries
+                    dict(m=3, alt=("AGG", "CGG", "TGG", "GGG", "NAG")), dict(m=2, pam="CGG", alt=("TAG",))):
             m, alt, start, own = cfg["m"], cfg.get("alt", ()), cfg.get("start", False), cfg.get("pam", "NGG")
             pams = np.tile(np.frombuffer(own.encode(), np.uint8), (len(guides), 1))
             opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
