@@ -412,6 +412,62 @@ def test_two_sided_pieces_exceptions_and_windows(monkeypatch, capfd):
         oidx.close()
 
 
+def test_many_literal_n_windows(monkeypatch, capfd):
+    """hundreds of windows with a literal N under the PAM (a scaffold-level assembly has thousands of N
+    runs): the window list is scanned in several passes of 64, by both kinds of item - through the
+    PAM-pair tables every such site comes from the list, with the strand tables only the other strand's
+    share does - and every site is found exactly once"""
+    import re
+    monkeypatch.setenv("GS_PREFIX_K", "13")
+    monkeypatch.setenv("GS_DEBUG", "1")
+    rng = np.random.default_rng(77)
+    text, names, lengths = synth.make_genome([260_000, 140_000], seed=21, n_blocks=False)
+    text = text.copy()
+    fam = text[2000:2020].copy()
+    for c in range(500):
+        site = fam.copy()
+        for j in rng.choice(20, size=int(rng.integers(0, 5)), replace=False):
+            site[j] = rng.choice([x for x in b"ACGT" if x != site[j]])
+        pam = bytes(rng.choice([b"NGG", b"NGG", b"NGG", b"NAG", b"ANG", b"GNN", b"TGG"]))
+        w = np.concatenate([site, np.frombuffer(pam, np.uint8)])
+        if c % 2:
+            w = synth.reverse_complement_bytes(w)
+        at = 3000 + 780 * c + int(rng.integers(0, 700))
+        text[at:at + 23] = w
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        sampled, _, _, _ = synth.sample_guides(text, 30, seed=9)
+        guides = [fam.tobytes().decode(), synth.reverse_complement_bytes(fam).tobytes().decode()]
+        swap = {65: 67, 67: 71, 71: 84, 84: 65}
+        for pos in ((0,), (5, 6), (12,), (2, 15), (18, 19), (1, 9, 17)):
+            g2 = fam.copy()
+            for q in pos:
+                g2[q] = swap[int(g2[q])]
+            guides.append(g2.tobytes().decode())
+        guides += [sampled[i].tobytes().decode() for i in range(sampled.shape[0])]
+        seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (len(guides), 1))
+        for m, alt, no_tables in ((3, (), False), (4, ("NAG",), False), (3, (), True), (2, ("NGN",), False)):
+            if no_tables:
+                monkeypatch.setenv("GS_NO_PAIRTAB", "1")
+            capfd.readouterr()
+            offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt)
+            monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
+            mt = re.search(r"literal-N windows (\d+) \+ (\d+)", capfd.readouterr().err)
+            assert mt and int(mt.group(1)) > 128 and int(mt.group(2)) > 128, mt   # more than two passes of 64 per strand
+            opts = ol.make_opts(mismatches=m, alt_pams=alt)
+            n_lit = 0
+            for i, g in enumerate(guides):
+                exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
+                assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, (i, m, alt, no_tables)
+                n_lit += sum(1 for e in exp if e[3][20:].startswith("N"))
+            assert n_lit > 100, n_lit   # sites whose PAM shows the genome's literal N
+    finally:
+        gidx.close()
+        oidx.close()
+
+
 @pytest.mark.parametrize("pk,L", [("13", 20), ("11", 16), ("12", 18)])
 def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
     """the table depth that makes k_search seed from both strands (sites with >= 2 substitutions
