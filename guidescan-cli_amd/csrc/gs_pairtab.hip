@@ -299,10 +299,15 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
   if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
   const double rows_bytes = 10.0 * ((double)ix->strand[0].n + (double)ix->strand[1].n) / 16.0 * 1.5;
   const double tmp_bytes = 8.0 * (double)(1ull << (2 * k)) + 64e6;
+  double room = (double)free_b - reserve;
+  if (const char *e = getenv("GS_INDEX_BUDGET_GB")) { /* the cap on the whole index covers its derived tables too */
+    const double left = atof(e) * 1e9 - (double)gs_index_device_bytes(ix);
+    if (left < room) room = left;
+  }
   for (;;) {
     const uint32_t nrot = rot_first + 1 < k ? k - 1 - rot_first : 0;
     const double need = 2.0 * entry_bytes * (1 + nrot) + rows_bytes + tmp_bytes;
-    if (need <= ((double)free_b - reserve) * share) break; /* share < 1: another pair's tables are still to come */
+    if (need <= room * share) break; /* share < 1: another pair's tables are still to come */
     if (nrot == 0) {
       if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] PAM-pair table %u: not enough free memory (%.1f GB), skipped\n", code, 1e-9 * (double)free_b);
       return GS_OK;
