@@ -189,7 +189,12 @@ def main():
     alg_bytes_per_launch = 64.0 * n_lines + 16.0 * st_cnt["n_matches"]
     search_s = (ms_search / K) / 1e3
     achieved = alg_bytes_per_launch / search_s / 1e9 if search_s > 0 else 0.0
-    traffic, traffic_src = recorded_traffic(args.workload, batch, m)
+    traffic, traffic_src, issue = recorded_traffic(args.workload, batch, m)
+    if issue:
+        # what binds the kernel when the bytes do not: VALU wave-instructions of the same dispatch (SQ_INSTS_VALU
+        # of a separate --pmc pass) against the SIMDs' issue slots - 4 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz
+        issue = dict(issue, valu_frac_of_issue_cycles=issue["valu_wave_instructions"] * 4.0 /
+                     (1024 * 2.4e9 * issue["duration_ms"] * 1e-3), source=traffic_src.replace("fetch_size", "sq_wave_cycles").split(" + ")[0])
     ref_bytes = 128.0 * n_ext_ref_per_guide * batch
     out = {
         "metric": f"guides/sec off-target enum, <={m} mismatches",
@@ -211,7 +216,7 @@ def main():
                    "parallelism": f"replicated index, guide batch sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": traffic_src,
+                     "traffic_source": traffic_src, "instruction_issue": issue,
                      "alg_bytes_per_launch": alg_bytes_per_launch,
                      "avg_launch_ms": ms_search / K,
                      "requests_per_guide": {k: v / batch for k, v in lines.items()},
@@ -401,13 +406,13 @@ def recorded_traffic(workload, batch, m):
     workload WITH THESE SOURCES (a stale number is worse than none)."""
     f = ROOT / "profiles" / "traffic.json"
     if not f.exists():
-        return None, None
+        return None, None, None
     stamp = kernel_stamp()
     for rec in json.loads(f.read_text()):
         if (rec["workload"] == workload and rec["batch"] == batch and rec["mismatches"] == m
                 and rec.get("kernel_sha") == stamp):
-            return rec["fetch_bytes"] + rec["write_bytes"], rec["source"]
-    return None, None
+            return rec["fetch_bytes"] + rec["write_bytes"], rec["source"], rec.get("issue")
+    return None, None, None
 
 
 def side_steps(torch, api, gidx, d_seqs, d_pams, batch, i, L, P, m, text, names, lengths):

@@ -3,7 +3,7 @@
 FETCH_SIZE / WRITE_SIZE bytes of the timed k_search dispatch and a hash of the kernel sources
 (bench.py only reports `roofline.traffic` when the hash matches the sources it runs).
 
-    tools/make_traffic_json.py TAG WORKLOAD BATCH M FETCH.json WRITE.json
+    tools/make_traffic_json.py TAG WORKLOAD BATCH M FETCH.json WRITE.json [SQ.json]
 
 FETCH.json / WRITE.json are tools/pmc_summary.py outputs of `rocprofv3 --pmc FETCH_SIZE` /
 `--pmc WRITE_SIZE` passes of `bench.py --steps 1 --warmup 0 --cpu-sample 0` (tools/profile_round.sh);
@@ -31,11 +31,17 @@ def main():
         return rows[0][counter] * 1024.0, rows[0]["duration_ms"]
     fetch, dur_f = pick(ffile, "FETCH_SIZE")
     write, dur_w = pick(wfile, "WRITE_SIZE")
+    issue = None
+    if len(sys.argv) > 7 and Path(sys.argv[7]).exists():   # the SQ pass: instruction issue of the same dispatch
+        valu, dur_s = pick(sys.argv[7], "SQ_INSTS_VALU")
+        salu, _ = pick(sys.argv[7], "SQ_INSTS_SALU")
+        issue = {"valu_wave_instructions": valu / 1024.0, "salu_wave_instructions": salu / 1024.0, "duration_ms": dur_s}
     out = ROOT / "profiles" / "traffic.json"
     recs = json.loads(out.read_text()) if out.exists() else []
     recs = [r for r in recs if not (r["workload"] == workload and r["batch"] == int(batch) and r["mismatches"] == int(m))]
     recs.append({"workload": workload, "batch": int(batch), "mismatches": int(m), "fetch_bytes": int(fetch),
                  "write_bytes": int(write), "duration_ms_under_pmc": [dur_f, dur_w],
+                 "issue": issue,
                  "kernel_sha": bench.kernel_stamp(),
                  "source": f"profiles/{tag}_pmc_fetch_size.json + {tag}_pmc_write_size.json: rocprofv3 --pmc FETCH_SIZE / "
                            f"WRITE_SIZE (separate passes, tools/profile_round.sh) of `bench.py --steps 1 --warmup 0 "

@@ -25,5 +25,5 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST
   python3 tools/pmc_summary.py $OUT/pmc_$name k_search k_order k_locate > $SUM/${NAME}_pmc_$name.json
 done
 B=$(python3 -c "import json;print(json.loads(open('$SUM/${NAME}_bench_under_rocprof.json').read().strip().splitlines()[-1])['config']['guides_per_step_per_gpu'])")
-python3 tools/make_traffic_json.py $NAME $WL $B $M $SUM/${NAME}_pmc_fetch_size.json $SUM/${NAME}_pmc_write_size.json && cp profiles/traffic.json $SUM/traffic.json
+python3 tools/make_traffic_json.py $NAME $WL $B $M $SUM/${NAME}_pmc_fetch_size.json $SUM/${NAME}_pmc_write_size.json $SUM/${NAME}_pmc_sq_wave_cycles.json && cp profiles/traffic.json $SUM/traffic.json
 ls -la $SUM
