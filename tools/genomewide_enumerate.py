@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1_000_000)
     ap.add_argument("--max-guides", type=int, default=4_000_000, help="per rank; 0 = the whole candidate set")
     ap.add_argument("--score", action="store_true")
+    ap.add_argument("--sorted", action="store_true",
+                    help="collect every candidate on the device first and enumerate them in lexicographic order: guides "
+                         "that run at the same time then read neighbouring table lines (single GPU)")
     a = ap.parse_args()
     import torch
     api = import_module("guidescan-cli_amd.api")
@@ -46,6 +49,68 @@ def main():
     t_gen = t_enum = t_score = 0.0
     off = 0
     spec_sum = 0.0
+    if a.sorted:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        parts_s, parts_p = [], []
+        for name, ln in zip(names, lengths):
+            d_chr = torch.from_numpy(text[off:off + ln]).cuda()
+            off += ln
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            km = api.generate_kmers(None, "NGG", 20, device=local, chrm_device_ptr=d_chr.data_ptr(), chrm_len=ln)
+            t_gen += time.perf_counter() - t0
+            s = torch.empty((km.n, 20), dtype=torch.uint8, device="cuda")
+            p = torch.empty((km.n, 3), dtype=torch.uint8, device="cuda")
+            assert hip.hipMemcpy(s.data_ptr(), km.seqs_ptr, 20 * km.n, 3) == 0
+            assert hip.hipMemcpy(p.data_ptr(), km.pams_ptr, 3 * km.n, 3) == 0
+            parts_s.append(s)
+            parts_p.append(p)
+            n_cand += km.n
+            km.close()
+            del d_chr
+        seqs = torch.cat(parts_s)
+        pams = torch.cat(parts_p)
+        del parts_s, parts_p
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        code = torch.zeros(256, dtype=torch.int64, device="cuda")
+        for i, ch in enumerate(b"ACGT"):
+            code[ch] = i
+        keys = torch.zeros(seqs.shape[0], dtype=torch.int64, device="cuda")
+        step = 1 << 24
+        for lo in range(0, seqs.shape[0], step):
+            c = code[seqs[lo:lo + step].long()]
+            k = torch.zeros(c.shape[0], dtype=torch.int64, device="cuda")
+            for i in range(20):
+                k |= c[:, i] << (2 * (19 - i))
+            keys[lo:lo + step] = k
+            del c, k
+        order = torch.argsort(keys)
+        del keys
+        seqs_s = torch.empty_like(seqs)
+        pams_s = torch.empty_like(pams)
+        for lo in range(0, order.shape[0], step):
+            seqs_s[lo:lo + step] = seqs[order[lo:lo + step]]
+            pams_s[lo:lo + step] = pams[order[lo:lo + step]]
+        del seqs, pams, order
+        torch.cuda.synchronize()
+        t_sort = time.perf_counter() - t0
+        total = seqs_s.shape[0] if not a.max_guides else min(a.max_guides, seqs_s.shape[0])
+        for lo in range(0, total, a.batch):
+            n = min(a.batch, total - lo)
+            t0 = time.perf_counter()
+            d_off, d_hits, st = gidx.enumerate_device(seqs_s.data_ptr() + lo * 20, n, 20, pams_s.data_ptr() + lo * 3, 3,
+                                                      mismatches=a.mismatches)
+            t_enum += time.perf_counter() - t0
+            n_guides += n
+            n_hits += st["n_hits"]
+        print(json.dumps({"workload": a.workload, "mismatches": a.mismatches, "order": "lexicographic", "candidates_scanned": n_cand,
+                          "guides_enumerated": n_guides, "hits": n_hits, "kmers_generate_s": t_gen, "sort_s": t_sort,
+                          "enumerate_s": t_enum, "guides_per_s": n_guides / t_enum}))
+        gidx.close()
+        return
     for name, ln in zip(names, lengths):
         if a.max_guides and n_guides >= a.max_guides:
             break
