@@ -105,6 +105,8 @@ def test_cost_model_thresholds_at_the_baseline_geometry():
     assert api.choose_thresholds(3, 9, 5, 6, 4.0)[:4] == [2, 2, 1, 1]
     assert api.choose_thresholds(6, 9, 5, 6, 4.0)[:6] == [4, 3, 3, 2, 2, 1]
     assert api.choose_thresholds(3, 8, 6, 6, 1.0, 0.4, 1.6)[:4] == [2, 2, 1, 1]
+    assert api.choose_thresholds(4, 8, 6, 6, 1.0, 0.4, 1.6)[:5] == [3, 2, 2, 1, 1]
+    assert api.choose_thresholds(6, 8, 6, 6, 1.0, 0.4, 1.6)[:7] == [3, 3, 3, 2, 2, 1, 1]   # profiles/r02_sweep_astar_deep.txt
     for m in range(1, 8):
         t = api.choose_thresholds(m, 8, 6, 6, 1.0, 0.4, 1.6)
         assert all(t[i] >= t[i + 1] for i in range(7))   # non-increasing in o
