@@ -130,6 +130,14 @@ struct gs_pairtab_host {
   uint64_t bytes = 0, used = 0;
 };
 
+struct gs_recipe_set {
+  gs_buffer buf;
+  uint64_t key[2] = {0, 0};
+  bool valid = false;
+  uint32_t n_full = 0, n_a = 0, n_b = 0;
+  uint32_t a_rot_first = 31; /* lowest consumption step whose rotated copy the `a` list reads (31: none) */
+};
+
 struct gs_index {
   int device = 0;
   uint64_t genome_length = 0;
@@ -140,7 +148,10 @@ struct gs_index {
       /* device-wide ordering of guides with more matches than an LDS sort holds (gs_search.hip) */
       w_b_src, w_b_cnt, w_b_prefix, w_b_recs, w_b_w0, w_b_w0b, w_b_w1, w_b_idx, w_b_idxb, w_b_keep, w_b_keeps,
       w_b_rows, w_b_rowss, w_b_redo_pos,
-      w_score, w_score_io; /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
+      w_score, w_score_io, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
+      /* overflow arena of k_search (gs_search.hip): records, chunk owners + sequence numbers, chunks per item */
+      w_arena, w_arena_meta, w_nchunk;
+  uint64_t arena_chunks = 4096; /* chunks of 1,024 records the next batch's arena holds: grown when a batch needed more */
   /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
   double seen_mean[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
   double seen_max[8] = {0};
@@ -152,11 +163,13 @@ struct gs_index {
   unsigned long long last_counters[16] = {0}; /* k_search's stats array of the last gs_enumerate_device call */
   std::vector<gs_nrun> nruns_text; /* 'N' runs of the forward text */
   gs_buffer w_cand;                /* per-batch literal-N candidate windows (device) */
-  gs_buffer w_rec;                 /* seed recipes of the last (budget, geometry, thresholds): full | a | b */
-  uint64_t rec_key[2] = {0, 0};
-  bool rec_valid = false;
-  uint32_t n_rec_full = 0, n_rec_a = 0, n_rec_b = 0;
-  uint32_t rec_a_rot_first = 31;   /* lowest consumption step whose rotated copy rec_a reads (31: none) */
+  /* seed recipes of the last two (budget, geometry, thresholds) - the CLI's --threshold pass alternates two
+   * budgets on one handle: full | a | b per set; rec_cur = the set the last call used */
+  gs_recipe_set rec[2];
+  uint32_t rec_cur = 0;
+  /* PAM pairs whose tables did not fit next to the rest (bit per pair code): not tried again until memory
+   * is released (gs_pairtab_forget_nofit) */
+  uint32_t pairtab_nofit = 0;
   /* PAM-pair tables (gs_pairtab.hip), built on first use for the pairs a batch's patterns end in */
   gs_pairtab_host pairtab[2];
   bool pairtab_off = false; /* a batch ran out of memory next to them: not built again on this handle */
@@ -189,6 +202,8 @@ gs_status gs_device_suffix_array(const uint8_t *d_text, uint64_t n, uint32_t *d_
 gs_status gs_strand_from_device(const uint8_t *d_text, uint32_t *d_sa_owned, uint64_t n,
                                 gs_strand *out, hipStream_t st);
 void gs_strand_free(gs_strand *s);
+/* gs_verify.hip: rows of a device-resident suffix array that are out of range or repeat a value */
+gs_status gs_count_bad_sa_rows(const uint32_t *d_sa, uint64_t n, hipStream_t st, uint64_t *bad);
 
 /* SDSL importer (gs_sdsl_import.cpp): reads <path> into BWT bytes + SA samples */
 gs_status gs_sdsl_read(const char *path, std::vector<uint8_t> &bwt, std::vector<uint64_t> &sa_samples,

@@ -12,6 +12,8 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <system_error>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 
@@ -693,7 +695,7 @@ static void scan_n_runs(const uint8_t *text, uint64_t len, std::vector<gs_nrun> 
 
 /* ---------------- C-ABI: index lifecycle -------------------------------------- */
 static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t *sa_fwd,
-                              const uint32_t *sa_rev, int device, gs_index **out) {
+                              const uint32_t *sa_rev, int device, gs_index **out, gs_status bad_sa = GS_ERR_ARG) {
   if (!text || !out || len < 1) return GS_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -738,6 +740,15 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
     const uint8_t *d_t = s == 0 ? d_fwd : d_rev;
     if (given) {
       GS_HIP(hipMemcpy(d_sa, given, 4 * n, hipMemcpyHostToDevice));
+      /* a suffix array from outside (a file, the caller): every value in range and none twice, or no
+       * table is derived from it - the builders read text[sa[r] - j] without looking */
+      uint64_t bad = 0;
+      if ((rc = gs_count_bad_sa_rows(d_sa, n, st, &bad)) == GS_OK && bad) {
+        gs_set_error("the suffix array given for the " + std::string(s ? "reverse" : "forward") + " strand is not a permutation of its rows (" +
+                     std::to_string(bad) + " bad rows)");
+        rc = bad_sa;
+      }
+      if (rc != GS_OK) continue;
     } else {
       rc = gs_device_suffix_array(d_t, n, d_sa, st);
     }
@@ -775,11 +786,24 @@ extern "C" gs_status gs_index_build_with_sa(const uint8_t *text, uint64_t len, c
  * The device layout is derived data (210 GB at hg38 size, rebuilt from text + suffix arrays in a few
  * seconds); what is worth storing is the result of the sort: 4 bytes per row and strand. */
 struct gs_sa_header {
-  char magic[8]; /* "GSAMDSA1" */
+  char magic[8]; /* "GSAMDSA2" ("GSAMDSA1": the same without payload checksums, still read) */
   uint64_t n;    /* rows per strand = text length + 1 */
   uint64_t text_hash;
-  uint64_t reserved[5];
+  uint64_t sa_hash[2]; /* checksum of each strand's payload (sa_hash_update over its n entries) */
+  uint64_t reserved[3];
 };
+/* running checksum of suffix-array entries, two at a time; chunks chain through h */
+static uint64_t sa_hash_update(uint64_t h, const uint32_t *p, size_t m) {
+  size_t i = 0;
+  for (; i + 2 <= m; i += 2) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+    h ^= h >> 32;
+  }
+  if (i < m) h = (h ^ p[i]) * 1099511628211ull;
+  return h;
+}
 static uint64_t text_fingerprint(const uint8_t *text, uint64_t len) {
   /* every byte of the text, eight at a time (a suffix array of another text would give wrong hits
    * silently, so no sampling): ~0.5 s at 3.1 GB */
@@ -804,9 +828,10 @@ extern "C" gs_status gs_index_save_sa(gs_index *ix, const uint8_t *text, uint64_
   }
   gs_sa_header h;
   memset(&h, 0, sizeof(h));
-  memcpy(h.magic, "GSAMDSA1", 8);
+  memcpy(h.magic, "GSAMDSA2", 8);
   h.n = ix->strand[0].n;
   h.text_hash = text_fingerprint(text, len);
+  h.sa_hash[0] = h.sa_hash[1] = 0x9E3779B97F4A7C15ull;
   bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
   const size_t chunk = 64u << 20; /* entries per copy */
   std::vector<uint32_t> buf;
@@ -825,7 +850,10 @@ extern "C" gs_status gs_index_save_sa(gs_index *ix, const uint8_t *text, uint64_
         return GS_ERR_DEVICE;
       }
       ok = fwrite(buf.data(), 4, m, f) == m;
+      h.sa_hash[s] = sa_hash_update(h.sa_hash[s], buf.data(), m);
     }
+  /* the header again, now with the payload checksums */
+  ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, f) == 1;
   ok = fclose(f) == 0 && ok;
   if (!ok) {
     gs_set_error(std::string("short write to ") + path);
@@ -843,8 +871,9 @@ extern "C" gs_status gs_index_open_sa(const uint8_t *text, uint64_t len, const c
   }
   gs_sa_header h;
   const uint64_t n = len + 1;
-  bool ok = fread(&h, sizeof(h), 1, f) == 1 && !memcmp(h.magic, "GSAMDSA1", 8) && h.n == n &&
-            h.text_hash == text_fingerprint(text, len);
+  bool ok = fread(&h, sizeof(h), 1, f) == 1 && (!memcmp(h.magic, "GSAMDSA2", 8) || !memcmp(h.magic, "GSAMDSA1", 8)) &&
+            h.n == n && h.text_hash == text_fingerprint(text, len);
+  const bool summed = ok && h.magic[7] == '2';
   std::vector<uint32_t> sa[2];
   try {
     for (int s = 0; s < 2 && ok; s++) {
@@ -856,11 +885,26 @@ extern "C" gs_status gs_index_open_sa(const uint8_t *text, uint64_t len, const c
     return GS_ERR_NOMEM;
   }
   fclose(f);
+  if (ok && summed) {
+    /* a damaged payload of the right length must not reach the builders: both strands' checksums, side by side */
+    uint64_t got[2] = {0, 0};
+    auto sum = [&](int s) { got[s] = sa_hash_update(0x9E3779B97F4A7C15ull, sa[s].data(), (size_t)n); };
+    try {
+      std::thread t1(sum, 1);
+      sum(0);
+      t1.join();
+    } catch (const std::system_error &) { /* no second thread to be had */
+      sum(0);
+      sum(1);
+    }
+    ok = got[0] == h.sa_hash[0] && got[1] == h.sa_hash[1];
+  }
   if (!ok) {
-    gs_set_error(std::string(path) + " is not the suffix-array file of this genome text");
+    gs_set_error(std::string(path) + " is not the suffix-array file of this genome text (or is damaged)");
     return GS_ERR_FORMAT;
   }
-  return build_common(text, len, sa[0].data(), sa[1].data(), device, out);
+  /* files without checksums (and any file, again): build_common checks that each array is a permutation */
+  return build_common(text, len, sa[0].data(), sa[1].data(), device, out, GS_ERR_FORMAT);
 }
 
 extern "C" void gs_index_close(gs_index *ix) {
@@ -874,7 +918,7 @@ extern "C" void gs_index_close(gs_index *ix) {
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_tmp, &ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix,
                        &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx, &ix->w_b_idxb,
                        &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_redo_pos,
-                       &ix->w_cand, &ix->w_rec, &ix->w_score, &ix->w_score_io};
+                       &ix->w_cand, &ix->rec[0].buf, &ix->rec[1].buf, &ix->w_score, &ix->w_score_io, &ix->w_arena, &ix->w_arena_meta, &ix->w_nchunk};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)

@@ -31,7 +31,7 @@
 #ifndef VQ_DRAIN
 #define VQ_DRAIN 64 /* verify as soon as this many seeds wait (a seeding step adds at most 64) */
 #endif
-#define WAVE_LDS_FAST (VQ_CAP + 32 + DTAB) /* 16-byte entries per wave of the table-only variant: 3.9 KiB */
+#define WAVE_LDS_FAST (VQ_CAP + 32 + DTAB + 1) /* 16-byte entries per wave of the table-only variant: 3.9 KiB */
 #define WAVE_LDS_ENTRIES (STACK_ENTRIES + WAVE_LDS_FAST) /* the walking variant adds the X/G stacks: 8 KiB */
 #define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
 
@@ -49,6 +49,16 @@ struct gs_search_args {
   uint4 *slots;          /* [n_items][cap] match records {key_lo, key_hi, sp, ep} */
   const uint64_t *slot_off; /* optional: item s owns slots [slot_off[s], slot_off[s+1]) instead */
   uint32_t *counts;      /* [n_items] matches found (may exceed cap -> overflow) */
+  /* Overflow arena: an item whose matches outgrow its slots continues in chunks of ARENA_CHUNK records
+   * taken from one array with an atomic counter (chunk c belongs to item chunk_item[c] and holds its
+   * records cap + chunk_seq[c] * ARENA_CHUNK ...), so no item is searched twice; nchunk[item] = {chunks
+   * taken, the last one}.  An item is complete when counts <= cap + chunks * ARENA_CHUNK; when the arena
+   * runs out the item keeps counting and the host falls back to the exact-size second pass. */
+  uint4 *arena;          /* or nullptr */
+  uint32_t *arena_next;  /* chunks handed out */
+  uint32_t *chunk_item, *chunk_seq;
+  uint2 *nchunk;         /* [n_items] */
+  uint32_t arena_chunks; /* chunks the arena holds */
   uint32_t *work;        /* work-queue head */
   unsigned long long *stats; /* [0] n_ext, [1] overflow items, [4] two-sided items, [5] one-sided, [8..] request counters */
   uint32_t n_items, L, P, m, cap;
@@ -92,6 +102,8 @@ struct gs_search_args {
   const uint4 *cand[2];
   uint32_t n_cand[2];
 };
+#define ARENA_SHIFT 10u
+#define ARENA_CHUNK (1u << ARENA_SHIFT) /* records per overflow chunk (16 KiB): one atomic per 1,024 matches */
 #define DSC_LO 27u  /* descriptor.y bits 29:27: fewest substitutions allowed among the remaining guide symbols */
 #define DSC_EXC 30u /* descriptor.y bit 30: the interval holds exception rows (gs_strand_dev::exc_row) */
 
@@ -123,6 +135,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
   const uint32_t lane = lane_id();
   unsigned long long n_ext = 0, n_ovf = 0;
+  uint32_t n_fail = 0; /* items that needed more overflow chunks than the arena had left */
   uint32_t n_two = 0, n_fb = 0, n_pair = 0; /* items seeded from both strands / one-sided although two-sided seeding is on */
   /* request counters (CNT): table lines, ctx16 lines, ctx words, SA/ISA gathers of the search, Occ lines */
   uint32_t c_tab = 0, c_c16 = 0, c_ctx = 0, c_isa = 0, c_occ = 0, c_rec = 0;
@@ -148,6 +161,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   uint2 *own2 = (uint2 *)(vq + VQ_CAP);        /* owner markers of a pass, two per lane */
   uint32_t *own = (uint32_t *)own2;
   uint4 *dtab = vq + VQ_CAP + 32;              /* substitution table of the item: {index xor, path lo, path hi, -} */
+  uint32_t *wmisc = (uint32_t *)(dtab + DTAB); /* overflow chunks of the item: {taken, the last one, the one before} */
 
   for (;;) {
     uint32_t item = 0;
@@ -183,6 +197,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     const uint32_t item_cap = a.slot_off ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : a.cap;
     uint32_t n_match = 0;
     if (a.append) n_match = __builtin_amdgcn_readfirstlane(a.counts[slot]);
+    if (a.arena != nullptr) {
+      uint2 nc = make_uint2(0u, 0u);
+      if (a.append) nc = a.nchunk[slot];
+      if (lane < 3u) wmisc[lane] = lane == 0u ? nc.x : lane == 1u ? nc.y : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
     uint32_t xs = 0, gs = 0; /* sizes of the X and G stacks */
     /* what this strand's seeds are looked up in and verified against: the strand's own table and
      * context arrays, or (set per item, below) a PAM-pair table and its rows */
@@ -223,17 +243,49 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       }
       const uint64_t be = __ballot(em);
       if (be) {
+        const uint32_t hi = n_match + (uint32_t)__popcll(be); /* one past the last record of this emission */
+        if (hi > item_cap && a.arena != nullptr) {
+          /* the emission reaches beyond the item's slots: take overflow chunks up to its last record
+           * (wave-uniform; at most two per emission, almost always none) */
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]);
+          const uint32_t need = (hi - item_cap + ARENA_CHUNK - 1u) >> ARENA_SHIFT;
+          while (nch < need) {
+            uint32_t id = 0;
+            if (lane == 0) id = atomicAdd(a.arena_next, 1u);
+            id = __builtin_amdgcn_readfirstlane(id);
+            if (id >= a.arena_chunks) break; /* arena exhausted: the item goes on counting only */
+            if (lane == 0) {
+              a.chunk_item[id] = slot;
+              a.chunk_seq[id] = nch;
+              wmisc[2] = wmisc[1];
+              wmisc[1] = id;
+            }
+            nch++;
+          }
+          if (lane == 0) wmisc[0] = nch;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
         if (em) {
           const uint32_t idx = n_match + lanes_below(be);
+          /* bit 0: the record is a single row at the table depth whose text position still
+           * has to move left by v_rem symbols (k_locate) */
+          const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
+                               ((cmeta & PATH_MASK) << 8) | vflag;
+          const uint4 rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
           if (idx < item_cap) {
-            /* bit 0: the record is a single row at the table depth whose text position still
-             * has to move left by v_rem symbols (k_locate) */
-            const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
-                                 ((cmeta & PATH_MASK) << 8) | vflag;
-            out[idx] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
+            out[idx] = rec;
+          } else if (a.arena != nullptr) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint32_t e = idx - item_cap, sq = e >> ARENA_SHIFT;
+            const uint32_t nch = wmisc[0];
+            if (sq < nch) {
+              const uint32_t id = sq + 1u == nch ? wmisc[1] : wmisc[2];
+              a.arena[((size_t)id << ARENA_SHIFT) | (e & (ARENA_CHUNK - 1u))] = rec;
+            }
           }
         }
-        n_match += __popcll(be);
+        n_match = hi;
       }
     };
 
@@ -1054,10 +1106,17 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     }
     if (lane == 0) a.counts[slot] = n_match;
     if (n_match > item_cap) n_ovf++;
+    if (a.arena != nullptr) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
+      if (lane == 0) a.nchunk[slot] = make_uint2(nch, last);
+      if (n_match > item_cap && n_match - item_cap > (nch << ARENA_SHIFT)) n_fail++;
+    }
   }
   if (lane == 0) {
     if (n_ext) atomicAdd(&a.stats[0], n_ext);
     if (n_ovf) atomicAdd(&a.stats[1], n_ovf);
+    if (n_fail) atomicAdd(&a.stats[6], (unsigned long long)n_fail);
     if (n_two) atomicAdd(&a.stats[4], (unsigned long long)n_two);
     if (n_fb) atomicAdd(&a.stats[5], (unsigned long long)n_fb);
     if (n_pair) atomicAdd(&a.stats[7], (unsigned long long)n_pair);
@@ -1531,6 +1590,49 @@ __global__ void k_patch_overflow(const uint32_t *list, uint32_t n_o, const uint3
   if (i < n_o) nhits[list[i]] = nhits2[i];
 }
 
+/* ---- overflow arena -> contiguous records (instead of a second search pass) ------------------------
+ * The guides on the overflow list have their first `cap` records per item in the main slot array and the
+ * rest in arena chunks (gs_search_args::arena).  Item j of the list (2 * position + strand) is copied to
+ * dst at dst_off[j] (exact-size layout) or at j * cap2 (fixed stride): blocks [0, 2 n_o) copy the slot
+ * parts, one block per chunk the rest. */
+struct gs_agather_args {
+  const uint4 *slots, *arena;
+  const uint32_t *counts;                 /* per item of the main pass (exact) */
+  const uint32_t *chunk_item, *chunk_seq; /* per chunk */
+  const uint32_t *list;                   /* overflow guides */
+  const uint32_t *redo_pos;               /* guide -> position in list */
+  const uint64_t *dst_off;                /* 2 n_o + 1 offsets, or nullptr: stride cap2 */
+  uint4 *dst;
+  uint32_t n_o, cap, cap2, n_used;
+};
+__global__ __launch_bounds__(256) void k_arena_gather(gs_agather_args a) {
+  const uint32_t b = blockIdx.x;
+  const uint4 *src;
+  uint32_t j, first, nrec;
+  if (b < 2u * a.n_o) {
+    j = b;
+    const uint32_t item = 2u * a.list[j >> 1] + (j & 1u);
+    const uint32_t c = a.counts[item];
+    src = a.slots + (size_t)item * a.cap;
+    first = 0;
+    nrec = c < a.cap ? c : a.cap;
+  } else {
+    const uint32_t c = b - 2u * a.n_o;
+    if (c >= a.n_used) return;
+    const uint32_t item = a.chunk_item[c];
+    const uint32_t pos = a.redo_pos[item >> 1];
+    if (pos == 0xFFFFFFFFu) return; /* cannot happen: an item with chunks overflowed its slots */
+    j = 2u * pos + (item & 1u);
+    const uint32_t cnt = a.counts[item], e0 = a.chunk_seq[c] << ARENA_SHIFT;
+    if (cnt <= a.cap + e0) return;
+    src = a.arena + ((size_t)c << ARENA_SHIFT);
+    first = a.cap + e0;
+    nrec = cnt - first < ARENA_CHUNK ? cnt - first : ARENA_CHUNK;
+  }
+  uint4 *dst = a.dst + (a.dst_off ? (size_t)a.dst_off[j] : (size_t)j * a.cap2) + first;
+  for (uint32_t i = threadIdx.x; i < nrec; i += blockDim.x) dst[i] = src[i];
+}
+
 /* ---- guides with more matches than an LDS sort can hold: repeat-derived guides at any budget,
  * every guide at <= 6 mismatches on a genome of this size (~5,400 matches per item).  Their match
  * records are compacted into one array (item order = guide order), ordered by two stable
@@ -1899,7 +2001,11 @@ static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m
                      0};
   if (astar)
     for (uint32_t o = 0; o < 8; o++) key[1] |= (uint64_t)(astar[o] > 15 ? 15u : astar[o]) << (4 * o);
-  if (ix->rec_valid && ix->rec_key[0] == key[0] && ix->rec_key[1] == key[1]) return GS_OK;
+  for (uint32_t i = 0; i < 2; i++)
+    if (ix->rec[i].valid && ix->rec[i].key[0] == key[0] && ix->rec[i].key[1] == key[1]) {
+      ix->rec_cur = i;
+      return GS_OK;
+    }
   std::vector<uint64_t> all;
   build_recipes_a(all, k, m, v_rem, nullptr, rot);
   const size_t n_full = all.size();
@@ -1914,20 +2020,24 @@ static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m
     gs_set_error("seed plan too large for this mismatch budget");
     return GS_ERR_UNSUPPORTED;
   }
-  ix->rec_valid = false;
-  gs_status rc = gs_reserve(ix->w_rec, 8 * all.size() + 64);
+  /* into the set the last call did not use (or an empty one) */
+  const uint32_t slot = !ix->rec[ix->rec_cur].valid ? ix->rec_cur : ix->rec_cur ^ 1u;
+  gs_recipe_set &R = ix->rec[slot];
+  R.valid = false;
+  gs_status rc = gs_reserve(R.buf, 8 * all.size() + 64);
   if (rc != GS_OK) return rc;
-  GS_HIP(hipMemcpyAsync(ix->w_rec.p, all.data(), 8 * all.size(), hipMemcpyHostToDevice, st));
+  GS_HIP(hipMemcpyAsync(R.buf.p, all.data(), 8 * all.size(), hipMemcpyHostToDevice, st));
   GS_HIP(hipStreamSynchronize(st)); /* `all` is a local */
-  ix->n_rec_full = (uint32_t)n_full;
-  ix->n_rec_a = (uint32_t)n_a;
-  ix->n_rec_b = (uint32_t)n_b;
-  ix->rec_a_rot_first = 31;
+  R.n_full = (uint32_t)n_full;
+  R.n_a = (uint32_t)n_a;
+  R.n_b = (uint32_t)n_b;
+  R.a_rot_first = 31;
   for (size_t i = n_full; i < n_full + n_a; i++)
-    if (all[i] & 64u) ix->rec_a_rot_first = std::min(ix->rec_a_rot_first, (uint32_t)(all[i] >> 7) & 31u);
-  ix->rec_key[0] = key[0];
-  ix->rec_key[1] = key[1];
-  ix->rec_valid = true;
+    if (all[i] & 64u) R.a_rot_first = std::min(R.a_rot_first, (uint32_t)(all[i] >> 7) & 31u);
+  R.key[0] = key[0];
+  R.key[1] = key[1];
+  R.valid = true;
+  ix->rec_cur = slot;
   if (getenv("GS_DEBUG"))
     fprintf(stderr, "[gs] seed recipes: %zu one-sided, %zu + %zu two-sided (%.1f MB)\n", n_full, n_a, n_b, 8e-6 * all.size());
   return GS_OK;
@@ -2193,7 +2303,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
           if (s == 2) continue;
           const bool frozen = (flags & GS_FLAG_NO_NEW_TABLES) != 0; /* use what the handle holds, build nothing */
           if (!have && frozen) continue;
-          if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], frozen ? 31u : ix->rec_a_rot_first,
+          if ((rc = gs_pairtab_ensure(ix, s, v_rem, want[i], frozen ? 31u : ix->rec[ix->rec_cur].a_rot_first,
                                       have ? 1.0 : 1.0 / (double)to_build, st)) != GS_OK)
             return rc;
           if (!have && to_build) to_build--;
@@ -2292,11 +2402,33 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
 
 
   const bool count_req = (flags & GS_FLAG_COUNT_REQUESTS) != 0;
+  /* overflow arena of the main pass (gs_search_args::arena): sized from what earlier batches on this
+   * handle needed; a batch that needs more falls back to the exact-size second pass and leaves a larger
+   * arena to the next one */
+  uint32_t arena_chunks = 0;
+  {
+    uint64_t want = ix->arena_chunks;
+    if (const char *e = getenv("GS_ARENA_CHUNKS")) want = (uint64_t)atoll(e);
+    if (getenv("GS_NO_ARENA")) want = 0;
+    if (want > (1ull << 21)) want = 1ull << 21; /* 32 GB of records */
+    if (want) {
+      if (gs_reserve(ix->w_arena, sizeof(uint4) * (want << ARENA_SHIFT)) != GS_OK ||
+          gs_reserve(ix->w_arena_meta, 8 * want + 64) != GS_OK || gs_reserve(ix->w_nchunk, sizeof(uint2) * (2 * n + 2)) != GS_OK) {
+        (void)hipGetLastError();
+        want = 0; /* no room: the second pass serves the overflowing guides */
+      }
+    }
+    arena_chunks = (uint32_t)want;
+  }
+  uint32_t *d_arena_next = d_work + 4;
+  uint64_t arena_fail = 0; /* items of the main pass the arena had no chunk left for */
   auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
                         uint32_t cap_, unsigned long long h_stats[2],
-                        const uint64_t *slot_off = nullptr) -> gs_status {
+                        const uint64_t *slot_off = nullptr, bool with_arena = false) -> gs_status {
     GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 16, st)); /* n_ext, overflow items */
+    GS_HIP(hipMemsetAsync(d_stats + 6, 0, 8, st));   /* items the arena failed */
     GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
+    if (with_arena) GS_HIP(hipMemsetAsync(d_arena_next, 0, 4, st));
     gs_search_args sa;
     memset(&sa, 0, sizeof(sa));
     sa.sd[0] = ix->strand[0].d;
@@ -2311,6 +2443,14 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     sa.P = P;
     sa.m = mismatches;
     sa.cap = cap_;
+    if (with_arena) {
+      sa.arena = (uint4 *)ix->w_arena.p;
+      sa.arena_next = d_arena_next;
+      sa.chunk_item = (uint32_t *)ix->w_arena_meta.p;
+      sa.chunk_seq = sa.chunk_item + arena_chunks;
+      sa.nchunk = (uint2 *)ix->w_nchunk.p;
+      sa.arena_chunks = arena_chunks;
+    }
     sa.v_max = VERIFY_MAX_DEFAULT;
     if (const char *e = getenv("GS_VERIFY_MAX")) {
       const long v = atol(e);
@@ -2325,15 +2465,16 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       sa.v_rem = v_rem;
       sa.x_len = x_len;
       sa.bdeep = deep ? 1u : 0u;
-      sa.rec_full = (const uint2 *)ix->w_rec.p;
-      sa.n_rec_full = ix->n_rec_full;
+      const gs_recipe_set &R = ix->rec[ix->rec_cur];
+      sa.rec_full = (const uint2 *)R.buf.p;
+      sa.n_rec_full = R.n_full;
       if (bidir) {
         sa.bidir = 1;
         sa.astar = astar_packed;
-        sa.rec_a = sa.rec_full + ix->n_rec_full;
-        sa.n_rec_a = ix->n_rec_a;
-        sa.rec_b = sa.rec_a + ix->n_rec_a;
-        sa.n_rec_b = ix->n_rec_b;
+        sa.rec_a = sa.rec_full + R.n_full;
+        sa.n_rec_a = R.n_a;
+        sa.rec_b = sa.rec_a + R.n_a;
+        sa.n_rec_b = R.n_b;
         sa.n_pt = n_pt;
         for (uint32_t i = 0; i < n_pt; i++) {
           sa.pt[i][0] = ix->pairtab[pt_slot[i]].d[0];
@@ -2376,9 +2517,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         hipLaunchKernelGGL(k_search_fast, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
     }
     GS_HIP(hipEventRecord(ix->ev[2], st));
-    GS_HIP(hipMemcpyAsync(h_stats, d_stats, 16, hipMemcpyDeviceToHost, st));
+    unsigned long long h7[7] = {0};
+    GS_HIP(hipMemcpyAsync(h7, d_stats, sizeof(h7), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
+    h_stats[0] = h7[0];
+    h_stats[1] = h7[1];
+    if (with_arena) arena_fail = h7[6];
     float ms = 0.f;
     hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]);
     ms_search += ms;
@@ -2602,7 +2747,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
   unsigned long long h_stats[2] = {0, 0};
   if ((rc = run_search((const gs_guide_rec *)ix->w_grec.p, n32, (uint4 *)ix->w_slots.p,
-                       (uint32_t *)ix->w_counts.p, cap, h_stats)) != GS_OK)
+                       (uint32_t *)ix->w_counts.p, cap, h_stats, nullptr, arena_chunks != 0)) != GS_OK)
     return rc;
   if (stats) stats->n_ext = h_stats[0];
   GS_HIP(hipMemsetAsync(d_stats + 2, 0, 8, st)); /* match counter */
@@ -2652,30 +2797,81 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
                        (const uint32_t *)ix->w_counts.p, (const uint32_t *)ix->w_ovf_list.p, n_o,
                        (uint32_t *)ix->w_counts2.p);
     uint32_t need_cap = 0;
-    {
-      std::vector<uint32_t> c2(2 * (size_t)n_o);
-      GS_HIP(hipMemcpyAsync(c2.data(), ix->w_counts2.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost, st));
-      GS_HIP(hipStreamSynchronize(st));
-      for (uint32_t c : c2) need_cap = c > need_cap ? c : need_cap;
+    uint64_t need_chunks = 0;
+    std::vector<uint32_t> c2(2 * (size_t)n_o);
+    GS_HIP(hipMemcpyAsync(c2.data(), ix->w_counts2.p, 8 * (size_t)n_o, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    for (uint32_t c : c2) {
+      need_cap = c > need_cap ? c : need_cap;
+      if (c > cap) need_chunks += (c - cap + ARENA_CHUNK - 1u) >> ARENA_SHIFT;
     }
+    /* the overflowing items' records beyond their slots are in the arena - unless it ran out (or is off):
+     * then these guides are searched once more with slots of the exact sizes, and the next batch gets
+     * the arena this one would have needed */
+    const bool arena_ok = arena_chunks != 0 && arena_fail == 0;
+    if (arena_chunks != 0 && !getenv("GS_ARENA_CHUNKS") && need_chunks + need_chunks / 4 + 64 > ix->arena_chunks)
+      ix->arena_chunks = need_chunks + need_chunks / 4 + 64;
+    uint32_t n_used = 0;
+    if (arena_ok) {
+      GS_HIP(hipMemcpyAsync(&n_used, d_arena_next, 4, hipMemcpyDeviceToHost, st));
+      if ((rc = gs_reserve(ix->w_b_redo_pos, 4 * ((size_t)n + 1))) != GS_OK) return rc;
+      hipLaunchKernelGGL(k_fill_u32, dim3((n32 + 255) / 256), dim3(256), 0, st, (uint32_t *)ix->w_b_redo_pos.p,
+                         0xFFFFFFFFu, n32);
+      hipLaunchKernelGGL(k_mark_redo, dim3((n_o + 255) / 256), dim3(256), 0, st, (const uint32_t *)ix->w_ovf_list.p,
+                         n_o, (uint32_t *)ix->w_b_redo_pos.p);
+      GS_HIP(hipStreamSynchronize(st));
+      if (n_used > arena_chunks) n_used = arena_chunks;
+    }
+    auto arena_gather = [&](const uint64_t *dst_off, uint32_t cap2_) {
+      gs_agather_args ga;
+      ga.slots = (const uint4 *)ix->w_slots.p;
+      ga.arena = (const uint4 *)ix->w_arena.p;
+      ga.counts = (const uint32_t *)ix->w_counts.p;
+      ga.chunk_item = (const uint32_t *)ix->w_arena_meta.p;
+      ga.chunk_seq = ga.chunk_item + arena_chunks;
+      ga.list = (const uint32_t *)ix->w_ovf_list.p;
+      ga.redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
+      ga.dst_off = dst_off;
+      ga.dst = (uint4 *)ix->w_slots2.p;
+      ga.n_o = n_o;
+      ga.cap = cap;
+      ga.cap2 = cap2_;
+      ga.n_used = n_used;
+      hipLaunchKernelGGL(k_arena_gather, dim3(2u * n_o + n_used), dim3(256), 0, st, ga);
+    };
     if (!big_batch && need_cap <= LDS_CAP_MAX) {
-      /* one more pass with slots every redo guide fits, ordered in LDS */
+      /* slots every one of these guides fits, ordered in LDS */
       cap2 = 128;
       while (cap2 < need_cap) cap2 <<= 1;
       if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (size_t)cap2 * 2 * n_o)) != GS_OK) return rc;
-      unsigned long long h2[2] = {0, 0};
-      if ((rc = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
-                           (uint32_t *)ix->w_counts2.p, cap2, h2)) != GS_OK)
-        return rc;
-      if (h2[1] != 0) {
-        gs_set_error("internal: redo pass overflowed slots sized from exact counts");
-        return GS_ERR_DEVICE;
+      if (arena_ok) {
+        arena_gather(nullptr, cap2);
+      } else {
+        unsigned long long h2[2] = {0, 0};
+        if ((rc = run_search((const gs_guide_rec *)ix->w_grec2.p, n_o, (uint4 *)ix->w_slots2.p,
+                             (uint32_t *)ix->w_counts2.p, cap2, h2)) != GS_OK)
+          return rc;
+        if (h2[1] != 0) {
+          gs_set_error("internal: redo pass overflowed slots sized from exact counts");
+          return GS_ERR_DEVICE;
+        }
       }
       if ((rc = run_order((uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_counts2.p,
                           (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2, need_cap)) != GS_OK)
         return rc;
     } else {
-      if ((rc = redo_exact(n_o)) != GS_OK) return rc;
+      if (arena_ok) {
+        /* the exact-size array the second pass would have filled, filled by copies */
+        std::vector<uint64_t> h_slot_off(2 * (size_t)n_o + 1, 0);
+        for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + c2[i];
+        if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (h_slot_off.back() + 1))) != GS_OK) return rc;
+        if ((rc = gs_reserve(ix->w_h_off, 8 * h_slot_off.size())) != GS_OK) return rc;
+        GS_HIP(hipMemcpyAsync(ix->w_h_off.p, h_slot_off.data(), 8 * h_slot_off.size(), hipMemcpyHostToDevice, st));
+        GS_HIP(hipStreamSynchronize(st)); /* h_slot_off is a local */
+        arena_gather((const uint64_t *)ix->w_h_off.p, 0);
+      } else if ((rc = redo_exact(n_o)) != GS_OK) {
+        return rc;
+      }
       redo_big = true;
       if (!big_batch) {
         /* the redo list alone goes through the device-wide sort */
@@ -2735,7 +2931,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu; slots %u per item, "
             "%u guides redone%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (device-wide ordering)" : "");
   h_stats3[6] = n_o;
-  h_stats3[7] = (h_stats3[7] << 8) | (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u); /* items through PAM-pair tables above the flags */
+  h_stats3[7] = (h_stats3[7] << 8) | (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u) |
+                (n_o && arena_chunks != 0 && arena_fail == 0 ? 4u : 0u); /* bit 2: the overflowing guides came out of the arena, no second pass */ /* items through PAM-pair tables above the flags */
   h_stats3[13] = cap;
   memcpy(ix->last_counters, h_stats3, sizeof(h_stats3));
   /* matches per item seen at this budget: sizes the slots of the next batch */

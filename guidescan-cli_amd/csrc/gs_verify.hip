@@ -59,6 +59,34 @@ __device__ __forceinline__ uint64_t v_run_left(const gs_vrun *runs, uint32_t nru
   return p < r.end ? r.end - p : 0;
 }
 
+/* rows of a device-resident suffix array that are out of range or repeat a value (0: a permutation of [0, n)).
+ * What a suffix array that did not come from this library's own sort is put through before any table is
+ * derived from it (gs_index_open_sa, gs_index_build_with_sa): the builders read text[sa[r] - j] unchecked. */
+gs_status gs_count_bad_sa_rows(const uint32_t *d_sa, uint64_t n, hipStream_t st, uint64_t *bad) {
+  uint32_t *bitmap = nullptr;
+  unsigned long long *d_bad = nullptr;
+  const size_t words = (size_t)((n + 31) / 32);
+  if (hipMalloc(&bitmap, 4 * words + 8) != hipSuccess) {
+    (void)hipGetLastError();
+    return GS_ERR_NOMEM;
+  }
+  d_bad = (unsigned long long *)(bitmap + ((words + 1) & ~(size_t)1));
+  hipError_t e = hipMemsetAsync(bitmap, 0, 4 * words + 8, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_v_permutation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_sa, n, bitmap, d_bad);
+    unsigned long long h = 0;
+    e = hipMemcpyAsync(&h, d_bad, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    *bad = h;
+  }
+  hipFree(bitmap);
+  if (e != hipSuccess) {
+    gs_set_error(std::string("suffix-array check: ") + hipGetErrorString(e));
+    return GS_ERR_DEVICE;
+  }
+  return GS_OK;
+}
+
 struct gs_vorder_args {
   const uint8_t *text; /* n bytes: the strand's text and the 0 sentinel */
   const uint32_t *sa;
@@ -77,6 +105,11 @@ __global__ void k_v_order(gs_vorder_args a) {
   uint64_t r = i * stride + v_hash(i ^ a.seed) % stride;
   if (r + 1 >= a.n) r = a.n - 2;
   const uint64_t pa = a.sa[r], pb = a.sa[r + 1];
+  /* values out of range (what the verifier is there to diagnose) must not be used as text offsets */
+  if (pa >= a.n || pb >= a.n || pa == pb) {
+    atomicAdd(&a.out[0], 1ull);
+    return;
+  }
   /* BWT symbol of row r in the Occ block against the text (k_build_words, gs_index.hip) */
   {
     const uint32_t *b = (const uint32_t *)(a.blocks + (r >> GS_BLOCK_SHIFT) * 4);
@@ -86,10 +119,6 @@ __global__ void k_v_order(gs_vorder_args a) {
     const int cls = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
     const bool ok = cls < 0 ? ex == 1u : (ex == 0u && (lo | (hi << 1)) == (uint32_t)cls);
     if (!ok) atomicAdd(&a.out[2], 1ull);
-  }
-  if (pa >= a.n || pb >= a.n || pa == pb) {
-    atomicAdd(&a.out[0], 1ull);
-    return;
   }
   uint64_t x = pa, y = pb;
   for (uint64_t step = 0; step < a.max_steps; ++step) {

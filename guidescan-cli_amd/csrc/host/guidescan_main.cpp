@@ -247,6 +247,7 @@ struct batch {
   std::vector<float> spec;
   std::vector<char> skip;
   std::string error;
+  bool handed = false; /* a device thread took it (set under enumerate_job::mtx) */
   bool ready = false;
 };
 
@@ -606,6 +607,7 @@ int do_enumerate(int argc, char **argv) {
           job.cv.wait(lk, [&] { return job.in_flight < job.max_in_flight || job.next_batch >= job.batches.size(); });
           if (job.next_batch >= job.batches.size()) return;
           bi = job.next_batch++;
+          job.batches[bi].handed = true;
           job.in_flight++;
         }
         batch &b = job.batches[bi];
@@ -619,11 +621,14 @@ int do_enumerate(int argc, char **argv) {
           std::lock_guard<std::mutex> lk(job.mtx);
           job.s_device += std::chrono::duration<double>(std::chrono::steady_clock::now() - ts).count();
         }
-        /* text formatting of this batch overlaps the device work of the next one */
+        /* text formatting of this batch overlaps the device work of the next one.  The thread object is
+         * stored under the mutex the formatter takes before it sets `ready`: the writer joins
+         * formatters[bi] only after it has seen `ready`, i.e. after this assignment is complete */
+        std::lock_guard<std::mutex> lk(job.mtx);
         formatters[bi] = std::thread([&job, &b]() {
           const auto tf = std::chrono::steady_clock::now();
           if (b.error.empty()) format_batch(job, b);
-          std::lock_guard<std::mutex> lk(job.mtx);
+          std::lock_guard<std::mutex> lk2(job.mtx);
           job.s_format += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();
           b.ready = true;
           job.cv.notify_all();
@@ -634,8 +639,11 @@ int do_enumerate(int argc, char **argv) {
   for (size_t bi = 0; bi < job.batches.size(); bi++) {
     batch &b = job.batches[bi];
     {
+      /* after an error no more batches are handed out (next_batch is moved to the end below): a batch
+       * that no device thread took will never become ready, and neither will any behind it */
       std::unique_lock<std::mutex> lk(job.mtx);
-      job.cv.wait(lk, [&] { return b.ready; });
+      job.cv.wait(lk, [&] { return b.ready || (!b.handed && job.next_batch >= job.batches.size()); });
+      if (!b.ready) break;
     }
     formatters[bi].join();
     if (!b.error.empty()) {

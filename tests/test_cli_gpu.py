@@ -132,3 +132,64 @@ def test_stored_suffix_arrays_skip_the_sort(tmp_path):
     (tmp_path / "v.sa").unlink()
     run(tmp_path / "v", out3)
     assert out2.read_bytes() == out3.read_bytes()
+
+
+def test_damaged_suffix_array_files_are_refused(tmp_path):
+    """a PREFIX.sa of the right length whose payload is damaged never reaches the table builders:
+    the payload checksums catch it (GS_ERR_FORMAT); a file in the older format without checksums,
+    and a caller-supplied array, are checked for being permutations of their rows"""
+    d = ol.ROOT / "tests" / "golden" / "toy"
+    subprocess.run([str(CLI), "index", "--index", str(tmp_path / "t"), str(d / "toy.fa")], check=True, timeout=300)
+    text = np.fromfile(tmp_path / "t.dna", dtype=np.uint8)
+    g = api.GenomeIndex.build(text, device=0)
+    g.save_sa(text, tmp_path / "a.sa")
+    sa0, sa1 = g.suffix_array(0).copy(), g.suffix_array(1).copy()
+    g.close()
+    raw = bytearray((tmp_path / "a.sa").read_bytes())
+    assert raw[:8] == b"GSAMDSA2"
+    n = text.shape[0] + 1
+    # (1) two rows swapped (still a permutation): only the checksum can tell
+    bad = bytearray(raw)
+    bad[64 + 4 * 10:64 + 4 * 11], bad[64 + 4 * 11:64 + 4 * 12] = raw[64 + 4 * 11:64 + 4 * 12], raw[64 + 4 * 10:64 + 4 * 11]
+    (tmp_path / "b.sa").write_bytes(bad)
+    with pytest.raises(api.GsError) as e:
+        api.GenomeIndex.open_sa(text, tmp_path / "b.sa", device=0)
+    assert e.value.status == 6
+    # (2) the older header (no checksums) with an out-of-range value and with a repeated value
+    for what in ("range", "twice"):
+        old = bytearray(raw)
+        old[:8] = b"GSAMDSA1"
+        old[24:40] = bytes(16)
+        at = 64 + 4 * (n + 7)  # a row of the reverse strand's array
+        old[at:at + 4] = (0xFFFFFFF0).to_bytes(4, "little") if what == "range" else raw[at + 4:at + 8]
+        (tmp_path / "c.sa").write_bytes(old)
+        with pytest.raises(api.GsError) as e:
+            api.GenomeIndex.open_sa(text, tmp_path / "c.sa", device=0)
+        assert e.value.status == 6, what
+    # the older format, undamaged, still opens
+    old = bytearray(raw)
+    old[:8] = b"GSAMDSA1"
+    old[24:40] = bytes(16)
+    (tmp_path / "d.sa").write_bytes(old)
+    g3 = api.GenomeIndex.open_sa(text, tmp_path / "d.sa", device=0)
+    assert np.array_equal(g3.suffix_array(1), sa1)
+    g3.close()
+    # (3) caller-supplied arrays (gs_index_build_with_sa): bad argument
+    sa_bad = sa0.copy()
+    sa_bad[5] = sa_bad[6]
+    with pytest.raises(api.GsError) as e:
+        api.GenomeIndex.build(text, device=0, sa_fwd=sa_bad, sa_rev=sa1)
+    assert e.value.status == 1
+
+
+def test_a_failing_batch_ends_the_run(tmp_path):
+    """an error in any batch makes `enumerate` return 1 after the batches already handed out - it must
+    not wait for batches no device thread will ever take (more batches than 2 x devices in flight)"""
+    d = ol.ROOT / "tests" / "golden" / "toy"
+    subprocess.run([str(CLI), "index", "--index", str(tmp_path / "t"), str(d / "toy.fa")], check=True, timeout=300)
+    for extra in ([], ["--gpus", "1", "-n", "2"]):
+        r = subprocess.run([str(CLI), "enumerate", str(tmp_path / "t"), "-f", str(d / "kmers.csv"), "-o",
+                            str(tmp_path / "o.csv"), "-m", "8", "--batch-size", "1"] + extra,
+                           timeout=120, capture_output=True, text=True)
+        assert r.returncode == 1, r.stderr
+        assert "error:" in r.stderr

@@ -546,9 +546,16 @@ def test_config1_saccer3_sized_1k_guides_m1():
         oidx.close()
 
 
-def test_repeat_guide_with_thousands_of_matches():
-    """a guide whose (guide, strand) match count exceeds the LDS sort (2048): exact-size redo,
-    device-wide comparator sort, per-record locate - still bit-exact and in CSR order"""
+ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2")]
+
+
+@pytest.mark.parametrize("arena", ARENA_MODES, ids=["arena", "second-pass", "arena-exhausted"])
+def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
+    """a guide whose (guide, strand) match count exceeds the LDS sort (2048): its records beyond the slots
+    come out of the overflow arena (or, arena off / too small, from the exact-size second pass), then the
+    device-wide sort and the per-record locate - still bit-exact and in CSR order"""
+    if arena:
+        monkeypatch.setenv(*arena)
     rng = np.random.default_rng(7)
     site = np.frombuffer(b"GATTACAGATTACAGATTAC", np.uint8)
     chunks = []
@@ -577,6 +584,8 @@ def test_repeat_guide_with_thousands_of_matches():
                 assert got == exp, (i, m, faithful)
                 big = max(big, len(set((e[2], e[3]) for e in exp)))
             assert big > 2048
+            ctr = gidx.last_counters()
+            assert ctr["guides_redone"] >= 1 and ctr["overflow_from_arena"] == (arena is None), (ctr, m, faithful)
     finally:
         gidx.close()
         oidx.close()
@@ -608,12 +617,15 @@ def test_bulge_aware_search_bit_exact(toy_gpu, cfg):
             assert general_hits_as_records(offsets, hits, i) == exp, (k.id, cfg)
 
 
-def test_repeat_family_genome_bit_exact(monkeypatch):
+@pytest.mark.parametrize("arena", ARENA_MODES, ids=["arena", "second-pass", "arena-exhausted"])
+def test_repeat_family_genome_bit_exact(monkeypatch, arena):
     """a genome with 45 % of its bases in repeat families (synth.plant_repeats: SINE-like, LINE-like,
     tandem arrays, segmental duplications, both strands), table depth forced to the hg38 code path:
     guides drawn from the families have hundreds to thousands of near-copies - large intervals
     verified in pieces, slot overflow, LDS and device-wide ordering - and stay bit-exact"""
     monkeypatch.setenv("GS_PREFIX_K", "13")
+    if arena:
+        monkeypatch.setenv(arena[0], "1")   # one chunk: the first family guide exhausts it
     text, names, lengths = synth.make_repeat_genome([2_000_000, 1_000_000], seed=4)
     oidx = ol.OracleIndex(text)
     gidx = api.GenomeIndex.build(text, device=0)
