@@ -917,7 +917,7 @@ extern "C" void gs_index_close(gs_index *ix) {
                        &ix->w_ovf_list, &ix->w_grec2, &ix->w_slots2, &ix->w_counts2, &ix->w_nmatch2,
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_tmp, &ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix,
                        &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx, &ix->w_b_idxb,
-                       &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_redo_pos,
+                       &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_redo_pos, &ix->w_b_s, &ix->w_b_tab,
                        &ix->w_cand, &ix->rec[0].buf, &ix->rec[1].buf, &ix->w_score, &ix->w_score_io, &ix->w_arena, &ix->w_arena_meta, &ix->w_nchunk};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
@@ -962,7 +962,9 @@ gs_status gs_reserve(gs_buffer &b, size_t bytes) {
   if (b.p) hipFree(b.p);
   b.p = nullptr;
   b.cap = 0;
-  size_t want = bytes + bytes / 4 + 256;
+  /* room to grow without another allocation: a quarter on top, a sixteenth for buffers beyond 1 GiB
+   * (the workspace of a repeat-rich batch is tens of GB next to a 220 GB index) */
+  size_t want = bytes + (bytes > ((size_t)1 << 30) ? bytes / 16 : bytes / 4) + 256;
   if (hipMalloc(&b.p, want) != hipSuccess) {
     (void)hipGetLastError(); /* or the next call that reports the last error (rocPRIM does) fails with this one */
     if (hipMalloc(&b.p, bytes) != hipSuccess) {

@@ -59,6 +59,11 @@ struct gs_search_args {
   uint32_t *chunk_item, *chunk_seq;
   uint2 *nchunk;         /* [n_items] */
   uint32_t arena_chunks; /* chunks the arena holds */
+  /* Every loop of an item counts its rounds against max_iter; an item that passes it gives up, raises
+   * *err and the wave skips what is left of the queue, so the grid always drains and the call fails with
+   * GS_ERR_DEVICE instead of hanging the device (a table damaged in memory, a code-generation fault). */
+  uint32_t max_iter;
+  uint32_t *err;
   uint32_t *work;        /* work-queue head */
   unsigned long long *stats; /* [0] n_ext, [1] overflow items, [4] two-sided items, [5] one-sided, [8..] request counters */
   uint32_t n_items, L, P, m, cap;
@@ -136,6 +141,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   const uint32_t lane = lane_id();
   unsigned long long n_ext = 0, n_ovf = 0;
   uint32_t n_fail = 0; /* items that needed more overflow chunks than the arena had left */
+  bool bailed = false; /* an item of this wave passed the iteration bound */
   uint32_t n_two = 0, n_fb = 0, n_pair = 0; /* items seeded from both strands / one-sided although two-sided seeding is on */
   /* request counters (CNT): table lines, ctx16 lines, ctx words, SA/ISA gathers of the search, Occ lines */
   uint32_t c_tab = 0, c_c16 = 0, c_ctx = 0, c_isa = 0, c_occ = 0, c_rec = 0;
@@ -185,10 +191,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     const uint32_t gr_pam3 = __builtin_amdgcn_readfirstlane(gp[5]);
     const uint32_t gr_npams = __builtin_amdgcn_readfirstlane(gp[6]);
     const uint32_t gr_valid = __builtin_amdgcn_readfirstlane(gp[7]);
-    if (!gr_valid) {
+    if (!gr_valid || bailed) {
       if (lane == 0) a.counts[slot] = 0;
       continue;
     }
+    uint32_t guard = 0; /* rounds of this item's loops */
     const gs_strand_dev &sd = a.sd[strand];
     const uint4 *__restrict__ blocks = sd.blocks;
     const uint32_t npams = P ? gr_npams : 1u;
@@ -715,6 +722,10 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         uint64_t ppath = 0;
         bool bfinal = nlanes == 0u;
         for (;;) {
+          if (++guard > a.max_iter) {
+            bailed = true;
+            break;
+          }
           uint32_t rem = 0, first = 0, jb = 0, lo = 0, eflag = 0;
           uint64_t cmeta = 0;
           if (!bfinal) {
@@ -795,6 +806,10 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
            * started) until a pass can be filled - a pass costs the same instructions for 10 seeds as
            * for 64; intervals larger than a descriptor holds are queued piece by piece */
           for (;;) {
+            if (++guard > a.max_iter) {
+              bailed = true;
+              break;
+            }
             const uint64_t bq = __ballot(rem != 0u);
             if (bq && qn + WAVE <= VQ_CAP) {
               const uint32_t rows = rem < a.v_max ? rem : a.v_max;
@@ -815,7 +830,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             }
             break;
           }
-          if (bfinal) break;
+          if (bfinal || bailed) break;
           bc0 += WAVE;
           if (bc0 >= nlanes) {
             bc0 = 0;
@@ -856,6 +871,10 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     }
 
     for (;;) {
+      if (bailed || ++guard > a.max_iter) {
+        bailed = true;
+        break;
+      }
       const uint32_t total = xs + gs;
       if (seeds_left && total <= seed_low) {
         /* ---- seed depth-k nodes from the prefix interval table -------------------------
@@ -919,6 +938,10 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
          * everything once the seeds are exhausted. */
         uint32_t rem = (ver && !(a.dbg_skip & 1u)) ? ecnt : 0u, first = ent.x;
         for (;;) {
+          if (++guard > a.max_iter) {
+            bailed = true;
+            break;
+          }
           const uint64_t bq = __ballot(rem != 0u);
           if (bq && qn + WAVE <= VQ_CAP) {
             const uint32_t rows = rem < a.v_max ? rem : a.v_max;
@@ -1117,6 +1140,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     if (n_ext) atomicAdd(&a.stats[0], n_ext);
     if (n_ovf) atomicAdd(&a.stats[1], n_ovf);
     if (n_fail) atomicAdd(&a.stats[6], (unsigned long long)n_fail);
+    if (bailed) atomicOr(a.err, 1u);
     if (n_two) atomicAdd(&a.stats[4], (unsigned long long)n_two);
     if (n_fb) atomicAdd(&a.stats[5], (unsigned long long)n_fb);
     if (n_pair) atomicAdd(&a.stats[7], (unsigned long long)n_pair);
@@ -1724,6 +1748,172 @@ __global__ void k_big_locate(gs_blocate2_args a) {
     out[h] = o;
   }
 }
+
+/* ---- the same ordering with ONE radix sort (the form that runs whenever its sort word fits 64 bits) ----
+ * What orders a guide's records is (mismatches, index, match.sequence, row).  match.sequence travels in
+ * the key as per-position codes (52 bits), but among the sequences with j substitutions in L positions
+ * and P PAM symbols there are only C(L,j) 3^j 5^P of them: their lexicographic RANK (combinatorial number
+ * system, position 0 most significant as in the key) orders them exactly and needs 22 bits at L = 20,
+ * j <= 3, P = 3 instead of 52.  Sort word W = guide of the set | mismatches (3) | index (1) | rank: 39 bits
+ * for 8 k guides.  Two stable sorts: by first row (32-bit keys, four passes over 8-byte pairs), then by W
+ * (five passes over 12-byte pairs) - nine passes and 184 bytes moved per record where sorting the raw key
+ * took thirteen passes and 312 bytes.  (Sorting by W alone and ordering the rows inside each run of equal W
+ * afterwards was tried: on a repeat-rich genome a third of the records sit in runs of 10^4 and more - the
+ * family's consensus sequence - and the run-by-run passes cost more than the row sort does.) */
+struct gs_big2_tab {
+  unsigned long long n[32][8]; /* n[a][r] = C(a, r) 3^r: sequences of a positions with r substitutions */
+};
+__device__ __forceinline__ unsigned long long big2_rank(const unsigned long long key, const uint32_t L, const uint32_t P,
+                                                         const unsigned long long *nt /* [32][8] in LDS */,
+                                                         const unsigned long long pam_mul) {
+  const unsigned long long path = key >> 8;
+  uint32_t j = 0;
+  for (uint32_t t = 0; t < L; t++) j += ((path >> (50u - 2u * t)) & 3ull) != 0ull;
+  if (j > 7u) j = 7u;
+  uint32_t r = j;
+  unsigned long long rank = 0;
+  for (uint32_t t = 0; t < L && r != 0u; t++) {
+    const uint32_t c = (uint32_t)(path >> (50u - 2u * t)) & 3u;
+    if (c) {
+      const uint32_t a = L - 1u - t; /* positions behind this one */
+      /* smaller sequences with the same prefix: a 0 here (r substitutions behind), or one of the c-1 lower codes */
+      rank += nt[a * 8u + r] + (unsigned long long)(c - 1u) * nt[a * 8u + r - 1u];
+      r--;
+    }
+  }
+  unsigned long long pr = 0;
+  for (uint32_t u = 0; u < P; u++) {
+    const uint32_t c = (uint32_t)(path >> (49u - 2u * L - 3u * u)) & 7u;
+    pr = pr * 5ull + (c < 4u ? c : 4u);
+  }
+  return rank * pam_mul + pr;
+}
+struct gs_big2_compact_args {
+  const uint4 *slots_main, *slots_alt;
+  const gs_big_src *src;
+  /* from_arena: the set's records are read where k_search left them - an item's first `cap` records in the
+   * main slot array, the rest in its arena chunks - instead of from a contiguous copy */
+  const uint4 *arena;
+  const uint32_t *chunk_item, *chunk_seq, *counts;
+  const uint32_t *list, *redo_pos; /* the set is the overflow list (set guide j = list[j]); nullptr: the whole batch */
+  uint32_t cap, n_used, from_arena;
+  const unsigned long long *prefix;
+  const gs_big2_tab *tab;
+  uint4 *recs;
+  unsigned long long *W;
+  uint32_t *rowkey, *idx;
+  unsigned long long pam_mul;
+  uint32_t n_items, L, P, rbits;
+};
+/* one workgroup per set item: copy its records to the compact array and build their sort words */
+__global__ __launch_bounds__(256) void k_big2_compact(gs_big2_compact_args a) {
+  __shared__ unsigned long long nt[32 * 8];
+  for (uint32_t i = threadIdx.x; i < 32u * 8u; i += blockDim.x) nt[i] = a.tab->n[i >> 3][i & 7u];
+  __syncthreads();
+  const uint4 *in;
+  unsigned long long b, e, g;
+  if (!a.from_arena) {
+    const uint32_t item = blockIdx.x;
+    if (item >= a.n_items) return;
+    b = a.prefix[item];
+    e = a.prefix[item + 1];
+    const gs_big_src s = a.src[item];
+    in = (s.alt ? a.slots_alt : a.slots_main) + s.off;
+    g = item >> 1;
+  } else if (blockIdx.x < a.n_items) {
+    const uint32_t sb = blockIdx.x; /* item of the set -> item of the batch */
+    const uint32_t item = a.list ? 2u * a.list[sb >> 1] + (sb & 1u) : sb;
+    const uint32_t c = a.counts[item];
+    in = a.slots_main + (size_t)item * a.cap;
+    b = a.prefix[sb];
+    e = b + (c < a.cap ? c : a.cap);
+    g = sb >> 1;
+  } else {
+    const uint32_t c = blockIdx.x - a.n_items;
+    if (c >= a.n_used) return;
+    const uint32_t item = a.chunk_item[c];
+    uint32_t sb = item;
+    if (a.list) {
+      const uint32_t pos = a.redo_pos[item >> 1];
+      if (pos == 0xFFFFFFFFu) return;
+      sb = 2u * pos + (item & 1u);
+    }
+    const uint32_t cnt = a.counts[item], e0 = a.chunk_seq[c] << ARENA_SHIFT;
+    if (cnt <= a.cap + e0) return;
+    in = a.arena + ((size_t)c << ARENA_SHIFT);
+    b = a.prefix[sb] + a.cap + e0;
+    const uint32_t left = cnt - a.cap - e0;
+    e = b + (left < ARENA_CHUNK ? left : ARENA_CHUNK);
+    g = sb >> 1;
+  }
+  for (unsigned long long r = b + threadIdx.x; r < e; r += blockDim.x) {
+    const uint4 v = in[r - b];
+    const unsigned long long key = ((unsigned long long)v.y << 32) | v.x;
+    a.recs[r] = v;
+    a.W[r] = (g << (4u + a.rbits)) | ((key >> 60) << a.rbits) | big2_rank(key, a.L, a.P, nt, a.pam_mul);
+    a.rowkey[r] = v.z;
+    a.idx[r] = (uint32_t)r;
+  }
+}
+/* records per item of the set when they are read from the slots and the arena (the main pass counted exactly) */
+__global__ void k_big2_counts(const uint32_t *counts, const uint32_t *list, uint32_t n_items, unsigned long long *cnt64) {
+  const uint32_t sb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sb >= n_items) return;
+  cnt64[sb] = counts[list ? 2u * list[sb >> 1] + (sb & 1u) : sb];
+}
+__global__ void k_big2_gather(const uint4 *recs, const uint32_t *idx, uint64_t T, uint4 *out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < T) out[r] = recs[idx[r]];
+}
+__global__ void k_big2_gather_w(const unsigned long long *W, const uint32_t *idx, uint64_t T, unsigned long long *out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < T) out[r] = W[idx[r]];
+}
+/* keep[r] = 1 when ordered record r starts a new (guide, key, first row); rows[r] = its row count */
+__global__ void k_big2_flags(const uint4 *S2, const unsigned long long *W, uint64_t T, uint32_t *keep,
+                             unsigned long long *rows) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= T) return;
+  const uint4 c = S2[r];
+  bool f = true;
+  if (r > 0 && W[r - 1] == W[r]) {
+    const uint4 p = S2[r - 1];
+    f = !(p.x == c.x && p.y == c.y && p.z == c.z);
+  }
+  keep[r] = f ? 1u : 0u;
+  rows[r] = f ? (unsigned long long)(c.w - c.z + 1u) : 0ull;
+}
+struct gs_blocate3_args {
+  gs_strand_dev sd[2];
+  const uint4 *S2;
+  const unsigned long long *W;
+  const uint32_t *keep;
+  const unsigned long long *row_scan;
+  const unsigned long long *prefix;
+  const uint32_t *gmap;
+  const uint64_t *offsets;
+  gs_hit *hits;
+  uint64_t genome_length, T;
+  uint32_t v_rem, gshift;
+};
+__global__ void k_big2_locate(gs_blocate3_args a) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.T || !a.keep[r]) return;
+  const uint4 m = a.S2[r];
+  const uint32_t g = (uint32_t)(a.W[r] >> a.gshift);
+  const uint64_t key = ((uint64_t)m.y << 32) | m.x;
+  const uint32_t strand = (uint32_t)(key >> 60) & 1u;
+  gs_hit *out = a.hits + a.offsets[a.gmap ? a.gmap[g] : g] + (a.row_scan[r] - a.row_scan[a.prefix[2 * g]]);
+  const uint32_t cnt = m.w - m.z + 1u;
+  for (uint32_t h = 0; h < cnt; ++h) {
+    const uint64_t sa = (uint64_t)a.sd[strand].sa[m.z + h] - ((key & 1ull) ? a.v_rem : 0u);
+    gs_hit o;
+    o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
+    o.key = key & ~1ull;
+    out[h] = o;
+  }
+}
+
 /* sources of the set items: the main slot array, or - for guides on the redo list - the exact-size array */
 __global__ void k_big_sources(const uint32_t *counts_main, const uint32_t *redo_pos, const uint64_t *slot_off2,
                               const uint32_t *counts2, uint32_t n_items, uint32_t cap, gs_big_src *src,
@@ -2428,6 +2618,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     GS_HIP(hipMemsetAsync(ix->w_misc.p, 0, 16, st)); /* n_ext, overflow items */
     GS_HIP(hipMemsetAsync(d_stats + 6, 0, 8, st));   /* items the arena failed */
     GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
+    GS_HIP(hipMemsetAsync(d_work + 5, 0, 4, st));
     if (with_arena) GS_HIP(hipMemsetAsync(d_arena_next, 0, 4, st));
     gs_search_args sa;
     memset(&sa, 0, sizeof(sa));
@@ -2451,6 +2642,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       sa.nchunk = (uint2 *)ix->w_nchunk.p;
       sa.arena_chunks = arena_chunks;
     }
+    sa.max_iter = getenv("GS_SEARCH_MAX_ITER") ? (uint32_t)atol(getenv("GS_SEARCH_MAX_ITER")) : (1u << 26);
+    sa.err = d_work + 5;
     sa.v_max = VERIFY_MAX_DEFAULT;
     if (const char *e = getenv("GS_VERIFY_MAX")) {
       const long v = atol(e);
@@ -2517,13 +2710,17 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         hipLaunchKernelGGL(k_search_fast, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
     }
     GS_HIP(hipEventRecord(ix->ev[2], st));
-    unsigned long long h7[7] = {0};
+    unsigned long long h7[20] = {0}; /* the stats and, behind them, the work words */
     GS_HIP(hipMemcpyAsync(h7, d_stats, sizeof(h7), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
     h_stats[0] = h7[0];
     h_stats[1] = h7[1];
     if (with_arena) arena_fail = h7[6];
+    if (((const uint32_t *)(h7 + 16))[5] != 0u) {
+      gs_set_error("internal: an item of the search passed its iteration bound (GS_SEARCH_MAX_ITER)");
+      return GS_ERR_DEVICE;
+    }
     float ms = 0.f;
     hipEventElapsedTime(&ms, ix->ev[1], ix->ev[2]);
     ms_search += ms;
@@ -2587,17 +2784,50 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
    * list, in the exact-size array slots2/slot_off2.  Leaves nmatch/nhits per set guide and the
    * sorted arrays k_big_locate reads once the CSR offsets exist. */
   uint64_t big_T = 0;
-  bool big_used = false;
+  bool big_used = false, big_v2 = false;
+  uint32_t big_gshift = 0;
+  /* the device-wide ordering runs in its one-word form (k_big2_*) when the sort word fits 64 bits */
+  unsigned long long big_pam_mul = 1, big_n_max = 1;
+  gs_big2_tab big_tab;
+  uint32_t big_rbits = 1;
+  {
+    for (uint32_t a = 0; a < 32; a++)
+      for (uint32_t r = 0; r < 8; r++) {
+        unsigned long long v = 0;
+        if (r <= a) {
+          double c = 1;
+          for (uint32_t i = 0; i < r; i++) c = c * (double)(a - i) / (double)(i + 1);
+          v = (unsigned long long)(c + 0.5);
+          for (uint32_t i = 0; i < r; i++) v *= 3ull;
+        }
+        big_tab.n[a][r] = v;
+      }
+    for (uint32_t j = 0; j <= mismatches && j <= L && j < 8; j++) big_n_max = std::max(big_n_max, big_tab.n[L][j]);
+    for (uint32_t u = 0; u < P; u++) big_pam_mul *= 5ull;
+    while (big_rbits < 63 && ((big_n_max * big_pam_mul - 1ull) >> big_rbits) != 0ull) big_rbits++;
+  }
+  auto big_fits_v2 = [&](uint32_t n_set) -> bool {
+    uint32_t gbits = 1;
+    while ((1ull << gbits) < n_set) gbits++;
+    return gbits + 4 + big_rbits <= 64 && !getenv("GS_BIG_ORDER_V1");
+  };
+  /* arena_list != nullptr or arena_all: the set's records are read from the main slots and the overflow
+   * arena (the set = the guides of arena_list, or the whole batch), not from a contiguous copy */
   auto big_order = [&](uint32_t n_set, const uint32_t *counts_main, uint32_t cap_, const uint32_t *redo_pos,
                        const uint64_t *slot_off2, const uint32_t *counts2, uint32_t *nmatch_out,
-                       uint32_t *nhits_out) -> gs_status {
+                       uint32_t *nhits_out, bool from_arena = false, const uint32_t *arena_list = nullptr,
+                       uint32_t n_used = 0) -> gs_status {
     gs_status r2;
     const uint32_t n_it = 2 * n_set;
     if ((r2 = gs_reserve(ix->w_b_src, sizeof(gs_big_src) * ((size_t)n_it + 1))) != GS_OK) return r2;
     if ((r2 = gs_reserve(ix->w_b_cnt, 8 * ((size_t)n_it + 2))) != GS_OK) return r2;
     if ((r2 = gs_reserve(ix->w_b_prefix, 8 * ((size_t)n_it + 2))) != GS_OK) return r2;
-    hipLaunchKernelGGL(k_big_sources, dim3((n_it + 255) / 256), dim3(256), 0, st, counts_main, redo_pos, slot_off2,
-                       counts2, n_it, cap_, (gs_big_src *)ix->w_b_src.p, (unsigned long long *)ix->w_b_cnt.p);
+    if (from_arena)
+      hipLaunchKernelGGL(k_big2_counts, dim3((n_it + 255) / 256), dim3(256), 0, st, (const uint32_t *)ix->w_counts.p, arena_list,
+                         n_it, (unsigned long long *)ix->w_b_cnt.p);
+    else
+      hipLaunchKernelGGL(k_big_sources, dim3((n_it + 255) / 256), dim3(256), 0, st, counts_main, redo_pos, slot_off2,
+                         counts2, n_it, cap_, (gs_big_src *)ix->w_b_src.p, (unsigned long long *)ix->w_b_cnt.p);
     GS_HIP(hipMemsetAsync((unsigned long long *)ix->w_b_cnt.p + n_it, 0, 8, st));
     size_t tb = 0;
     GS_HIP(rocprim::exclusive_scan(nullptr, tb, (unsigned long long *)ix->w_b_cnt.p,
@@ -2617,10 +2847,15 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     big_T = T;
     big_used = true;
+    big_v2 = big_fits_v2(n_set);
+    if (from_arena && !big_v2) {
+      gs_set_error("internal: device-wide ordering from the arena without its one-word form");
+      return GS_ERR_DEVICE;
+    }
     if ((r2 = gs_reserve(ix->w_b_recs, 16 * (T + 1))) != GS_OK) return r2;
     if ((r2 = gs_reserve(ix->w_b_w0, 8 * (T + 1))) != GS_OK) return r2;
     if ((r2 = gs_reserve(ix->w_b_w0b, 8 * (T + 1))) != GS_OK) return r2;
-    if ((r2 = gs_reserve(ix->w_b_w1, 8 * (T + 1))) != GS_OK) return r2;
+    if (!big_v2 && (r2 = gs_reserve(ix->w_b_w1, 8 * (T + 1))) != GS_OK) return r2;
     if ((r2 = gs_reserve(ix->w_b_idx, 4 * (T + 1))) != GS_OK) return r2;
     if ((r2 = gs_reserve(ix->w_b_idxb, 4 * (T + 1))) != GS_OK) return r2;
     if ((r2 = gs_reserve(ix->w_b_keep, 4 * (T + 2))) != GS_OK) return r2;
@@ -2631,7 +2866,61 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     unsigned long long *w0 = (unsigned long long *)ix->w_b_w0.p, *w0b = (unsigned long long *)ix->w_b_w0b.p,
                        *w1 = (unsigned long long *)ix->w_b_w1.p;
     uint32_t *idx = (uint32_t *)ix->w_b_idx.p, *idxb = (uint32_t *)ix->w_b_idxb.p;
-    if (T) {
+    uint32_t gbits = 1;
+    while ((1ull << gbits) < n_set) gbits++;
+    const uint32_t rbits = big_rbits;
+    const unsigned long long pam_mul = big_pam_mul;
+    big_gshift = 4 + rbits;
+    if (T && big_v2) {
+      if ((r2 = gs_reserve(ix->w_b_s, 16 * (T + 1))) != GS_OK) return r2;
+      if ((r2 = gs_reserve(ix->w_b_tab, sizeof(gs_big2_tab))) != GS_OK) return r2;
+      GS_HIP(hipMemcpy(ix->w_b_tab.p, &big_tab, sizeof(big_tab), hipMemcpyHostToDevice));
+      unsigned long long *W = w0, *Wb = w0b;
+      uint4 *S2 = (uint4 *)ix->w_b_s.p;
+      uint32_t *rk = (uint32_t *)ix->w_b_keep.p, *rkb = (uint32_t *)ix->w_b_keeps.p; /* free until the flags are written */
+      gs_big2_compact_args ca;
+      memset(&ca, 0, sizeof(ca));
+      ca.slots_main = (const uint4 *)ix->w_slots.p;
+      ca.slots_alt = (const uint4 *)ix->w_slots2.p;
+      ca.src = (const gs_big_src *)ix->w_b_src.p;
+      if (from_arena) {
+        ca.from_arena = 1;
+        ca.arena = (const uint4 *)ix->w_arena.p;
+        ca.chunk_item = (const uint32_t *)ix->w_arena_meta.p;
+        ca.chunk_seq = ca.chunk_item + arena_chunks;
+        ca.counts = (const uint32_t *)ix->w_counts.p;
+        ca.list = arena_list;
+        ca.redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
+        ca.cap = cap;
+        ca.n_used = n_used;
+      }
+      ca.prefix = (const unsigned long long *)ix->w_b_prefix.p;
+      ca.tab = (const gs_big2_tab *)ix->w_b_tab.p;
+      ca.recs = recs;
+      ca.W = W;
+      ca.rowkey = rk;
+      ca.idx = idx;
+      ca.pam_mul = pam_mul;
+      ca.n_items = n_it;
+      ca.L = L;
+      ca.P = P;
+      ca.rbits = rbits;
+      hipLaunchKernelGGL(k_big2_compact, dim3(n_it + (from_arena ? n_used : 0u)), dim3(256), 0, st, ca);
+      size_t s1 = 0, s2 = 0;
+      GS_HIP(rocprim::radix_sort_pairs(nullptr, s1, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
+      GS_HIP(rocprim::radix_sort_pairs(nullptr, s2, Wb, W, idxb, idx, (size_t)T, 0, gbits + 4 + rbits, st));
+      if ((r2 = gs_reserve(ix->w_h_tmp, std::max(s1, s2) + 16)) != GS_OK) return r2;
+      tbs = ix->w_h_tmp.cap;
+      GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
+      const unsigned gT = (unsigned)((T + 255) / 256);
+      hipLaunchKernelGGL(k_big2_gather_w, dim3(gT), dim3(256), 0, st, (const unsigned long long *)W, (const uint32_t *)idxb, T, Wb);
+      tbs = ix->w_h_tmp.cap;
+      GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, Wb, W, idxb, idx, (size_t)T, 0, gbits + 4 + rbits, st));
+      /* W = the sort words in final order, idx = where each record sits in recs */
+      hipLaunchKernelGGL(k_big2_gather, dim3(gT), dim3(256), 0, st, (const uint4 *)recs, (const uint32_t *)idx, T, S2);
+      hipLaunchKernelGGL(k_big2_flags, dim3(gT), dim3(256), 0, st, (const uint4 *)S2, (const unsigned long long *)W, T,
+                         (uint32_t *)ix->w_b_keep.p, (unsigned long long *)ix->w_b_rows.p);
+    } else if (T) {
       hipLaunchKernelGGL(k_big_compact, dim3(n_it), dim3(256), 0, st, (const uint4 *)ix->w_slots.p,
                          (const uint4 *)ix->w_slots2.p, (const gs_big_src *)ix->w_b_src.p,
                          (const unsigned long long *)ix->w_b_prefix.p, n_it, recs, w0, w1, idx);
@@ -2701,6 +2990,25 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   };
   auto big_locate = [&](const uint32_t *gmap) {
     if (!big_T) return;
+    if (big_v2) {
+      gs_blocate3_args la;
+      la.sd[0] = ix->strand[0].d;
+      la.sd[1] = ix->strand[1].d;
+      la.S2 = (const uint4 *)ix->w_b_s.p;
+      la.W = (const unsigned long long *)ix->w_b_w0.p;
+      la.keep = (const uint32_t *)ix->w_b_keep.p;
+      la.row_scan = (const unsigned long long *)ix->w_b_rowss.p;
+      la.prefix = (const unsigned long long *)ix->w_b_prefix.p;
+      la.gmap = gmap;
+      la.offsets = (const uint64_t *)ix->w_offsets.p;
+      la.hits = (gs_hit *)ix->w_hits.p;
+      la.genome_length = ix->genome_length;
+      la.T = big_T;
+      la.v_rem = v_rem;
+      la.gshift = big_gshift;
+      hipLaunchKernelGGL(k_big2_locate, dim3((unsigned)((big_T + 255) / 256)), dim3(256), 0, st, la);
+      return;
+    }
     gs_blocate2_args la;
     la.sd[0] = ix->strand[0].d;
     la.sd[1] = ix->strand[1].d;
@@ -2775,8 +3083,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       return rc;
 
   /* ---- redo only the guides whose matches did not fit their slots ---- */
-  uint32_t n_o = 0, cap2 = cap;
-  bool redo_big = false;
+  uint32_t n_o = 0, cap2 = cap, n_used = 0;
+  bool redo_big = false, arena_direct = false; /* arena_direct: the ordering reads the slots and the arena themselves */
   if (h_stats[1] != 0) {
     if ((rc = gs_reserve(ix->w_ovf_list, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
     GS_HIP(hipMemsetAsync(d_nlist, 0, 4, st));
@@ -2811,7 +3119,6 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     const bool arena_ok = arena_chunks != 0 && arena_fail == 0;
     if (arena_chunks != 0 && !getenv("GS_ARENA_CHUNKS") && need_chunks + need_chunks / 4 + 64 > ix->arena_chunks)
       ix->arena_chunks = need_chunks + need_chunks / 4 + 64;
-    uint32_t n_used = 0;
     if (arena_ok) {
       GS_HIP(hipMemcpyAsync(&n_used, d_arena_next, 4, hipMemcpyDeviceToHost, st));
       if ((rc = gs_reserve(ix->w_b_redo_pos, 4 * ((size_t)n + 1))) != GS_OK) return rc;
@@ -2860,7 +3167,9 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
                           (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2, need_cap)) != GS_OK)
         return rc;
     } else {
-      if (arena_ok) {
+      if (arena_ok && big_fits_v2(big_batch ? n32 : n_o)) {
+        arena_direct = true; /* no copy at all: the ordering's first kernel reads slots and chunks */
+      } else if (arena_ok) {
         /* the exact-size array the second pass would have filled, filled by copies */
         std::vector<uint64_t> h_slot_off(2 * (size_t)n_o + 1, 0);
         for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + c2[i];
@@ -2877,7 +3186,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         /* the redo list alone goes through the device-wide sort */
         if ((rc = big_order(n_o, nullptr, 0, nullptr, (const uint64_t *)ix->w_h_off.p,
                             (const uint32_t *)ix->w_counts2.p, (uint32_t *)ix->w_nmatch2.p,
-                            (uint32_t *)ix->w_nhits2.p)) != GS_OK)
+                            (uint32_t *)ix->w_nhits2.p, arena_direct, (const uint32_t *)ix->w_ovf_list.p, n_used)) != GS_OK)
           return rc;
       }
     }
@@ -2899,7 +3208,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     if ((rc = big_order(n32, (const uint32_t *)ix->w_counts.p, cap, redo_pos, (const uint64_t *)ix->w_h_off.p,
                         (const uint32_t *)ix->w_counts2.p, (uint32_t *)ix->w_nmatch.p,
-                        (uint32_t *)ix->w_nhits.p)) != GS_OK)
+                        (uint32_t *)ix->w_nhits.p, arena_direct, nullptr, n_used)) != GS_OK)
       return rc;
   }
 

@@ -66,12 +66,12 @@ gs_status gs_count_bad_sa_rows(const uint32_t *d_sa, uint64_t n, hipStream_t st,
   uint32_t *bitmap = nullptr;
   unsigned long long *d_bad = nullptr;
   const size_t words = (size_t)((n + 31) / 32);
-  if (hipMalloc(&bitmap, 4 * words + 8) != hipSuccess) {
+  if (hipMalloc(&bitmap, 4 * words + 16) != hipSuccess) { /* the bitmap, then the 8-byte aligned counter */
     (void)hipGetLastError();
     return GS_ERR_NOMEM;
   }
   d_bad = (unsigned long long *)(bitmap + ((words + 1) & ~(size_t)1));
-  hipError_t e = hipMemsetAsync(bitmap, 0, 4 * words + 8, st);
+  hipError_t e = hipMemsetAsync(bitmap, 0, 4 * words + 16, st);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_v_permutation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_sa, n, bitmap, d_bad);
     unsigned long long h = 0;

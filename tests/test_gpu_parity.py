@@ -546,10 +546,13 @@ def test_config1_saccer3_sized_1k_guides_m1():
         oidx.close()
 
 
-ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2")]
+ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
+               # the device-wide ordering in the form that serves sort words beyond 64 bits (raw keys)
+               ("GS_BIG_ORDER_V1", "1")]
+ARENA_IDS = ["arena", "second-pass", "arena-exhausted", "raw-key-order"]
 
 
-@pytest.mark.parametrize("arena", ARENA_MODES, ids=["arena", "second-pass", "arena-exhausted"])
+@pytest.mark.parametrize("arena", ARENA_MODES, ids=ARENA_IDS)
 def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
     """a guide whose (guide, strand) match count exceeds the LDS sort (2048): its records beyond the slots
     come out of the overflow arena (or, arena off / too small, from the exact-size second pass), then the
@@ -585,7 +588,7 @@ def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
                 big = max(big, len(set((e[2], e[3]) for e in exp)))
             assert big > 2048
             ctr = gidx.last_counters()
-            assert ctr["guides_redone"] >= 1 and ctr["overflow_from_arena"] == (arena is None), (ctr, m, faithful)
+            assert ctr["guides_redone"] >= 1 and ctr["overflow_from_arena"] == (arena is None or "ARENA" not in arena[0]), (ctr, m, faithful)
     finally:
         gidx.close()
         oidx.close()
@@ -617,7 +620,7 @@ def test_bulge_aware_search_bit_exact(toy_gpu, cfg):
             assert general_hits_as_records(offsets, hits, i) == exp, (k.id, cfg)
 
 
-@pytest.mark.parametrize("arena", ARENA_MODES, ids=["arena", "second-pass", "arena-exhausted"])
+@pytest.mark.parametrize("arena", ARENA_MODES, ids=ARENA_IDS)
 def test_repeat_family_genome_bit_exact(monkeypatch, arena):
     """a genome with 45 % of its bases in repeat families (synth.plant_repeats: SINE-like, LINE-like,
     tandem arrays, segmental duplications, both strands), table depth forced to the hg38 code path:
@@ -625,7 +628,7 @@ def test_repeat_family_genome_bit_exact(monkeypatch, arena):
     verified in pieces, slot overflow, LDS and device-wide ordering - and stay bit-exact"""
     monkeypatch.setenv("GS_PREFIX_K", "13")
     if arena:
-        monkeypatch.setenv(arena[0], "1")   # one chunk: the first family guide exhausts it
+        monkeypatch.setenv(arena[0], "1" if "ARENA" in arena[0] else arena[1])   # one chunk: the first family guide exhausts it
     text, names, lengths = synth.make_repeat_genome([2_000_000, 1_000_000], seed=4)
     oidx = ol.OracleIndex(text)
     gidx = api.GenomeIndex.build(text, device=0)
@@ -659,3 +662,21 @@ def test_raw_hit_counts_before_dedupe(toy_gpu):
     assert np.array_equal(off2, off1) and hits2.tobytes() == hits1.tobytes()      # the sets drop the duplicates
     assert np.array_equal(st2["raw_hits"], 2 * st1["raw_hits"])                   # the counter does not
     assert st1["raw_hits"].sum() > 0
+
+
+def test_search_iteration_bound_fails_cleanly(toy_gpu, monkeypatch):
+    """every loop of a search item counts against an iteration bound: with a tiny bound the call returns
+    GS_ERR_DEVICE (no hang, the grid drains), and the handle serves the next call as before"""
+    toy, oidx, gidx = toy_gpu
+    group = [k for k in toy["kmers"] if k.pam][:16]
+    seqs = np.array([list(k.sequence.encode()) for k in group], dtype=np.uint8)
+    pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8)
+    want = gidx.enumerate(seqs, pams, mismatches=3)
+    for faithful in (False, True):
+        monkeypatch.setenv("GS_SEARCH_MAX_ITER", "2")
+        with pytest.raises(api.GsError) as e:
+            gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
+        assert e.value.status == 2
+        monkeypatch.delenv("GS_SEARCH_MAX_ITER")
+        got = gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
+        assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes()
