@@ -148,7 +148,7 @@ struct gs_index {
       /* device-wide ordering of guides with more matches than an LDS sort holds (gs_search.hip) */
       w_b_src, w_b_cnt, w_b_prefix, w_b_recs, w_b_w0, w_b_w0b, w_b_w1, w_b_idx, w_b_idxb, w_b_keep, w_b_keeps,
       w_b_rows, w_b_rowss, w_b_redo_pos, w_b_s, w_b_tab,
-      w_score, w_score_io, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
+      w_score, w_score_io, w_score_tmp, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
       /* overflow arena of k_search (gs_search.hip): records, chunk owners + sequence numbers, chunks per item */
       w_arena, w_arena_meta, w_nchunk;
   uint64_t arena_chunks = 4096; /* chunks of 1,024 records the next batch's arena holds: grown when a batch needed more */

@@ -81,81 +81,133 @@ __device__ __forceinline__ bool sc_sentinel(const uint64_t *cum, uint32_t n_chr,
   return s < 0 || e > len; /* :46-48 */
 }
 
-__global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score(gs_score_args a) {
+/* Two kernels.  k_score_hits: one thread per hit - its CFD (printer.hpp:98-113) and the three facts the
+ * aggregation needs (distance, dropped at a chromosome boundary, perfect xGG hit); every hit is
+ * independent, so guides with 10^5 hits spread over the whole chip.  k_score_sum: one wavefront per guide
+ * walks its hits in order - only the float additions are sequential (they are not associative and the
+ * reference adds hit by hit) and --max-off-targets' per-distance counters. */
+__global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, uint64_t n_hits, float *cf, uint8_t *info) {
   __shared__ double s_tab[336];
   for (uint32_t i = threadIdx.x; i < 336u; i += blockDim.x) s_tab[i] = a.tab[i];
   __syncthreads();
-  const uint32_t lane = threadIdx.x & (WAVE - 1u);
-  const uint32_t wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
   const uint32_t L = a.L, P = a.P, slen = L + P;
   /* pam = match_sequence.substr(20, 3) when the sequence has at least 20 symbols */
   const uint32_t pam_len = slen < 20u ? 0u : (slen - 20u < 3u ? slen - 20u : 3u);
   const bool scored = L == 20u && pam_len == 3u; /* printer.hpp:99 */
+  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_hits; h += (uint64_t)gridDim.x * blockDim.x) {
+    /* the guide of hit h: last g with offsets[g] <= h (neighbouring threads walk the same path) */
+    uint32_t lo = 0, hi = a.n;
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (a.offsets[mid] <= h)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const uint8_t *gd = a.guides + (size_t)lo * L;
+    const gs_hit hit = a.hits[h];
+    const uint64_t path = (hit.key >> 8) & ((1ull << 52) - 1ull);
+    const uint32_t d = (uint32_t)(hit.key >> 61);
+    float c = 1.0f;
+    uint32_t pgg = 0u;
+    bool lw;
+    if (scored) {
+      /* positions in order (each product is rounded to float before the next, printer.hpp:104-109).  A
+       * position enters when match_sequence[i] differs from the guide's symbol, case-sensitively: always
+       * where the hit has a substitution (lower case); elsewhere never when the guide was searched as
+       * given, while with --start the two strings are compared as the reference compares them */
+      uint64_t todo = a.start ? 0xFFFFFull : 0ull;
+      if (!a.start)
+        for (uint32_t i = 0; i < 20u; ++i) todo |= (uint64_t)(((path >> (50u - 2u * i)) & 3ull) != 0ull) << i;
+      while (todo) {
+        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t su = sc_seq_at(gd, L, a.start, path, i, lw);
+        const uint32_t mu = sc_comp_upper(su); /* match_sequence[i] = complement(sequence[i]), case kept */
+        const uint32_t gc = gd[i];
+        if (lw || gc != mu) {
+          const int r = sc_bidx(gc);  /* 'T' is looked up as 'U': same slot */
+          const int dd = sc_bidx(su); /* toupper(complement(match_sequence[i])) == sequence[i] */
+          const double sc = (r >= 0 && dd >= 0) ? s_tab[(r * 4 + dd) * 20 + (int)i] : 0.0;
+          c = (float)((double)c * sc);
+        }
+      }
+      const int b1 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, lw)));
+      const int b2 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, lw)));
+      const double ps = (b1 >= 0 && b2 >= 0) ? s_tab[320 + b1 * 4 + b2] : 0.0;
+      c = (float)((double)c * ps);
+    }
+    if (d == 0u && pam_len == 3u) { /* perfect NGG-style hit, printer.hpp:145-146 / :262 */
+      bool l1, l2;
+      const uint32_t p1 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, l1));
+      const uint32_t p2 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, l2));
+      pgg = (!l1 && !l2 && p1 == 'G' && p2 == 'G') ? 1u : 0u;
+    }
+    const uint32_t sent = sc_sentinel(a.chr_cum, a.n_chr, (long long)hit.pos, L, P) ? 1u : 0u;
+    cf[h] = c;
+    info[h] = (uint8_t)(d | (sent << 3) | (pgg << 4));
+  }
+}
+
+__global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a, const float *cf, const uint8_t *info) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1u);
+  const uint32_t wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
   for (uint32_t g = blockIdx.x * nw + wave; g < a.n; g += gridDim.x * nw) {
     const uint64_t hb = a.offsets[g], he = a.offsets[g + 1u];
-    const uint8_t *gd = a.guides + (size_t)g * L;
     float sum = 0.0f;
     uint32_t perfect = 0u, cur_d = 0xFFFFFFFFu;
-    long long raw = 0, kept = 0;
+    unsigned long long raw = 0, kept = 0; /* hits / hits that counted so far at distance cur_d */
+    const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
     for (uint64_t h0 = hb; h0 < he; h0 += WAVE) {
       const uint64_t h = h0 + lane;
-      float c = 1.0f;
-      uint32_t info = 0u;
-      if (h < he) {
-        const gs_hit hit = a.hits[h];
-        const uint64_t path = (hit.key >> 8) & ((1ull << 52) - 1ull);
-        const uint32_t d = (uint32_t)(hit.key >> 61);
-        bool lw;
-        if (scored) {
-          for (uint32_t i = 0; i < 20u; ++i) {
-            const uint32_t su = sc_seq_at(gd, L, a.start, path, i, lw);
-            /* match_sequence[i] = complement(sequence[i]), case kept; compared with the guide
-             * case-sensitively, so a lower-case symbol always differs */
-            const uint32_t mu = sc_comp_upper(su);
-            const uint32_t gc = gd[i];
-            if (lw || gc != mu) {
-              const int r = sc_bidx(gc);  /* 'T' is looked up as 'U': same slot */
-              const int dd = sc_bidx(su); /* toupper(complement(match_sequence[i])) == sequence[i] */
-              const double sc = (r >= 0 && dd >= 0) ? s_tab[(r * 4 + dd) * 20 + (int)i] : 0.0;
-              c = (float)((double)c * sc);
-            }
+      const bool valid = h < he;
+      float c = 0.0f;
+      uint32_t d = 8u, sent = 0u, pgg = 0u;
+      if (valid) {
+        c = cf[h];
+        const uint32_t inf = info[h];
+        d = inf & 7u;
+        sent = (inf >> 3) & 1u;
+        pgg = (inf >> 4) & 1u;
+      }
+      /* --max-off-targets: a hit is passed over when `max_off` hits of its distance came before it - CSV:
+       * counted on the raw index (printer.hpp:259); SAM: on the hits that counted (:129), i.e. the ones not
+       * dropped at a chromosome boundary (while below the bound every such hit counts).  Hits are ordered by
+       * distance, so both counts are prefix counts inside the distance class: per lane from ballots, across
+       * the 64-hit blocks through (cur_d, raw, kept). */
+      bool skip = false;
+      if (a.max_off != -1) {
+        uint64_t same = 0, same_ok = 0;
+        for (uint32_t dv = 0; dv < 8u; ++dv) {
+          const uint64_t b1 = __ballot(valid && d == dv), b2 = __ballot(valid && d == dv && !sent);
+          if (d == dv) {
+            same = b1;
+            same_ok = b2;
           }
-          const int b1 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, lw)));
-          const int b2 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, lw)));
-          const double ps = (b1 >= 0 && b2 >= 0) ? s_tab[320 + b1 * 4 + b2] : 0.0;
-          c = (float)((double)c * ps);
         }
-        uint32_t pgg = 0u;
-        if (d == 0u && pam_len == 3u) { /* perfect NGG-style hit, printer.hpp:145-146 / :262 */
-          bool l1, l2;
-          const uint32_t p1 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, l1));
-          const uint32_t p2 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, l2));
-          pgg = (!l1 && !l2 && p1 == 'G' && p2 == 'G') ? 1u : 0u;
+        const unsigned long long before = (a.sam ? (unsigned long long)__popcll(same_ok & below) : (unsigned long long)__popcll(same & below)) +
+                                          (d == cur_d ? (a.sam ? kept : raw) : 0ull);
+        skip = valid && before >= (unsigned long long)a.max_off;
+        /* carry: the class of the block's last hit */
+        const uint32_t nv = (uint32_t)__popcll(__ballot(valid));
+        const uint32_t d_last = (uint32_t)__shfl((int)d, (int)(nv - 1u));
+        const unsigned long long n_last = __popcll(__ballot(valid && d == d_last)),
+                                 ok_last = __popcll(__ballot(valid && d == d_last && !sent));
+        if (d_last == cur_d) {
+          raw += n_last;
+          kept += ok_last;
+        } else {
+          cur_d = d_last;
+          raw = n_last;
+          kept = ok_last;
         }
-        const uint32_t sent = sc_sentinel(a.chr_cum, a.n_chr, (long long)hit.pos, L, P) ? 1u : 0u;
-        info = d | (sent << 3) | (pgg << 4);
-        if (a.cfd) a.cfd[h] = c;
       }
-      const uint32_t cnt = (uint32_t)(he - h0 < (uint64_t)WAVE ? he - h0 : (uint64_t)WAVE);
-      const uint32_t cbits = __float_as_uint(c);
-      for (uint32_t i = 0; i < cnt; ++i) { /* sequential, wave-uniform */
-        const uint32_t inf = (uint32_t)__shfl((int)info, (int)i);
-        const float ci = __uint_as_float((uint32_t)__shfl((int)cbits, (int)i));
-        const uint32_t di = inf & 7u;
-        if (di != cur_d) {
-          cur_d = di;
-          raw = 0;
-          kept = 0;
-        }
-        /* CSV: `i >= max_off_targets` on the raw index (printer.hpp:259); SAM: on the kept hits (:129) */
-        const bool skip = a.max_off != -1 && (a.sam ? kept : raw) >= a.max_off;
-        raw++;
-        if (skip) continue;
-        perfect |= (inf >> 4) & 1u;
-        if ((inf >> 3) & 1u) continue; /* boundary sentinel: no CFD */
-        sum += ci;
-        kept++;
-      }
+      if (__ballot(valid && !skip && pgg != 0u)) perfect = 1u;
+      /* the sum itself runs hit by hit (float addition is not associative and the reference adds in
+       * order): hits that do not count add +0, which leaves every partial sum as it is */
+      const uint32_t abits = __float_as_uint((valid && !skip && !sent) ? c : 0.0f);
+#pragma unroll
+      for (int i = 0; i < WAVE; ++i) sum += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)abits, i));
     }
     if (!perfect) sum += 1.0f;
     float sp = 0.0f;
@@ -211,9 +263,21 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   int cus = 256;
   if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess && prop.multiProcessorCount > 0)
     cus = prop.multiProcessorCount;
+  /* hits of the batch (the last offset), their CFDs (the caller's array or one of the handle's) and facts */
+  uint64_t n_hits = 0;
+  GS_HIP(hipMemcpyAsync(&n_hits, (const uint64_t *)d_offsets + n, 8, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  if ((rc = gs_reserve(ix->w_score_tmp, (d_cfd ? 0 : 4 * n_hits) + n_hits + 64)) != GS_OK) return rc;
+  float *cf = d_cfd ? (float *)d_cfd : (float *)ix->w_score_tmp.p;
+  uint8_t *info = (uint8_t *)ix->w_score_tmp.p + (d_cfd ? 0 : 4 * n_hits);
+  if (n_hits) {
+    uint64_t gh = (n_hits + 255) / 256;
+    if (gh > (uint64_t)cus * 32u) gh = (uint64_t)cus * 32u;
+    hipLaunchKernelGGL(k_score_hits, dim3((uint32_t)gh), dim3(256), 0, st, a, n_hits, cf, info);
+  }
   uint32_t grid = (uint32_t)((n + SCORE_WAVES - 1) / SCORE_WAVES);
   if (grid > (uint32_t)cus * 16u) grid = (uint32_t)cus * 16u;
-  hipLaunchKernelGGL(k_score, dim3(grid), dim3(WAVE * SCORE_WAVES), 0, st, a);
+  hipLaunchKernelGGL(k_score_sum, dim3(grid), dim3(WAVE * SCORE_WAVES), 0, st, a, (const float *)cf, (const uint8_t *)info);
   GS_HIP(hipStreamSynchronize(st));
   GS_HIP(hipGetLastError());
   return GS_OK;

@@ -3050,8 +3050,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   };
 
   /* ---- main pass ---- */
-  const uint32_t LDS_CAP_MAX = 4096; /* k_order: 2 * cap records of 16 bytes in LDS */
-  const bool big_batch = cap > LDS_CAP_MAX; /* every guide through the device-wide sort */
+  const uint32_t LDS_CAP_MAX = 4096; /* k_order_wg: 2 * cap records of 16 bytes in LDS */
+  /* every guide through the device-wide sort: slots beyond what LDS orders, and - measured at hg38 size,
+   * m <= 5: 96.8 ms per 100 k guides against 105.5 - from 1,024 slots on, where the bitonic network over
+   * 16-byte records in LDS costs more than nine radix passes (m <= 4, 512 slots: 32.9 against 35.1, LDS kept) */
+  uint32_t wide_from = 1024;
+  if (const char *e = getenv("GS_ORDER_WIDE_FROM")) wide_from = (uint32_t)atol(e);
+  const bool big_batch = cap > LDS_CAP_MAX || (cap >= wide_from && big_fits_v2(n32));
   if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
   unsigned long long h_stats[2] = {0, 0};
   if ((rc = run_search((const gs_guide_rec *)ix->w_grec.p, n32, (uint4 *)ix->w_slots.p,
