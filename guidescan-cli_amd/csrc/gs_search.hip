@@ -2602,10 +2602,23 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (getenv("GS_NO_ARENA")) want = 0;
     if (want > (1ull << 21)) want = 1ull << 21; /* 32 GB of records */
     if (want) {
-      if (gs_reserve(ix->w_arena, sizeof(uint4) * (want << ARENA_SHIFT)) != GS_OK ||
-          gs_reserve(ix->w_arena_meta, 8 * want + 64) != GS_OK || gs_reserve(ix->w_nchunk, sizeof(uint2) * (2 * n + 2)) != GS_OK) {
+      auto reserve_arena = [&]() {
+        return gs_reserve(ix->w_arena, sizeof(uint4) * (want << ARENA_SHIFT)) == GS_OK &&
+               gs_reserve(ix->w_arena_meta, 8 * want + 64) == GS_OK && gs_reserve(ix->w_nchunk, sizeof(uint2) * (2 * n + 2)) == GS_OK;
+      };
+      if (!reserve_arena()) {
+        /* no room: give back what only the paths without the arena use (the exact-size array of a second
+         * pass, the ordered copy that otherwise lives in the arena, the raw-key sort word) and try again */
         (void)hipGetLastError();
-        want = 0; /* no room: the second pass serves the overflowing guides */
+        for (gs_buffer *b : {&ix->w_slots2, &ix->w_b_s, &ix->w_b_w1}) {
+          if (b->p) hipFree(b->p);
+          b->p = nullptr;
+          b->cap = 0;
+        }
+        if (!reserve_arena()) {
+          (void)hipGetLastError();
+          want = 0; /* the second pass serves the overflowing guides */
+        }
       }
     }
     arena_chunks = (uint32_t)want;
@@ -2785,6 +2798,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
    * sorted arrays k_big_locate reads once the CSR offsets exist. */
   uint64_t big_T = 0;
   bool big_used = false, big_v2 = false;
+  void *big_s2 = nullptr; /* the records in final order (one-word form) */
   uint32_t big_gshift = 0;
   /* the device-wide ordering runs in its one-word form (k_big2_*) when the sort word fits 64 bits */
   unsigned long long big_pam_mul = 1, big_n_max = 1;
@@ -2872,11 +2886,15 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     const unsigned long long pam_mul = big_pam_mul;
     big_gshift = 4 + rbits;
     if (T && big_v2) {
-      if ((r2 = gs_reserve(ix->w_b_s, 16 * (T + 1))) != GS_OK) return r2;
+      /* the records in final order go where the arena's chunks were (read for the last time by the
+       * compaction) when they fit there: 16 bytes per record less next to a 220 GB index */
+      const bool s2_in_arena = from_arena && ix->w_arena.cap >= 16 * (T + 1);
+      if (!s2_in_arena && (r2 = gs_reserve(ix->w_b_s, 16 * (T + 1))) != GS_OK) return r2;
+      big_s2 = s2_in_arena ? ix->w_arena.p : ix->w_b_s.p;
       if ((r2 = gs_reserve(ix->w_b_tab, sizeof(gs_big2_tab))) != GS_OK) return r2;
       GS_HIP(hipMemcpy(ix->w_b_tab.p, &big_tab, sizeof(big_tab), hipMemcpyHostToDevice));
       unsigned long long *W = w0, *Wb = w0b;
-      uint4 *S2 = (uint4 *)ix->w_b_s.p;
+      uint4 *S2 = (uint4 *)big_s2;
       uint32_t *rk = (uint32_t *)ix->w_b_keep.p, *rkb = (uint32_t *)ix->w_b_keeps.p; /* free until the flags are written */
       gs_big2_compact_args ca;
       memset(&ca, 0, sizeof(ca));
@@ -2994,7 +3012,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       gs_blocate3_args la;
       la.sd[0] = ix->strand[0].d;
       la.sd[1] = ix->strand[1].d;
-      la.S2 = (const uint4 *)ix->w_b_s.p;
+      la.S2 = (const uint4 *)big_s2;
       la.W = (const unsigned long long *)ix->w_b_w0.p;
       la.keep = (const uint32_t *)ix->w_b_keep.p;
       la.row_scan = (const unsigned long long *)ix->w_b_rowss.p;

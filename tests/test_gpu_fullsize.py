@@ -17,6 +17,9 @@ What is compared with what:
    files written through the compiled SDSL containers.  Done at hg38 size for sampled guides and
    genome-wide candidates at m = 3 and for config 5's depth at m = 6.
 
+ * the repeat-rich path at size: tests/test_gpu_fullsize_rep.py (a module of its own: its hg38-sized
+   index needs the HBM this module's holds).
+
 The reference legs need oracle/_ref (prebuilt, travels with the snapshot); nothing reads
 /root/reference.  The SDSL index files are written by background threads while the GPU tests run."""
 import ctypes as C
@@ -87,9 +90,37 @@ def check_batch_properties(text, seqs, positions, strands, off, pos, key):
     return int(idx.size)
 
 
-def three_paths_same_bytes(torch, gidx, d_seqs, d_pams, n, m, n_walk):
-    """two-sided seeding == one-sided seeding (whole batch) == reference-order walk (first n_walk)"""
+def device_result_to_host(hip, d_off, d_hits, n, n_hits):
+    off = np.empty(n + 1, dtype=np.int64)
+    hits = np.empty((max(n_hits, 1), 2), dtype=np.int64)
+    assert hip.hipMemcpy(off.ctypes.data, d_off, 8 * (n + 1), 2) == 0
+    if n_hits:
+        assert hip.hipMemcpy(hits.ctypes.data, d_hits, 16 * n_hits, 2) == 0
+    return off, hits[:n_hits]
+
+
+def three_paths_same_bytes(torch, gidx, d_seqs, d_pams, n, m, n_walk, on_host=False):
+    """two-sided seeding == one-sided seeding (whole batch) == reference-order walk (first n_walk).
+    on_host: the copies that are compared live in host memory (hit lists of several GB next to an index
+    that fills the HBM)"""
     hip = _hip()
+    if on_host:
+        d_off, d_hits, st = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
+        off, hits = device_result_to_host(hip, d_off, d_hits, n, st["n_hits"])
+        os.environ["GS_NO_BIDIR"] = "1"
+        try:
+            d_o, d_h, st2 = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
+            o2, h2 = device_result_to_host(hip, d_o, d_h, n, st2["n_hits"])
+        finally:
+            del os.environ["GS_NO_BIDIR"]
+        assert np.array_equal(o2, off) and h2.tobytes() == hits.tobytes(), "one-sided and two-sided seeding differ"
+        del o2, h2
+        d_o, d_h, st3 = gidx.enumerate_device(d_seqs.data_ptr(), n_walk, 20, d_pams.data_ptr(), 3, mismatches=m,
+                                              faithful=True)
+        o3, h3 = device_result_to_host(hip, d_o, d_h, n_walk, st3["n_hits"])
+        nh = int(off[n_walk])
+        assert np.array_equal(o3, off[:n_walk + 1]) and h3.tobytes() == hits[:nh].tobytes(), "walk and fast path differ"
+        return off, hits, st, st3
     d_off, d_hits, st = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
     off, hits = device_result_to_torch(torch, hip, d_off, d_hits, n, st["n_hits"])
     os.environ["GS_NO_BIDIR"] = "1"
@@ -151,9 +182,11 @@ def test_config2_chr1_sized_100k_guides_m3():
 class Hg38:
     """the hg38-sized genome, its device index, and (in the background) the reference's index files"""
 
-    def __init__(self):
+    def __init__(self, lengths=None, repeats=False):
         t0 = time.time()
-        self.text, self.names, self.lengths = synth.make_genome(synth.GRCH38_LENGTHS, seed=1)
+        lengths = synth.GRCH38_LENGTHS if lengths is None else lengths
+        make = synth.make_repeat_genome if repeats else synth.make_genome
+        self.text, self.names, self.lengths = make(lengths, seed=1)
         self.t_gen = time.time() - t0
         t0 = time.time()
         self.gidx = api.GenomeIndex.build(self.text, device=0)
@@ -332,3 +365,4 @@ def test_hg38_alt_pam_through_two_pair_tables_equals_the_compiled_reference(hg38
     header, want = hg38.run_reference("m3nag", ids, seqs, 3, os.cpu_count() or 8, alt=("NAG",))
     assert len(want) >= len(ids) and len(got) == len(want)
     assert got == want
+

@@ -1,0 +1,55 @@
+"""The repeat-rich path at its real sizes, on the GPU box (`pytest -m gpu`): bench.py's chr1rep and hg38rep
+workloads - 45 % of the bases in repeat families (synth.plant_repeats), so a third of the sampled guides
+overflow their 64 first-pass slots into the arena, are ordered device-wide and have 10^3 .. 4 x 10^5 hits.
+
+A module of its own: the hg38-sized index of test_gpu_fullsize.py must have left the HBM before this one's is
+built (module-scoped fixtures end with their module).  The reference legs need oracle/_ref (prebuilt,
+travels with the snapshot); nothing reads /root/reference."""
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+from test_gpu_fullsize import Hg38, _hip, check_batch_properties, three_paths_same_bytes
+
+synth = import_module("guidescan-cli_amd.synth")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("size", ["chr1", "hg38"])
+def test_repeat_rich_lines_equal_the_compiled_reference(size):
+    """The bench's own 20,000 guides at <= 3 mismatches on the repeat-rich genome of the given size.
+    (1) Two-sided seeding, one-sided seeding and the reference-order walk return the same bytes for the
+    whole batch.  (2) For 256 guides - the 48 with the most hits (10^4 and more each) and 208 spread over
+    the rest - every CSV line the compiled reference writes (coordinates, match sequences, distances,
+    specificity summed over 10^4 .. 10^5 hits in the reference's order) equals the product's (device search
+    through the overflow arena and the device-wide ordering + k_score + text encoder)."""
+    import torch
+    rep = Hg38([synth.CHR1_LENGTH] if size == "chr1" else None, repeats=True)
+    try:
+        n = 20_000
+        seqs, pams, pos, strands = synth.sample_guides(rep.text, n, seed=1000)
+        d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+        off, hits, st, st_walk = three_paths_same_bytes(torch, rep.gidx, d_seqs, d_pams, n, 3, n, on_host=True)
+        check_batch_properties(rep.text, seqs, pos, strands, off, hits[:, 0], hits[:, 1].view(np.uint64))
+        rep.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=3)
+        ctr = rep.gidx.last_counters()
+        assert ctr["guides_redone"] > n // 10 and ctr["overflow_from_arena"] and ctr["redo_ordered_device_wide"], ctr
+        per_guide = np.diff(off)
+        del hits
+        order = np.argsort(-per_guide, kind="stable")
+        heavy = order[:48]
+        assert int((per_guide[heavy] >= 10_000).sum()) >= 32, per_guide[heavy]
+        rest = order[48:]
+        pick = np.sort(np.concatenate([heavy, rest[:: max(1, rest.shape[0] // 208)][:208]]))
+        assert pick.shape[0] == 256
+        ids = [f"r{int(i)}" for i in pick]
+        got, n_hits = rep.product_lines(ids, seqs[pick], 3)
+        assert n_hits == int(per_guide[pick].sum()) >= 32 * 10_000
+        header, want = rep.run_reference("rep3", ids, seqs[pick], 3, os.cpu_count() or 8)
+        assert len(got) == len(want)
+        assert got == want
+    finally:
+        rep.close()
