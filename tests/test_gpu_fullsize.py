@@ -353,6 +353,42 @@ def test_config5_hg38_depth_m6_lines_equal_the_compiled_reference(hg38):
     assert got == want
 
 
+def test_config5_hg38_m6_2048_guides_properties_and_paths(hg38):
+    """BASELINE config 5 beyond the 64 guides the reference leg can afford: 2,048 guides at <= 6 mismatches
+    (2.2 x 10^7 hits) + CFD.  Every guide through the device-wide ordering (12 k slots per item) and - the
+    same bytes - through one-sided seeding; own site at distance 0, keys ascending, a specificity in (0, 1]
+    for every guide, and the first 64 guides' lists equal the lists of the 64-guide batch the reference
+    leg compares line by line (a batch's composition must not change a guide's result)"""
+    import torch
+    n = 2048
+    seqs, pams, pos, strands = synth.sample_guides(hg38.text, n, seed=1000)
+    d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+    hip = _hip()
+    d_off, d_hits, st = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=6)
+    ctr = hg38.gidx.last_counters()
+    assert ctr["ordered_device_wide"], ctr
+    off, hits = device_result_to_host(hip, d_off, d_hits, n, st["n_hits"])
+    assert st["n_hits"] > n * 5000
+    check_batch_properties(hg38.text, seqs, pos, strands, off, hits[:, 0], hits[:, 1].view(np.uint64))
+    d_spec = torch.empty(n, dtype=torch.float32, device="cuda")
+    hg38.gidx.score_device(hg38.gs, d_seqs.data_ptr(), n, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
+    spec = d_spec.cpu().numpy()
+    assert np.all(np.isfinite(spec)) and np.all(spec > 0) and np.all(spec <= 1.0)
+    os.environ["GS_NO_BIDIR"] = "1"
+    try:
+        d_o, d_h, st2 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=6)
+        o2, h2 = device_result_to_host(hip, d_o, d_h, n, st2["n_hits"])
+    finally:
+        del os.environ["GS_NO_BIDIR"]
+    assert np.array_equal(o2, off) and h2.tobytes() == hits.tobytes(), "one-sided and two-sided seeding differ"
+    # the 64-guide batch of the reference leg (same seed: the same first guides)
+    off64, hits64, _ = hg38.gidx.enumerate(seqs[:64], pams[:64], mismatches=6)
+    assert np.array_equal(off64.astype(np.int64), off[:65])
+    assert hits64.tobytes() == np.ascontiguousarray(hits[:int(off[64])]).tobytes()
+    _, spec64 = hg38.gidx.score(hg38.gs, seqs[:64], 3, off64, hits64, want_cfd=False)
+    assert np.array_equal(np.asarray(spec64, dtype=np.float32), spec[:64])
+
+
 def test_hg38_alt_pam_through_two_pair_tables_equals_the_compiled_reference(hg38):
     """`-a NAG` at hg38 size: the guides' own NGG and the alt pattern end in different pairs of bases, so
     the batch needs two PAM-pair tables (with their deep tables) next to the 184 GB of strand tables -
