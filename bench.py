@@ -200,6 +200,8 @@ def main():
         "metric": f"guides/sec off-target enum, <={m} mismatches",
         "value": value,
         "unit": "guides/s",
+        # the same timed region in hits: what a repeat-rich genome is priced in (guides/s falls with the hits per guide)
+        "hits_per_s": n_hits * world / elapsed,
         "n_gpus": world,
         "steps": K,
         "warmup": args.warmup,
@@ -216,6 +218,10 @@ def main():
                    "parallelism": f"replicated index, guide batch sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     # PMC counters cannot be read from inside the process that is being timed: `traffic` is
+                     # the recorded figure of a separate rocprofv3 --pmc pass of this command with these
+                     # kernel sources (hash checked), or null
+                     "traffic_measured_in_this_run": False,
                      "traffic_source": traffic_src, "instruction_issue": issue,
                      "alg_bytes_per_launch": alg_bytes_per_launch,
                      "avg_launch_ms": ms_search / K,
@@ -268,6 +274,8 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m,
                                                              args.cpu_sample)
+                if "hwpopcnt" in out["cpu_baseline"]:   # BASELINE.md section 3's second reference row
+                    out["cpu_baseline_hwpopcnt"] = out["cpu_baseline"].pop("hwpopcnt")
             except Exception as e:  # the baseline is a side figure: never lose the bench line to it
                 if args.cpu_kind == "reference":
                     raise
@@ -609,6 +617,24 @@ def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample):
                             "csv", "complete", str(m), "0", "0", "-1", "-1", "0"], env=env, check=True,
                            timeout=3600, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
         dt = float(re.search(r"kmers in ([0-9.eE+-]+) s", r.stderr.decode()).group(1))
+        # the same run by the build with hardware POPCNT (oracle/Makefile: -march=x86-64-v3; the box's own
+        # -march=native cannot be built there, the reference's sources do not travel)
+        hw = None
+        shim_hw = ol.ORACLE_DIR / "_ref" / "gs_ref_enumerate_hwpopcnt"
+        if shim_hw.exists():
+            try:
+                r2 = subprocess.run([str(shim_hw), os.path.join(td, "g"), os.path.join(td, "k.csv"), os.path.join(td, "o2.csv"),
+                                     "csv", "complete", str(m), "0", "0", "-1", "-1", "0"], env=env, check=True,
+                                    timeout=3600, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+                dt2 = float(re.search(r"kmers in ([0-9.eE+-]+) s", r2.stderr.decode()).group(1))
+                with open(os.path.join(td, "o.csv"), "rb") as f1, open(os.path.join(td, "o2.csv"), "rb") as f2:
+                    same = sorted(f1.read().splitlines()) == sorted(f2.read().splitlines())
+                hw = {"value": sample / dt2, "unit": "guides/s", "cores": cores, "kind": "reference",
+                      "sample": f"the same {sample} guides through the reference built -O3 -DNDEBUG -march=x86-64-v3 "
+                                f"(hardware POPCNT in sdsl bits::cnt), {cores} threads, {dt2:.1f} s",
+                      "same_lines_as_the_as_shipped_build": same}
+            except Exception as e:   # a host CPU below x86-64-v3, or any failure of the side run: no second row
+                print(f"[bench] hardware-POPCNT reference row skipped: {e!r}", file=sys.stderr)
         # the baseline's output doubles as a parity check at this size: its data lines (row order
         # varies with the thread count, so as a sorted list) against the product's lines for the
         # same guides - device search, device scoring, gs_format_guide_scored
@@ -628,11 +654,14 @@ def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample):
             print(f"[bench] PARITY FAILURE: {len(want)} reference lines vs {len(got)} product lines", file=sys.stderr)
     finally:
         shutil.rmtree(td, ignore_errors=True)
-    return {"value": sample / dt, "unit": "guides/s", "cores": cores, "kind": "reference",
-            "sample": f"first {sample} guides of rank 0's batch through the compiled reference "
-                      f"(process_kmers_to_stream, CSV out, built -O3 -DNDEBUG as its Release build), {cores} threads, "
-                      f"{dt:.1f} s; SDSL index files written in {t_files:.0f} s (untimed)",
-            "parity": parity}
+    out = {"value": sample / dt, "unit": "guides/s", "cores": cores, "kind": "reference",
+           "sample": f"first {sample} guides of rank 0's batch through the compiled reference "
+                     f"(process_kmers_to_stream, CSV out, built -O3 -DNDEBUG as its Release build), {cores} threads, "
+                     f"{dt:.1f} s; SDSL index files written in {t_files:.0f} s (untimed)",
+           "parity": parity}
+    if hw:
+        out["hwpopcnt"] = hw
+    return out
 
 
 if __name__ == "__main__":
