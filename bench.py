@@ -107,6 +107,9 @@ def main():
     gidx = api.GenomeIndex.build(text, device=local_rank)
     torch.cuda.synchronize()
     t_index = time.time() - t0
+    # HBM left on this rank's GPU next to the index (RCCL's buffers exist by now: the rendezvous and the
+    # barriers of shared_genome ran before the build), again after the timed steps (PAM-pair tables + workspace)
+    free_after_index = int(torch.cuda.mem_get_info()[0])
 
     nb = args.steps + args.warmup
     # every step and every rank gets its own guides (seeded): shard r of the global batch
@@ -170,6 +173,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    mem = {"rank": rank, "index_build_s": round(t_index, 1), "free_after_index_bytes": free_after_index,
+           "index_bytes_after_steps": int(gidx.device_bytes), "free_after_steps_bytes": int(torch.cuda.mem_get_info()[0]),
+           "hbm_total_bytes": int(torch.cuda.mem_get_info()[1])}
+    per_rank = [mem]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mem)
     K = args.steps
     guides_total = batch * K * world
     value = guides_total / elapsed
@@ -253,7 +263,8 @@ def main():
                    "overflow_items_first_pass": req["overflow_items"], "guides_redone": req["guides_redone"],
                    "slots_per_item": req["slots_per_item"], "matches_max_per_item": req["matches_max_per_item"],
                    "ordered_device_wide": req["ordered_device_wide"],
-                   "redo_ordered_device_wide": req["redo_ordered_device_wide"]},
+                   "redo_ordered_device_wide": req["redo_ordered_device_wide"],
+                   "overflow_from_arena": req["overflow_from_arena"], "per_rank_memory": per_rank},
     }
 
     if rank == 0:

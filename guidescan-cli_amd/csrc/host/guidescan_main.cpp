@@ -490,6 +490,9 @@ int do_enumerate(int argc, char **argv) {
   /* one index per device, built side by side (src/guidescan.cxx:226-251 fans the guides out over
    * threads that share one index; here every GPU holds its own copy in HBM) */
   auto t0 = std::chrono::steady_clock::now();
+  /* GS_CLI_SAME_DEVICE=1: every worker builds its index on `device` itself - the fan-out, the batch queue
+   * and the ordered writer run with N workers on a box with one GPU (tests) */
+  const int dev_step = getenv("GS_CLI_SAME_DEVICE") ? 0 : 1;
   std::vector<gs_index *> ix((size_t)gpus, nullptr);
   {
     std::vector<gs_status> brc((size_t)gpus, GS_OK);
@@ -498,15 +501,15 @@ int do_enumerate(int argc, char **argv) {
     for (int d = 0; d < gpus; d++)
       bt.emplace_back([&, d]() {
         if (from_sdsl) {
-          brc[d] = gs_index_open_sdsl(prefix.c_str(), device + d, &ix[d]);
+          brc[d] = gs_index_open_sdsl(prefix.c_str(), device + d * dev_step, &ix[d]);
         } else {
           /* stored suffix arrays (guidescan index --store-sa) skip the sort; a file that does not
            * belong to this text is ignored */
           brc[d] = GS_ERR_IO;
           if (std::ifstream(prefix + ".sa"))
-            brc[d] = gs_index_open_sa((const uint8_t *)text.data(), text.size(), (prefix + ".sa").c_str(), device + d, &ix[d]);
+            brc[d] = gs_index_open_sa((const uint8_t *)text.data(), text.size(), (prefix + ".sa").c_str(), device + d * dev_step, &ix[d]);
           if (brc[d] == GS_ERR_IO || brc[d] == GS_ERR_FORMAT)
-            brc[d] = gs_index_build((const uint8_t *)text.data(), text.size(), device + d, &ix[d]);
+            brc[d] = gs_index_build((const uint8_t *)text.data(), text.size(), device + d * dev_step, &ix[d]);
         }
         if (brc[d] != GS_OK) bmsg[d] = gs_status_string(brc[d]);
       });

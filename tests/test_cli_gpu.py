@@ -1,6 +1,7 @@
 """End to end through the C++ host that keeps the reference's command line: `guidescan index` +
 `guidescan enumerate` on the toy genome must write the reference's output files byte for byte
 (tests/golden/toy/ref_*, -n 1 order).  GPU only."""
+import os
 import subprocess
 from importlib import import_module
 
@@ -193,3 +194,19 @@ def test_a_failing_batch_ends_the_run(tmp_path):
                            timeout=120, capture_output=True, text=True)
         assert r.returncode == 1, r.stderr
         assert "error:" in r.stderr
+
+
+def test_cli_fans_batches_out_over_several_workers(tmp_path):
+    """`enumerate --gpus N`: one index and one host thread per device pull batches from a shared queue and
+    the writer puts them back in input order.  With GS_CLI_SAME_DEVICE=1 the N workers all sit on device 0,
+    so the queue / in-flight bound / ordered writer run with 3 workers on a one-GPU box: the file equals
+    the reference's byte for byte, whatever the batch size"""
+    d = ol.ROOT / "tests" / "golden" / "toy"
+    subprocess.run([str(CLI), "index", "--index", str(tmp_path / "t"), str(d / "toy.fa")], check=True, timeout=300)
+    env = dict(os.environ, GS_CLI_SAME_DEVICE="1")
+    for bs in ("1", "5", "1000"):
+        out = tmp_path / f"o{bs}.csv"
+        subprocess.run([str(CLI), "enumerate", str(tmp_path / "t"), "-f", str(d / "kmers.csv"), "-o", str(out), "-m", "3",
+                        "--gpus", "3", "--batch-size", bs, "-n", "2"], check=True, timeout=300, env=env,
+                       capture_output=True, text=True)
+        assert out.read_bytes() == (d / "ref_m3_csv.csv").read_bytes(), bs

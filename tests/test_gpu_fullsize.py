@@ -183,6 +183,10 @@ class Hg38:
     """the hg38-sized genome, its device index, and (in the background) the reference's index files"""
 
     def __init__(self, lengths=None, repeats=False):
+        # torch's runtime first: initialised only after an index has filled the HBM it reported
+        # "No HIP GPUs are available" on the GPU box
+        import torch
+        torch.zeros(1, device="cuda")
         t0 = time.time()
         lengths = synth.GRCH38_LENGTHS if lengths is None else lengths
         make = synth.make_repeat_genome if repeats else synth.make_genome
@@ -402,3 +406,37 @@ def test_hg38_alt_pam_through_two_pair_tables_equals_the_compiled_reference(hg38
     assert len(want) >= len(ids) and len(got) == len(want)
     assert got == want
 
+
+
+def test_hg38_out_of_memory_drops_the_pair_tables_and_redoes_the_batch(hg38):
+    """the PAM-pair and deep tables are derived data (56 GB next to 184 GB of strand tables): a batch whose
+    workspace no longer fits drops them and is redone without them - same bytes, no error.  Forced here by
+    a ballast allocation that leaves less room than the batch needs.  (Last test of the module: the handle
+    goes on without its pair tables afterwards.)"""
+    import torch
+    n = 200_000
+    seqs, pams, pos, strands = synth.sample_guides(hg38.text, n, seed=1003)
+    d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+    hip = _hip()
+    d_off, d_hits, st = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=4)
+    ctr = hg38.gidx.last_counters()
+    assert ctr["items_pair_tables"] > 0, ctr
+    off, hits = device_result_to_host(hip, d_off, d_hits, n, st["n_hits"])
+    bytes_with_tables = hg38.gidx.device_bytes
+    # leave ~1 GB: the next batch at a larger budget (its slots alone are several GB) cannot get its workspace
+    free, total = torch.cuda.mem_get_info()
+    ballast = torch.empty(max(0, free - (1 << 30)), dtype=torch.uint8, device="cuda")
+    try:
+        d_o, d_h, st2 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=5)
+        ctr2 = hg38.gidx.last_counters()
+        assert ctr2["items_pair_tables"] == 0, ctr2                    # redone without the tables ...
+        assert hg38.gidx.device_bytes < bytes_with_tables - 20e9       # ... which are gone from the HBM
+        assert st2["n_hits"] > st["n_hits"]
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
+    # and the m <= 4 batch, now through the strand tables alone, returns the same bytes as before
+    d_o, d_h, st3 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=4)
+    assert hg38.gidx.last_counters()["items_pair_tables"] == 0
+    o3, h3 = device_result_to_host(hip, d_o, d_h, n, st3["n_hits"])
+    assert np.array_equal(o3, off) and h3.tobytes() == hits.tobytes()

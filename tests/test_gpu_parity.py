@@ -486,7 +486,8 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
         seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
         for cfg in (dict(m=3), dict(m=2), dict(m=4), dict(m=3, alt=("NAG",)), dict(m=3, start=True),
                     dict(m=5, alt=("NAG", "NGA")), dict(m=6), dict(m=1), dict(m=4, alt=("NGN",)),
-                    dict(m=3, start=True, pam="TTN"), dict(m=3, pam="NAG", alt=("NGG",)), dict(m=3, one_table=True, alt=("NAG",)),
+                    dict(m=3, start=True, pam="TTN"), dict(m=3, start=True, pam="TTTN"), dict(m=2, pam="NNGG"),
+                    dict(m=3, pam="NAG", alt=("NGG",)), dict(m=3, one_table=True, alt=("NAG",)),
                     dict(m=4, no_tables=True), dict(m=3), dict(m=3, pam="NCG", frozen=True), dict(m=2, frozen=True),
                     # six patterns = two passes of the kernel, two pairs; concrete first symbols pick one of a deep line's entries
                     dict(m=3, alt=("AGG", "CGG", "TGG", "GGG", "NAG")), dict(m=2, pam="CGG", alt=("TAG",))):
@@ -513,11 +514,11 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
                            and not (cfg.get("frozen") and own != "NGG"))
             assert (cnt["items_pair_tables"] > 0) == want_tables, (cfg, cnt)
             # ... and when every pattern of the batch has one (3-symbol PAMs), the other strand's side uses the deep tables
-            assert ("with deep tables" in err) == want_tables, (cfg, err)
+            assert ("with deep tables" in err) == (want_tables and len(own) == 3), (cfg, err)
             total = 0
             for i, g in enumerate(guides):
-                exp, _ = oracle_hits_as_records(oidx, g, own, opts, 3, start)
-                assert gpu_hits_as_records(offsets, hits, i, g, 3, start) == exp, (i, cfg, pk)
+                exp, _ = oracle_hits_as_records(oidx, g, own, opts, len(own), start)
+                assert gpu_hits_as_records(offsets, hits, i, g, len(own), start) == exp, (i, cfg, pk)
                 total += len(exp)
             assert total > 100 or start or m < 2 or own != "NGG"
     finally:
