@@ -101,6 +101,8 @@ struct gs_strand {
   gs_strand_dev d{};
   void *blocks = nullptr, *sa = nullptr, *run_start = nullptr, *run_cum = nullptr, *ptab = nullptr, *ctx = nullptr, *ctx16 = nullptr, *ptab_rot = nullptr, *isa = nullptr, *exc_row = nullptr, *exc_sym = nullptr, *xr_start = nullptr, *xr_cum = nullptr, *xr_seg = nullptr, *C256 = nullptr;
   bool has_sym[256] = {false}; /* bytes present in this strand's text */
+  /* the rotated table copies this strand may hold (gs_strand_rot_ensure builds them on first use): first step, count (0: none), table depth */
+  uint32_t rot_plan_first = 31, rot_plan_n = 0, rot_k = 0;
   uint64_t n = 0;
   uint64_t C_acgtn[5] = {0, 0, 0, 0, 0};
   uint64_t bytes = 0;
@@ -173,6 +175,7 @@ struct gs_index {
   /* PAM-pair tables (gs_pairtab.hip), built on first use for the pairs a batch's patterns end in */
   gs_pairtab_host pairtab[2];
   bool pairtab_off = false; /* a batch ran out of memory next to them: not built again on this handle */
+  bool rot_off = false;     /* the same for the strand tables' rotated copies */
 };
 
 /* make sure slot `slot` holds the tables of pair `code` at context depth v_rem with rotated copies from
@@ -183,6 +186,9 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
 /* add the deep tables (the other strand's side, PAM of three symbols) to a valid slot; p.deep stays false when they do not fit */
 gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, uint32_t kb, hipStream_t st);
 void gs_pairtab_free(gs_index *ix, uint32_t slot);
+/* gs_index.hip: the strand tables' rotated copies, built by the first batch that reads them */
+gs_status gs_strand_rot_ensure(gs_index *ix, hipStream_t st);
+bool gs_strand_rot_release(gs_index *ix);
 
 #define GS_HIP(expr)                                                              \
   do {                                                                            \

@@ -642,26 +642,18 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
       (void)hipGetLastError();
     }
   }
-  uint4 *rot = nullptr;
-  if (ctx && nrot && !getenv("GS_NO_ROT") && base_bytes + (isa ? isa_bytes : 0.0) + rot_bytes <= budget) {
-    /* one copy per step rot_first..k-2: steps up to k-3 serve the budget-0 variants (their last
-     * substituted step), step k-2 the budget-1 variants (substitutions of the second-last
-     * symbol next to each other) */
-    if (hipMalloc(&rot, bytes * nrot) == hipSuccess) {
-      for (uint32_t p = 0; p < nrot; p++)
-        hipLaunchKernelGGL(k_rot_copy, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, rot, k, rot_first + p, p);
-      s->bytes += bytes * nrot;
-    } else {
-      rot = nullptr; /* not enough memory: the plain table serves every class */
-      (void)hipGetLastError();
-    }
-  }
+  /* the rotated copies are derived data written in milliseconds: built by the first batch that reads them
+   * (gs_strand_rot_ensure) - a batch served by PAM-pair and deep tables never does, and their 86 GB at hg38
+   * size are better left to those tables and to the workspace */
+  s->rot_plan_first = rot_first;
+  s->rot_plan_n = (ctx && nrot && !getenv("GS_NO_ROT") && base_bytes + (isa ? isa_bytes : 0.0) + rot_bytes <= budget) ? nrot : 0;
+  s->rot_k = k;
   GS_HIP(hipStreamSynchronize(st));
   s->isa = isa;
   s->d.isa = isa;
-  s->ptab_rot = rot;
-  s->d.ptab_rot = rot;
-  s->d.rot_first = rot ? rot_first : 31u;
+  s->ptab_rot = nullptr;
+  s->d.ptab_rot = nullptr;
+  s->d.rot_first = 31u;
   s->ptab = tab;
   s->d.ptab = tab;
   s->ctx = ctx;
@@ -670,6 +662,54 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   s->d.ctx16 = ctx16;
   s->bytes += bytes;
   return GS_OK;
+}
+
+/* rotated copies of both strand tables (gs_strand_dev::ptab_rot), built when a batch reads them: one copy per
+ * step rot_first..k-2 - steps up to k-3 serve the budget-0 variants (their last substituted step), step k-2
+ * the budget-1 variants (substitutions of the second-last symbol next to each other).  Kept afterwards;
+ * released when a batch runs short of memory (gs_strand_rot_release).  No room (beyond `reserve` bytes left
+ * for the batch), GS_NO_ROT or GS_INDEX_BUDGET_GB: the plain tables serve every class. */
+gs_status gs_strand_rot_ensure(gs_index *ix, hipStream_t st) {
+  for (int s = 0; s < 2; s++) {
+    gs_strand &S = ix->strand[s];
+    if (S.ptab_rot || !S.rot_plan_n || !S.ptab || ix->rot_off) continue;
+    const uint64_t entries = 1ull << (2 * S.rot_k);
+    const size_t bytes = sizeof(uint4) * entries * S.rot_plan_n;
+    size_t free_b = 0, total_b = 0;
+    GS_HIP(hipMemGetInfo(&free_b, &total_b));
+    double reserve = 32e9; /* they are dropped first when a batch runs short, and written again in 50 ms */
+    if (reserve > 0.125 * (double)total_b) reserve = 0.125 * (double)total_b;
+    uint4 *rot = nullptr;
+    if ((double)bytes + reserve > (double)free_b || hipMalloc(&rot, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      continue;
+    }
+    for (uint32_t p = 0; p < S.rot_plan_n; p++)
+      hipLaunchKernelGGL(k_rot_copy, dim3(nblk(entries, 256)), dim3(256), 0, st, (const uint4 *)S.ptab, rot, S.rot_k,
+                         S.rot_plan_first + p, p);
+    GS_HIP(hipStreamSynchronize(st));
+    S.ptab_rot = rot;
+    S.d.ptab_rot = rot;
+    S.d.rot_first = S.rot_plan_first;
+    S.bytes += bytes;
+    if (getenv("GS_DEBUG"))
+      fprintf(stderr, "[gs] strand %d: %u rotated table copies built (%.1f GB)\n", s, S.rot_plan_n, 1e-9 * (double)bytes);
+  }
+  return GS_OK;
+}
+bool gs_strand_rot_release(gs_index *ix) {
+  bool any = false;
+  for (int s = 0; s < 2; s++) {
+    gs_strand &S = ix->strand[s];
+    if (!S.ptab_rot) continue;
+    hipFree(S.ptab_rot);
+    S.bytes -= sizeof(uint4) * (1ull << (2 * S.rot_k)) * S.rot_plan_n;
+    S.ptab_rot = nullptr;
+    S.d.ptab_rot = nullptr;
+    S.d.rot_first = 31u;
+    any = true;
+  }
+  return any;
 }
 
 /* maximal runs of 'N' in the forward text, with 40 bytes of text on either side */

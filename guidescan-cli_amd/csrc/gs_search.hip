@@ -2247,8 +2247,16 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   try { /* the plans and lists built per batch live in std containers: nothing may throw across the C boundary */
     gs_status rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream,
                                          d_offsets, d_hits, stats);
+    /* the batch's workspace did not fit next to the derived tables: they go, one kind at a time - first the
+     * strand tables' rotated copies, then the PAM-pair tables - and the batch is redone */
+    if (rc == GS_ERR_NOMEM && ix && gs_strand_rot_release(ix)) {
+      (void)hipGetLastError();
+      ix->rot_off = true;
+      if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: rotated table copies dropped, batch redone without them\n");
+      rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets,
+                                 d_hits, stats);
+    }
     if (rc == GS_ERR_NOMEM && ix && (ix->pairtab[0].valid || ix->pairtab[1].valid)) {
-      /* the batch's workspace did not fit next to the PAM-pair tables: they are derived data and go first */
       (void)hipGetLastError();
       gs_pairtab_free(ix, 0);
       gs_pairtab_free(ix, 1);
@@ -2513,6 +2521,11 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (all_deep) break;
     try_deep = false; /* not every pattern has its deep table: plan again with the strand tables on that side */
   }
+  /* the strand tables' rotated copies: read by this strand's seeds of items without PAM-pair tables, by the
+   * other strand's seeds unless the deep tables take them, by one-sided items - built now if any of that
+   * can happen in this batch (a batch whose every pattern has its pair + deep tables reads none) */
+  if (table_seeding && !(bidir && deep && n_pt != 0 && n_pt == n_codes && h_pairs[16] == 0))
+    if ((rc = gs_strand_rot_ensure(ix, st)) != GS_OK) return rc;
   if (bidir) {
     /* windows where a literal 'N' of the genome lies under the PAM (index.hpp:139-149) and the
      * guide part is plain A,C,G,T: the other strand's table cannot hold them (its k-mers spell the
