@@ -24,12 +24,16 @@
 
 /* A PAM-pair table (gs_pairtab.hip): the depth-k prefix table restricted to the rows whose left context
  * has the pair `code` (two 2-bit symbols) at offsets v_rem-2, v_rem-1 and only A,C,G,T nearer than
- * that.  Entry = {first of its rows in the table's own row arrays, rows, z, w}: with one row z is
- * that row's context word and w its row in the strand's suffix array; with more z, w are the
- * strand table's pair masks over these rows only. */
+ * that.  Entry = 8 bytes {first of its rows in the table's own row arrays, rows (6 bits) | filter (26 bits)}:
+ * the 16 two-symbol extensions of a (k-2)-mer are ONE 128-byte block.  rows = 63: 63 or more - the row
+ * arrays then hold a header slot at `first` (rowid[first] = the count) and the rows behind it.  Filter:
+ * with one row its nearest 13 context symbols (2 bits each); with more, for each of the nearest 6
+ * context positions the set of symbols its rows show there (4 bits each): a query symbol outside the
+ * set is a substitution in every row. */
+#define GS_PT_BIG 63u
 struct gs_pairtab_dev {
-  const uint4 *tab;
-  const uint4 *rot;      /* rotated copies of consumption steps rot_first .. k-2 */
+  const uint2 *tab;
+  const uint2 *rot;      /* rotated copies of consumption steps rot_first .. k-3 */
   const uint16_t *c16;   /* per row of the table: nearest eight context symbols */
   const uint32_t *ctx;   /* all sixteen */
   const uint32_t *rowid; /* its row in the strand's suffix array */
@@ -136,8 +140,8 @@ struct gs_recipe_set {
   gs_buffer buf;
   uint64_t key[2] = {0, 0};
   bool valid = false;
-  uint32_t n_full = 0, n_a = 0, n_b = 0;
-  uint32_t a_rot_first = 31; /* lowest consumption step whose rotated copy the `a` list reads (31: none) */
+  uint32_t n_full = 0, n_a = 0, n_b = 0, n_a8 = 0; /* full | a | b | a as read through PAM-pair tables */
+  uint32_t a_rot_first = 31; /* lowest consumption step whose rotated copy the PAM-pair list reads (31: none) */
 };
 
 struct gs_index {

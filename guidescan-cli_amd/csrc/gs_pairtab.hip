@@ -9,8 +9,9 @@
  * only the rows with exactly that pair at context offsets v_rem-2, v_rem-1 can hold a site: one row in
  * sixteen.  Collecting those rows per k-mer gives a table of the same shape whose intervals hold
  * 0.7 rows instead of 11.5 at hg38 size: half the entries are empty (the seed dies with the table
- * read), a third hold one row whose context word sits in the entry itself (no second read), the
- * rest are filtered by pair masks over their few rows.  Rows with a symbol outside A,C,G,T among
+ * read), a third hold one row whose context symbols sit in the entry itself (no second read), the
+ * rest are filtered by per-position symbol sets over their few rows.  Entries are 8 bytes
+ * (gs_common.h, gs_pairtab_dev): the 16 two-symbol extensions of a variant are one 128-byte block.  Rows with a symbol outside A,C,G,T among
  * the nearest v_rem are left out: k_search reports those sites from the literal-N window list.
  * Derived data, built on the device from the strand's table and ctx[] on first use (~0.1 s at hg38
  * size), 4.3 GB per table copy + 10 bytes per selected row.
@@ -31,7 +32,7 @@ struct pt_args {
   /* outputs */
   uint32_t *count;       /* per k-mer: selected rows */
   const uint32_t *start; /* exclusive sums of count[] */
-  uint4 *out;
+  uint2 *out;
   uint16_t *c16;
   uint32_t *octx, *rowid;
 };
@@ -65,41 +66,45 @@ __global__ void k_pt_count(pt_args a) {
   const bool flagged = (e.y >> 31) != 0u;
   uint32_t c = 0;
   for (uint32_t j = 0; j < cnt; j++) c += pt_selected(a, e.x + j, a.ctx[e.x + j], flagged) ? 1u : 0u;
-  a.count[i] = c;
+  a.count[i] = c + (c >= GS_PT_BIG ? 1u : 0u); /* slots in the row arrays: a header slot in front of 63 rows and more */
 }
 
 __global__ void k_pt_fill(pt_args a) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.entries) return;
-  const uint32_t mine = a.count[i];
-  const uint32_t at = a.start[i];
-  uint4 o = make_uint4(at, mine, 0u, 0u);
-  if (mine) {
+  const uint32_t slots = a.count[i];
+  uint32_t at = a.start[i];
+  uint2 o = make_uint2(at, 0u);
+  if (slots) {
     const uint4 e = a.tab[i];
     const uint32_t cnt = e.y & 0x7FFFFFFFu;
     const bool flagged = (e.y >> 31) != 0u;
-    const uint32_t o0 = a.mask_off & 15u, o1 = (a.mask_off >> 4) & 15u, o2 = (a.mask_off >> 8) & 15u, o3 = (a.mask_off >> 12) & 15u;
-    uint32_t c = 0, mz = 0, mw = 0, lw = 0, lr = 0;
+    const bool big = slots > GS_PT_BIG; /* 63 rows and more: header slot + rows */
+    const uint32_t mine = big ? slots - 1u : slots;
+    if (big) {
+      a.c16[at] = 0;
+      a.octx[at] = 0;
+      a.rowid[at] = mine;
+      at++;
+    }
+    uint32_t c = 0, sets = 0, lw = 0;
     for (uint32_t j = 0; j < cnt && c < mine; j++) {
       const uint32_t r = e.x + j, w = a.ctx[r];
       if (!pt_selected(a, r, w, flagged)) continue;
       a.c16[at + c] = (uint16_t)w;
       a.octx[at + c] = w;
       a.rowid[at + c] = r;
-      mz |= (1u << ((w >> (2u * o0)) & 15u)) | (1u << (16u + ((w >> (2u * o1)) & 15u)));
-      mw |= (1u << ((w >> (2u * o2)) & 15u)) | (1u << (16u + ((w >> (2u * o3)) & 15u)));
+      for (uint32_t p = 0; p < 6u; p++) sets |= 1u << (4u * p + ((w >> (2u * p)) & 3u));
       lw = w;
-      lr = r;
       c++;
     }
-    o.z = mine == 1u ? lw : mz;
-    o.w = mine == 1u ? lr : mw;
+    o.y = (big ? GS_PT_BIG : mine) | ((mine == 1u ? (lw & 0x3FFFFFFu) : sets) << 6);
   }
   a.out[i] = o;
 }
 
 /* rot[slot][perm_p(i)] = tab[i]: the field of consumption step p moves to bits 1:0 (gs_index.hip k_rot_copy) */
-__global__ void k_pt_rot(const uint4 *tab, uint4 *rot, uint32_t k, uint32_t p, uint32_t slot) {
+__global__ void k_pt_rot(const uint2 *tab, uint2 *rot, uint32_t k, uint32_t p, uint32_t slot) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >> (2 * k)) return;
   const uint32_t sh = 2u * (k - 1u - p);
@@ -218,37 +223,37 @@ static gs_status build_one(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, 
   GS_HIP(hipStreamSynchronize(st));
   const uint64_t rows = (uint64_t)last_start + last_count;
   void **m = p.mem[s];
-  const uint32_t nrot = rot_from + 1 < k ? k - 1 - rot_from : 0; /* steps rot_from .. k-2 */
-  if (hipMalloc(&m[0], sizeof(uint4) * entries) != hipSuccess || hipMalloc(&m[2], 2 * rows + 64) != hipSuccess ||
+  const uint32_t nrot = rot_from + 2 < k ? k - 2 - rot_from : 0; /* steps rot_from .. k-3 (step k-2's variants sit in the plain table's 128-byte blocks) */
+  if (hipMalloc(&m[0], sizeof(uint2) * entries) != hipSuccess || hipMalloc(&m[2], 2 * rows + 64) != hipSuccess ||
       hipMalloc(&m[3], 4 * rows + 16) != hipSuccess || hipMalloc(&m[4], 4 * rows + 16) != hipSuccess ||
-      (nrot && hipMalloc(&m[1], sizeof(uint4) * entries * nrot) != hipSuccess)) {
+      (nrot && hipMalloc(&m[1], sizeof(uint2) * entries * nrot) != hipSuccess)) {
     (void)hipGetLastError();
     return GS_ERR_NOMEM;
   }
   GS_HIP(hipMemsetAsync(m[2], 0, 2 * rows + 64, st)); /* k_search reads whole groups of eight */
   a.start = d_start;
-  a.out = (uint4 *)m[0];
+  a.out = (uint2 *)m[0];
   a.c16 = (uint16_t *)m[2];
   a.octx = (uint32_t *)m[3];
   a.rowid = (uint32_t *)m[4];
   hipLaunchKernelGGL(k_pt_fill, dim3(nb), dim3(256), 0, st, a);
   for (uint32_t j = 0; j < nrot; j++)
-    hipLaunchKernelGGL(k_pt_rot, dim3(nb), dim3(256), 0, st, (const uint4 *)m[0], (uint4 *)m[1], k, rot_from + j, j);
+    hipLaunchKernelGGL(k_pt_rot, dim3(nb), dim3(256), 0, st, (const uint2 *)m[0], (uint2 *)m[1], k, rot_from + j, j);
   GS_HIP(hipStreamSynchronize(st));
   GS_HIP(hipGetLastError());
   gs_pairtab_dev &d = p.d[s];
-  d.tab = (const uint4 *)m[0];
-  d.rot = (const uint4 *)m[1];
+  d.tab = (const uint2 *)m[0];
+  d.rot = (const uint2 *)m[1];
   d.c16 = (const uint16_t *)m[2];
   d.ctx = (const uint32_t *)m[3];
   d.rowid = (const uint32_t *)m[4];
   d.rot_first = nrot ? rot_from : 31u;
   d.code = p.code;
-  p.bytes += sizeof(uint4) * entries * (1 + nrot) + 10 * rows;
+  p.bytes += sizeof(uint2) * entries * (1 + nrot) + 10 * rows;
   if (getenv("GS_DEBUG"))
     fprintf(stderr, "[gs] PAM-pair table: strand %d, pair %u at context depth %u: %llu of %llu rows, %u rotated copies, %.2f GB\n",
             s, p.code, p.v_rem, (unsigned long long)rows, (unsigned long long)S.n, nrot,
-            1e-9 * (double)(sizeof(uint4) * entries * (1 + nrot) + 10 * rows));
+            1e-9 * (double)(sizeof(uint2) * entries * (1 + nrot) + 10 * rows));
   return GS_OK;
 }
 
@@ -293,7 +298,7 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
   /* fit into what is free, keeping room for the batch workspace: drop rotated copies first */
   size_t free_b = 0, total_b = 0;
   GS_HIP(hipMemGetInfo(&free_b, &total_b));
-  const double entry_bytes = 16.0 * (double)(1ull << (2 * k));
+  const double entry_bytes = 8.0 * (double)(1ull << (2 * k));
   double reserve = 64e9; /* slots, sort buffers and hits of a large batch at a high budget */
   if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
   if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
@@ -305,7 +310,7 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
     if (left < room) room = left;
   }
   for (;;) {
-    const uint32_t nrot = rot_first + 1 < k ? k - 1 - rot_first : 0;
+    const uint32_t nrot = rot_first + 2 < k ? k - 2 - rot_first : 0;
     const double need = 2.0 * entry_bytes * (1 + nrot) + rows_bytes + tmp_bytes;
     if (need <= room * share) break; /* share < 1: another pair's tables are still to come */
     if (nrot == 0) {

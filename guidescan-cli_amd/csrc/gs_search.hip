@@ -79,6 +79,10 @@ struct gs_search_args {
    *   rec_b    : the other strand's share, steps counted as y = guide symbol L-1-y */
   const uint2 *rec_full, *rec_a, *rec_b;
   uint32_t n_rec_full, n_rec_a, n_rec_b;
+  /* rec_a for items whose seeds go through PAM-pair tables (8-byte entries: the two-symbol extensions of a
+   * variant are one 128-byte block, so the class with one substitution left needs no rotated copy) */
+  const uint2 *rec_a8;
+  uint32_t n_rec_a8;
   /* PAM-pair tables (gs_pairtab.hip): this strand's seeds of an item whose PAM patterns all end (in
    * consumption order) in one of these pairs of concrete bases are looked up among the rows that
    * have that pair in place - a sixteenth of the genome's rows - instead of all of them */
@@ -214,6 +218,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     /* what this strand's seeds are looked up in and verified against: the strand's own table and
      * context arrays, or (set per item, below) a PAM-pair table and its rows */
     const uint4 *atab = sd.ptab, *arot = sd.ptab_rot;
+    const uint2 *atab8 = nullptr, *arot8 = nullptr; /* a PAM-pair table's 8-byte entries */
     uint32_t arot_first = sd.rot_first;
     const uint16_t *a16 = sd.ctx16;
     const uint32_t *actx = sd.ctx, *arow = nullptr;
@@ -549,8 +554,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     };
     /* a recipe applied to the exact k-mer index `pidx` / path `path`; returns the entry's address */
     /* kd = symbols the table is indexed by, dbl = log2 of the uint4 per index */
-    auto apply_recipe = [&](const uint2 rc, const uint4 *tab, const uint4 *rot, const uint32_t rot_first, const uint32_t kd,
-                            const uint32_t dbl, uint32_t &pidx, uint64_t &path) __attribute__((always_inline)) -> const uint4 * {
+    auto apply_recipe = [&](const uint2 rc, const uint32_t rot_first, const uint32_t kd, uint32_t &pidx, uint64_t &path,
+                            bool &in_rot) __attribute__((always_inline)) -> size_t {
       const uint32_t k = kd, n = rc.x & 7u;
       uint64_t f = (((uint64_t)rc.y << 32) | rc.x) >> 12;
       uint32_t plo = (uint32_t)path, phi = (uint32_t)(path >> 32);
@@ -562,16 +567,18 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         phi |= e.z;
       }
       path = ((uint64_t)phi << 32) | plo;
-      const uint4 *ep = tab + ((size_t)pidx << dbl);
+      size_t ei = pidx;
+      in_rot = false;
       const uint32_t rs = (rc.x >> 7) & 31u;
       if ((rc.x & 64u) != 0u && rs >= rot_first) {
         /* the copy rotated at step rs: that step's symbol and everything after it swap places, so the
          * recipes that differ only at step rs are neighbours in one 64-byte line */
         const uint32_t sh = 2u * (k - 1u - rs);
         const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) | ((pidx >> sh) & 3u);
-        ep = rot + ((((size_t)(rs - rot_first) << (2u * k)) + ridx) << dbl);
+        ei = ((size_t)(rs - rot_first) << (2u * k)) + ridx;
+        in_rot = true;
       }
-      return ep;
+      return ei;
     };
     uint32_t pidx0 = 0; /* table index of the exact k-prefix of the query */
     /* context mask of this strand's seeds (gs_strand_dev::ptab): the query's symbol pairs at the four
@@ -774,8 +781,9 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             uint32_t pidx = pidxb;
             uint64_t path = ppath;
             /* deep tables: the line of the recipe's (k-2)-mer holds one entry per base under the N */
-            const uint4 *ep = apply_recipe(rc, deep ? a.pt[bslot][strand ^ 1u].deep : sb.ptab, sb.ptab_rot,
-                                           deep ? 31u : sb.rot_first, deep ? nYb : k, deep ? 2u : 0u, pidx, path);
+            bool brot;
+            const size_t bei = apply_recipe(rc, deep ? 31u : sb.rot_first, deep ? nYb : k, pidx, path, brot);
+            const uint4 *ep = deep ? a.pt[bslot][strand ^ 1u].deep + (bei << 2) : (brot ? sb.ptab_rot : sb.ptab) + bei;
             if (deep) {
               ep += bx;
               act = act && ((bxset >> bx) & 1u) != 0u;
@@ -845,8 +853,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         n_fb++; /* every seed from this strand */
       } else {
         n_two++;
-        rec = a.rec_a;
-        nrec = a.n_rec_a;
+        rec = pslots ? a.rec_a8 : a.rec_a;
+        nrec = pslots ? a.n_rec_a8 : a.n_rec_a;
         if (pslots) n_pair++;
       }
     }
@@ -854,8 +862,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t s = (pslots & 1u) ? 0u : 1u;
       pslots &= ~(1u << s);
       const gs_pairtab_dev &p = a.pt[s][strand];
-      atab = p.tab;
-      arot = p.rot;
+      atab8 = p.tab;
+      arot8 = p.rot;
       arot_first = p.rot_first;
       a16 = p.c16;
       actx = p.ctx;
@@ -865,6 +873,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     /* the guide symbols this strand's seeds leave to the context check */
     const uint32_t gA = L - a.pt_k, gmaskA = gA >= 16u ? 0xFFFFFFFFu : ((1u << (2u * gA)) - 1u);
     const uint32_t qremA = seeding ? (uint32_t)(gr_q >> (2u * a.pt_k)) & gmaskA : 0u;
+    /* against a PAM-pair table entry's filter: the nearest 13 symbols of a single row; the query's nearest 6
+     * as one-hot nibbles against the symbol sets of several rows */
+    const uint32_t gmask13 = gA >= 13u ? 0x3FFFFFFu : gmaskA;
+    uint32_t qhot = 0u;
+    for (uint32_t j = 0; j < 6u && j < gA; ++j) qhot |= 1u << (4u * j + ((qremA >> (2u * j)) & 3u));
     if (seeding) {
       fill_dtab(false);
       if (nrec == 0u) seeds_left = false;
@@ -898,29 +911,50 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         uint32_t pidx = pidx0;
         uint64_t path = 0;
         uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-        {
-          const uint4 *ep = apply_recipe(rc, atab, arot, arot_first, a.pt_k, 0u, pidx, path);
-          if (act) ent = *ep;
-          count_lines(c_tab, act, ep);
-        }
-        const uint32_t ecnt = ent.y & 0x7FFFFFFFu, eflag = ent.y >> 31;
-        /* context mask: drop the seed when fewer of the query's symbol pairs occur to the left of its
-         * interval's rows than the remaining budget can break, or none of the PAM's pairs does */
+        bool in_rot;
+        const size_t ei = apply_recipe(rc, arot_first, a.pt_k, pidx, path, in_rot);
         const uint32_t bl = m - kk; /* budget left (>= 0 by construction) */
         bool hopeless = false;
-        if (arow != nullptr && ecnt == 1u) {
-          /* a PAM-pair table's entry with one row carries that row's context word */
-          const uint32_t xf = (ent.z ^ qremA) & gmaskA;
-          hopeless = (uint32_t)__popc((xf | (xf >> 1)) & 0x55555555u) > bl;
-        } else if (use_mask && eflag == 0u) {
-          const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
-          uint32_t intact = 0;
-#pragma unroll
-          for (uint32_t j = 0; j < 4u; ++j) {
-            if ((g_pairs >> j) & 1u) intact += (em[j] >> ((qpairs >> (4u * j)) & 15u)) & 1u;
-            if (((pam_pairs >> j) & 1u) && (em[j] & pam16[j]) == 0u) hopeless = true;
+        uint32_t ecnt, eflag = 0u;
+        if (arow != nullptr) {
+          /* PAM-pair table: 8-byte entry {first row of the table's own arrays, rows (6 bits) | filter} */
+          const uint2 *ep = (in_rot ? arot8 : atab8) + ei;
+          uint2 e8 = make_uint2(0u, 0u);
+          if (act) e8 = *ep;
+          count_lines(c_tab, act, ep);
+          ent.x = e8.x;
+          ecnt = e8.y & 63u;
+          const uint32_t filt = e8.y >> 6;
+          if (ecnt == 1u) {
+            const uint32_t xf = (filt ^ qremA) & gmask13; /* the row's own context symbols */
+            hopeless = (uint32_t)__popc((xf | (xf >> 1)) & 0x55555555u) > bl;
+          } else if (ecnt > 1u) {
+            /* a query symbol none of the rows shows at its position is a substitution in every row */
+            hopeless = (uint32_t)__popc(qhot & ~filt) > bl;
+            if (ecnt == GS_PT_BIG && !hopeless) { /* 63 rows and more: the count sits in a header slot in front of them */
+              ecnt = arow[ent.x];
+              ent.x += 1u;
+              if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(true));
+            }
           }
-          hopeless = hopeless || intact + bl < n_gpairs;
+        } else {
+          const uint4 *ep = (in_rot ? arot : atab) + ei;
+          if (act) ent = *ep;
+          count_lines(c_tab, act, ep);
+          ecnt = ent.y & 0x7FFFFFFFu;
+          eflag = ent.y >> 31;
+          /* context mask: drop the seed when fewer of the query's symbol pairs occur to the left of its
+           * interval's rows than the remaining budget can break, or none of the PAM's pairs does */
+          if (use_mask && eflag == 0u) {
+            const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
+            uint32_t intact = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+              if ((g_pairs >> j) & 1u) intact += (em[j] >> ((qpairs >> (4u * j)) & 15u)) & 1u;
+              if (((pam_pairs >> j) & 1u) && (em[j] & pam16[j]) == 0u) hopeless = true;
+            }
+            hopeless = hopeless || intact + bl < n_gpairs;
+          }
         }
         const bool live = act && ecnt != 0u && !hopeless && !(a.dbg_skip & 2u);
         const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
@@ -2080,7 +2114,8 @@ static inline uint64_t recipe_word(uint32_t n, uint32_t lo, bool rot, uint32_t r
 /* this strand's seeds: variants of the first k-2 steps with j substitutions (ax of them among the first
  * nX steps, set X) x the two-symbol extensions the budget allows; two-sided (astar != nullptr): only
  * what has ax < astar[substitutions outside X] */
-static void build_recipes_a(std::vector<uint64_t> &out, uint32_t k, uint32_t m, uint32_t nX, const uint32_t *astar, bool rot) {
+static void build_recipes_a(std::vector<uint64_t> &out, uint32_t k, uint32_t m, uint32_t nX, const uint32_t *astar, bool rot,
+                            bool pair8 = false) {
   const uint32_t kp = k - 2, xmask = nX >= 32 ? 0xFFFFFFFFu : (1u << nX) - 1u;
   auto mine = [&](uint32_t ax, uint32_t o) { return !astar || (o < 8 && ax < astar[o]); };
   const uint32_t jmax = std::min(std::min(m, kp), 7u);
@@ -2114,7 +2149,8 @@ static void build_recipes_a(std::vector<uint64_t> &out, uint32_t k, uint32_t m, 
             for (uint32_t e1 = 0; e1 < 4; e1++) emit(e2, e1, false, 0);
         } else if (eb == 1) { /* one line of the plain table + one of the copy rotated at step k-2 */
           for (uint32_t e1 = 0; e1 < 4; e1++) emit(0, e1, false, 0);
-          for (uint32_t e2 = 1; e2 < 4; e2++) emit(e2, 0, rot, k - 2);
+          /* a PAM-pair table's 8-byte entries: the three are in the same 128-byte block as the four */
+          for (uint32_t e2 = 1; e2 < 4; e2++) emit(e2, 0, rot && !pair8, k - 2);
         } else {
           emit(0, 0, rot && j >= 1, plast);
         }
@@ -2200,11 +2236,14 @@ static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m
   build_recipes_a(all, k, m, v_rem, nullptr, rot);
   const size_t n_full = all.size();
   size_t n_a = 0, n_b = 0;
+  size_t n_a8 = 0;
   if (astar) {
     build_recipes_a(all, k, m, v_rem, astar, rot);
     n_a = all.size() - n_full;
     build_recipes_b(all, k, L, P, m, v_rem, astar, rot, deep);
     n_b = all.size() - n_full - n_a;
+    build_recipes_a(all, k, m, v_rem, astar, rot, true); /* this strand's share read through PAM-pair tables */
+    n_a8 = all.size() - n_full - n_a - n_b;
   }
   if (all.size() >= (1ull << 31)) {
     gs_set_error("seed plan too large for this mismatch budget");
@@ -2221,8 +2260,9 @@ static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m
   R.n_full = (uint32_t)n_full;
   R.n_a = (uint32_t)n_a;
   R.n_b = (uint32_t)n_b;
-  R.a_rot_first = 31;
-  for (size_t i = n_full; i < n_full + n_a; i++)
+  R.n_a8 = (uint32_t)n_a8;
+  R.a_rot_first = 31; /* of the list read through PAM-pair tables */
+  for (size_t i = n_full + n_a + n_b; i < all.size(); i++)
     if (all[i] & 64u) R.a_rot_first = std::min(R.a_rot_first, (uint32_t)(all[i] >> 7) & 31u);
   R.key[0] = key[0];
   R.key[1] = key[1];
@@ -2694,6 +2734,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         sa.n_rec_a = R.n_a;
         sa.rec_b = sa.rec_a + R.n_a;
         sa.n_rec_b = R.n_b;
+        sa.rec_a8 = sa.rec_b + R.n_b;
+        sa.n_rec_a8 = R.n_a8;
         sa.n_pt = n_pt;
         for (uint32_t i = 0; i < n_pt; i++) {
           sa.pt[i][0] = ix->pairtab[pt_slot[i]].d[0];
