@@ -17,12 +17,21 @@ ARGS="--workload $WL --mismatches $M --batch $BATCH --cpu-sample 0"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -- python3 bench.py $ARGS > $SUM/${NAME}_bench_under_rocprof.json 2> $OUT/stats.err
 echo "stats rc=$?"
 f=$(find $OUT/stats -name '*kernel_stats.csv' | head -1)
-if [ -n "$f" ]; then (head -1 "$f"; grep -E 'k_(search|order|locate|prepare|scan|score|km_|collect|gather|patch|huge|compact|sort_)' "$f") > $SUM/${NAME}_kernel_stats.csv; fi
+# every kernel of the run (rocPRIM's sorts and scans included), names cut to 110 characters; the index
+# builder's kernels (k_sa_*, k_ctx_build, ...) are in there too: they run once, before the timed steps
+if [ -n "$f" ]; then python3 - "$f" > $SUM/${NAME}_kernel_stats.csv <<'PY'
+import csv, sys
+w = csv.writer(sys.stdout)
+for row in csv.reader(open(sys.argv[1])):
+    row[0] = row[0][:110]
+    w.writerow(row)
+PY
+fi
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY"; do
   name=$(echo $pass | cut -d' ' -f1 | tr 'A-Z' 'a-z')
-  rocprofv3 --pmc $pass -f csv --kernel-include-regex 'k_search|k_order|k_locate' -d $OUT/pmc_$name -- python3 bench.py $ARGS --steps 1 --warmup 0 > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+  rocprofv3 --pmc $pass -f csv --kernel-include-regex 'k_search|k_order|k_locate|k_big2|k_score' -d $OUT/pmc_$name -- python3 bench.py $ARGS --steps 1 --warmup 0 > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
   echo "pmc $name rc=$?"
-  python3 tools/pmc_summary.py $OUT/pmc_$name k_search k_order k_locate > $SUM/${NAME}_pmc_$name.json
+  python3 tools/pmc_summary.py $OUT/pmc_$name k_search k_order k_locate k_big2 k_score > $SUM/${NAME}_pmc_$name.json
 done
 B=$(python3 -c "import json;print(json.loads(open('$SUM/${NAME}_bench_under_rocprof.json').read().strip().splitlines()[-1])['config']['guides_per_step_per_gpu'])")
 python3 tools/make_traffic_json.py $NAME $WL $B $M $SUM/${NAME}_pmc_fetch_size.json $SUM/${NAME}_pmc_write_size.json $SUM/${NAME}_pmc_sq_wave_cycles.json && cp profiles/traffic.json $SUM/traffic.json
