@@ -139,7 +139,11 @@ struct gs_search_args {
 /* WALK: the Occ walk (X/G stacks, G fan-out) is compiled in - the reference-order walk from the root
  * and inputs whose remainder does not fit ctx[].  The table-only variant (every interval resolved
  * against the context arrays) needs neither the 3.5 KiB stack array per wave nor that code. */
-template <bool CNT, bool WALK>
+/* SPEC: the batch's every PAM pattern (three symbols) has its PAM-pair table and deep table, so every item
+ * seeds this strand's side through a pair table and the other strand's through a deep table, none is
+ * one-sided: the strand tables' side of the seeding (pair masks, rotated copies, PAM expansion) is compiled
+ * out together with the wave-uniform state it keeps alive. */
+template <bool CNT, bool WALK, bool SPEC = false>
 __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk) {
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
   const uint32_t lane = lane_id();
@@ -537,7 +541,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     /* the substitution table of the item: entry 4 * step + digit = what substituting the digit-th
      * other base at that step does to the k-mer's table index and to the path; digit 3 = nothing */
     auto fill_dtab = [&](const bool sideB) __attribute__((always_inline)) {
-      const uint32_t k = a.pt_k, nYb = a.bdeep ? L - a.x_len : k - P, nst = sideB ? nYb : k;
+      const uint32_t k = a.pt_k, nYb = (SPEC || a.bdeep) ? L - a.x_len : k - P, nst = sideB ? nYb : k;
       for (uint32_t e = lane; e < 4u * nst; e += WAVE) {
         const uint32_t s = e >> 2, d = e & 3u;
         const uint32_t t = sideB ? L - 1u - s : s; /* guide symbol the step consumes */
@@ -590,11 +594,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     uint32_t n_gpairs = 0;
     uint32_t pam_pairs = 0;   /* bit j: pair position j lies inside the PAM */
     uint32_t pam16[4] = {0u, 0u, 0u, 0u}; /* PAM pair positions: the 16-bit set of pairs some pattern allows */
-    const bool use_mask = seeding;
+    const bool use_mask = seeding && !SPEC;
     if (seeding) {
       for (uint32_t t = 0; t < a.pt_k; ++t)
         pidx0 |= ((uint32_t)(gr_q >> (2u * t)) & 3u) << (2u * (a.pt_k - 1u - t));
-      for (uint32_t j = 0; j < 4u; ++j) {
+      for (uint32_t j = 0; j < 4u && !SPEC; ++j) {
         const uint32_t s0 = a.pt_k + ((sd.mask_off >> (4u * j)) & 15u), s1 = s0 + 1u;
         if (s1 < L) {
           qpairs |= ((uint32_t)(gr_q >> (2u * s0)) & 15u) << (4u * j);
@@ -636,7 +640,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       bool fallback = false;
       const gs_strand_dev &sb = a.sd[strand ^ 1u];
       const uint32_t k = a.pt_k, sx = a.x_len, nY = k - P;
-      for (uint32_t pj = 0; pj < npams; ++pj) {
+      for (uint32_t pj = 0; pj < npams && !SPEC; ++pj) {
         const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
         uint32_t nn = 0;
         for (uint32_t u = 0; u < P; ++u) nn += ((pw >> (3u * u)) & 7u) == 4u;
@@ -701,7 +705,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         /* context mask for the other strand's seeds: the symbols it consumes next are the complemented
          * X symbols, last first - all guide symbols: up to four pairs, each broken by at most one
          * of the substitutions the seed's budget leaves for X */
-        const uint32_t deep = a.bdeep;
+        const uint32_t deep = SPEC ? 1u : a.bdeep;
         const uint32_t boffs = deep ? 0x6420u : sb.mask_off; /* the deep tables' masks: pairs at 0, 2, 4, 6 */
         uint32_t qpairs_b = 0, b_pairs = 0, n_bpairs = 0;
         for (uint32_t j = 0; j < 4u; ++j) {
@@ -916,7 +920,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         const uint32_t bl = m - kk; /* budget left (>= 0 by construction) */
         bool hopeless = false;
         uint32_t ecnt, eflag = 0u;
-        if (arow != nullptr) {
+        if (SPEC || arow != nullptr) {
           /* PAM-pair table: 8-byte entry {first row of the table's own arrays, rows (6 bits) | filter} */
           const uint2 *ep = (in_rot ? arot8 : atab8) + ei;
           uint2 e8 = make_uint2(0u, 0u);
@@ -1189,15 +1193,21 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   }
 }
 
-#define GS_DEF_SEARCH(NAME, CNT, WALK, WEU)                                                                          \
+#define GS_DEF_SEARCH(NAME, CNT, WALK, SPEC, WEU)                                                                    \
   __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(WEU, WEU))) void NAME(          \
       gs_search_args a) {                                                                                             \
     __shared__ uint4 s_stack[SEARCH_WAVES][(WALK) ? WAVE_LDS_ENTRIES : WAVE_LDS_FAST];                                 \
-    k_search_body<CNT, WALK>(a, s_stack[threadIdx.x / WAVE]);                                                          \
+    k_search_body<CNT, WALK, SPEC>(a, s_stack[threadIdx.x / WAVE]);                                                    \
   }
-GS_DEF_SEARCH(k_search_walk, false, true, GS_WAVES_EU)       /* reference-order walk; remainders beyond ctx[] */
-GS_DEF_SEARCH(k_search_fast, false, false, GS_WAVES_EU_FAST) /* the timed kernel */
-GS_DEF_SEARCH(k_search_count, true, false, GS_WAVES_EU_FAST) /* the same with the request tally (bench.py) */
+GS_DEF_SEARCH(k_search_walk, false, true, false, GS_WAVES_EU)       /* reference-order walk; remainders beyond ctx[] */
+GS_DEF_SEARCH(k_search_fast, false, false, false, GS_WAVES_EU_FAST) /* table seeding, any mix of tables */
+GS_DEF_SEARCH(k_search_count, true, false, false, GS_WAVES_EU_FAST) /* the same with the request tally (bench.py) */
+/* every item through PAM-pair + deep tables: what an NGG / NAG / TTN ... batch runs (the timed kernel of bench.py) */
+#ifndef GS_WAVES_EU_PD
+#define GS_WAVES_EU_PD 8
+#endif
+GS_DEF_SEARCH(k_search_fast_pd, false, false, true, GS_WAVES_EU_PD)
+GS_DEF_SEARCH(k_search_count_pd, true, false, true, GS_WAVES_EU_PD)
 
 /* ---- prepare: ASCII -> packed records (process.hpp:51-63) ------------------ */
 __device__ __forceinline__ int base_code(uint8_t c) {
@@ -2754,7 +2764,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     const size_t dyn = 0;
     const size_t lds_wg = sizeof(uint4) * (walk ? WAVE_LDS_ENTRIES : WAVE_LDS_FAST) * SEARCH_WAVES;
     uint32_t per_cu = (uint32_t)(160u * 1024u / lds_wg);
-    const uint32_t weu = walk ? GS_WAVES_EU : GS_WAVES_EU_FAST;
+    /* every item through PAM-pair + deep tables (no pattern ends in an N, each has its tables): the kernel
+     * without the strand tables' side of the seeding */
+    const bool spec = !walk && sa.bidir && sa.bdeep && n_pt != 0 && n_pt == n_codes && h_pairs[16] == 0 && !getenv("GS_NO_SPEC");
+    const uint32_t weu = walk ? GS_WAVES_EU : spec ? GS_WAVES_EU_PD : GS_WAVES_EU_FAST;
     if (per_cu > weu) per_cu = weu; /* 4 SIMDs x weu waves = weu four-wave workgroups per CU */
     uint32_t grid = (uint32_t)cus * per_cu;
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
@@ -2772,6 +2785,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       if (c) GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
       if (walk)
         hipLaunchKernelGGL(k_search_walk, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+      else if (spec && count_req)
+        hipLaunchKernelGGL(k_search_count_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+      else if (spec)
+        hipLaunchKernelGGL(k_search_fast_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (count_req)
         hipLaunchKernelGGL(k_search_count, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else

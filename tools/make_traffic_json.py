@@ -25,9 +25,11 @@ def main():
     def pick(path, counter):
         """the timed step = the first k_search_fast dispatch after the counting pass (k_search_count)"""
         d = json.loads(Path(path).read_text())
-        counting = d.get("k_search_count", [])
+        # k_search_fast / k_search_count, or their instantiation for batches served by pair + deep tables (_pd)
+        counting = d.get("k_search_count", []) + d.get("k_search_count_pd", [])
         after = max((e["dispatch_id"] for e in counting), default=-1)
-        rows = [e for e in d["k_search_fast"] if e["dispatch_id"] > after]
+        rows = sorted([e for e in d.get("k_search_fast", []) + d.get("k_search_fast_pd", []) if e["dispatch_id"] > after],
+                      key=lambda e: e["dispatch_id"])
         return rows[0][counter] * 1024.0, rows[0]["duration_ms"]
     fetch, dur_f = pick(ffile, "FETCH_SIZE")
     write, dur_w = pick(wfile, "WRITE_SIZE")
