@@ -152,6 +152,9 @@ def lib():
     L.gs_enumerate_general.restype = i32
     L.gs_enumerate_general.argtypes = [vp, vp, u64, u32, vp, u32, C.c_char_p, u32, u32, u32, u32, u32,
                                        C.POINTER(vp)]
+    L.gs_enumerate_general_pams.restype = i32
+    L.gs_enumerate_general_pams.argtypes = [vp, vp, u64, u32, vp, u32, C.c_char_p, vp, u32, u32, u32, u32, u32,
+                                            C.POINTER(vp)]
     L.gs_index_last_guide_flags.restype = i32
     L.gs_index_last_guide_flags.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
     L.gs_format_guide_ex.restype = i32
@@ -183,7 +186,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_enumerate_bulges", "gs_result_ex_get", "gs_result_ex_free", "gs_decode_sequence_ex",
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
-           "gs_index_last_guide_flags", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
+           "gs_index_last_guide_flags", "gs_enumerate_general_pams", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
            "gs_debug_seed_recipes", "gs_debug_choose_thresholds"]
 
 

@@ -72,6 +72,9 @@ struct gs_gsearch_args {
   uint32_t *counts;
   uint32_t *work;   /* [0] work-queue head, [1] error flag (iteration bound hit) */
   uint8_t alt[32][8]; /* alt PAM patterns in consumption order */
+  uint8_t plen[40];   /* symbols of pattern j (alt PAMs, then the guides' own at n_alt): the reference searches
+                         alt PAMs of any length next to the guides' PAM (process.hpp:51-56) */
+  uint32_t p_max;     /* the longest of them */
   uint32_t n_items, L, P, m, n_alt, max_rna, max_dna;
   uint32_t max_iter; /* per-item iteration bound */
 };
@@ -86,9 +89,8 @@ __global__ __launch_bounds__(WAVE) void k_search_general(gs_gsearch_args a) {
   const uint32_t lane = lane_id();
   uint4 *stk = s_stack;
   const uint32_t L = a.L, P = a.P, m = a.m;
-  const uint32_t T_end = L + P;
   const uint32_t npams = P ? a.n_alt + 1u : 1u;
-  const uint32_t reserve = (GFAN - 1) * (T_end + a.max_dna + npams + 4u);
+  const uint32_t reserve = (GFAN - 1) * (L + a.p_max + a.max_dna + npams + 4u);
   const uint32_t limit = GSTACK > reserve ? GSTACK - reserve : 1u;
   const uint32_t BASES[4] = {'A', 'C', 'G', 'T'};
   for (;;) {
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(WAVE) void k_search_general(gs_gsearch_args a) {
       if (guide_step) qc = gg->q[t];
       if (active && inpam) qc = pamid < a.n_alt ? a.alt[pamid][t - L] : gg->pam[t - L];
       const bool wild = active && inpam && qc == 'N'; /* PAM 'N': literal N, then A,T,C,G at cost 0 (index.hpp:139-169) */
+      const uint32_t T_end = L + a.plen[pamid < 40u ? pamid : 39u]; /* where this pattern's PAM stage ends */
 #pragma unroll
       for (uint32_t c = 0; c < 4u; ++c) {
         const uint32_t csp = sd.C[c] + oa[c], cep = sd.C[c] + ob[c] - 1u;
@@ -366,10 +369,18 @@ static uint8_t gen_comp(uint8_t c) {
 static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
                                    const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,
                                    uint32_t mismatches, uint32_t rna_bulges, uint32_t dna_bulges, uint32_t flags,
-                                   gs_result_ex **out) {
+                                   gs_result_ex **out, const uint32_t *alt_lens = nullptr) {
   if (!ix || !out || (n && !guides) || (n && P && !guide_pams) || (n_alt && !alt_pams)) return GS_ERR_ARG;
+  uint32_t p_max = P;
+  for (uint32_t j = 0; alt_lens && j < n_alt && j < 32; j++) {
+    if (alt_lens[j] < 1 || alt_lens[j] > 8) {
+      gs_set_error("alt PAMs of 1 to 8 symbols");
+      return GS_ERR_UNSUPPORTED;
+    }
+    p_max = std::max(p_max, alt_lens[j]);
+  }
   if (L < 1 || L > 31 || P > 8 || mismatches > 7 || n_alt > 31 || rna_bulges > 3 || dna_bulges > 3 ||
-      L + dna_bulges + P > 32 || n >= (1ull << 30)) {
+      L + dna_bulges + p_max > 32 || n >= (1ull << 30)) {
     gs_set_error("general path supports L<=31, P<=8, mismatches<=7, <=31 alt PAMs, <=3 bulges of each kind, "
                  "L+dna_bulges+P<=32");
     return GS_ERR_UNSUPPORTED;
@@ -417,11 +428,18 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
   }
   gs_gsearch_args sa;
   memset(&sa, 0, sizeof(sa));
-  for (uint32_t j = 0; j < (P ? n_alt : 0u); j++)
-    for (uint32_t u = 0; u < P; u++) {
-      const uint8_t *p = (const uint8_t *)alt_pams + j * P;
-      sa.alt[j][u] = start ? p[P - 1 - u] : gen_comp(p[u]);
+  {
+    size_t at = 0; /* alt PAMs back to back: P symbols each, or alt_lens[j] */
+    for (uint32_t j = 0; j < (P ? n_alt : 0u); j++) {
+      const uint32_t pl = alt_lens ? alt_lens[j] : P;
+      const uint8_t *p = (const uint8_t *)alt_pams + at;
+      for (uint32_t u = 0; u < pl; u++) sa.alt[j][u] = start ? p[pl - 1 - u] : gen_comp(p[u]);
+      sa.plen[j] = (uint8_t)pl;
+      at += pl;
     }
+    sa.plen[P ? n_alt : 0u] = (uint8_t)P;
+    sa.p_max = p_max;
+  }
   GS_TRY(d_g.get(sizeof(gs_gen_guide) * n));
   GS_TRY(d_cnt.get(8 * n));
   GS_TRY(d_misc.get(64));
@@ -570,6 +588,20 @@ extern "C" gs_status gs_enumerate_general(gs_index *ix, const char *guides, uint
   try {
     return enumerate_general(ix, guides, n, L, guide_pams, P, alt_pams, n_alt, mismatches, rna_bulges, dna_bulges,
                              flags, out);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
+}
+/* the same with alt PAMs of their own lengths (alt_pams: the patterns back to back, alt_lens[j] symbols each) */
+extern "C" gs_status gs_enumerate_general_pams(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
+                                               const char *guide_pams, uint32_t P, const char *alt_pams,
+                                               const uint32_t *alt_lens, uint32_t n_alt, uint32_t mismatches,
+                                               uint32_t rna_bulges, uint32_t dna_bulges, uint32_t flags,
+                                               gs_result_ex **out) {
+  if (n_alt && !alt_lens) return GS_ERR_ARG;
+  try {
+    return enumerate_general(ix, guides, n, L, guide_pams, P, alt_pams, n_alt, mismatches, rna_bulges, dna_bulges,
+                             flags, out, alt_lens);
   } catch (const std::bad_alloc &) {
     return GS_ERR_NOMEM;
   }

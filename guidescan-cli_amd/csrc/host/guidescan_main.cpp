@@ -258,6 +258,7 @@ struct enumerate_job {
   gs_genome_structure cgs{};
   std::vector<const char *> names;
   std::string alts;
+  std::vector<uint32_t> alt_lens; /* symbols of each alt PAM: any length next to the guides' PAM (process.hpp:51-56) */
   uint32_t n_alt = 0;
   uint32_t mismatches = 3, rna = 0, dna = 0, tflags = 0, sflags = 0;
   long long max_off = -1, threshold = -1;
@@ -344,11 +345,25 @@ static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
   const uint32_t L = (uint32_t)job.kmers[b.lo].sequence.size(), P = (uint32_t)job.kmers[b.lo].pam.size();
   const uint32_t n_alt = P ? job.n_alt : 0;
   const bool bulges = job.rna > 0 || job.dna > 0;
+  /* an alt PAM shorter or longer than the batch's PAM: the fixed-width fast path does not take it; the
+   * general path searches every pattern at its own length, as the reference does */
+  bool mixed = false;
+  for (uint32_t j = 0; j < n_alt; j++) mixed = mixed || job.alt_lens[j] != P;
   gs_status rc;
   /* --threshold t (process.hpp:66-76): a guide with more than one hit within t mismatches (both
    * indexes, bulges off; counted per PAM pattern, before duplicate sequences collapse) is dropped
    * before the real search */
-  if (job.threshold > 0) {
+  if (job.threshold > 0 && mixed) {
+    gs_result_ex *cx = nullptr;
+    rc = gs_enumerate_general_pams(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), job.alt_lens.data(), n_alt,
+                                   (uint32_t)job.threshold, 0, 0, job.sflags, &cx);
+    if (rc != GS_OK) return gs_status_string(rc);
+    const uint32_t *xraw = nullptr;
+    gs_result_ex_raw_hits(cx, &xraw);
+    b.skip.assign(n, 0);
+    for (size_t g = 0; g < n; g++) b.skip[g] = xraw[g] > 1;
+    gs_result_ex_free(cx);
+  } else if (job.threshold > 0) {
     gs_result *cres = nullptr;
     rc = gs_enumerate(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), n_alt, (uint32_t)job.threshold,
                       job.sflags | GS_FLAG_RAW_COUNTS, &cres);
@@ -382,10 +397,10 @@ static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
     }
     gs_result_free(cres);
   }
-  if (bulges) {
-    /* bulge-aware search: index.hpp:250-375 behind gs_enumerate_general */
-    rc = gs_enumerate_general(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), n_alt, job.mismatches,
-                              job.rna, job.dna, job.sflags, &b.resx);
+  if (bulges || mixed) {
+    /* bulge-aware search: index.hpp:250-375 behind gs_enumerate_general; alt PAMs of other lengths: the same entry */
+    rc = gs_enumerate_general_pams(ix, b.seqs.data(), n, L, b.pams.data(), P, job.alts.data(), job.alt_lens.data(), n_alt,
+                                   job.mismatches, job.rna, job.dna, job.sflags, &b.resx);
     if (rc != GS_OK) return gs_status_string(rc);
     b.gen_of.resize(n);
     for (size_t g = 0; g < n; g++) b.gen_of[g] = (uint32_t)g;
@@ -583,18 +598,16 @@ int do_enumerate(int argc, char **argv) {
     job.batches.push_back(std::move(b));
     done = end;
   }
-  /* alt PAMs shorter or longer than the guides' PAM can never complete a match of the same length
-   * class: the reference searches them all the same (process.hpp:51-56) and so does the general
-   * path; the fixed-width fast path takes the ones of the batch's PAM length */
-  size_t palen = 0;
-  for (auto &b : job.batches) palen = std::max(palen, job.kmers[b.lo].pam.size());
+  /* alt PAMs are searched whatever their length, next to each guide's own PAM (process.hpp:51-56): a batch
+   * whose PAM length they all share goes through the fast path, any other through the general path */
   for (auto &a : alt_pams) {
-    if (a.size() != palen) {
-      std::cerr << "error: alt PAM " << a << " differs in length from the guides' PAM\n";
+    if (a.empty() || a.size() > 8) {
+      std::cerr << "error: alt PAM " << a << ": 1 to 8 symbols\n";
       for (gs_index *p : ix) gs_index_close(p);
       return 1;
     }
     job.alts += a;
+    job.alt_lens.push_back((uint32_t)a.size());
     job.n_alt++;
   }
 

@@ -307,6 +307,14 @@ gs_status gs_enumerate_general(gs_index *ix, const char *guides, uint64_t n, uin
                                const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,
                                uint32_t mismatches, uint32_t rna_bulges, uint32_t dna_bulges,
                                uint32_t flags, gs_result_ex **out);
+/* The same with alt PAMs of their own lengths: the reference searches every pattern of `-a` next to the
+ * guides' PAM whatever its length (process.hpp:51-56 -> index.hpp:182-216: the PAM stage of a pattern ends
+ * after its own symbols), so a hit's match.sequence has L + that pattern's length symbols.  alt_pams: the
+ * n_alt patterns back to back, alt_lens[j] symbols each (1..8). */
+gs_status gs_enumerate_general_pams(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
+                                    const char *guide_pams, uint32_t P, const char *alt_pams,
+                                    const uint32_t *alt_lens, uint32_t n_alt, uint32_t mismatches,
+                                    uint32_t rna_bulges, uint32_t dna_bulges, uint32_t flags, gs_result_ex **out);
 /* the same function under the name the bulge options were first served by */
 gs_status gs_enumerate_bulges(gs_index *ix, const char *guides, uint64_t n, uint32_t L,
                               const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,

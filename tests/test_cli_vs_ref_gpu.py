@@ -114,3 +114,29 @@ def test_cli_accepts_what_the_reference_accepts(tmp_path):
         subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(kcsv), "-o", str(out), "-n", "2",
                         "--batch-size", "7"] + cli_args(**cfg), check=True, timeout=300)
         assert out.read_bytes() == want, cfg
+
+
+def test_cli_alt_pams_of_other_lengths_equal_the_compiled_reference(tmp_path):
+    """`-a` patterns shorter or longer than the guides' PAM: the reference searches each at its own length
+    next to the guides' own (process.hpp:51-56), so rows of one guide carry match sequences of different
+    lengths; the CLI routes such batches through the general path (gs_enumerate_general_pams) and writes the
+    same files - CSV and SAM, with --threshold (counted per pattern), --start, a bulge, --max-off-targets"""
+    text, names, lengths, rows = pipe.random_case(601)
+    kcsv = tmp_path / "kmers.csv"
+    pipe.synth.write_kmers_csv(kcsv, [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows],
+                               [names[0]] * len(rows), [1] * len(rows), [r[3] for r in rows])
+    oidx = ol.OracleIndex(text)
+    try:
+        pipe.write_reference_index(oidx, text.shape[0] + 1, tmp_path / "r.idx", names, lengths)
+    finally:
+        oidx.close()
+    text.tofile(tmp_path / "g.dna")
+    (tmp_path / "g.gs").write_text("".join(f"{a}\n{b}\n" for a, b in zip(names, lengths)))
+    for cfg in (dict(m=2, alt=("NG",)), dict(m=2, alt=("NGGN", "NAG")), dict(m=3, fmt="sam", alt=("G", "NNGRRT")),
+                dict(m=1, start=True, alt=("TTTN",)), dict(m=2, thr=1, alt=("NG",)), dict(m=2, maxo=3, alt=("NGGNG",), complete=False),
+                dict(m=1, rna=1, alt=("NGAN",))):
+        want = pipe.run_shim(tmp_path / "r.idx", kcsv, tmp_path / "want", **cfg)
+        out = tmp_path / "got"
+        subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(kcsv), "-o", str(out), "-n", "2",
+                        "--batch-size", "9"] + cli_args(**cfg), check=True, timeout=300)
+        assert out.read_bytes() == want, cfg
