@@ -349,6 +349,9 @@ static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
    * general path searches every pattern at its own length, as the reference does */
   bool mixed = false;
   for (uint32_t j = 0; j < n_alt; j++) mixed = mixed || job.alt_lens[j] != P;
+  /* a match sequence beyond the 52 bits of the fast path's key (23-mers with a four-symbol PAM): the general
+   * path carries sequences as bytes */
+  if (2 * L + 3 * P > 52) mixed = true;
   gs_status rc;
   /* --threshold t (process.hpp:66-76): a guide with more than one hit within t mismatches (both
    * indexes, bulges off; counted per PAM pattern, before duplicate sequences collapse) is dropped

@@ -140,3 +140,36 @@ def test_cli_alt_pams_of_other_lengths_equal_the_compiled_reference(tmp_path):
         subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(kcsv), "-o", str(out), "-n", "2",
                         "--batch-size", "9"] + cli_args(**cfg), check=True, timeout=300)
         assert out.read_bytes() == want, cfg
+
+
+def test_cli_guides_beyond_the_fast_key_equal_the_compiled_reference(tmp_path):
+    """23-mers with a four-symbol PAM at the 5' end (Cas12a: TTTN + --start): 2L + 3P = 58 bits of match
+    sequence do not fit the fast path's 52-bit key, so the CLI sends the batch through the general path; the
+    files equal the compiled reference's.  Guides are read off the genome behind TTT sites, so they hit."""
+    text, names, lengths, _ = pipe.random_case(701)
+    t = text.tobytes()
+    rows, at = [], 0
+    while len(rows) < 10:
+        at = t.find(b"TTT", at + 1)
+        assert at >= 0
+        w = t[at:at + 27]
+        if len(w) == 27 and set(w) <= set(b"ACGT"):
+            rows.append((f"c{len(rows)}", w[4:].decode(), "TTTN", "+"))
+            at += 40
+    kcsv = tmp_path / "kmers.csv"
+    pipe.synth.write_kmers_csv(kcsv, [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows],
+                               [names[0]] * len(rows), [1] * len(rows), [r[3] for r in rows])
+    oidx = ol.OracleIndex(text)
+    try:
+        pipe.write_reference_index(oidx, text.shape[0] + 1, tmp_path / "r.idx", names, lengths)
+    finally:
+        oidx.close()
+    text.tofile(tmp_path / "g.dna")
+    (tmp_path / "g.gs").write_text("".join(f"{a}\n{b}\n" for a, b in zip(names, lengths)))
+    for cfg in (dict(m=2, start=True), dict(m=3, start=True, fmt="sam"), dict(m=1, start=True, alt=("TTN",))):
+        want = pipe.run_shim(tmp_path / "r.idx", kcsv, tmp_path / "want", **cfg)
+        assert want.count(b"\n") > len(rows)
+        out = tmp_path / "got"
+        subprocess.run([str(CLI), "enumerate", str(tmp_path / "g"), "-f", str(kcsv), "-o", str(out), "-n", "2",
+                        "--batch-size", "4"] + cli_args(**cfg), check=True, timeout=300)
+        assert out.read_bytes() == want, cfg
