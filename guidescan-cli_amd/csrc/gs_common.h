@@ -180,6 +180,7 @@ struct gs_index {
   gs_pairtab_host pairtab[2];
   bool pairtab_off = false; /* a batch ran out of memory next to them: not built again on this handle */
   bool rot_off = false;     /* the same for the strand tables' rotated copies */
+  bool big_long_runs = false; /* a batch showed long runs of one sequence (repeat-rich genome): the device-wide ordering sorts by row, then by word (gs_search.hip) */
 };
 
 /* make sure slot `slot` holds the tables of pair `code` at context depth v_rem with rotated copies from

@@ -1913,6 +1913,42 @@ __global__ void k_big2_gather_w(const unsigned long long *W, const uint32_t *idx
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r < T) out[r] = W[idx[r]];
 }
+/* After a sort by W alone: put the rows inside each run of equal W in order.  Nearly every run holds one
+ * record (a sequence found at one row: every record of a batch on a repeat-free genome), a few hold several
+ * (the same sequence at several rows): thread r finds its run by looking at most `short_max` words either
+ * way, counts the records that go before it (smaller first row, ties by position) and stores its record's
+ * position there.  A run longer than that raises *long_run: the batch is then ordered by the two sorts
+ * (rows, then W) instead, and so are the handle's later batches - a repeat-rich genome has runs of 10^4. */
+__global__ __launch_bounds__(256) void k_big2_runs(const unsigned long long *W, const uint32_t *idx_in, const uint4 *recs,
+                                                   uint64_t T, uint32_t short_max, uint32_t *idx_out, uint32_t *long_run) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= T) return;
+  const unsigned long long w = W[r];
+  const uint32_t mine = idx_in[r];
+  if (!(r > 0 && W[r - 1] == w) && !(r + 1 < T && W[r + 1] == w)) { /* a run of one */
+    idx_out[r] = mine;
+    return;
+  }
+  uint64_t s = r, e = r + 1;
+  while (s > 0 && r - s < short_max && W[s - 1] == w) s--;
+  while (e < T && e - r < short_max && W[e] == w) e++;
+  if ((s > 0 && W[s - 1] == w) || (e < T && W[e] == w) || e - s > short_max) {
+    *long_run = 1u;
+    idx_out[r] = mine;
+    return;
+  }
+  const uint32_t myrow = recs[mine].z;
+  uint64_t rank = 0;
+  for (uint64_t j = s; j < e; j++) {
+    const uint32_t z = recs[idx_in[j]].z;
+    rank += (z < myrow || (z == myrow && j < r)) ? 1u : 0u;
+  }
+  idx_out[s + rank] = mine;
+}
+__global__ void k_iota_u32(uint32_t *p, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = (uint32_t)i;
+}
 /* keep[r] = 1 when ordered record r starts a new (guide, key, first row); rows[r] = its row count */
 __global__ void k_big2_flags(const uint4 *S2, const unsigned long long *W, uint64_t T, uint32_t *keep,
                              unsigned long long *rows) {
@@ -2302,6 +2338,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
     if (rc == GS_ERR_NOMEM && ix && gs_strand_rot_release(ix)) {
       (void)hipGetLastError();
       ix->rot_off = true;
+      ix->pairtab_nofit = 0; /* 86 GB came back: a pair that did not fit may now */
       if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: rotated table copies dropped, batch redone without them\n");
       rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets,
                                  d_hits, stats);
@@ -2452,6 +2489,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   for (uint32_t c = 0; c < 16; c++) {
     if (!h_pairs[c]) continue;
     n_codes++;
+    if (ix->pairtab_nofit & (1u << c)) continue; /* its tables did not fit on this handle: not tried again */
     if (want[0] == 16 || h_pairs[c] > h_pairs[want[0]]) {
       want[1] = want[0];
       want[0] = c;
@@ -2560,7 +2598,39 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
             return rc;
           if (ix->pairtab[s].valid) pt_slot[n_pt++] = s;
         }
-        if (n_pt == n_want || n_want < 2 || round == 1 || (flags & GS_FLAG_NO_NEW_TABLES)) break;
+        if (n_pt == n_want || n_want < 2 || (flags & GS_FLAG_NO_NEW_TABLES)) break;
+        /* a pair whose tables did not fit: remembered on the handle, so that later batches do not free and
+         * rebuild the first pair's tables every call for nothing (cleared when memory is given back) */
+        auto mark_missing = [&]() {
+          for (uint32_t i = 0; i < max_pt; i++) {
+            if (want[i] == 16) continue;
+            bool have = false;
+            for (uint32_t j = 0; j < 2; j++)
+              have = have || (ix->pairtab[j].valid && ix->pairtab[j].code == want[i] && ix->pairtab[j].v_rem == v_rem);
+            if (!have) ix->pairtab_nofit |= 1u << want[i];
+          }
+        };
+        if (round == 1) {
+          mark_missing();
+          break;
+        }
+        /* round 1 frees a valid first table only when two tables without any rotated copy are known to fit */
+        {
+          size_t free_b = 0, total_b = 0;
+          GS_HIP(hipMemGetInfo(&free_b, &total_b));
+          double reserve = 64e9;
+          if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
+          if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
+          double room = (double)free_b + (double)ix->pairtab[0].bytes + (double)ix->pairtab[1].bytes - reserve;
+          if (const char *e = getenv("GS_INDEX_BUDGET_GB"))
+            room = std::min(room, atof(e) * 1e9 - (double)(ix->strand[0].bytes + ix->strand[1].bytes));
+          const double one = 2.0 * 8.0 * (double)(1ull << (2 * ix->pt_k)) + 10.0 * 1.5 * ((double)ix->strand[0].n + (double)ix->strand[1].n) / 16.0 +
+                             8.0 * (double)(1ull << (2 * ix->pt_k)) + 64e6;
+          if (2.0 * one > room) {
+            mark_missing();
+            break;
+          }
+        }
         gs_pairtab_free(ix, 0);
         gs_pairtab_free(ix, 1);
       }
@@ -2871,6 +2941,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   uint64_t big_T = 0;
   bool big_used = false, big_v2 = false;
   void *big_s2 = nullptr; /* the records in final order (one-word form) */
+  const unsigned long long *big_wfinal = nullptr; /* and their sort words */
   uint32_t big_gshift = 0;
   /* the device-wide ordering runs in its one-word form (k_big2_*) when the sort word fits 64 bits */
   unsigned long long big_pam_mul = 1, big_n_max = 1;
@@ -3000,15 +3071,45 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       GS_HIP(rocprim::radix_sort_pairs(nullptr, s1, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
       GS_HIP(rocprim::radix_sort_pairs(nullptr, s2, Wb, W, idxb, idx, (size_t)T, 0, gbits + 4 + rbits, st));
       if ((r2 = gs_reserve(ix->w_h_tmp, std::max(s1, s2) + 16)) != GS_OK) return r2;
-      tbs = ix->w_h_tmp.cap;
-      GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
       const unsigned gT = (unsigned)((T + 255) / 256);
-      hipLaunchKernelGGL(k_big2_gather_w, dim3(gT), dim3(256), 0, st, (const unsigned long long *)W, (const uint32_t *)idxb, T, Wb);
-      tbs = ix->w_h_tmp.cap;
-      GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, Wb, W, idxb, idx, (size_t)T, 0, gbits + 4 + rbits, st));
-      /* W = the sort words in final order, idx = where each record sits in recs */
-      hipLaunchKernelGGL(k_big2_gather, dim3(gT), dim3(256), 0, st, (const uint4 *)recs, (const uint32_t *)idx, T, S2);
-      hipLaunchKernelGGL(k_big2_flags, dim3(gT), dim3(256), 0, st, (const uint4 *)S2, (const unsigned long long *)W, T,
+      const unsigned long long *W_final = nullptr;
+      const uint32_t *idx_final = nullptr;
+      /* One sort by W and the rows put in order inside its (short, rare) runs - unless this handle has seen a
+       * batch with long runs of one sequence (a repeat-rich genome): then, and for the batch that shows the
+       * first such run, two stable sorts: by first row, then by W. */
+      uint32_t short_max = 32;
+      if (const char *e = getenv("GS_BIG2_SHORT")) short_max = (uint32_t)std::max(1l, atol(e));
+      if (!ix->big_long_runs && !getenv("GS_BIG2_TWO_SORTS")) {
+        tbs = ix->w_h_tmp.cap;
+        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, W, Wb, idx, idxb, (size_t)T, 0, gbits + 4 + rbits, st));
+        uint32_t *d_long = d_work + 6;
+        GS_HIP(hipMemsetAsync(d_long, 0, 4, st));
+        hipLaunchKernelGGL(k_big2_runs, dim3(gT), dim3(256), 0, st, (const unsigned long long *)Wb, (const uint32_t *)idxb,
+                           (const uint4 *)recs, T, short_max, idx, d_long);
+        uint32_t h_long = 0;
+        GS_HIP(hipMemcpyAsync(&h_long, d_long, 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        if (!h_long) {
+          W_final = Wb;
+          idx_final = idx;
+        } else {
+          ix->big_long_runs = true;
+          hipLaunchKernelGGL(k_iota_u32, dim3(gT), dim3(256), 0, st, idx, T);
+        }
+      }
+      if (!W_final) {
+        tbs = ix->w_h_tmp.cap;
+        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
+        hipLaunchKernelGGL(k_big2_gather_w, dim3(gT), dim3(256), 0, st, (const unsigned long long *)W, (const uint32_t *)idxb, T, Wb);
+        tbs = ix->w_h_tmp.cap;
+        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, Wb, W, idxb, idx, (size_t)T, 0, gbits + 4 + rbits, st));
+        W_final = W;
+        idx_final = idx;
+      }
+      big_wfinal = W_final;
+      /* W_final = the sort words in final order, idx_final = where each record sits in recs */
+      hipLaunchKernelGGL(k_big2_gather, dim3(gT), dim3(256), 0, st, (const uint4 *)recs, idx_final, T, S2);
+      hipLaunchKernelGGL(k_big2_flags, dim3(gT), dim3(256), 0, st, (const uint4 *)S2, W_final, T,
                          (uint32_t *)ix->w_b_keep.p, (unsigned long long *)ix->w_b_rows.p);
     } else if (T) {
       hipLaunchKernelGGL(k_big_compact, dim3(n_it), dim3(256), 0, st, (const uint4 *)ix->w_slots.p,
@@ -3085,7 +3186,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       la.sd[0] = ix->strand[0].d;
       la.sd[1] = ix->strand[1].d;
       la.S2 = (const uint4 *)big_s2;
-      la.W = (const unsigned long long *)ix->w_b_w0.p;
+      la.W = big_wfinal;
       la.keep = (const uint32_t *)ix->w_b_keep.p;
       la.row_scan = (const unsigned long long *)ix->w_b_rowss.p;
       la.prefix = (const unsigned long long *)ix->w_b_prefix.p;

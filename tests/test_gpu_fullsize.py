@@ -415,35 +415,40 @@ def test_hg38_alt_pam_through_two_pair_tables_equals_the_compiled_reference(hg38
 
 
 
-def test_hg38_out_of_memory_drops_the_pair_tables_and_redoes_the_batch(hg38):
-    """the PAM-pair and deep tables are derived data (56 GB next to 184 GB of strand tables): a batch whose
-    workspace no longer fits drops them and is redone without them - same bytes, no error.  Forced here by
-    a ballast allocation that leaves less room than the batch needs.  (Last test of the module: the handle
-    goes on without its pair tables afterwards.)"""
+def test_hg38_out_of_memory_drops_derived_tables_and_redoes_the_batch(hg38):
+    """the strand tables' rotated copies (86 GB, built by the one-sided runs above) and the PAM-pair / deep
+    tables (26 GB) are derived data: a batch whose workspace no longer fits drops them - the rotated copies
+    first, the pair tables next - and is redone without them: same bytes, no error.  Forced here by ballast
+    allocations that leave 1 GB.  (Last test of the module: the handle goes on without them afterwards.)"""
     import torch
-    n = 200_000
+    n = 260_000
     seqs, pams, pos, strands = synth.sample_guides(hg38.text, n, seed=1003)
     d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
     hip = _hip()
-    d_off, d_hits, st = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=4)
-    ctr = hg38.gidx.last_counters()
-    assert ctr["items_pair_tables"] > 0, ctr
-    off, hits = device_result_to_host(hip, d_off, d_hits, n, st["n_hits"])
-    bytes_with_tables = hg38.gidx.device_bytes
-    # leave ~1 GB: the next batch at a larger budget (its slots alone are several GB) cannot get its workspace
-    free, total = torch.cuda.mem_get_info()
-    ballast = torch.empty(max(0, free - (1 << 30)), dtype=torch.uint8, device="cuda")
-    try:
-        d_o, d_h, st2 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=5)
-        ctr2 = hg38.gidx.last_counters()
-        assert ctr2["items_pair_tables"] == 0, ctr2                    # redone without the tables ...
-        assert hg38.gidx.device_bytes < bytes_with_tables - 20e9       # ... which are gone from the HBM
-        assert st2["n_hits"] > st["n_hits"]
-    finally:
-        del ballast
-        torch.cuda.empty_cache()
+    n4 = 200_000
+    d_off, d_hits, st = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n4, 20, d_pams.data_ptr(), 3, mismatches=4)
+    assert hg38.gidx.last_counters()["items_pair_tables"] > 0
+    off, hits = device_result_to_host(hip, d_off, d_hits, n4, st["n_hits"])
+
+    def starved(n_guides):
+        """one m <= 5 call with 1 GB of HBM left; returns the bytes the handle gave back"""
+        before = hg38.gidx.device_bytes
+        free, total = torch.cuda.mem_get_info()
+        ballast = torch.empty(max(0, free - (1 << 30)), dtype=torch.uint8, device="cuda")
+        try:
+            _, _, st5 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n_guides, 20, d_pams.data_ptr(), 3, mismatches=5)
+            assert st5["n_hits"] > 1000 * n_guides
+        finally:
+            del ballast
+            torch.cuda.empty_cache()
+        return before - hg38.gidx.device_bytes
+
+    freed1 = starved(200_000)          # its slots alone are 11 GB: something has to go
+    assert freed1 > 20e9, freed1
+    freed2 = starved(260_000)          # a larger batch again: the next kind of table goes
+    assert freed1 + freed2 > 100e9, (freed1, freed2)   # both kinds are gone: 86 GB + 26 GB
     # and the m <= 4 batch, now through the strand tables alone, returns the same bytes as before
-    d_o, d_h, st3 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=4)
+    d_o, d_h, st3 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n4, 20, d_pams.data_ptr(), 3, mismatches=4)
     assert hg38.gidx.last_counters()["items_pair_tables"] == 0
-    o3, h3 = device_result_to_host(hip, d_o, d_h, n, st3["n_hits"])
+    o3, h3 = device_result_to_host(hip, d_o, d_h, n4, st3["n_hits"])
     assert np.array_equal(o3, off) and h3.tobytes() == hits.tobytes()

@@ -549,8 +549,11 @@ def test_config1_saccer3_sized_1k_guides_m1():
 
 ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                # the device-wide ordering in the form that serves sort words beyond 64 bits (raw keys)
-               ("GS_BIG_ORDER_V1", "1")]
-ARENA_IDS = ["arena", "second-pass", "arena-exhausted", "raw-key-order"]
+               ("GS_BIG_ORDER_V1", "1"),
+               # the one-word form as one sort + rows ordered inside the runs of equal words, whatever their length
+               # (the default gives up on runs beyond 32 records and sorts by row first), and the two sorts from the start
+               ("GS_BIG2_SHORT", "1000000"), ("GS_BIG2_TWO_SORTS", "1")]
+ARENA_IDS = ["arena", "second-pass", "arena-exhausted", "raw-key-order", "one-sort-and-runs", "two-sorts"]
 
 
 @pytest.mark.parametrize("arena", ARENA_MODES, ids=ARENA_IDS)
