@@ -95,15 +95,21 @@ __global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, uint64_t n_
   const uint32_t pam_len = slen < 20u ? 0u : (slen - 20u < 3u ? slen - 20u : 3u);
   const bool scored = L == 20u && pam_len == 3u; /* printer.hpp:99 */
   for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_hits; h += (uint64_t)gridDim.x * blockDim.x) {
-    /* the guide of hit h: last g with offsets[g] <= h (neighbouring threads walk the same path) */
+    /* the guide of hit h: last g with offsets[g] <= h.  One binary search per wavefront (for its first hit,
+     * on scalar loads), then a short walk: 64 consecutive hits belong to one guide on a repeat-rich
+     * batch and to five on a batch with 13 hits per guide */
+    const uint64_t h_lane0 = h - (threadIdx.x & (WAVE - 1u));
+    const uint64_t h_first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(h_lane0 >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)h_lane0); /* wave-uniform: scalar loads below */
     uint32_t lo = 0, hi = a.n;
     while (hi - lo > 1u) {
       const uint32_t mid = (lo + hi) >> 1;
-      if (a.offsets[mid] <= h)
+      if (a.offsets[mid] <= h_first)
         lo = mid;
       else
         hi = mid;
     }
+    while (lo + 1u < a.n && a.offsets[lo + 1u] <= h) lo++;
     const uint8_t *gd = a.guides + (size_t)lo * L;
     const gs_hit hit = a.hits[h];
     const uint64_t path = (hit.key >> 8) & ((1ull << 52) - 1ull);
@@ -158,14 +164,27 @@ __global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a
     uint32_t perfect = 0u, cur_d = 0xFFFFFFFFu;
     unsigned long long raw = 0, kept = 0; /* hits / hits that counted so far at distance cur_d */
     const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
+    /* the next block's loads are in flight while this block's additions run (a guide with 4 x 10^5 hits is
+     * 6,900 blocks on one wavefront: their load latency, not the additions, set its time) */
+    float c_next = 0.0f;
+    uint32_t inf_next = 8u;
+    if (hb + lane < he) {
+      c_next = cf[hb + lane];
+      inf_next = info[hb + lane];
+    }
     for (uint64_t h0 = hb; h0 < he; h0 += WAVE) {
       const uint64_t h = h0 + lane;
       const bool valid = h < he;
-      float c = 0.0f;
+      const float c = c_next;
+      const uint32_t inf = inf_next;
+      c_next = 0.0f;
+      inf_next = 8u;
+      if (h + WAVE < he) {
+        c_next = cf[h + WAVE];
+        inf_next = info[h + WAVE];
+      }
       uint32_t d = 8u, sent = 0u, pgg = 0u;
       if (valid) {
-        c = cf[h];
-        const uint32_t inf = info[h];
         d = inf & 7u;
         sent = (inf >> 3) & 1u;
         pgg = (inf >> 4) & 1u;
