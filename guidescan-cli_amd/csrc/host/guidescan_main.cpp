@@ -8,7 +8,7 @@
  *       PREFIX.dna (= the reference's <fasta>.forward.dna: upper-cased concatenated sequence,
  *       seq_io.cxx:57-63).  The FM-index itself is built on the GPU when `enumerate` starts
  *       (~25 s at hg38 size, about what the reference needs to load its index files).
- *   guidescan enumerate PREFIX -f KMERS.csv -o OUT [-m 3] [-a PAM ...] [--format csv|sam]
+ *   guidescan enumerate PREFIX -f KMERS.csv -o OUT [-m 3] [-a PAM ...] [--format csv|sam|bam]
  *       [--mode succinct|complete] [--max-off-targets N] [--start] [--device D] [--gpus N] [--batch-size B]
  *       --gpus N: one index per device (devices D .. D+N-1), one host thread per device pulling batches
  *       from a shared queue, output written in input order (src/guidescan.cxx:226-251 is the
@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "guidescan_amd.h"
+#include "bam_writer.hpp"
 
 namespace {
 
@@ -169,7 +170,7 @@ bool read_kmers(const std::string &path, std::vector<kmer_row> &rows, std::strin
 
 int usage() {
   std::cerr << "usage: guidescan index [--index PREFIX] [--store-sa [--device D]] GENOME.fa\n"
-               "       guidescan enumerate PREFIX -f KMERS -o OUT [-m N] [-a PAM]... [--format csv|sam]\n"
+               "       guidescan enumerate PREFIX -f KMERS -o OUT [-m N] [-a PAM]... [--format csv|sam|bam]\n"
                "                 [--mode succinct|complete] [--max-off-targets N] [--start]\n"
                "                 [--rna-bulges N] [--dna-bulges N] [-t THRESHOLD] [-n FORMAT_THREADS]\n"
                "                 [--device D] [--gpus N] [--batch-size B]\n";
@@ -269,7 +270,24 @@ struct enumerate_job {
   size_t in_flight = 0;    /* searched but not yet written: bounds the host memory held by results */
   size_t max_in_flight = 2;
   double s_device = 0, s_format = 0, s_write = 0; /* seconds spent per stage (stages overlap) */
+  /* --format bam: the SAM lines of the encoder, turned into BAM records and BGZF blocks by the formatting
+   * threads (bam_writer.hpp; the reference leaves that step to `samtools view -b`, manual/manual.tex:581-582) */
+  bool bam = false;
+  std::map<std::string, int32_t> refid;
 };
+
+/* a part's SAM text -> BGZF-compressed BAM records (in place: the text is released) */
+static bool part_to_bam(const enumerate_job &job, text_part &part) {
+  std::string raw;
+  bool ok = true;
+  if (part.p) ok = bam::records(part.p, part.n, job.refid, raw);
+  if (ok && !part.s.empty()) ok = bam::records(part.s.data(), part.s.size(), job.refid, raw);
+  if (part.p) gs_free(part.p);
+  part.p = nullptr;
+  part.n = 0;
+  part.s.clear();
+  return ok && bam::bgzf_append(raw, part.s);
+}
 
 /* text of one batch from its hit lists: contiguous guide ranges formatted in parallel */
 static void format_batch(enumerate_job &job, batch &b) {
@@ -300,6 +318,7 @@ static void format_batch(enumerate_job &job, batch &b) {
         prc[t] = gs_format_guides_scored(&job.cgs, ck.data(), hi - lo, v.guide_offsets + lo, v.hits, b.spec.data() + lo,
                                          b.skip.empty() ? nullptr : (const uint8_t *)b.skip.data() + lo, job.mismatches,
                                          job.tflags | job.sflags, job.max_off, &part.p, &part.n);
+        if (prc[t] == GS_OK && job.bam && !part_to_bam(job, part)) prc[t] = GS_ERR_FORMAT;
         return;
       }
       char *tx = nullptr;
@@ -326,6 +345,7 @@ static void format_batch(enumerate_job &job, batch &b) {
         part.s.append(tx, tl);
         gs_free(tx);
       }
+      if (job.bam && !part_to_bam(job, part)) prc[t] = GS_ERR_FORMAT;
     });
   }
   for (auto &th : pool) th.join();
@@ -475,7 +495,7 @@ int do_enumerate(int argc, char **argv) {
     else return usage();
   }
   if (prefix.empty() || kmers_file.empty() || output.empty()) return usage();
-  if ((format != "csv" && format != "sam") || (mode != "succinct" && mode != "complete")) return usage();
+  if ((format != "csv" && format != "sam" && format != "bam") || (mode != "succinct" && mode != "complete")) return usage();
   if (gpus < 1 || mismatches < 0 || rna < 0 || dna < 0) return usage();
   enumerate_job job;
   std::string err;
@@ -562,7 +582,9 @@ int do_enumerate(int argc, char **argv) {
   };
   for (auto &n : job.gs.names) job.names.push_back(n.c_str());
   job.cgs = gs_genome_structure{job.names.data(), job.gs.lengths.data(), (uint32_t)job.names.size()};
-  job.tflags = (format == "sam" ? GS_TEXT_SAM : 0u) | (mode == "complete" ? GS_TEXT_COMPLETE : 0u);
+  job.tflags = (format != "csv" ? GS_TEXT_SAM : 0u) | (mode == "complete" ? GS_TEXT_COMPLETE : 0u);
+  job.bam = format == "bam";
+  for (size_t i = 0; i < job.gs.names.size(); i++) job.refid[job.gs.names[i]] = (int32_t)i;
   job.sflags = start ? GS_FLAG_PAM_AT_START : 0u;
   {
     /* the PAM-pair tables cost ~0.3 s per device at hg38 size and save ~15 ms per million guides: short
@@ -581,8 +603,15 @@ int do_enumerate(int argc, char **argv) {
   char *txt = nullptr;
   size_t len = 0;
   gs_format_header(&job.cgs, job.tflags, &txt, &len);
-  write_ok = pwrite_all(txt, len, file_off);
-  file_off += len;
+  if (job.bam) { /* the header block: magic, the SAM header text, the reference list */
+    std::string hz;
+    write_ok = bam::bgzf_append(bam::header(std::string(txt, len), job.gs.names, job.gs.lengths), hz) &&
+               pwrite_all(hz.data(), hz.size(), file_off);
+    file_off += hz.size();
+  } else {
+    write_ok = pwrite_all(txt, len, file_off);
+    file_off += len;
+  }
   gs_free(txt);
 
   /* batches of equal (L, P) in input order: the device call takes fixed-width rows.  The hit lists
@@ -692,6 +721,12 @@ int do_enumerate(int argc, char **argv) {
     }
   }
   for (auto &th : devs) th.join();
+  if (job.bam && !rcode) { /* the empty block that ends a BGZF file */
+    std::string eof;
+    bam::bgzf_eof(eof);
+    if (!pwrite_all(eof.data(), eof.size(), file_off)) write_ok = false;
+    file_off += eof.size();
+  }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::cout << "Processed " << job.kmers.size() << " kmers in " << secs << " seconds.\n";
   std::cout << "Stages (overlapping): device " << job.s_device << " s, text formatting " << job.s_format
@@ -702,6 +737,54 @@ int do_enumerate(int argc, char **argv) {
   return (write_ok && !rcode) ? 0 : 1;
 }
 
+/* guidescan sam2bam IN.sam OUT.bam: the encoder of `enumerate --format bam` on a SAM file (what the reference's
+ * manual does with `samtools view -b`); the references come from the file's @SQ lines */
+int do_sam2bam(int argc, char **argv) {
+  if (argc != 2) return usage();
+  std::ifstream in(argv[0], std::ios::binary);
+  if (!in) {
+    std::cerr << "error: cannot read " << argv[0] << "\n";
+    return 1;
+  }
+  std::string text((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  std::string head;
+  std::vector<std::string> names;
+  std::vector<uint64_t> lengths;
+  std::map<std::string, int32_t> refid;
+  size_t at = 0;
+  while (at < text.size() && text[at] == '@') {
+    size_t e = text.find('\n', at);
+    e = e == std::string::npos ? text.size() : e + 1;
+    const std::string line = text.substr(at, e - at);
+    if (line.compare(0, 3, "@SQ") == 0) {
+      std::string sn;
+      uint64_t ln = 0;
+      std::stringstream ss(line);
+      std::string f;
+      while (std::getline(ss, f, '\t')) {
+        while (!f.empty() && (f.back() == '\n' || f.back() == '\r')) f.pop_back();
+        if (f.compare(0, 3, "SN:") == 0) sn = f.substr(3);
+        if (f.compare(0, 3, "LN:") == 0) ln = strtoull(f.c_str() + 3, nullptr, 10);
+      }
+      refid[sn] = (int32_t)names.size();
+      names.push_back(sn);
+      lengths.push_back(ln);
+    }
+    head += line;
+    at = e;
+  }
+  std::string out, raw;
+  if (!bam::bgzf_append(bam::header(head, names, lengths), out) || !bam::records(text.data() + at, text.size() - at, refid, raw) ||
+      !bam::bgzf_append(raw, out)) {
+    std::cerr << "error: malformed SAM line in " << argv[0] << "\n";
+    return 1;
+  }
+  bam::bgzf_eof(out);
+  std::ofstream o(argv[1], std::ios::binary);
+  o.write(out.data(), (std::streamsize)out.size());
+  return o.good() ? 0 : 1;
+}
+
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -710,6 +793,7 @@ int main(int argc, char **argv) {
     return 0;
   }
   if (argc < 2) return usage();
+  if (!strcmp(argv[1], "sam2bam")) return do_sam2bam(argc - 2, argv + 2);
   if (!strcmp(argv[1], "index")) return do_index(argc - 2, argv + 2);
   if (!strcmp(argv[1], "enumerate")) return do_enumerate(argc - 2, argv + 2);
   return usage();

@@ -210,3 +210,21 @@ def test_cli_fans_batches_out_over_several_workers(tmp_path):
                         "--gpus", "3", "--batch-size", bs, "-n", "2"], check=True, timeout=300, env=env,
                        capture_output=True, text=True)
         assert out.read_bytes() == (d / "ref_m3_csv.csv").read_bytes(), bs
+
+
+def test_format_bam_decodes_to_the_sam_file(tmp_path):
+    """`enumerate --format bam`: BGZF blocks of BAM records written by the formatting threads; decoded with
+    the tests' own reader the file is the `--format sam` file of the same run (which equals the
+    reference's), whatever the batch size and the number of formatting threads"""
+    import bam_reader
+    d = ol.ROOT / "tests" / "golden" / "toy"
+    subprocess.run([str(CLI), "index", "--index", str(tmp_path / "t"), str(d / "toy.fa")], check=True, timeout=300)
+    for extra, ref in ((["-m", "3", "-a", "NAG"], "ref_m3_sam_nag.sam"), (["-m", "2", "--mode", "succinct"], "ref_m2_sam_succinct.sam")):
+        want = (d / ref).read_text()
+        want = "".join("\t".join(f if (i != 2 or f) else "*" for i, f in enumerate(l.split("\t"))) if not l.startswith("@") else l
+                       for l in want.splitlines(keepends=True))
+        for bs, nt in (("1000", "1"), ("7", "3")):
+            out = tmp_path / "o.bam"
+            subprocess.run([str(CLI), "enumerate", str(tmp_path / "t"), "-f", str(d / "kmers.csv"), "-o", str(out), "--format", "bam",
+                            "--batch-size", bs, "-n", nt] + extra, check=True, timeout=300, capture_output=True)
+            assert bam_reader.to_sam(out) == want, (ref, bs, nt)
