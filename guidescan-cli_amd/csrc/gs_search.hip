@@ -65,6 +65,7 @@ struct gs_search_args {
   uint32_t max_iter;
   uint32_t *err;
   uint32_t *work;        /* work-queue head */
+  uint32_t take;         /* items a wave takes per visit to the work counter (>= 1) */
   unsigned long long *stats; /* [0] n_ext, [1] overflow items, [4] two-sided items, [5] one-sided, [8..] request counters */
   uint32_t n_items, L, P, m, cap;
   /* prefix-table seeding (pt_k = 0: walk from the root).  The seeds of an item are listed in
@@ -177,11 +178,20 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   uint4 *dtab = vq + VQ_CAP + 32;              /* substitution table of the item: {index xor, path lo, path hi, -} */
   uint32_t *wmisc = (uint32_t *)(dtab + DTAB); /* overflow chunks of the item: {taken, the last one, the one before} */
 
+  /* Items are taken from the work counter `take` at a time: one atomic on one word serves about 88 waves per
+   * microsecond chip-wide (MI355X_MICROARCH.md, dequeue), so a counter bumped once per item held a launch of
+   * 2 M items at 22.9 ms whatever the items did (measured with the seeding switched off: 22.9 of 26.5 ms) */
+  uint32_t item_next = 0, item_end = 0;
   for (;;) {
-    uint32_t item = 0;
-    if (lane == 0) item = atomicAdd(a.work, 1u);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= a.n_items) break; /* exit condition every wave reaches */
+    if (item_next == item_end) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(a.work, a.take);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base >= a.n_items) break; /* exit condition every wave reaches */
+      item_next = base;
+      item_end = base + a.take < a.n_items ? base + a.take : a.n_items;
+    }
+    const uint32_t item = item_next++;
     /* all forward-index items first, then all reverse-index items: at any moment the waves
      * touch one strand's Occ array, which halves the hot footprint (TLB reach) */
     const uint32_t n_guides = a.n_items >> 1;
@@ -2787,6 +2797,15 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       sa.chunk_seq = sa.chunk_item + arena_chunks;
       sa.nchunk = (uint2 *)ix->w_nchunk.p;
       sa.arena_chunks = arena_chunks;
+    }
+    /* items per visit to the work counter: enough to keep the counter far from its ~88 visits per microsecond,
+     * few enough that every resident wave still gets several visits (balance at the tail) */
+    {
+      const uint64_t waves = (uint64_t)cus * 32u;
+      uint64_t take = (2ull * ng) / (waves * 64u); /* 2 M items: 3 (23.8 ms against 26.4 one at a time; 8: 24.4, 64: 26.2) */
+      take = take < 1 ? 1 : take > 4 ? 4 : take;
+      if (const char *e = getenv("GS_SEARCH_TAKE")) take = (uint64_t)std::max(1l, atol(e));
+      sa.take = (uint32_t)take;
     }
     sa.max_iter = getenv("GS_SEARCH_MAX_ITER") ? (uint32_t)atol(getenv("GS_SEARCH_MAX_ITER")) : (1u << 26);
     sa.err = d_work + 5;
