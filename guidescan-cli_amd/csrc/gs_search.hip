@@ -144,6 +144,33 @@ struct gs_search_args {
  * seeds this strand's side through a pair table and the other strand's through a deep table, none is
  * one-sided: the strand tables' side of the seeding (pair masks, rotated copies, PAM expansion) is compiled
  * out together with the wave-uniform state it keeps alive. */
+/* Path codes of up to 16 symbols at once (2-bit fields of T = text, Q = query): 0 where they agree, else the
+ * text base's place among the three other bases, A<C<G<T, counted from 1 (what the walk writes per
+ * substitution, index.hpp:230-247) = T + [T < Q]; no field carries into its neighbour (T < Q <= 3). */
+__device__ __forceinline__ uint32_t path_codes16(const uint32_t T, const uint32_t Q) {
+  const uint32_t x = T ^ Q;
+  const uint32_t ne = (x | (x >> 1)) & 0x55555555u;
+  const uint32_t nq = ~T & Q; /* text bit 0 under query bit 1 */
+  const uint32_t lt = ((nq >> 1) | ((~x >> 1) & nq)) & 0x55555555u; /* high bits decide, else the low ones */
+  return (T + lt) & (ne * 3u);
+}
+/* the 2-bit fields of x in reverse order (field 0 <-> field 15) */
+__device__ __forceinline__ uint32_t rev_fields16(const uint32_t x) {
+  const uint32_t r = __brev(x);
+  return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+}
+/* a wave-uniform pointer as a scalar register pair of its own: values that arrive together in one wide
+ * kernel-argument load otherwise stay one 8- or 16-register tuple, which the register allocator spills and
+ * reloads whole (16 v_readlane for one pointer in the seeding loops) */
+template <typename T>
+__device__ __forceinline__ const T *own_sgprs(const T *p) {
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)p);
+  uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)p >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  /* (a pointer rebuilt from integers is a flat one to the compiler: say that it is global memory) */
+  return (const T *)(const T __attribute__((address_space(1))) *)(((uint64_t)hi << 32) | lo);
+}
+
 template <bool CNT, bool WALK, bool SPEC = false>
 __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk) {
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
@@ -213,7 +240,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       if (lane == 0) a.counts[slot] = 0;
       continue;
     }
-    uint32_t guard = 0; /* rounds of this item's loops */
+    uint32_t guard_left = a.max_iter; /* rounds this item's loops may still take (every outer step runs a counted inner loop) */
     const gs_strand_dev &sd = a.sd[strand];
     const uint4 *__restrict__ blocks = sd.blocks;
     const uint32_t npams = P ? gr_npams : 1u;
@@ -341,12 +368,13 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
      * then decided from the full word ctx[row] - and, when the table entry says the interval has
      * exception rows (a symbol outside A,C,G,T within 16 symbols to the left), from the row's
      * entry in the exception list, which holds the true symbols.  Both arrays are padded by one group. */
+    uint32_t qrem_b = 0; /* the other strand's side: the complemented first x_len guide symbols, last first */
     auto verify = [&](const bool modeB, const uint32_t take, uint4 *dsrc) __attribute__((always_inline)) {
       const uint32_t k = a.pt_k;
       const gs_strand_dev &sv = modeB ? a.sd[strand ^ 1u] : sd;
       /* the context arrays the rows live in: the other strand's, this strand's, or the rows of a PAM-pair table */
-      const uint16_t *const v16 = modeB ? sv.ctx16 : a16;
-      const uint32_t *const vctx = modeB ? sv.ctx : actx;
+      const uint16_t *const v16 = modeB ? own_sgprs(sv.ctx16) : a16;
+      const uint32_t *const vctx = modeB ? own_sgprs(sv.ctx) : actx;
       /* lane l < take brings seed descriptor dsrc[l] = {first row, mismatches so far << 14 |
        * rows << 17 | lower bound << 27 | exceptions << 30, path lo, path hi}; the first group of
        * each seed is added to .y here */
@@ -363,13 +391,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       if (lane < take) dsrc[lane].y = mine.y | excl;
       const uint32_t g = modeB ? a.x_len : L - k; /* guide symbols among the remaining ones */
       const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
-      uint32_t qrem;
-      if (modeB) {
-        qrem = 0;
-        for (uint32_t j = 0; j < g; ++j) qrem |= (3u - ((uint32_t)(gr_q >> (2u * (g - 1u - j))) & 3u)) << (2u * j);
-      } else {
-        qrem = (uint32_t)(gr_q >> (2u * k)) & gmask;
-      }
+      const uint32_t qrem = modeB ? qrem_b : ((uint32_t)(gr_q >> (2u * k)) & gmask);
       /* first level: the 16-bit words see the nearest g8 <= 8 guide symbols; two rows per dword */
       const uint32_t g8 = g < 8u ? g : 8u;
       const uint32_t gm8 = (1u << (2u * g8)) - 1u;
@@ -490,14 +512,9 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           if (!__ballot(gok)) continue;
           const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PATH_MASK;
           if (modeB) {
-            uint64_t gpath = 0;
-            for (uint32_t j = 0; j < g; ++j) {
-              const uint32_t t = g - 1u - j;
-              const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
-              const uint32_t tb = 3u - ((w >> (2u * j)) & 3u); /* the base as this strand reads it */
-              const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-              gpath |= (uint64_t)code << (50u - 2u * t);
-            }
+            /* word symbol j is guide symbol g-1-j, complemented: the bases as this strand reads them against
+             * the guide's own; code j belongs at path bit 50 - 2 (g-1-j) */
+            const uint64_t gpath = (uint64_t)path_codes16(~w & gmask, ~qrem & gmask) << (52u - 2u * g);
             uint32_t rowA = 0;
             if (gok) {
               /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
@@ -527,13 +544,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               ppath |= (uint64_t)(isn ? 3u : (tb < 3u ? tb : 4u)) << (49u - 2u * L - 3u * u);
             }
             if (!__ballot(ok)) continue;
-            uint64_t gpath = 0;
-            for (uint32_t v = 0; v < g; ++v) {
-              const uint32_t qc = (qrem >> (2u * v)) & 3u;
-              const uint32_t tb = (w >> (2u * v)) & 3u;
-              const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-              gpath |= (uint64_t)code << (50u - 2u * (k + v));
-            }
+            /* word symbol v is guide symbol k+v: code v belongs at path bit 50 - 2 (k+v), the fields in reverse order */
+            const uint64_t gpath = ((uint64_t)rev_fields16(path_codes16(w & gmask, qrem)) << 32) >> (12u + 2u * k);
             const uint64_t mmeta = ((uint64_t)(kv + mmv) << 56) | spath | gpath | ppath;
             route(ok, true, false, orow, orow, mmeta, 1u);
           }
@@ -569,22 +581,26 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     /* a recipe applied to the exact k-mer index `pidx` / path `path`; returns the entry's address */
     /* kd = symbols the table is indexed by, dbl = log2 of the uint4 per index */
     auto apply_recipe = [&](const uint2 rc, const uint32_t rot_first, const uint32_t kd, uint32_t &pidx, uint64_t &path,
-                            bool &in_rot) __attribute__((always_inline)) -> size_t {
+                            bool &in_rot, const bool has_rot = true) __attribute__((always_inline)) -> size_t {
       const uint32_t k = kd, n = rc.x & 7u;
       uint64_t f = (((uint64_t)rc.y << 32) | rc.x) >> 12;
       uint32_t plo = (uint32_t)path, phi = (uint32_t)(path >> 32);
-      for (uint32_t i = 0; __ballot(i < n) != 0ull; ++i) {
-        const uint4 e = dtab[(uint32_t)f & 127u];
-        f >>= 7;
-        pidx ^= e.x;
-        plo |= e.y;
-        phi |= e.z;
+      /* three substitutions per round, their table entries read side by side (entry 3 = step 0, digit 3 = nothing) */
+      for (uint32_t i = 0; __ballot(i < n) != 0ull; i += 3u) {
+        const uint32_t f0 = (uint32_t)f & 127u, f1 = (uint32_t)(f >> 7) & 127u, f2 = (uint32_t)(f >> 14) & 127u;
+        const uint4 e0 = dtab[i < n ? f0 : 3u];
+        const uint4 e1 = dtab[i + 1u < n ? f1 : 3u];
+        const uint4 e2 = dtab[i + 2u < n ? f2 : 3u];
+        f >>= 21;
+        pidx ^= e0.x ^ e1.x ^ e2.x;
+        plo |= e0.y | e1.y | e2.y;
+        phi |= e0.z | e1.z | e2.z;
       }
       path = ((uint64_t)phi << 32) | plo;
       size_t ei = pidx;
       in_rot = false;
       const uint32_t rs = (rc.x >> 7) & 31u;
-      if ((rc.x & 64u) != 0u && rs >= rot_first) {
+      if (has_rot && (rc.x & 64u) != 0u && rs >= rot_first) { /* (the deep tables have no rotated copies) */
         /* the copy rotated at step rs: that step's symbol and everything after it swap places, so the
          * recipes that differ only at step rs are neighbours in one 64-byte line */
         const uint32_t sh = 2u * (k - 1u - rs);
@@ -599,8 +615,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
      * pair positions after the table depth.  A pair of two guide steps may be broken by a
      * substitution (each substitution breaks at most one pair); a pair of two PAM steps must occur
      * as one of the pairs the PAM patterns allow; a pair straddling guide and PAM is not tested. */
-    uint32_t qpairs = 0;      /* 4 bits per pair position: the query's pair */
-    uint32_t g_pairs = 0;     /* bit j: pair position j lies inside the guide */
+    uint32_t asel_z = 0, asel_w = 0; /* the bit of the query's pair in each of the entry's 16-bit masks (guide pair positions) */
     uint32_t n_gpairs = 0;
     uint32_t pam_pairs = 0;   /* bit j: pair position j lies inside the PAM */
     uint32_t pam16[4] = {0u, 0u, 0u, 0u}; /* PAM pair positions: the 16-bit set of pairs some pattern allows */
@@ -611,8 +626,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       for (uint32_t j = 0; j < 4u && !SPEC; ++j) {
         const uint32_t s0 = a.pt_k + ((sd.mask_off >> (4u * j)) & 15u), s1 = s0 + 1u;
         if (s1 < L) {
-          qpairs |= ((uint32_t)(gr_q >> (2u * s0)) & 15u) << (4u * j);
-          g_pairs |= 1u << j;
+          const uint32_t v = (uint32_t)(gr_q >> (2u * s0)) & 15u;
+          if (j < 2u)
+            asel_z |= 1u << (16u * j + v);
+          else
+            asel_w |= 1u << (16u * (j - 2u) + v);
           n_gpairs++;
         } else if (s0 >= L && s1 < T_end) {
           pam_pairs |= 1u << j;
@@ -717,17 +735,21 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
          * of the substitutions the seed's budget leaves for X */
         const uint32_t deep = SPEC ? 1u : a.bdeep;
         const uint32_t boffs = deep ? 0x6420u : sb.mask_off; /* the deep tables' masks: pairs at 0, 2, 4, 6 */
-        uint32_t qpairs_b = 0, b_pairs = 0, n_bpairs = 0;
+        /* bsel: the bit of the query's pair in each of the entry's four 16-bit masks (z: positions 0, 1; w: 2, 3) */
+        uint32_t bsel_z = 0, bsel_w = 0, n_bpairs = 0;
         for (uint32_t j = 0; j < 4u; ++j) {
           const uint32_t o = (boffs >> (4u * j)) & 15u;
           if (o + 1u < sx) { /* both symbols inside X */
             const uint32_t v = (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - o))) & 3u)) |
                                ((3u - ((uint32_t)(gr_q >> (2u * (sx - 2u - o))) & 3u)) << 2);
-            qpairs_b |= v << (4u * j);
-            b_pairs |= 1u << j;
+            if (j < 2u)
+              bsel_z |= 1u << (16u * j + v);
+            else
+              bsel_w |= 1u << (16u * (j - 2u) + v);
             n_bpairs++;
           }
         }
+        for (uint32_t j = 0; j < sx; ++j) qrem_b |= (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - j))) & 3u)) << (2u * j);
         /* lanes of one pass over the recipes: one per recipe, or - deep tables - four, one per base under the N */
         const uint32_t nlanes = deep ? 4u * a.n_rec_b : a.n_rec_b;
         fill_dtab(true);
@@ -739,14 +761,15 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         /* steps over (PAM pattern bpj, expansion be of its N's, 64 lanes from bc0 of the recipes' lane
          * space), then one last round that only drains the queue: written as one loop so that the
          * verification is instantiated once */
-        uint32_t bpj = 0, be = 0, bc0 = 0, bnn = 0, pidxb = 0, bxset = 0, bslot = 0;
+        uint32_t bpj = 0, be = 0, bc0 = 0, bnn = 0, pidxb = 0, bxset = 0;
+        const uint4 *bdeep = nullptr; /* the deep table of the pattern's pair */
         uint64_t ppath = 0;
         bool bfinal = nlanes == 0u;
+        /* the recipe of the step after this one is on its way while this one's entries are read: the list is
+         * the same for every expansion and pattern, a step past its end starts it again */
+        uint2 rc_next = make_uint2(0u, 0u);
+        if (lane < nlanes) rc_next = a.rec_b[deep ? lane >> 2 : lane];
         for (;;) {
-          if (++guard > a.max_iter) {
-            bailed = true;
-            break;
-          }
           uint32_t rem = 0, first = 0, jb = 0, lo = 0, eflag = 0;
           uint64_t cmeta = 0;
           if (!bfinal) {
@@ -761,7 +784,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               if (deep) {
                 /* the table of the pattern's pair; its first symbol picks the bases to take (bit 3 - base) */
                 const uint32_t c0 = (pw >> (3u * (P - 2u))) & 7u, c1 = (pw >> (3u * (P - 1u))) & 7u, cn = pw & 7u;
-                bslot = (a.n_pt > 1u && (c0 | (c1 << 2)) == a.pt[1][strand].code) ? 1u : 0u;
+                const uint32_t bslot = (a.n_pt > 1u && (c0 | (c1 << 2)) == a.pt[1][strand].code) ? 1u : 0u;
+                bdeep = own_sgprs(a.pt[bslot][strand ^ 1u].deep);
                 bxset = cn == 4u ? 15u : 1u << (3u - cn);
                 bnn = 0;
                 for (uint32_t u = 1; u < P; ++u)
@@ -787,8 +811,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             const uint32_t idx = bc0 + lane;
             const uint32_t ri = deep ? idx >> 2 : idx, bx = idx & 3u;
             bool act = idx < nlanes;
-            uint2 rc = make_uint2(0u, 0u);
-            if (act) rc = a.rec_b[ri];
+            const uint2 rc = act ? rc_next : make_uint2(0u, 0u);
+            {
+              const uint32_t nidx = (bc0 + WAVE >= nlanes ? 0u : bc0 + WAVE) + lane;
+              rc_next = make_uint2(0u, 0u);
+              if (nidx < nlanes) rc_next = a.rec_b[deep ? nidx >> 2 : nidx];
+            }
             count_lines(c_rec, act, a.rec_b + ri);
             jb = rc.x & 7u;
             lo = (rc.x >> 3) & 7u;
@@ -796,8 +824,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             uint64_t path = ppath;
             /* deep tables: the line of the recipe's (k-2)-mer holds one entry per base under the N */
             bool brot;
-            const size_t bei = apply_recipe(rc, deep ? 31u : sb.rot_first, deep ? nYb : k, pidx, path, brot);
-            const uint4 *ep = deep ? a.pt[bslot][strand ^ 1u].deep + (bei << 2) : (brot ? sb.ptab_rot : sb.ptab) + bei;
+            const size_t bei = apply_recipe(rc, deep ? 31u : sb.rot_first, deep ? nYb : k, pidx, path, brot, !deep);
+            const uint4 *ep = deep ? bdeep + (bei << 2) : (brot ? sb.ptab_rot : sb.ptab) + bei;
             if (deep) {
               ep += bx;
               act = act && ((bxset >> bx) & 1u) != 0u;
@@ -814,11 +842,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
              * X can break: no row can match */
             const uint32_t bl = m - jb;
             if (!eflag) {
-              const uint32_t em[4] = {mz & 0xFFFFu, mz >> 16, mw & 0xFFFFu, mw >> 16};
-              uint32_t intact = 0;
-#pragma unroll
-              for (uint32_t j = 0; j < 4u; ++j)
-                if ((b_pairs >> j) & 1u) intact += (em[j] >> ((qpairs_b >> (4u * j)) & 15u)) & 1u;
+              const uint32_t intact = (uint32_t)__popc(mz & bsel_z) + (uint32_t)__popc(mw & bsel_w);
               if (intact + bl < n_bpairs) live = false;
             }
             cmeta = ((uint64_t)k << 59) | ((uint64_t)jb << 56) | path;
@@ -828,10 +852,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
            * started) until a pass can be filled - a pass costs the same instructions for 10 seeds as
            * for 64; intervals larger than a descriptor holds are queued piece by piece */
           for (;;) {
-            if (++guard > a.max_iter) {
+            if (guard_left == 0u) {
               bailed = true;
               break;
             }
+            guard_left--;
             const uint64_t bq = __ballot(rem != 0u);
             if (bq && qn + WAVE <= VQ_CAP) {
               const uint32_t rows = rem < a.v_max ? rem : a.v_max;
@@ -876,12 +901,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t s = (pslots & 1u) ? 0u : 1u;
       pslots &= ~(1u << s);
       const gs_pairtab_dev &p = a.pt[s][strand];
-      atab8 = p.tab;
-      arot8 = p.rot;
+      atab8 = own_sgprs(p.tab);
+      arot8 = own_sgprs(p.rot);
       arot_first = p.rot_first;
-      a16 = p.c16;
-      actx = p.ctx;
-      arow = p.rowid;
+      a16 = own_sgprs(p.c16);
+      actx = own_sgprs(p.ctx);
+      arow = own_sgprs(p.rowid);
     };
     if (pslots) next_pairtab();
     /* the guide symbols this strand's seeds leave to the context check */
@@ -896,11 +921,18 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       fill_dtab(false);
       if (nrec == 0u) seeds_left = false;
     }
+    /* as on the other side: the next step's recipe is requested a step ahead */
+    uint2 rc_ahead = make_uint2(0u, 0u);
+    if (seeding && lane < nrec) rc_ahead = rec[lane];
 
     for (;;) {
-      if (bailed || ++guard > a.max_iter) {
-        bailed = true;
-        break;
+      if (bailed) break;
+      if constexpr (WALK) { /* the seeding steps count in their queue loop */
+        if (guard_left == 0u) {
+          bailed = true;
+          break;
+        }
+        guard_left--;
       }
       const uint32_t total = xs + gs;
       if (seeds_left && total <= seed_low) {
@@ -918,8 +950,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
          * their last substituted step read one line of that step's rotated copy. */
         const uint32_t l = spos + lane;
         const bool act = l < nrec;
-        uint2 rc = make_uint2(0u, 0u);
-        if (act) rc = rec[l];
+        const uint2 rc = act ? rc_ahead : make_uint2(0u, 0u);
+        {
+          const uint32_t nl = (spos + WAVE >= nrec ? 0u : spos + WAVE) + lane; /* past the end: the next table's pass */
+          rc_ahead = make_uint2(0u, 0u);
+          if (nl < nrec) rc_ahead = rec[nl];
+        }
         count_lines(c_rec, act, rec + l);
         const uint32_t kk = rc.x & 7u;
         uint32_t pidx = pidx0;
@@ -961,12 +997,10 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
            * interval's rows than the remaining budget can break, or none of the PAM's pairs does */
           if (use_mask && eflag == 0u) {
             const uint32_t em[4] = {ent.z & 0xFFFFu, ent.z >> 16, ent.w & 0xFFFFu, ent.w >> 16};
-            uint32_t intact = 0;
+            const uint32_t intact = (uint32_t)__popc(ent.z & asel_z) + (uint32_t)__popc(ent.w & asel_w);
 #pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-              if ((g_pairs >> j) & 1u) intact += (em[j] >> ((qpairs >> (4u * j)) & 15u)) & 1u;
+            for (uint32_t j = 0; j < 4u; ++j)
               if (((pam_pairs >> j) & 1u) && (em[j] & pam16[j]) == 0u) hopeless = true;
-            }
             hopeless = hopeless || intact + bl < n_gpairs;
           }
         }
@@ -986,10 +1020,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
          * everything once the seeds are exhausted. */
         uint32_t rem = (ver && !(a.dbg_skip & 1u)) ? ecnt : 0u, first = ent.x;
         for (;;) {
-          if (++guard > a.max_iter) {
+          if (guard_left == 0u) {
             bailed = true;
             break;
           }
+          guard_left--;
           const uint64_t bq = __ballot(rem != 0u);
           if (bq && qn + WAVE <= VQ_CAP) {
             const uint32_t rows = rem < a.v_max ? rem : a.v_max;
