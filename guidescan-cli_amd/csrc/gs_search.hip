@@ -1893,6 +1893,10 @@ struct gs_big2_compact_args {
   uint32_t *rowkey, *idx;
   unsigned long long pam_mul;
   uint32_t n_items, L, P, rbits;
+  /* row_bits != 0: the sort word carries the low row_bits bits of the record's first row (+ row_off) below it:
+   * one sort orders the words and - nearly - the rows inside a run of equal words (big_order) */
+  uint32_t row_bits;
+  uint32_t row_off; /* tests: moves where the rows of a run cross a multiple of 2^row_bits */
 };
 /* one workgroup per set item: copy its records to the compact array and build their sort words */
 __global__ __launch_bounds__(256) void k_big2_compact(gs_big2_compact_args a) {
@@ -1939,8 +1943,13 @@ __global__ __launch_bounds__(256) void k_big2_compact(gs_big2_compact_args a) {
     const uint4 v = in[r - b];
     const unsigned long long key = ((unsigned long long)v.y << 32) | v.x;
     a.recs[r] = v;
-    a.W[r] = (g << (4u + a.rbits)) | ((key >> 60) << a.rbits) | big2_rank(key, a.L, a.P, nt, a.pam_mul);
-    a.rowkey[r] = v.z;
+    const unsigned long long w = (g << (4u + a.rbits)) | ((key >> 60) << a.rbits) | big2_rank(key, a.L, a.P, nt, a.pam_mul);
+    if (a.row_bits) {
+      a.W[r] = (w << a.row_bits) | (((unsigned long long)v.z + a.row_off) & ((1ull << a.row_bits) - 1ull));
+    } else {
+      a.W[r] = w;
+      a.rowkey[r] = v.z;
+    }
     a.idx[r] = (uint32_t)r;
   }
 }
@@ -1990,18 +1999,130 @@ __global__ __launch_bounds__(256) void k_big2_runs(const unsigned long long *W, 
   }
   idx_out[s + rank] = mine;
 }
+/* largest of n 64-bit counts (a grid-stride loop, one atomic per wave) */
+__global__ void k_max_u64(const unsigned long long *v, uint32_t n, unsigned long long *out) {
+  unsigned long long mx = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    mx = v[i] > mx ? v[i] : mx;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long x = __shfl_xor(mx, o);
+    mx = x > mx ? x : mx;
+  }
+  if (lane_id() == 0 && mx) atomicMax(out, mx);
+}
+/* the composite word of records whose plain words and first rows are already there (the batch that shows a
+ * handle its first long run) */
+__global__ void k_big2_comp(const unsigned long long *W, const uint32_t *rowkey, uint64_t T, uint32_t row_bits,
+                            uint32_t row_off, unsigned long long *Wc) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= T) return;
+  Wc[r] = (W[r] << row_bits) | (((unsigned long long)rowkey[r] + row_off) & ((1ull << row_bits) - 1ull));
+}
+/* After ONE sort by (word << row_bits | low row_bits bits of the row): inside a run of equal words the rows are in
+ * order by their low bits.  They are scattered over the suffix array interval of the run's k-mer (this strand's
+ * hits carry the row of the suffix v_rem symbols into the site), so wherever that interval reaches across a
+ * multiple of 2^row_bits the run is out of order: the full rows show a descent.  Every descent goes on a list;
+ * k_big2_fixruns then orders each such run by (row >> row_bits), stably. */
+__global__ void k_big2_wraps(const uint4 *S2, const unsigned long long *Wc, uint64_t T, uint32_t row_bits, uint32_t *list,
+                             uint32_t *n_list) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0 || r >= T) return;
+  if ((Wc[r] >> row_bits) == (Wc[r - 1] >> row_bits) && S2[r].z < S2[r - 1].z) list[atomicAdd(n_list, 1u)] = (uint32_t)r;
+}
+/* One workgroup per listed descent; the first to claim the run (claimed[] = zeros) puts it in order: the records
+ * are in order by the low bits of row + row_off, so a stable partition by the high part - one pass per value it
+ * takes between its least and its greatest, two nearly always - finishes the job.  tmp = the unordered records'
+ * array (read for the last time by the gather), used at the run's own positions. */
+__global__ __launch_bounds__(256) void k_big2_fixruns(uint4 *S2, uint4 *tmp, const unsigned long long *Wc, uint64_t T,
+                                                      uint32_t row_bits, uint32_t row_off, const uint32_t *list, uint32_t n,
+                                                      uint32_t *claimed) {
+  __shared__ unsigned long long s_b[2];
+  __shared__ uint32_t s_take, s_lo, s_hi, s_w[4];
+  const uint32_t tid = threadIdx.x, wave = tid / WAVE, lane = lane_id();
+  for (uint32_t d = blockIdx.x; d < n; d += gridDim.x) {
+    const uint64_t s = list[d];
+    if (tid == 0) {
+      const unsigned long long w = Wc[s] >> row_bits;
+      uint64_t lo = 0, hi = s; /* first position of the word: in [0, s] */
+      while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((Wc[mid] >> row_bits) < w)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      s_b[0] = lo;
+      s_take = atomicExch(&claimed[lo], 1u) == 0u ? 1u : 0u;
+      lo = s + 1; /* one past its last position: in (s, T] */
+      hi = T;
+      while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((Wc[mid] >> row_bits) <= w)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      s_b[1] = lo;
+      s_lo = 0xFFFFFFFFu;
+      s_hi = 0u;
+    }
+    __syncthreads();
+    const uint64_t start = s_b[0], end = s_b[1], len = end - start;
+    const bool mine = s_take != 0u;
+    __syncthreads(); /* (thread 0 writes these again in the next round) */
+    if (!mine) continue; /* wave-uniform and workgroup-uniform: another workgroup has the run */
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint64_t i = tid; i < len; i += blockDim.x) {
+      const uint32_t h = (uint32_t)(((unsigned long long)S2[start + i].z + row_off) >> row_bits);
+      lo = h < lo ? h : lo;
+      hi = h > hi ? h : hi;
+    }
+    atomicMin(&s_lo, lo);
+    atomicMax(&s_hi, hi);
+    __syncthreads();
+    const uint32_t hmin = s_lo, hmax = s_hi;
+    uint64_t base = 0;
+    for (uint32_t v = hmin; v <= hmax; ++v) {
+      for (uint64_t c = 0; c < len; c += blockDim.x) {
+        const uint64_t i = c + tid;
+        uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+        bool f = false;
+        if (i < len) {
+          rec = S2[start + i];
+          f = (uint32_t)(((unsigned long long)rec.z + row_off) >> row_bits) == v;
+        }
+        const uint64_t b = __ballot(f);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (uint32_t q = 0; q < blockDim.x / WAVE; ++q) {
+          if (q < wave) before += s_w[q];
+          total += s_w[q];
+        }
+        if (f) tmp[start + base + before + lanes_below(b)] = rec;
+        base += total;
+        __syncthreads();
+      }
+      if (v == 0xFFFFFFFFu) break;
+    }
+    __threadfence();
+    __syncthreads();
+    for (uint64_t i = tid; i < len; i += blockDim.x) S2[start + i] = tmp[start + i];
+    __syncthreads();
+  }
+}
 __global__ void k_iota_u32(uint32_t *p, uint64_t n) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = (uint32_t)i;
 }
 /* keep[r] = 1 when ordered record r starts a new (guide, key, first row); rows[r] = its row count */
 __global__ void k_big2_flags(const uint4 *S2, const unsigned long long *W, uint64_t T, uint32_t *keep,
-                             unsigned long long *rows) {
+                             unsigned long long *rows, uint32_t wshift) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= T) return;
   const uint4 c = S2[r];
   bool f = true;
-  if (r > 0 && W[r - 1] == W[r]) {
+  if (r > 0 && (W[r - 1] >> wshift) == (W[r] >> wshift)) {
     const uint4 p = S2[r - 1];
     f = !(p.x == c.x && p.y == c.y && p.z == c.z);
   }
@@ -3002,6 +3123,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   void *big_s2 = nullptr; /* the records in final order (one-word form) */
   const unsigned long long *big_wfinal = nullptr; /* and their sort words */
   uint32_t big_gshift = 0;
+  bool big_comp = false;    /* the ordering ran as one sort by (word, low bits of the row) */
+  uint32_t big_fixed = 0;   /* descents it found inside runs (k_big2_fixruns) */
   /* the device-wide ordering runs in its one-word form (k_big2_*) when the sort word fits 64 bits */
   unsigned long long big_pam_mul = 1, big_n_max = 1;
   gs_big2_tab big_tab;
@@ -3125,22 +3248,41 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       ca.L = L;
       ca.P = P;
       ca.rbits = rbits;
+      /* Long runs of one sequence (a repeat-rich genome; the handle remembers having seen one): ONE sort by
+       * (word << b | low b bits of the first row), b = what 64 bits leave, instead of a sort by row and a
+       * stable one by word; the runs it leaves out of order (k_big2_wraps) are put right one by one
+       * (k_big2_fixruns).  b < 32 needs no run longer than 2^b (a run is no longer than the largest item):
+       * two rows of a run may then differ by a multiple of 2^b only through the high part.  0: not usable. */
+      const uint32_t wbits = gbits + 4 + rbits;
+      auto composite_bits = [&]() -> uint32_t {
+        if (getenv("GS_BIG2_NO_COMPOSITE") || wbits >= 64) return 0u;
+        uint32_t rb = 64 - wbits > 32 ? 32u : 64u - wbits;
+        if (const char *e = getenv("GS_BIG2_ROWBITS")) rb = std::min<uint32_t>(rb, (uint32_t)std::max(1l, atol(e)));
+        return rb;
+      };
+      const bool two_from_start = ix->big_long_runs || getenv("GS_BIG2_TWO_SORTS");
+      uint32_t rowb = two_from_start ? composite_bits() : 0u;
+      ca.row_bits = rowb;
+      ca.row_off = getenv("GS_BIG2_ROWOFF") ? (uint32_t)atol(getenv("GS_BIG2_ROWOFF")) : 0u;
       hipLaunchKernelGGL(k_big2_compact, dim3(n_it + (from_arena ? n_used : 0u)), dim3(256), 0, st, ca);
-      size_t s1 = 0, s2 = 0;
+      size_t s1 = 0, s2 = 0, s3 = 0;
       GS_HIP(rocprim::radix_sort_pairs(nullptr, s1, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
-      GS_HIP(rocprim::radix_sort_pairs(nullptr, s2, Wb, W, idxb, idx, (size_t)T, 0, gbits + 4 + rbits, st));
-      if ((r2 = gs_reserve(ix->w_h_tmp, std::max(s1, s2) + 16)) != GS_OK) return r2;
+      GS_HIP(rocprim::radix_sort_pairs(nullptr, s2, Wb, W, idxb, idx, (size_t)T, 0, wbits, st));
+      GS_HIP(rocprim::radix_sort_pairs(nullptr, s3, Wb, W, idxb, idx, (size_t)T, 0, 64, st));
+      if ((r2 = gs_reserve(ix->w_h_tmp, std::max(std::max(s1, s2), s3) + 16)) != GS_OK) return r2;
       const unsigned gT = (unsigned)((T + 255) / 256);
       const unsigned long long *W_final = nullptr;
       const uint32_t *idx_final = nullptr;
+      uint32_t wshift = 0;
+      bool comp_in_wb = false; /* the composite words were built from the plain ones, into Wb */
       /* One sort by W and the rows put in order inside its (short, rare) runs - unless this handle has seen a
        * batch with long runs of one sequence (a repeat-rich genome): then, and for the batch that shows the
        * first such run, two stable sorts: by first row, then by W. */
       uint32_t short_max = 32;
       if (const char *e = getenv("GS_BIG2_SHORT")) short_max = (uint32_t)std::max(1l, atol(e));
-      if (!ix->big_long_runs && !getenv("GS_BIG2_TWO_SORTS")) {
+      if (!two_from_start) {
         tbs = ix->w_h_tmp.cap;
-        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, W, Wb, idx, idxb, (size_t)T, 0, gbits + 4 + rbits, st));
+        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, W, Wb, idx, idxb, (size_t)T, 0, wbits, st));
         uint32_t *d_long = d_work + 6;
         GS_HIP(hipMemsetAsync(d_long, 0, 4, st));
         hipLaunchKernelGGL(k_big2_runs, dim3(gT), dim3(256), 0, st, (const unsigned long long *)Wb, (const uint32_t *)idxb,
@@ -3154,22 +3296,56 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         } else {
           ix->big_long_runs = true;
           hipLaunchKernelGGL(k_iota_u32, dim3(gT), dim3(256), 0, st, idx, T);
+          rowb = composite_bits();
+          if (rowb) { /* the plain words and the rows are there: the composite words go where the failed order was */
+            hipLaunchKernelGGL(k_big2_comp, dim3(gT), dim3(256), 0, st, (const unsigned long long *)W, (const uint32_t *)rk, T, rowb,
+                               ca.row_off, Wb);
+            comp_in_wb = true;
+          }
         }
+      }
+      if (!W_final && rowb) {
+        unsigned long long *src = comp_in_wb ? Wb : W, *dst = comp_in_wb ? W : Wb;
+        tbs = ix->w_h_tmp.cap;
+        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, src, dst, idx, idxb, (size_t)T, 0, wbits + rowb, st));
+        W_final = dst;
+        idx_final = idxb;
+        wshift = rowb;
+        big_comp = true;
       }
       if (!W_final) {
         tbs = ix->w_h_tmp.cap;
         GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
         hipLaunchKernelGGL(k_big2_gather_w, dim3(gT), dim3(256), 0, st, (const unsigned long long *)W, (const uint32_t *)idxb, T, Wb);
         tbs = ix->w_h_tmp.cap;
-        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, Wb, W, idxb, idx, (size_t)T, 0, gbits + 4 + rbits, st));
+        GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, Wb, W, idxb, idx, (size_t)T, 0, wbits, st));
         W_final = W;
         idx_final = idx;
       }
       big_wfinal = W_final;
+      big_gshift = 4 + rbits + wshift;
       /* W_final = the sort words in final order, idx_final = where each record sits in recs */
       hipLaunchKernelGGL(k_big2_gather, dim3(gT), dim3(256), 0, st, (const uint4 *)recs, idx_final, T, S2);
+      if (wshift && (wshift < 32 || ca.row_off != 0)) {
+        /* the descents go into the array the flags' row counts are written to afterwards, the claims into the
+         * flags' own; each run that shows one is put in order through the unordered records' array */
+        uint32_t *d_n = d_work + 6, h_n = 0, *list = (uint32_t *)ix->w_b_rows.p;
+        GS_HIP(hipMemsetAsync(d_n, 0, 4, st));
+        hipLaunchKernelGGL(k_big2_wraps, dim3(gT), dim3(256), 0, st, (const uint4 *)S2, W_final, T, wshift, list, d_n);
+        GS_HIP(hipMemcpyAsync(&h_n, d_n, 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        if (h_n) {
+          GS_HIP(hipMemsetAsync(ix->w_b_keep.p, 0, 4 * (size_t)(T + 1), st));
+          hipLaunchKernelGGL(k_big2_fixruns, dim3(std::min<uint32_t>(h_n, 8192u)), dim3(256), 0, st, S2, recs, W_final, T, wshift,
+                             ca.row_off, (const uint32_t *)list, h_n, (uint32_t *)ix->w_b_keep.p);
+        }
+        big_fixed += h_n;
+        if (getenv("GS_DEBUG"))
+          fprintf(stderr, "[gs] composite ordering: %llu records, word bits %u, row bits %u, %u descents inside runs\n", T, wbits,
+                  wshift, h_n);
+      }
       hipLaunchKernelGGL(k_big2_flags, dim3(gT), dim3(256), 0, st, (const uint4 *)S2, W_final, T,
-                         (uint32_t *)ix->w_b_keep.p, (unsigned long long *)ix->w_b_rows.p);
+                         (uint32_t *)ix->w_b_keep.p, (unsigned long long *)ix->w_b_rows.p, wshift);
     } else if (T) {
       hipLaunchKernelGGL(k_big_compact, dim3(n_it), dim3(256), 0, st, (const uint4 *)ix->w_slots.p,
                          (const uint4 *)ix->w_slots2.p, (const gs_big_src *)ix->w_b_src.p,
@@ -3496,7 +3672,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
             "%u guides redone%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (device-wide ordering)" : "");
   h_stats3[6] = n_o;
   h_stats3[7] = (h_stats3[7] << 8) | (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u) |
-                (n_o && arena_chunks != 0 && arena_fail == 0 ? 4u : 0u); /* bit 2: the overflowing guides came out of the arena, no second pass */ /* items through PAM-pair tables above the flags */
+                (n_o && arena_chunks != 0 && arena_fail == 0 ? 4u : 0u) | /* bit 2: the overflowing guides came out of the arena, no second pass */
+                (big_comp ? 8u : 0u) | (big_fixed ? 16u : 0u);           /* bits 3, 4: ordered by one sort of (word, row bits); runs put right afterwards */ /* items through PAM-pair tables above the flags */
   h_stats3[13] = cap;
   memcpy(ix->last_counters, h_stats3, sizeof(h_stats3));
   /* matches per item seen at this budget: sizes the slots of the next batch */

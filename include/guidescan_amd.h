@@ -146,7 +146,9 @@ void gs_index_close(gs_index *ix);
  * Occ walk, [1] items whose matches overflowed their slots, [2] distinct matches, [4] items seeded
  * from both strands' tables, [5] items seeded one-sided although two-sided seeding was on, [6] guides
  * redone because their matches overflowed the first pass's slots, [7] bit 0: the whole batch was ordered
- * device-wide, bit 1: the redone guides were, [13] slots per item of the first pass, [14] / [15] sum and
+ * device-wide, bit 1: the redone guides were, bit 2: the overflowing guides' records came out of the arena,
+ * bit 3: the device-wide ordering ran as one sort of (sort word, low bits of the first row), bit 4: it had runs
+ * to put right afterwards, [13] slots per item of the first pass, [14] / [15] sum and
  * maximum of the per-item match counts; with
  * GS_FLAG_COUNT_REQUESTS also the 64-byte lines requested by the search kernel: [8] prefix-table
  * lines, [9] 16-bit context lines, [10] 32-bit context words, [11] SA/ISA gathers of the search,

@@ -552,8 +552,16 @@ ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                ("GS_BIG_ORDER_V1", "1"),
                # the one-word form as one sort + rows ordered inside the runs of equal words, whatever their length
                # (the default gives up on runs beyond 32 records and sorts by row first), and the two sorts from the start
-               ("GS_BIG2_SHORT", "1000000"), ("GS_BIG2_TWO_SORTS", "1")]
-ARENA_IDS = ["arena", "second-pass", "arena-exhausted", "raw-key-order", "one-sort-and-runs", "two-sorts"]
+               ("GS_BIG2_SHORT", "1000000"),
+               # long runs from the start: one sort of (word, row bits) - all 32 row bits on these small genomes -,
+               # and the two stable sorts it replaces
+               ("GS_BIG2_TWO_SORTS", "1"), ("GS_BIG2_TWO_SORTS", "1", "GS_BIG2_NO_COMPOSITE", "1")]
+ARENA_IDS = ["arena", "second-pass", "arena-exhausted", "raw-key-order", "one-sort-and-runs", "composite-sort", "two-sorts"]
+
+
+def set_mode(monkeypatch, arena):
+    for i in range(0, len(arena or ()), 2):
+        monkeypatch.setenv(arena[i], arena[i + 1])
 
 
 @pytest.mark.parametrize("arena", ARENA_MODES, ids=ARENA_IDS)
@@ -561,8 +569,7 @@ def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
     """a guide whose (guide, strand) match count exceeds the LDS sort (2048): its records beyond the slots
     come out of the overflow arena (or, arena off / too small, from the exact-size second pass), then the
     device-wide sort and the per-record locate - still bit-exact and in CSR order"""
-    if arena:
-        monkeypatch.setenv(*arena)
+    set_mode(monkeypatch, arena)
     rng = np.random.default_rng(7)
     site = np.frombuffer(b"GATTACAGATTACAGATTAC", np.uint8)
     chunks = []
@@ -593,6 +600,52 @@ def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
             assert big > 2048
             ctr = gidx.last_counters()
             assert ctr["guides_redone"] >= 1 and ctr["overflow_from_arena"] == (arena is None or "ARENA" not in arena[0]), (ctr, m, faithful)
+    finally:
+        gidx.close()
+        oidx.close()
+
+
+def test_composite_ordering_puts_runs_right(monkeypatch):
+    """the device-wide ordering as ONE sort of (sort word, low bits of the first row): the rows of a run of equal
+    words are scattered over their k-mer's suffix array interval, and where that reaches across a multiple of
+    2^bits the run comes out of the sort out of order; k_big2_wraps finds such runs, k_big2_fixruns orders them by
+    the rows' high part.  Few row bits (13, 9, 5) on the genome of 7,000 near-copies, the multiples moved through
+    the runs by an offset: every result equals the oracle-checked one of the two stable sorts, and runs do get
+    put right."""
+    rng = np.random.default_rng(7)
+    site = np.frombuffer(b"GATTACAGATTACAGATTAC", np.uint8)
+    chunks = []
+    for i in range(7000):
+        s = site.copy()
+        for j in rng.choice(20, size=int(rng.integers(0, 4)), replace=False):
+            s[j] = rng.choice([c for c in b"ACGT" if c != s[j]])
+        pam = np.frombuffer(rng.choice([b"AGG", b"CGG", b"GGG", b"TGG"]), np.uint8)
+        filler = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(30, 60)))
+        chunks += [filler, s, pam]
+    text = np.concatenate(chunks)
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        seqs = np.array([list(site)], dtype=np.uint8)
+        pams = np.frombuffer(b"NGG", np.uint8).reshape(1, 3)
+        monkeypatch.setenv("GS_BIG2_TWO_SORTS", "1")
+        monkeypatch.setenv("GS_BIG2_NO_COMPOSITE", "1")
+        ref_off, ref_hits, _ = gidx.enumerate(seqs, pams, mismatches=3)
+        exp, _ = oracle_hits_as_records(oidx, site.tobytes().decode(), "NGG", ol.make_opts(3), 3)
+        assert gpu_hits_as_records(ref_off, ref_hits, 0, site.tobytes().decode(), 3) == exp
+        assert not gidx.last_counters()["ordered_by_one_composite_sort"]
+        monkeypatch.delenv("GS_BIG2_NO_COMPOSITE")
+        for bits, step in ((13, 512), (9, 64), (5, 8)):
+            monkeypatch.setenv("GS_BIG2_ROWBITS", str(bits))
+            fixed = 0
+            for off in range(0, 1 << bits, step):
+                monkeypatch.setenv("GS_BIG2_ROWOFF", str(off))
+                offsets, hits, _ = gidx.enumerate(seqs, pams, mismatches=3)
+                ctr = gidx.last_counters()
+                assert ctr["ordered_by_one_composite_sort"], (bits, off, ctr)
+                assert np.array_equal(offsets, ref_off) and hits.tobytes() == ref_hits.tobytes(), (bits, off)
+                fixed += bool(ctr["runs_turned_round"])
+            assert fixed >= 2, (bits, fixed)
     finally:
         gidx.close()
         oidx.close()
@@ -632,7 +685,7 @@ def test_repeat_family_genome_bit_exact(monkeypatch, arena):
     verified in pieces, slot overflow, LDS and device-wide ordering - and stay bit-exact"""
     monkeypatch.setenv("GS_PREFIX_K", "13")
     if arena:
-        monkeypatch.setenv(arena[0], "1" if "ARENA" in arena[0] else arena[1])   # one chunk: the first family guide exhausts it
+        set_mode(monkeypatch, (arena[0], "1") if "ARENA" in arena[0] else arena)   # one chunk: the first family guide exhausts it
     text, names, lengths = synth.make_repeat_genome([2_000_000, 1_000_000], seed=4)
     oidx = ol.OracleIndex(text)
     gidx = api.GenomeIndex.build(text, device=0)
