@@ -273,7 +273,9 @@ def main():
                    "slots_per_item": req["slots_per_item"], "matches_max_per_item": req["matches_max_per_item"],
                    "ordered_device_wide": req["ordered_device_wide"],
                    "redo_ordered_device_wide": req["redo_ordered_device_wide"],
-                   "overflow_from_arena": req["overflow_from_arena"], "per_rank_memory": per_rank},
+                   "overflow_from_arena": req["overflow_from_arena"],
+                   "ordered_by_one_composite_sort": req["ordered_by_one_composite_sort"],
+                   "runs_put_right_after_the_sort": req["runs_turned_round"], "per_rank_memory": per_rank},
     }
 
     if rank == 0:
