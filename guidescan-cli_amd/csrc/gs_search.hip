@@ -3257,8 +3257,11 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       auto composite_bits = [&]() -> uint32_t {
         if (getenv("GS_BIG2_NO_COMPOSITE") || wbits >= 64) return 0u;
         uint32_t rb = 64 - wbits > 32 ? 32u : 64u - wbits;
-        if (const char *e = getenv("GS_BIG2_ROWBITS")) rb = std::min<uint32_t>(rb, (uint32_t)std::max(1l, atol(e)));
-        return rb;
+        if (const char *e = getenv("GS_BIG2_ROWBITS")) return std::min<uint32_t>(rb, (uint32_t)std::max(1l, atol(e)));
+        /* the runs to put right afterwards multiply as the row bits shrink (hg38 size, 20 k repeat-rich guides:
+         * 243-548 per batch at 25 bits, 4.3 x 10^5 at 17 and 121 ms against the two sorts' 77): below 22 bits -
+         * sort words beyond 42 - the two sorts serve */
+        return rb >= 22 ? rb : 0u;
       };
       const bool two_from_start = ix->big_long_runs || getenv("GS_BIG2_TWO_SORTS");
       uint32_t rowb = two_from_start ? composite_bits() : 0u;
