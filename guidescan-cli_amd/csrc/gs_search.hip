@@ -1843,14 +1843,18 @@ __global__ void k_big_locate(gs_blocate2_args a) {
  * the key as per-position codes (52 bits), but among the sequences with j substitutions in L positions
  * and P PAM symbols there are only C(L,j) 3^j 5^P of them: their lexicographic RANK (combinatorial number
  * system, position 0 most significant as in the key) orders them exactly and needs 22 bits at L = 20,
- * j <= 3, P = 3 instead of 52.  Sort word W = guide of the set | mismatches (3) | index (1) | rank: 39 bits
- * for 8 k guides.  Two stable sorts: by first row (32-bit keys, four passes over 8-byte pairs), then by W
+ * j <= 3, P = 3 instead of 52.  Sort word W = guide of the set | (mismatches, index, rank) as one number -
+ * the class's base (gs_big2_tab::base: all sequences of the classes before it) + rank: 36 bits for 8 k guides.  Two stable sorts: by first row (32-bit keys, four passes over 8-byte pairs), then by W
  * (five passes over 12-byte pairs) - nine passes and 184 bytes moved per record where sorting the raw key
  * took thirteen passes and 312 bytes.  (Sorting by W alone and ordering the rows inside each run of equal W
  * afterwards was tried: on a repeat-rich genome a third of the records sit in runs of 10^4 and more - the
  * family's consensus sequence - and the run-by-run passes cost more than the row sort does.) */
 struct gs_big2_tab {
   unsigned long long n[32][8]; /* n[a][r] = C(a, r) 3^r: sequences of a positions with r substitutions */
+  /* base[mismatches << 1 | index]: the sequences that go before the class's first - every sequence with fewer
+   * mismatches on either index, and the class's own on index 0: (mismatches, index, rank) as ONE number, three
+   * bits narrower than the three fields side by side (a radix pass less at m = 5 and 6) */
+  unsigned long long base[16];
 };
 __device__ __forceinline__ unsigned long long big2_rank(const unsigned long long key, const uint32_t L, const uint32_t P,
                                                          const unsigned long long *nt /* [32][8] in LDS */,
@@ -1901,7 +1905,9 @@ struct gs_big2_compact_args {
 /* one workgroup per set item: copy its records to the compact array and build their sort words */
 __global__ __launch_bounds__(256) void k_big2_compact(gs_big2_compact_args a) {
   __shared__ unsigned long long nt[32 * 8];
+  __shared__ unsigned long long bs[16];
   for (uint32_t i = threadIdx.x; i < 32u * 8u; i += blockDim.x) nt[i] = a.tab->n[i >> 3][i & 7u];
+  if (threadIdx.x < 16u) bs[threadIdx.x] = a.tab->base[threadIdx.x];
   __syncthreads();
   const uint4 *in;
   unsigned long long b, e, g;
@@ -1943,7 +1949,7 @@ __global__ __launch_bounds__(256) void k_big2_compact(gs_big2_compact_args a) {
     const uint4 v = in[r - b];
     const unsigned long long key = ((unsigned long long)v.y << 32) | v.x;
     a.recs[r] = v;
-    const unsigned long long w = (g << (4u + a.rbits)) | ((key >> 60) << a.rbits) | big2_rank(key, a.L, a.P, nt, a.pam_mul);
+    const unsigned long long w = (g << (4u + a.rbits)) | (bs[(uint32_t)(key >> 60) & 15u] + big2_rank(key, a.L, a.P, nt, a.pam_mul));
     if (a.row_bits) {
       a.W[r] = (w << a.row_bits) | (((unsigned long long)v.z + a.row_off) & ((1ull << a.row_bits) - 1ull));
     } else {
@@ -3143,7 +3149,18 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       }
     for (uint32_t j = 0; j <= mismatches && j <= L && j < 8; j++) big_n_max = std::max(big_n_max, big_tab.n[L][j]);
     for (uint32_t u = 0; u < P; u++) big_pam_mul *= 5ull;
-    while (big_rbits < 63 && ((big_n_max * big_pam_mul - 1ull) >> big_rbits) != 0ull) big_rbits++;
+    /* (mismatches, index, rank) as one number below the guide: `4 + big_rbits` bits hold the count of all classes */
+    unsigned long long cum = 0;
+    for (uint32_t j = 0; j < 8; j++) {
+      const unsigned long long nj = j <= mismatches && j <= L ? big_tab.n[L][j] * big_pam_mul : 0ull;
+      big_tab.base[2 * j] = cum;
+      big_tab.base[2 * j + 1] = cum + nj;
+      cum += 2ull * nj;
+    }
+    uint32_t cbits = 4;
+    while (cbits < 63 && ((cum - 1ull) >> cbits) != 0ull) cbits++;
+    big_rbits = cbits - 4;
+    (void)big_n_max;
   }
   auto big_fits_v2 = [&](uint32_t n_set) -> bool {
     uint32_t gbits = 1;
