@@ -561,6 +561,7 @@ class GenomeIndex:
                     guides_redone=v[6], ordered_device_wide=bool(v[7] & 1), redo_ordered_device_wide=bool(v[7] & 2),
                     overflow_from_arena=bool(v[7] & 4),
                     ordered_by_one_composite_sort=bool(v[7] & 8), runs_turned_round=bool(v[7] & 16),
+                    ordered_in_tiles=bool(v[7] & 32), tile_ordering_gave_up=bool(v[7] & 64),
                     items_pair_tables=v[7] >> 8, recipe_lines=v[3],
                     slots_per_item=v[13], matches_sum=v[14], matches_max_per_item=v[15],
                     table_lines=v[8], ctx16_lines=v[9], ctx_words=v[10], sa_isa_gathers=v[11], occ_lines=v[12])

@@ -19,6 +19,10 @@
  *   uint64 ex[2]    1 = row holds a non-ACGT symbol ('\0' sentinel, N, IUPAC) or padding
  * One aligned 64-byte read answers Occ(c, i) for all four bases exactly, including
  * rows whose BWT symbol is not a base (no side table on the fast path). */
+/* overflow arena of k_search (gs_search.hip): records per chunk (16 KiB): one atomic per 1,024 matches */
+#define ARENA_SHIFT 10u
+#define ARENA_CHUNK (1u << ARENA_SHIFT)
+
 #define GS_BLOCK_ROWS 128u
 #define GS_BLOCK_SHIFT 7u
 
@@ -156,7 +160,10 @@ struct gs_index {
       w_b_rows, w_b_rowss, w_b_redo_pos, w_b_s, w_b_tab,
       w_score, w_score_io, w_score_tmp, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
       /* overflow arena of k_search (gs_search.hip): records, chunk owners + sequence numbers, chunks per item */
-      w_arena, w_arena_meta, w_nchunk;
+      w_arena, w_arena_meta, w_nchunk,
+      /* per-guide ordering in LDS tiles (gs_tileorder.hip): k_search's per-class counts, the plan's scans, tile
+       * descriptors, bucket space, chunk index, partitioned items, class starts, rank tables + flags */
+      w_cls, w_t_plan, w_t_tiles, w_t_buckets, w_t_chunkof, w_t_big, w_t_rel, w_t_tab;
   uint64_t arena_chunks = 4096; /* chunks of 1,024 records the next batch's arena holds: grown when a batch needed more */
   /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
   double seen_mean[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
@@ -180,6 +187,8 @@ struct gs_index {
   gs_pairtab_host pairtab[2];
   bool pairtab_off = false; /* a batch ran out of memory next to them: not built again on this handle */
   bool rot_off = false;     /* the same for the strand tables' rotated copies */
+  bool tile_order_off = false; /* a batch had interval records or one sequence at one row twice: the per-guide tile ordering is not tried again for that shape */
+  uint64_t tile_order_off_key = 0;
   bool big_long_runs = false; /* a batch showed long runs of one sequence (repeat-rich genome): the device-wide ordering sorts by row, then by word (gs_search.hip) */
 };
 
@@ -194,6 +203,36 @@ void gs_pairtab_free(gs_index *ix, uint32_t slot);
 /* gs_index.hip: the strand tables' rotated copies, built by the first batch that reads them */
 gs_status gs_strand_rot_ensure(gs_index *ix, hipStream_t st);
 bool gs_strand_rot_release(gs_index *ix);
+
+/* ---- gs_tileorder.hip: the per-guide ordering of the guides k_order's LDS does not hold ---- */
+struct gs_tileorder_in {
+  uint32_t n_set;         /* guides of the set */
+  const uint32_t *list;   /* device: set guide -> guide of the batch (nullptr: the whole batch) */
+  const uint32_t *redo_pos; /* device: guide of the batch -> set guide (with list) */
+  const uint32_t *counts; /* device [2 n]: records per item, exact */
+  const uint32_t *cls;    /* device [2 n][8]: records per item and mismatch count */
+  const uint4 *slots;     /* the main slot array, `cap` per item */
+  uint32_t cap;
+  const uint4 *arena;     /* overflow chunks and their owners */
+  const uint32_t *chunk_item, *chunk_seq;
+  uint32_t n_used;
+  uint32_t *nhits;        /* device [n]: set to the set guides' hit counts by the plan */
+  const uint64_t *offsets; /* device [n + 1]: valid when gs_tileorder_run is called */
+  gs_hit *hits;
+  uint32_t L, P, m, v_rem;
+};
+struct gs_tileorder_state {
+  uint32_t n_it = 0, n_tiles = 0, n_btiles = 0, n_chunks = 0, n_big = 0;
+  uint64_t n_records = 0; /* records of the set (set by gs_tileorder_run) */
+};
+/* does the sort word (class base + rank of the sequence, then the row) fit 64 bits? */
+bool gs_tileorder_fits(uint32_t L, uint32_t P, uint32_t m);
+/* plan: tiles, bucket space, chunk index, class starts; sets nhits of the set's guides.  *usable = false: an item is
+ * too large for this form (nothing else was changed) */
+gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t st, gs_tileorder_state &S, bool *usable);
+/* partition + order + write the hits; *violations != 0: an assumption did not hold (multi-row records, a sequence at
+ * one row twice, a bucket beyond its space) - the hits of the set are then not valid and the caller orders it the other way */
+gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder_state &S, hipStream_t st, uint32_t *violations);
 
 #define GS_HIP(expr)                                                              \
   do {                                                                            \

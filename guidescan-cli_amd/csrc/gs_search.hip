@@ -31,7 +31,7 @@
 #ifndef VQ_DRAIN
 #define VQ_DRAIN 64 /* verify as soon as this many seeds wait (a seeding step adds at most 64) */
 #endif
-#define WAVE_LDS_FAST (VQ_CAP + 32 + DTAB + 1) /* 16-byte entries per wave of the table-only variant: 3.9 KiB */
+#define WAVE_LDS_FAST (VQ_CAP + 32 + DTAB + 3) /* 16-byte entries per wave of the table-only variant: 3.9 KiB */
 #define WAVE_LDS_ENTRIES (STACK_ENTRIES + WAVE_LDS_FAST) /* the walking variant adds the X/G stacks: 8 KiB */
 #define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
 
@@ -59,6 +59,9 @@ struct gs_search_args {
   uint32_t *chunk_item, *chunk_seq;
   uint2 *nchunk;         /* [n_items] */
   uint32_t arena_chunks; /* chunks the arena holds */
+  /* with the arena: matches per item and mismatch count, [n_items][8] - what lets the per-guide ordering
+   * (gs_tileorder.hip) place an item's records among the other index's without a counting pass */
+  uint32_t *cls;
   /* Every loop of an item counts its rounds against max_iter; an item that passes it gives up, raises
    * *err and the wave skips what is left of the queue, so the grid always drains and the call fails with
    * GS_ERR_DEVICE instead of hanging the device (a table damaged in memory, a code-generation fault). */
@@ -112,8 +115,6 @@ struct gs_search_args {
   const uint4 *cand[2];
   uint32_t n_cand[2];
 };
-#define ARENA_SHIFT 10u
-#define ARENA_CHUNK (1u << ARENA_SHIFT) /* records per overflow chunk (16 KiB): one atomic per 1,024 matches */
 #define DSC_LO 27u  /* descriptor.y bits 29:27: fewest substitutions allowed among the remaining guide symbols */
 #define DSC_EXC 30u /* descriptor.y bit 30: the interval holds exception rows (gs_strand_dev::exc_row) */
 
@@ -203,7 +204,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   uint2 *own2 = (uint2 *)(vq + VQ_CAP);        /* owner markers of a pass, two per lane */
   uint32_t *own = (uint32_t *)own2;
   uint4 *dtab = vq + VQ_CAP + 32;              /* substitution table of the item: {index xor, path lo, path hi, -} */
-  uint32_t *wmisc = (uint32_t *)(dtab + DTAB); /* overflow chunks of the item: {taken, the last one, the one before} */
+  uint32_t *wmisc = (uint32_t *)(dtab + DTAB); /* overflow chunks of the item: {taken, the last one, the one before}; [4..11] matches per mismatch count */
 
   /* Items are taken from the work counter `take` at a time: one atomic on one word serves about 88 waves per
    * microsecond chip-wide (MI355X_MICROARCH.md, dequeue), so a counter bumped once per item held a launch of
@@ -238,6 +239,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     const uint32_t gr_valid = __builtin_amdgcn_readfirstlane(gp[7]);
     if (!gr_valid || bailed) {
       if (lane == 0) a.counts[slot] = 0;
+      if (a.arena != nullptr && lane < 8u) a.cls[(size_t)slot * 8u + lane] = 0u;
       continue;
     }
     uint32_t guard_left = a.max_iter; /* rounds this item's loops may still take (every outer step runs a counted inner loop) */
@@ -253,6 +255,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       uint2 nc = make_uint2(0u, 0u);
       if (a.append) nc = a.nchunk[slot];
       if (lane < 3u) wmisc[lane] = lane == 0u ? nc.x : lane == 1u ? nc.y : 0u;
+      if (lane >= 4u && lane < 12u) wmisc[lane] = a.append ? a.cls[(size_t)slot * 8u + (lane - 4u)] : 0u;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
     uint32_t xs = 0, gs = 0; /* sizes of the X and G stacks */
@@ -297,6 +300,16 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint64_t be = __ballot(em);
       if (be) {
         const uint32_t hi = n_match + (uint32_t)__popcll(be); /* one past the last record of this emission */
+        if (a.arena != nullptr) {
+          /* matches per mismatch count: lane d adds this emission's share of class d (one LDS add, distinct words) */
+          const uint32_t kk = META_K(cmeta);
+          uint32_t add = 0;
+          for (uint32_t d = 0; d <= m; ++d) {
+            const uint32_t c = (uint32_t)__popcll(__ballot(em && kk == d));
+            add = lane == d ? c : add;
+          }
+          if (add) atomicAdd(&wmisc[4u + lane], add);
+        }
         if (hi > item_cap && a.arena != nullptr) {
           /* the emission reaches beyond the item's slots: take overflow chunks up to its last record
            * (wave-uniform; at most two per emission, almost always none) */
@@ -1216,6 +1229,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
       if (lane == 0) a.nchunk[slot] = make_uint2(nch, last);
+      if (lane < 8u) a.cls[(size_t)slot * 8u + lane] = wmisc[4u + lane];
       if (n_match > item_cap && n_match - item_cap > (nch << ARENA_SHIFT)) n_fail++;
     }
   }
@@ -2914,7 +2928,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (want) {
       auto reserve_arena = [&]() {
         return gs_reserve(ix->w_arena, sizeof(uint4) * (want << ARENA_SHIFT)) == GS_OK &&
-               gs_reserve(ix->w_arena_meta, 8 * want + 64) == GS_OK && gs_reserve(ix->w_nchunk, sizeof(uint2) * (2 * n + 2)) == GS_OK;
+               gs_reserve(ix->w_arena_meta, 8 * want + 64) == GS_OK && gs_reserve(ix->w_nchunk, sizeof(uint2) * (2 * n + 2)) == GS_OK &&
+               gs_reserve(ix->w_cls, 32 * (2 * n + 2)) == GS_OK;
       };
       if (!reserve_arena()) {
         /* no room: give back what only the paths without the arena use (the exact-size array of a second
@@ -2963,6 +2978,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       sa.chunk_item = (uint32_t *)ix->w_arena_meta.p;
       sa.chunk_seq = sa.chunk_item + arena_chunks;
       sa.nchunk = (uint2 *)ix->w_nchunk.p;
+      sa.cls = (uint32_t *)ix->w_cls.p;
       sa.arena_chunks = arena_chunks;
     }
     /* items per visit to the work counter: enough to keep the counter far from its ~88 visits per microsecond,
@@ -3536,6 +3552,26 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   /* ---- redo only the guides whose matches did not fit their slots ---- */
   uint32_t n_o = 0, cap2 = cap, n_used = 0;
   bool redo_big = false, arena_direct = false; /* arena_direct: the ordering reads the slots and the arena themselves */
+  bool lds_redo = false, ovf_arena_ok = false; /* the overflowing guides fit k_order_wg's LDS; their records beyond the slots are in the arena */
+  std::vector<uint32_t> ovf_c2;                /* exact counts of the overflowing guides' items */
+  auto arena_gather = [&](const uint64_t *dst_off, uint32_t cap2_) {
+    gs_agather_args ga;
+    ga.slots = (const uint4 *)ix->w_slots.p;
+    ga.arena = (const uint4 *)ix->w_arena.p;
+    ga.counts = (const uint32_t *)ix->w_counts.p;
+    ga.chunk_item = (const uint32_t *)ix->w_arena_meta.p;
+    ga.chunk_seq = ga.chunk_item + arena_chunks;
+    ga.list = (const uint32_t *)ix->w_ovf_list.p;
+    ga.redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
+    ga.dst_off = dst_off;
+    ga.dst = (uint4 *)ix->w_slots2.p;
+    ga.n_o = n_o;
+    ga.cap = cap;
+    ga.cap2 = cap2_;
+    ga.n_used = n_used;
+    hipLaunchKernelGGL(k_arena_gather, dim3(2u * n_o + n_used), dim3(256), 0, st, ga);
+  };
+  auto arena_gather_exact = [&](const uint64_t *dst_off) { arena_gather(dst_off, 0u); };
   if (h_stats[1] != 0) {
     if ((rc = gs_reserve(ix->w_ovf_list, sizeof(uint32_t) * (n + 1))) != GS_OK) return rc;
     GS_HIP(hipMemsetAsync(d_nlist, 0, 4, st));
@@ -3580,24 +3616,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       GS_HIP(hipStreamSynchronize(st));
       if (n_used > arena_chunks) n_used = arena_chunks;
     }
-    auto arena_gather = [&](const uint64_t *dst_off, uint32_t cap2_) {
-      gs_agather_args ga;
-      ga.slots = (const uint4 *)ix->w_slots.p;
-      ga.arena = (const uint4 *)ix->w_arena.p;
-      ga.counts = (const uint32_t *)ix->w_counts.p;
-      ga.chunk_item = (const uint32_t *)ix->w_arena_meta.p;
-      ga.chunk_seq = ga.chunk_item + arena_chunks;
-      ga.list = (const uint32_t *)ix->w_ovf_list.p;
-      ga.redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
-      ga.dst_off = dst_off;
-      ga.dst = (uint4 *)ix->w_slots2.p;
-      ga.n_o = n_o;
-      ga.cap = cap;
-      ga.cap2 = cap2_;
-      ga.n_used = n_used;
-      hipLaunchKernelGGL(k_arena_gather, dim3(2u * n_o + n_used), dim3(256), 0, st, ga);
-    };
-    if (!big_batch && need_cap <= LDS_CAP_MAX) {
+    lds_redo = !big_batch && need_cap <= LDS_CAP_MAX;
+    if (lds_redo) {
       /* slots every one of these guides fits, ordered in LDS */
       cap2 = 128;
       while (cap2 < need_cap) cap2 <<= 1;
@@ -3617,71 +3637,163 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       if ((rc = run_order((uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_counts2.p,
                           (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, n_o, cap2, need_cap)) != GS_OK)
         return rc;
-    } else {
-      if (arena_ok && big_fits_v2(big_batch ? n32 : n_o)) {
-        arena_direct = true; /* no copy at all: the ordering's first kernel reads slots and chunks */
-      } else if (arena_ok) {
-        /* the exact-size array the second pass would have filled, filled by copies */
-        std::vector<uint64_t> h_slot_off(2 * (size_t)n_o + 1, 0);
-        for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + c2[i];
-        if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (h_slot_off.back() + 1))) != GS_OK) return rc;
-        if ((rc = gs_reserve(ix->w_h_off, 8 * h_slot_off.size())) != GS_OK) return rc;
-        GS_HIP(hipMemcpyAsync(ix->w_h_off.p, h_slot_off.data(), 8 * h_slot_off.size(), hipMemcpyHostToDevice, st));
-        GS_HIP(hipStreamSynchronize(st)); /* h_slot_off is a local */
-        arena_gather((const uint64_t *)ix->w_h_off.p, 0);
-      } else if ((rc = redo_exact(n_o)) != GS_OK) {
-        return rc;
+      hipLaunchKernelGGL(k_patch_overflow, dim3((n_o + 255) / 256), dim3(256), 0, st,
+                         (const uint32_t *)ix->w_ovf_list.p, n_o, (const uint32_t *)ix->w_nhits2.p,
+                         (uint32_t *)ix->w_nhits.p);
+    }
+    ovf_arena_ok = arena_ok;
+    ovf_c2.swap(c2);
+  }
+  /* ---- the set that LDS does not order: the overflowing guides beyond k_order_wg's reach, or - from 1,024 slots
+   * per item on - the whole batch.  Per guide in LDS tiles (gs_tileorder.hip) when k_search counted the classes
+   * (arena on) and the sort word fits; the device-wide ordering otherwise, and whenever a tile reports that one
+   * of its assumptions did not hold (then everything from the ordering on is done again that way). ---- */
+  const bool set_exists = big_batch || (n_o != 0 && !lds_redo);
+  /* (the walking kernel's records are intervals; a batch shape that showed overlapping PAM patterns is remembered) */
+  uint64_t tile_key = 1469598103934665603ull;
+  {
+    auto mix = [&](uint64_t v) { tile_key = (tile_key ^ v) * 1099511628211ull; };
+    mix(L);
+    mix(P);
+    mix(n_alt);
+    mix(flags & (GS_FLAG_PAM_AT_START | GS_FLAG_FAITHFUL_WALK));
+    for (uint32_t i = 0; i < n_alt * P; i++) mix((uint8_t)alt_pams[i]);
+  }
+  bool tile = set_exists && arena_chunks != 0 && (n_o == 0 || ovf_arena_ok) && v_rem != 0 && gs_tileorder_fits(L, P, mismatches) &&
+              !(ix->tile_order_off && ix->tile_order_off_key == tile_key) && !getenv("GS_NO_TILE_ORDER");
+  bool tile_used = false, tile_fell_back = false;
+  uint64_t total = 0;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    gs_tileorder_in ti;
+    gs_tileorder_state ts;
+    memset(&ti, 0, sizeof(ti));
+    if (set_exists && tile) {
+      if (n_o) {
+        if ((rc = gs_reserve(ix->w_b_redo_pos, 4 * ((size_t)n + 1))) != GS_OK) return rc;
+        hipLaunchKernelGGL(k_fill_u32, dim3((n32 + 255) / 256), dim3(256), 0, st, (uint32_t *)ix->w_b_redo_pos.p, 0xFFFFFFFFu, n32);
+        hipLaunchKernelGGL(k_mark_redo, dim3((n_o + 255) / 256), dim3(256), 0, st, (const uint32_t *)ix->w_ovf_list.p, n_o,
+                           (uint32_t *)ix->w_b_redo_pos.p);
       }
-      redo_big = true;
+      ti.n_set = big_batch ? n32 : n_o;
+      ti.list = big_batch ? nullptr : (const uint32_t *)ix->w_ovf_list.p;
+      ti.redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
+      ti.counts = (const uint32_t *)ix->w_counts.p;
+      ti.cls = (const uint32_t *)ix->w_cls.p;
+      ti.slots = (const uint4 *)ix->w_slots.p;
+      ti.cap = cap;
+      ti.arena = (const uint4 *)ix->w_arena.p;
+      ti.chunk_item = (const uint32_t *)ix->w_arena_meta.p;
+      ti.chunk_seq = ti.chunk_item + arena_chunks;
+      ti.n_used = n_used;
+      ti.nhits = (uint32_t *)ix->w_nhits.p;
+      ti.L = L;
+      ti.P = P;
+      ti.m = mismatches;
+      ti.v_rem = v_rem;
+      bool usable = false;
+      if ((rc = gs_tileorder_plan(ix, ti, st, ts, &usable)) != GS_OK) return rc;
+      if (!usable) tile = false;
+    }
+    if (set_exists && !tile) {
       if (!big_batch) {
+        if (ovf_arena_ok && big_fits_v2(n_o)) {
+          arena_direct = true; /* no copy at all: the ordering's first kernel reads slots and chunks */
+        } else if (ovf_arena_ok) {
+          /* the exact-size array the second pass would have filled, filled by copies */
+          std::vector<uint64_t> h_slot_off(2 * (size_t)n_o + 1, 0);
+          for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + ovf_c2[i];
+          if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (h_slot_off.back() + 1))) != GS_OK) return rc;
+          if ((rc = gs_reserve(ix->w_h_off, 8 * h_slot_off.size())) != GS_OK) return rc;
+          GS_HIP(hipMemcpyAsync(ix->w_h_off.p, h_slot_off.data(), 8 * h_slot_off.size(), hipMemcpyHostToDevice, st));
+          GS_HIP(hipStreamSynchronize(st)); /* h_slot_off is a local */
+          arena_gather_exact((const uint64_t *)ix->w_h_off.p);
+        } else if ((rc = redo_exact(n_o)) != GS_OK) {
+          return rc;
+        }
+        redo_big = true;
         /* the redo list alone goes through the device-wide sort */
         if ((rc = big_order(n_o, nullptr, 0, nullptr, (const uint64_t *)ix->w_h_off.p,
                             (const uint32_t *)ix->w_counts2.p, (uint32_t *)ix->w_nmatch2.p,
                             (uint32_t *)ix->w_nhits2.p, arena_direct, (const uint32_t *)ix->w_ovf_list.p, n_used)) != GS_OK)
           return rc;
+        hipLaunchKernelGGL(k_patch_overflow, dim3((n_o + 255) / 256), dim3(256), 0, st,
+                           (const uint32_t *)ix->w_ovf_list.p, n_o, (const uint32_t *)ix->w_nhits2.p,
+                           (uint32_t *)ix->w_nhits.p);
+      } else {
+        /* every guide: records from the main slots, or from the arena / the exact-size array for redo guides */
+        const uint32_t *redo_pos = nullptr;
+        if (n_o) {
+          if (ovf_arena_ok && big_fits_v2(n32)) {
+            arena_direct = true;
+          } else if (ovf_arena_ok) {
+            std::vector<uint64_t> h_slot_off(2 * (size_t)n_o + 1, 0);
+            for (size_t i = 0; i < 2 * (size_t)n_o; i++) h_slot_off[i + 1] = h_slot_off[i] + ovf_c2[i];
+            if ((rc = gs_reserve(ix->w_slots2, sizeof(uint4) * (h_slot_off.back() + 1))) != GS_OK) return rc;
+            if ((rc = gs_reserve(ix->w_h_off, 8 * h_slot_off.size())) != GS_OK) return rc;
+            GS_HIP(hipMemcpyAsync(ix->w_h_off.p, h_slot_off.data(), 8 * h_slot_off.size(), hipMemcpyHostToDevice, st));
+            GS_HIP(hipStreamSynchronize(st));
+            arena_gather_exact((const uint64_t *)ix->w_h_off.p);
+          } else if ((rc = redo_exact(n_o)) != GS_OK) {
+            return rc;
+          }
+          redo_big = true;
+          if ((rc = gs_reserve(ix->w_b_redo_pos, 4 * ((size_t)n + 1))) != GS_OK) return rc;
+          hipLaunchKernelGGL(k_fill_u32, dim3((n32 + 255) / 256), dim3(256), 0, st, (uint32_t *)ix->w_b_redo_pos.p,
+                             0xFFFFFFFFu, n32);
+          hipLaunchKernelGGL(k_mark_redo, dim3((n_o + 255) / 256), dim3(256), 0, st, (const uint32_t *)ix->w_ovf_list.p,
+                             n_o, (uint32_t *)ix->w_b_redo_pos.p);
+          redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
+        }
+        if ((rc = big_order(n32, (const uint32_t *)ix->w_counts.p, cap, redo_pos, (const uint64_t *)ix->w_h_off.p,
+                            (const uint32_t *)ix->w_counts2.p, (uint32_t *)ix->w_nmatch.p,
+                            (uint32_t *)ix->w_nhits.p, arena_direct, nullptr, n_used)) != GS_OK)
+          return rc;
       }
     }
-    if (!big_batch)
-      hipLaunchKernelGGL(k_patch_overflow, dim3((n_o + 255) / 256), dim3(256), 0, st,
-                         (const uint32_t *)ix->w_ovf_list.p, n_o, (const uint32_t *)ix->w_nhits2.p,
-                         (uint32_t *)ix->w_nhits.p);
-  }
-  if (big_batch) {
-    /* every guide: records from the main slots, or from the exact-size array for redo guides */
-    const uint32_t *redo_pos = nullptr;
-    if (n_o) {
-      if ((rc = gs_reserve(ix->w_b_redo_pos, 4 * ((size_t)n + 1))) != GS_OK) return rc;
-      hipLaunchKernelGGL(k_fill_u32, dim3((n32 + 255) / 256), dim3(256), 0, st, (uint32_t *)ix->w_b_redo_pos.p,
-                         0xFFFFFFFFu, n32);
-      hipLaunchKernelGGL(k_mark_redo, dim3((n_o + 255) / 256), dim3(256), 0, st, (const uint32_t *)ix->w_ovf_list.p,
-                         n_o, (uint32_t *)ix->w_b_redo_pos.p);
-      redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
-    }
-    if ((rc = big_order(n32, (const uint32_t *)ix->w_counts.p, cap, redo_pos, (const uint64_t *)ix->w_h_off.p,
-                        (const uint32_t *)ix->w_counts2.p, (uint32_t *)ix->w_nmatch.p,
-                        (uint32_t *)ix->w_nhits.p, arena_direct, nullptr, n_used)) != GS_OK)
-      return rc;
-  }
 
-  hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_BLOCK), 0, st,
-                     (const uint32_t *)ix->w_nhits.p, (uint64_t *)ix->w_blocksums.p, n32);
-  hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st,
-                     (uint64_t *)ix->w_blocksums.p, nb);
-  hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st,
-                     (const uint32_t *)ix->w_nhits.p, (const uint64_t *)ix->w_blocksums.p,
-                     (uint64_t *)ix->w_offsets.p, n32, nb);
-  uint64_t total = 0;
-  GS_HIP(hipMemcpyAsync(&total, (uint64_t *)ix->w_offsets.p + n, 8, hipMemcpyDeviceToHost, st));
-  GS_HIP(hipStreamSynchronize(st));
-  if ((rc = gs_reserve(ix->w_hits, sizeof(gs_hit) * (total + 1))) != GS_OK) return rc;
-  if (big_batch) {
-    big_locate(nullptr);
-  } else {
-    run_locate((const uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_nmatch.p, nullptr, n32, cap);
-    if (n_o && !redo_big)
-      run_locate((const uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_nmatch2.p,
-                 (const uint32_t *)ix->w_ovf_list.p, n_o, cap2);
-    if (n_o && redo_big) big_locate((const uint32_t *)ix->w_ovf_list.p);
+    hipLaunchKernelGGL(k_scan_partial, dim3(nb), dim3(SCAN_BLOCK), 0, st,
+                       (const uint32_t *)ix->w_nhits.p, (uint64_t *)ix->w_blocksums.p, n32);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(1), dim3(SCAN_BLOCK), 0, st,
+                       (uint64_t *)ix->w_blocksums.p, nb);
+    hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_BLOCK), 0, st,
+                       (const uint32_t *)ix->w_nhits.p, (const uint64_t *)ix->w_blocksums.p,
+                       (uint64_t *)ix->w_offsets.p, n32, nb);
+    total = 0;
+    GS_HIP(hipMemcpyAsync(&total, (uint64_t *)ix->w_offsets.p + n, 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    if ((rc = gs_reserve(ix->w_hits, sizeof(gs_hit) * (total + 1))) != GS_OK) return rc;
+    if (!big_batch) {
+      run_locate((const uint4 *)ix->w_slots.p, (const uint32_t *)ix->w_nmatch.p, nullptr, n32, cap);
+      if (n_o && lds_redo)
+        run_locate((const uint4 *)ix->w_slots2.p, (const uint32_t *)ix->w_nmatch2.p,
+                   (const uint32_t *)ix->w_ovf_list.p, n_o, cap2);
+    }
+    if (!set_exists) break;
+    if (!tile) {
+      big_locate(big_batch ? nullptr : (const uint32_t *)ix->w_ovf_list.p);
+      break;
+    }
+    ti.offsets = (const uint64_t *)ix->w_offsets.p;
+    ti.hits = (gs_hit *)ix->w_hits.p;
+    uint32_t viol = 0;
+    if ((rc = gs_tileorder_run(ix, ti, ts, st, &viol)) != GS_OK) return rc;
+    if (!viol) {
+      tile_used = true;
+      /* matches counter: these guides were skipped by (or never went through) k_order */
+      unsigned long long cur = 0;
+      GS_HIP(hipMemcpy(&cur, d_stats + 2, 8, hipMemcpyDeviceToHost));
+      cur += ts.n_records;
+      GS_HIP(hipMemcpy(d_stats + 2, &cur, 8, hipMemcpyHostToDevice));
+      break;
+    }
+    if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] per-guide tile ordering gave up (flags %u): device-wide ordering instead\n", viol);
+    tile = false;
+    tile_fell_back = true;
+    /* overlapping PAM patterns or interval records are a property of the batch's shape: later batches of this handle skip the attempt */
+    if (viol & 3u) {
+      ix->tile_order_off = true;
+      ix->tile_order_off_key = tile_key;
+    }
   }
   GS_HIP(hipEventRecord(ix->ev[3], st));
   unsigned long long h_stats3[16] = {0};
@@ -3689,11 +3801,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   GS_HIP(hipStreamSynchronize(st));
   if (bidir && getenv("GS_DEBUG"))
     fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu; slots %u per item, "
-            "%u guides redone%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (device-wide ordering)" : "");
+            "%u guides redone%s%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (whole batch through the wide ordering)" : "",
+            tile_used ? " (per guide in LDS tiles)" : "");
   h_stats3[6] = n_o;
   h_stats3[7] = (h_stats3[7] << 8) | (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u) |
                 (n_o && arena_chunks != 0 && arena_fail == 0 ? 4u : 0u) | /* bit 2: the overflowing guides came out of the arena, no second pass */
-                (big_comp ? 8u : 0u) | (big_fixed ? 16u : 0u);           /* bits 3, 4: ordered by one sort of (word, row bits); runs put right afterwards */ /* items through PAM-pair tables above the flags */
+                (big_comp ? 8u : 0u) | (big_fixed ? 16u : 0u) |
+                (tile_used ? 32u : 0u) | (tile_fell_back ? 64u : 0u);    /* bits 5, 6: ordered per guide in LDS tiles; that form gave up and the device-wide one ran */           /* bits 3, 4: ordered by one sort of (word, row bits); runs put right afterwards */ /* items through PAM-pair tables above the flags */
   h_stats3[13] = cap;
   memcpy(ix->last_counters, h_stats3, sizeof(h_stats3));
   /* matches per item seen at this budget: sizes the slots of the next batch */

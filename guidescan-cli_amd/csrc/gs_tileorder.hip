@@ -1,0 +1,702 @@
+/*
+ * gs_tileorder.hip -- canonical order of guides with more matches than k_order holds in LDS, per guide.
+ *
+ * What orders a guide's hits is (mismatches, index, match.sequence, row) (process.hpp:100-115,
+ * structures.hpp:33-43).  An item of the search is one (guide, index): inside it the order is
+ * (mismatches, sequence, row), i.e. one 64-bit word K = (class base + lexicographic rank of the sequence) << 32 | row
+ * (the rank of gs_search.hip's big2_rank without the index bit: 32 bits at L = 20, P = 3, m <= 6).
+ * Instead of eight device-wide radix passes over (guide | rank | row bits) and five more passes to gather, flag,
+ * scan and locate, every item is ordered by itself:
+ *
+ *   k_to_plan       one workgroup: per set item the tiles, bucket space and arena chunks it needs; four scans
+ *   k_to_fill       tile descriptors, the chunk index of every item, per guide where each (mismatches, index)
+ *                   class starts in its hit list (from k_search's per-class counts), hits per guide
+ *   k_to_partition  items beyond one tile: a sample of their records ordered in LDS gives splitters; one
+ *                   streaming pass deals the records into buckets of at most TO_TILE records (sample sort:
+ *                   the full word decides, so a run of 10^4 equal sequences is split by row)
+ *   k_to_sort       one workgroup per tile (a small item where k_search left it, or a bucket): K of every
+ *                   record, LSD radix sort in LDS over the bits that vary inside the tile (eight-bit digits,
+ *                   wave64 ballot match for the stable rank inside a wave), then the hits - suffix array
+ *                   gather + coordinate rule (process.hpp:104, 111) - straight to their final place
+ *
+ * Two passes of HBM traffic for partitioned items (16 B read + 16 B written, twice), one for the rest.
+ * The path writes final hits on two assumptions it checks as it goes: every record is a single row, and no
+ * (sequence, row) occurs twice in an item (overlapping PAM patterns).  A tile that sees otherwise - or a bucket
+ * that outgrows its space - raises a flag; the caller then orders the batch with the device-wide form.
+ */
+#include "gs_device.h"
+
+#include <algorithm>
+
+#define TO_NT 512u                 /* threads of the sort and partition workgroups */
+#define TO_NW (TO_NT / WAVE)       /* 8 waves */
+#define TO_KPT 8u                  /* keys per thread */
+#define TO_TILE (TO_NT * TO_KPT)   /* 4,096 records per tile */
+#define TO_CSTR (TO_NW + 1u)       /* counters of one digit: one per wave + a pad word (bank spread) */
+#define TO_NCNT (256u * TO_CSTR)
+#define TO_EP ((TO_NCNT + TO_NT - 1u) / TO_NT)
+#define TO_NBMAX 1024u             /* buckets of one item */
+#define TO_DIRECT 0x80000000u
+
+/* flags raised by the kernels (gs_tileorder_run) */
+#define TO_F_MULTIROW 1u
+#define TO_F_DUP 2u
+#define TO_F_BUCKET 4u
+#define TO_F_BIG 8u
+#define TO_F_CLS 16u
+
+struct gs_to_tab {
+  unsigned long long n[32][8]; /* n[a][r] = C(a, r) 3^r */
+  unsigned long long base[8];  /* sequences of the classes with fewer mismatches (one index) */
+  unsigned long long pam_mul;
+};
+
+/* rank of a key's match.sequence among the sequences of its mismatch class: position 0 most significant, as
+ * the key's own bits order them (the same number gs_search.hip's big2_rank computes) */
+__device__ __forceinline__ unsigned long long to_rank(const unsigned long long key, const uint32_t L, const uint32_t P,
+                                                       const unsigned long long *nt, const unsigned long long pam_mul) {
+  const unsigned long long path = key >> 8;
+  uint32_t j = 0;
+  for (uint32_t t = 0; t < L; t++) j += ((path >> (50u - 2u * t)) & 3ull) != 0ull;
+  if (j > 7u) j = 7u;
+  uint32_t r = j;
+  unsigned long long rank = 0;
+  for (uint32_t t = 0; t < L && r != 0u; t++) {
+    const uint32_t c = (uint32_t)(path >> (50u - 2u * t)) & 3u;
+    if (c) {
+      const uint32_t a = L - 1u - t;
+      rank += nt[a * 8u + r] + (unsigned long long)(c - 1u) * nt[a * 8u + r - 1u];
+      r--;
+    }
+  }
+  unsigned long long pr = 0;
+  for (uint32_t u = 0; u < P; u++) {
+    const uint32_t c = (uint32_t)(path >> (49u - 2u * L - 3u * u)) & 7u;
+    pr = pr * 5ull + (c < 4u ? c : 4u);
+  }
+  return rank * pam_mul + pr;
+}
+__device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uint32_t L, const uint32_t P, const unsigned long long *nt,
+                                                       const unsigned long long *bs, const unsigned long long pam_mul) {
+  const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
+  const unsigned long long w = bs[(uint32_t)(key >> 61)] + to_rank(key, L, P, nt, pam_mul);
+  return (w << 32) | rec.z;
+}
+
+__device__ __forceinline__ uint32_t wave_or32(uint32_t x) {
+  for (int o = 32; o > 0; o >>= 1) x |= (uint32_t)__shfl_xor((int)x, o);
+  return x;
+}
+__device__ __forceinline__ uint32_t wave_and32(uint32_t x) {
+  for (int o = 32; o > 0; o >>= 1) x &= (uint32_t)__shfl_xor((int)x, o);
+  return x;
+}
+
+/* ---- LSD radix sort of n <= TO_TILE 64-bit words in LDS over the bits of V, by the whole workgroup ----------
+ * keys[TO_TILE] (+ idx[TO_TILE]: a 16-bit payload that moves with its key), cnt[TO_NCNT] counters, wsum[TO_NW].
+ * A pass takes the lowest bit of V still to do and the seven above it (the bits of that window that are in V):
+ * each wave owns a contiguous piece of the array and goes through it 64 keys at a time - lanes with equal digits
+ * find each other by one ballot per window bit, the first of them bumps the wave's counter of that digit, each
+ * keeps counter + lanes before it as its rank in the wave's piece - keys and ranks stay in registers; a flat
+ * exclusive scan over the counters (digit-major, wave-minor) turns them into each (digit, wave)'s first place;
+ * every key goes there + its rank.  Stable.  Places n .. (padded size) hold words of all ones, which every pass
+ * leaves behind the real ones. */
+template <bool WITH_IDX>
+__device__ __forceinline__ void to_radix(unsigned long long *keys, uint16_t *idx, uint32_t *cnt, uint32_t *wsum, const uint32_t n,
+                                         unsigned long long V) {
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), w = tid / WAVE;
+  const uint32_t per = ((n + TO_NW * WAVE - 1u) / (TO_NW * WAVE)) * WAVE; /* keys per wave, a multiple of 64 */
+  const uint32_t rounds = per / WAVE;
+  while (V) {
+    const uint32_t sh = (uint32_t)__builtin_ctzll(V);
+    const uint32_t wmask = (uint32_t)((V >> sh) & 0xFFull);
+    V &= ~(0xFFull << sh);
+    for (uint32_t i = tid; i < TO_NCNT; i += TO_NT) cnt[i] = 0u;
+    __syncthreads();
+    unsigned long long kreg[TO_KPT];
+    uint32_t lrank[TO_KPT];
+    uint32_t ireg[TO_KPT];
+#pragma unroll
+    for (uint32_t r = 0; r < TO_KPT; ++r) {
+      kreg[r] = ~0ull;
+      lrank[r] = 0u;
+      ireg[r] = 0u;
+      if (r < rounds) {
+        const uint32_t e = w * per + r * WAVE + lane;
+        const bool real = e < n;
+        const unsigned long long k = real ? keys[e] : ~0ull;
+        if constexpr (WITH_IDX) ireg[r] = real ? idx[e] : 0u;
+        const uint32_t d = (uint32_t)(k >> sh) & wmask;
+        unsigned long long same = ~0ull;
+        for (uint32_t bits = wmask; bits; bits &= bits - 1u) {
+          const uint32_t b = (uint32_t)__builtin_ctz(bits);
+          const bool one = ((d >> b) & 1u) != 0u;
+          const unsigned long long bal = __ballot(one);
+          same &= one ? bal : ~bal;
+        }
+        const uint32_t below = lanes_below(same), total = (uint32_t)__popcll(same);
+        const uint32_t c = cnt[d * TO_CSTR + w];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (below == 0u) cnt[d * TO_CSTR + w] = c + total;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        kreg[r] = k;
+        lrank[r] = c + below;
+      }
+    }
+    __syncthreads();
+    {
+      uint32_t v[TO_EP], s = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < TO_EP; ++j) {
+        const uint32_t i = tid * TO_EP + j;
+        v[j] = i < TO_NCNT ? cnt[i] : 0u;
+        s += v[j];
+      }
+      const uint32_t incl = wave_incl_sum(s);
+      if (lane == WAVE - 1u) wsum[w] = incl;
+      __syncthreads();
+      uint32_t base = incl - s;
+      for (uint32_t q = 0; q < w; ++q) base += wsum[q];
+#pragma unroll
+      for (uint32_t j = 0; j < TO_EP; ++j) {
+        const uint32_t i = tid * TO_EP + j;
+        if (i < TO_NCNT) cnt[i] = base;
+        base += v[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < TO_KPT; ++r) {
+      if (r < rounds) {
+        const uint32_t d = (uint32_t)(kreg[r] >> sh) & wmask;
+        const uint32_t pos = cnt[d * TO_CSTR + w] + lrank[r];
+        keys[pos] = kreg[r];
+        if constexpr (WITH_IDX) idx[pos] = (uint16_t)ireg[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+/* the bits in which the words of the tile differ (all threads get the result) */
+__device__ __forceinline__ unsigned long long to_varying(const unsigned long long *keys, const uint32_t n, uint32_t *red /* [4] */) {
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
+  if (tid < 4u) red[tid] = tid < 2u ? 0u : 0xFFFFFFFFu;
+  __syncthreads();
+  uint32_t olo = 0, ohi = 0, alo = 0xFFFFFFFFu, ahi = 0xFFFFFFFFu;
+  for (uint32_t e = tid; e < n; e += TO_NT) {
+    const unsigned long long k = keys[e];
+    olo |= (uint32_t)k;
+    ohi |= (uint32_t)(k >> 32);
+    alo &= (uint32_t)k;
+    ahi &= (uint32_t)(k >> 32);
+  }
+  olo = wave_or32(olo);
+  ohi = wave_or32(ohi);
+  alo = wave_and32(alo);
+  ahi = wave_and32(ahi);
+  if (lane == 0u) {
+    atomicOr(&red[0], olo);
+    atomicOr(&red[1], ohi);
+    atomicAnd(&red[2], alo);
+    atomicAnd(&red[3], ahi);
+  }
+  __syncthreads();
+  const unsigned long long o = ((unsigned long long)red[1] << 32) | red[0], a = ((unsigned long long)red[3] << 32) | red[2];
+  __syncthreads();
+  return n ? (o ^ a) : 0ull;
+}
+
+/* ---- the plan ------------------------------------------------------------------------------------------- */
+struct gs_to_plan_args {
+  const uint32_t *counts; /* per item of the batch: records (exact) */
+  const uint32_t *list;   /* set guide -> guide of the batch, or nullptr: the whole batch */
+  uint32_t n_it, cap;
+  uint32_t *tbase, *bbase, *cbase, *gbase; /* [n_it + 1] first tile / first bucket slot / first chunk-index entry / place on the list of partitioned items */
+  uint32_t *flags;
+};
+/* buckets of an item of c > TO_TILE records and the records each is meant to hold: the fewer samples per
+ * splitter a large item can afford (TO_TILE samples in all), the more room its buckets get */
+__device__ __host__ __forceinline__ uint32_t to_buckets(const uint32_t c) {
+  if (c <= TO_TILE) return 0u;
+  const uint32_t target = c <= 64u * (TO_TILE / 2u) ? TO_TILE / 2u : c <= 128u * (TO_TILE / 3u) ? TO_TILE / 3u : c <= 256u * (TO_TILE / 4u) ? TO_TILE / 4u
+                          : c <= 512u * (TO_TILE / 6u) ? TO_TILE / 6u : TO_TILE / 8u;
+  return (c + target - 1u) / target;
+}
+__global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
+  __shared__ uint32_t s_w[4][16], s_carry[4];
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), w = tid / WAVE;
+  if (tid < 4u) s_carry[tid] = 0u;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < a.n_it + 1u; i0 += 1024u) {
+    const uint32_t sb = i0 + tid;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    if (sb < a.n_it) {
+      const uint32_t item = a.list ? 2u * a.list[sb >> 1] + (sb & 1u) : sb;
+      const uint32_t c = a.counts[item];
+      uint32_t nb = to_buckets(c);
+      if (nb > TO_NBMAX) { /* an item beyond half a million records: the device-wide form orders this batch */
+        atomicOr(a.flags, TO_F_BIG);
+        nb = 0u;
+      }
+      v[0] = c == 0u ? 0u : nb ? nb : 1u;
+      v[1] = nb;
+      v[2] = c > a.cap ? (c - a.cap + ARENA_CHUNK - 1u) / ARENA_CHUNK : 0u;
+      v[3] = nb ? 1u : 0u;
+    }
+    uint32_t ex[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) {
+      const uint32_t incl = wave_incl_sum(v[q]);
+      if (lane == WAVE - 1u) s_w[q][w] = incl;
+      ex[q] = incl - v[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q) {
+      uint32_t b = s_carry[q];
+      for (uint32_t u = 0; u < w; ++u) b += s_w[q][u];
+      ex[q] += b;
+    }
+    if (sb <= a.n_it) {
+      a.tbase[sb] = ex[0];
+      a.bbase[sb] = ex[1];
+      a.cbase[sb] = ex[2];
+      a.gbase[sb] = ex[3];
+    }
+    __syncthreads();
+    if (tid == 1023u) {
+#pragma unroll
+      for (uint32_t q = 0; q < 4u; ++q) s_carry[q] = ex[q] + v[q];
+    }
+    __syncthreads();
+  }
+}
+
+/* ---- tile descriptors, chunk index, class starts ------------------------------------------------------------- */
+struct gs_to_fill_args {
+  const uint32_t *counts, *cls, *list;
+  uint32_t n_it, cap;
+  const uint32_t *tbase, *bbase, *gbase;
+  uint4 *tiles;     /* {set item | TO_DIRECT, bucket slot, records, records of the item in the buckets before} */
+  uint32_t *biglist; /* set items that are partitioned */
+  uint32_t *rel;    /* [n_set][16]: where class (mismatches d, index s) of the guide starts in its hit list, less the
+                       records of item s in classes before d: a record's place = rel[2d + s] + its rank in the item */
+  uint32_t *nhits;  /* of the batch: hits per guide */
+  uint32_t *flags;
+};
+__global__ __launch_bounds__(256) void k_to_fill(gs_to_fill_args a) {
+  const uint32_t sb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sb >= a.n_it) return;
+  const uint32_t g = a.list ? a.list[sb >> 1] : (sb >> 1);
+  const uint32_t item = 2u * g + (sb & 1u);
+  const uint32_t c = a.counts[item];
+  const uint32_t nb = to_buckets(c), tb = a.tbase[sb];
+  if (c != 0u && nb == 0u) a.tiles[tb] = make_uint4(sb | TO_DIRECT, 0u, c, 0u);
+  if (nb != 0u && nb <= TO_NBMAX) {
+    const uint32_t bb = a.bbase[sb];
+    for (uint32_t b = 0; b < nb; ++b) a.tiles[tb + b] = make_uint4(sb, bb + b, 0u, 0u);
+    a.biglist[a.gbase[sb]] = sb;
+  }
+  if ((sb & 1u) == 0u) {
+    const uint32_t *c0 = a.cls + (size_t)item * 8u, *c1 = c0 + 8u;
+    uint32_t p0 = 0, p1 = 0;
+    for (uint32_t d = 0; d < 8u; ++d) {
+      a.rel[(size_t)(sb >> 1) * 16u + 2u * d] = p1; /* index 0: the other index's records of the classes before */
+      p0 += c0[d];
+      a.rel[(size_t)(sb >> 1) * 16u + 2u * d + 1u] = p0; /* index 1: index 0's records up to and including this class */
+      p1 += c1[d];
+    }
+    const uint32_t cb = a.counts[item + 1u];
+    if (p0 != c || p1 != cb) atomicOr(a.flags, TO_F_CLS); /* (cannot happen: k_search counts both) */
+    a.nhits[g] = c + cb;
+  }
+}
+/* records of the set (flags[2..3] as one 64-bit count) */
+__global__ __launch_bounds__(256) void k_to_total(const uint32_t *counts, const uint32_t *list, uint32_t n_it, unsigned long long *out) {
+  unsigned long long v = 0;
+  for (uint64_t sb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sb < n_it; sb += (uint64_t)gridDim.x * blockDim.x)
+    v += counts[list ? 2u * list[sb >> 1] + ((uint32_t)sb & 1u) : (uint32_t)sb];
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane_id() == 0 && v) atomicAdd(out, v);
+}
+struct gs_to_chunk_args {
+  const uint32_t *counts, *chunk_item, *chunk_seq, *redo_pos, *cbase;
+  uint32_t *chunk_of;
+  uint32_t n_used, cap, by_list;
+};
+__global__ __launch_bounds__(256) void k_to_chunks(gs_to_chunk_args a) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.n_used) return;
+  const uint32_t item = a.chunk_item[c];
+  uint32_t sb = item;
+  if (a.by_list) {
+    const uint32_t pos = a.redo_pos[item >> 1];
+    if (pos == 0xFFFFFFFFu) return;
+    sb = 2u * pos + (item & 1u);
+  }
+  const uint32_t seq = a.chunk_seq[c];
+  if (a.counts[item] > a.cap + (seq << ARENA_SHIFT)) a.chunk_of[a.cbase[sb] + seq] = c;
+}
+
+/* record i of an item where k_search left it: its slots, then its arena chunks in order */
+struct gs_to_src {
+  const uint4 *slots, *arena;
+  const uint32_t *chunk_of;
+  uint32_t cap;
+};
+__device__ __forceinline__ const uint4 *to_addr(const gs_to_src &s, const uint32_t item, const uint32_t cb, const uint32_t i) {
+  if (i < s.cap) return s.slots + (size_t)item * s.cap + i;
+  const uint32_t e = i - s.cap;
+  return s.arena + (((size_t)s.chunk_of[cb + (e >> ARENA_SHIFT)] << ARENA_SHIFT) | (e & (ARENA_CHUNK - 1u)));
+}
+
+struct gs_to_run_args {
+  gs_to_src src;
+  const uint32_t *counts, *list;
+  const uint32_t *tbase, *bbase, *cbase;
+  const uint32_t *biglist;
+  uint4 *tiles;
+  uint4 *buckets;
+  const gs_to_tab *tab;
+  const uint32_t *rel;
+  const uint64_t *offsets;
+  gs_hit *hits;
+  const uint32_t *sa[2];
+  uint64_t genome_length;
+  uint32_t *flags;
+  uint32_t L, P, v_rem;
+};
+
+/* ---- items beyond one tile: splitters from a sample, then one streaming pass into buckets ---------------------- */
+__global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
+  __shared__ unsigned long long s_keys[TO_TILE];
+  __shared__ unsigned long long s_spl[TO_NBMAX];
+  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+  __shared__ uint32_t s_cnt[TO_NCNT], s_cur[TO_NBMAX], s_wsum[TO_NW], s_red[4];
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
+  for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
+  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
+  const unsigned long long pam_mul = a.tab->pam_mul;
+  const uint32_t sb = a.biglist[blockIdx.x];
+  const uint32_t g = a.list ? a.list[sb >> 1] : (sb >> 1);
+  const uint32_t item = 2u * g + (sb & 1u);
+  const uint32_t c = a.counts[item], nb = to_buckets(c);
+  const uint32_t bb = a.bbase[sb], tb = a.tbase[sb], cb = a.cbase[sb];
+  /* stratified sample: one record from each of `ns` equal stretches of the item (emission order is seed by seed,
+   * so a stretch is a few neighbouring sequences: no worse than independent draws) */
+  const uint32_t per = TO_TILE / nb < 64u ? TO_TILE / nb : 64u; /* samples per bucket */
+  const uint32_t ns = per * nb;
+  __syncthreads();
+  bool multi = false;
+  for (uint32_t j = tid; j < ns; j += TO_NT) {
+    const uint32_t lo = (uint32_t)(((unsigned long long)j * c) / ns), hi = (uint32_t)(((unsigned long long)(j + 1u) * c) / ns);
+    uint32_t h = j * 2654435761u ^ (sb * 40503u + 0x9E3779B9u);
+    h ^= h >> 15;
+    h *= 2246822519u;
+    h ^= h >> 13;
+    const uint32_t pos = lo + h % (hi - lo); /* hi > lo: c > TO_TILE >= ns */
+    const uint4 rec = *to_addr(a.src, item, cb, pos);
+    s_keys[j] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+  }
+  __syncthreads();
+  const unsigned long long V = to_varying(s_keys, ns, s_red);
+  to_radix<false>(s_keys, nullptr, s_cnt, s_wsum, ns, V);
+  unsigned long long spl_mine[2] = {0ull, 0ull};
+  for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) spl_mine[q] = s_keys[(b + 1u) * per - 1u];
+  __syncthreads();
+  for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) s_spl[b] = spl_mine[q];
+  for (uint32_t b = tid; b < nb; b += TO_NT) s_cur[b] = 0u;
+  __syncthreads();
+  uint4 *out = a.buckets + (size_t)bb * TO_TILE;
+  const uint32_t c_pad = ((c + TO_NT - 1u) / TO_NT) * TO_NT;
+  for (uint32_t i0 = tid; i0 < c_pad; i0 += 4u * TO_NT) {
+    uint4 rec[4];
+    bool on[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) { /* four loads in flight */
+      const uint32_t i = i0 + u * TO_NT;
+      on[u] = i < c;
+      rec[u] = on[u] ? *to_addr(a.src, item, cb, i) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      if (i0 - tid + u * TO_NT >= c_pad) break; /* workgroup-uniform */
+      uint32_t b = 0;
+      if (on[u]) {
+        multi = multi || rec[u].z != rec[u].w;
+        const unsigned long long K = to_word(rec[u], a.L, a.P, s_nt, s_bs, pam_mul);
+        uint32_t lo = 0, hi = nb - 1u; /* splitters below K */
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_spl[mid] < K)
+            lo = mid + 1u;
+          else
+            hi = mid;
+        }
+        b = lo;
+      }
+      /* one LDS atomic per wave when its records go to one bucket (the stretches of a long run), else one per lane */
+      const unsigned long long act = __ballot(on[u]);
+      if (act == 0ull) continue;
+      const uint32_t b0 = (uint32_t)__shfl((int)b, (int)__builtin_ctzll(act));
+      uint32_t pos;
+      if (__ballot(on[u] && b != b0) == 0ull) {
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(act)) base = atomicAdd(&s_cur[b0], (uint32_t)__popcll(act));
+        base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(act));
+        pos = base + lanes_below(act);
+      } else {
+        pos = on[u] ? atomicAdd(&s_cur[b], 1u) : 0u;
+      }
+      if (on[u] && pos < TO_TILE) out[(size_t)b * TO_TILE + pos] = rec[u];
+    }
+  }
+  if (multi) atomicOr(a.flags, TO_F_MULTIROW);
+  __syncthreads();
+  /* records per bucket and before it (the first wave: nb <= 1,024 = 16 per lane) */
+  if (tid < WAVE) {
+    const uint32_t each = (nb + WAVE - 1u) / WAVE;
+    uint32_t s = 0;
+    bool over = false;
+    for (uint32_t q = 0; q < each; ++q) {
+      const uint32_t b = tid * each + q;
+      if (b < nb) {
+        s += s_cur[b];
+        over = over || s_cur[b] > TO_TILE;
+      }
+    }
+    uint32_t run = wave_incl_sum(s) - s;
+    for (uint32_t q = 0; q < each; ++q) {
+      const uint32_t b = tid * each + q;
+      if (b < nb) {
+        const uint32_t n = s_cur[b];
+        a.tiles[tb + b].z = n < TO_TILE ? n : TO_TILE;
+        a.tiles[tb + b].w = run;
+        run += n;
+      }
+    }
+    if (over) atomicOr(a.flags, TO_F_BUCKET);
+  }
+}
+
+/* ---- one tile: order its records in LDS and write its hits -------------------------------------------------------- */
+__global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
+  __shared__ unsigned long long s_keys[TO_TILE];
+  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+  __shared__ uint16_t s_idx[TO_TILE];
+  __shared__ uint32_t s_cnt[TO_NCNT], s_wsum[TO_NW], s_red[4], s_flag;
+  const uint32_t tid = threadIdx.x;
+  const uint4 t = a.tiles[blockIdx.x];
+  const uint32_t n = t.z;
+  if (n == 0u) return;
+  for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
+  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
+  if (tid == 0u) s_flag = 0u;
+  const unsigned long long pam_mul = a.tab->pam_mul;
+  const bool direct = (t.x & TO_DIRECT) != 0u;
+  const uint32_t sb = t.x & ~TO_DIRECT;
+  const uint32_t gset = sb >> 1, strand = sb & 1u;
+  const uint32_t g = a.list ? a.list[gset] : gset;
+  const uint32_t item = 2u * g + strand;
+  const uint32_t cb = a.cbase[sb];
+  const uint4 *bucket = a.buckets + (size_t)t.y * TO_TILE;
+  __syncthreads();
+  bool multi = false;
+  for (uint32_t i = tid; i < n; i += TO_NT) {
+    const uint4 rec = direct ? *to_addr(a.src, item, cb, i) : bucket[i];
+    multi = multi || rec.z != rec.w;
+    s_keys[i] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+    s_idx[i] = (uint16_t)i;
+  }
+  if (multi) atomicOr(a.flags, TO_F_MULTIROW);
+  __syncthreads();
+  /* by the sequence word alone first: on a genome without repeat families every sequence of a tile occurs once and
+   * the rows never decide; only a tile that shows two rows of one sequence out of order is ordered by row, then by
+   * word again (there the words differ in few bits: a bucket of a long run holds one or two sequences) */
+  const unsigned long long V = to_varying(s_keys, n, s_red);
+  const unsigned long long Vw = V & 0xFFFFFFFF00000000ull, Vr = V & 0xFFFFFFFFull;
+  if (Vw) {
+    to_radix<true>(s_keys, s_idx, s_cnt, s_wsum, n, Vw);
+    bool bad = false;
+    for (uint32_t e = tid + 1u; e < n; e += TO_NT) {
+      const unsigned long long p = s_keys[e - 1u], q = s_keys[e];
+      bad = bad || ((p >> 32) == (q >> 32) && (uint32_t)q < (uint32_t)p);
+    }
+    if (bad) s_flag = 1u;
+  } else if (tid == 0u && Vr) {
+    s_flag = 1u;
+  }
+  __syncthreads();
+  if (s_flag) {
+    to_radix<true>(s_keys, s_idx, s_cnt, s_wsum, n, Vr);
+    if (Vw) to_radix<true>(s_keys, s_idx, s_cnt, s_wsum, n, Vw);
+  }
+  /* the hits: place = the guide's first + the class's start + rank in the item (process.hpp:100-115) */
+  const uint32_t *sa = a.sa[strand];
+  const uint32_t *rel = a.rel + (size_t)gset * 16u + strand;
+  gs_hit *out = a.hits + a.offsets[g] + t.w;
+  bool dup = false;
+  for (uint32_t r = tid; r < n; r += TO_NT) {
+    const unsigned long long K = s_keys[r];
+    const uint32_t i = s_idx[r];
+    const uint2 kk = *(const uint2 *)(direct ? to_addr(a.src, item, cb, i) : bucket + i);
+    const unsigned long long key = ((unsigned long long)kk.y << 32) | kk.x;
+    dup = dup || (r > 0u && s_keys[r - 1u] == K);
+    const uint32_t row = (uint32_t)K;
+    const uint64_t sap = (uint64_t)sa[row] - ((key & 1ull) ? a.v_rem : 0u);
+    gs_hit o;
+    o.pos = strand == 0u ? -(int64_t)sap : (int64_t)(a.genome_length - (sap + 1ull));
+    o.key = key & ~1ull;
+    out[rel[2u * (uint32_t)(key >> 61)] + r] = o;
+  }
+  if (dup) atomicOr(a.flags, TO_F_DUP);
+}
+
+/* ---- host side ------------------------------------------------------------------------------------------------ */
+static bool to_make_tab(uint32_t L, uint32_t P, uint32_t m, gs_to_tab &tab) {
+  memset(&tab, 0, sizeof(tab));
+  for (uint32_t a = 0; a < 32; a++)
+    for (uint32_t r = 0; r < 8; r++) {
+      unsigned long long v = 0;
+      if (r <= a) {
+        double c = 1;
+        for (uint32_t i = 0; i < r; i++) c = c * (double)(a - i) / (double)(i + 1);
+        v = (unsigned long long)(c + 0.5);
+        for (uint32_t i = 0; i < r; i++) v *= 3ull;
+      }
+      tab.n[a][r] = v;
+    }
+  tab.pam_mul = 1;
+  for (uint32_t u = 0; u < P; u++) tab.pam_mul *= 5ull;
+  long double cum = 0;
+  unsigned long long c64 = 0;
+  for (uint32_t j = 0; j < 8; j++) {
+    tab.base[j] = c64;
+    if (j <= m && j <= L) {
+      cum += (long double)tab.n[L][j] * (long double)tab.pam_mul;
+      c64 += tab.n[L][j] * tab.pam_mul;
+    }
+  }
+  return L >= 1 && L <= 31 && m <= 7 && cum < 4294967295.0L; /* the words stay below 2^32 - 1: all ones marks padding */
+}
+bool gs_tileorder_fits(uint32_t L, uint32_t P, uint32_t m) {
+  gs_to_tab tab;
+  return to_make_tab(L, P, m, tab);
+}
+
+gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t st, gs_tileorder_state &S, bool *usable) {
+  *usable = false;
+  gs_to_tab tab;
+  if (!to_make_tab(in.L, in.P, in.m, tab)) return GS_OK;
+  gs_status rc;
+  const uint32_t n_it = 2u * in.n_set;
+  S = gs_tileorder_state();
+  S.n_it = n_it;
+  if ((rc = gs_reserve(ix->w_t_plan, 4 * 4 * ((size_t)n_it + 1) + 64)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_tab, sizeof(gs_to_tab) + 64)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_rel, 64 * ((size_t)in.n_set + 1))) != GS_OK) return rc;
+  uint32_t *tbase = (uint32_t *)ix->w_t_plan.p, *bbase = tbase + (n_it + 1), *cbase = bbase + (n_it + 1), *gbase = cbase + (n_it + 1);
+  uint32_t *d_flags = (uint32_t *)((char *)ix->w_t_tab.p + sizeof(gs_to_tab));
+  GS_HIP(hipMemcpyAsync(ix->w_t_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice, st));
+  GS_HIP(hipMemsetAsync(d_flags, 0, 64, st));
+  gs_to_plan_args pa;
+  pa.counts = in.counts;
+  pa.list = in.list;
+  pa.n_it = n_it;
+  pa.cap = in.cap;
+  pa.tbase = tbase;
+  pa.bbase = bbase;
+  pa.cbase = cbase;
+  pa.gbase = gbase;
+  pa.flags = d_flags;
+  hipLaunchKernelGGL(k_to_plan, dim3(1), dim3(1024), 0, st, pa);
+  uint32_t tot[4] = {0, 0, 0, 0}, h_flags = 0;
+  GS_HIP(hipMemcpyAsync(&tot[0], tbase + n_it, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&tot[1], bbase + n_it, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&tot[2], cbase + n_it, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&tot[3], gbase + n_it, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st)); /* (tab is a local, too) */
+  if (h_flags) return GS_OK;
+  S.n_tiles = tot[0];
+  S.n_btiles = tot[1];
+  S.n_chunks = tot[2];
+  S.n_big = tot[3];
+  if ((rc = gs_reserve(ix->w_t_tiles, 16 * ((size_t)S.n_tiles + 1))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_buckets, 16 * (size_t)TO_TILE * S.n_btiles + 16)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_chunkof, 4 * ((size_t)S.n_chunks + 1))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_big, 4 * ((size_t)S.n_big + 1))) != GS_OK) return rc;
+  gs_to_fill_args fa;
+  fa.counts = in.counts;
+  fa.cls = in.cls;
+  fa.list = in.list;
+  fa.n_it = n_it;
+  fa.cap = in.cap;
+  fa.tbase = tbase;
+  fa.bbase = bbase;
+  fa.gbase = gbase;
+  fa.tiles = (uint4 *)ix->w_t_tiles.p;
+  fa.biglist = (uint32_t *)ix->w_t_big.p;
+  fa.rel = (uint32_t *)ix->w_t_rel.p;
+  fa.nhits = in.nhits;
+  fa.flags = d_flags;
+  hipLaunchKernelGGL(k_to_fill, dim3((n_it + 255) / 256), dim3(256), 0, st, fa);
+  hipLaunchKernelGGL(k_to_total, dim3(std::min<uint32_t>((n_it + 255) / 256, 512u)), dim3(256), 0, st, in.counts, in.list, n_it,
+                     (unsigned long long *)(d_flags + 2));
+  if (in.n_used) {
+    gs_to_chunk_args ca;
+    ca.counts = in.counts;
+    ca.chunk_item = in.chunk_item;
+    ca.chunk_seq = in.chunk_seq;
+    ca.redo_pos = in.redo_pos;
+    ca.cbase = cbase;
+    ca.chunk_of = (uint32_t *)ix->w_t_chunkof.p;
+    ca.n_used = in.n_used;
+    ca.cap = in.cap;
+    ca.by_list = in.list ? 1u : 0u;
+    hipLaunchKernelGGL(k_to_chunks, dim3((in.n_used + 255) / 256), dim3(256), 0, st, ca);
+  }
+  *usable = true;
+  return GS_OK;
+}
+
+gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder_state &S, hipStream_t st, uint32_t *violations) {
+  *violations = 0;
+  const uint32_t n_it = S.n_it;
+  uint32_t *tbase = (uint32_t *)ix->w_t_plan.p, *bbase = tbase + (n_it + 1), *cbase = bbase + (n_it + 1);
+  uint32_t *d_flags = (uint32_t *)((char *)ix->w_t_tab.p + sizeof(gs_to_tab));
+  gs_to_run_args ra;
+  ra.src.slots = in.slots;
+  ra.src.arena = in.arena;
+  ra.src.chunk_of = (const uint32_t *)ix->w_t_chunkof.p;
+  ra.src.cap = in.cap;
+  ra.counts = in.counts;
+  ra.list = in.list;
+  ra.tbase = tbase;
+  ra.bbase = bbase;
+  ra.cbase = cbase;
+  ra.biglist = (const uint32_t *)ix->w_t_big.p;
+  ra.tiles = (uint4 *)ix->w_t_tiles.p;
+  ra.buckets = (uint4 *)ix->w_t_buckets.p;
+  ra.tab = (const gs_to_tab *)ix->w_t_tab.p;
+  ra.rel = (const uint32_t *)ix->w_t_rel.p;
+  ra.offsets = in.offsets;
+  ra.hits = in.hits;
+  ra.sa[0] = ix->strand[0].d.sa;
+  ra.sa[1] = ix->strand[1].d.sa;
+  ra.genome_length = ix->genome_length;
+  ra.flags = d_flags;
+  ra.L = in.L;
+  ra.P = in.P;
+  ra.v_rem = in.v_rem;
+  if (S.n_big) hipLaunchKernelGGL(k_to_partition, dim3(S.n_big), dim3(TO_NT), 0, st, ra);
+  if (S.n_tiles) hipLaunchKernelGGL(k_to_sort, dim3(S.n_tiles), dim3(TO_NT), 0, st, ra);
+  uint32_t h[4] = {0, 0, 0, 0};
+  GS_HIP(hipMemcpyAsync(h, d_flags, 16, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  *violations = h[0];
+  S.n_records = ((uint64_t)h[3] << 32) | h[2];
+  GS_HIP(hipGetLastError());
+  return GS_OK;
+}

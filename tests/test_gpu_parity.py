@@ -548,15 +548,19 @@ def test_config1_saccer3_sized_1k_guides_m1():
 
 
 ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
-               # the device-wide ordering in the form that serves sort words beyond 64 bits (raw keys)
-               ("GS_BIG_ORDER_V1", "1"),
+               # the device-wide ordering (what serves batches the per-guide tile ordering does not take):
+               ("GS_NO_TILE_ORDER", "1"),
+               # ... in the form that serves sort words beyond 64 bits (raw keys)
+               ("GS_NO_TILE_ORDER", "1", "GS_BIG_ORDER_V1", "1"),
                # the one-word form as one sort + rows ordered inside the runs of equal words, whatever their length
                # (the default gives up on runs beyond 32 records and sorts by row first), and the two sorts from the start
-               ("GS_BIG2_SHORT", "1000000"),
+               ("GS_NO_TILE_ORDER", "1", "GS_BIG2_SHORT", "1000000"),
                # long runs from the start: one sort of (word, row bits) - all 32 row bits on these small genomes -,
                # and the two stable sorts it replaces
-               ("GS_BIG2_TWO_SORTS", "1"), ("GS_BIG2_TWO_SORTS", "1", "GS_BIG2_NO_COMPOSITE", "1")]
-ARENA_IDS = ["arena", "second-pass", "arena-exhausted", "raw-key-order", "one-sort-and-runs", "composite-sort", "two-sorts"]
+               ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1"),
+               ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1", "GS_BIG2_NO_COMPOSITE", "1")]
+ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "device-wide", "raw-key-order", "one-sort-and-runs", "composite-sort",
+             "two-sorts"]
 
 
 def set_mode(monkeypatch, arena):
@@ -600,6 +604,12 @@ def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
             assert big > 2048
             ctr = gidx.last_counters()
             assert ctr["guides_redone"] >= 1 and ctr["overflow_from_arena"] == (arena is None or "ARENA" not in arena[0]), (ctr, m, faithful)
+            # the default: ordered per guide in LDS tiles (the walk's interval records are not its business)
+            if arena is None:
+                assert ctr["ordered_in_tiles"] == (not faithful), (ctr, m, faithful)
+            elif "GS_NO_TILE_ORDER" in arena or "GS_NO_ARENA" in arena:
+                assert not ctr["ordered_in_tiles"], (ctr, m, faithful)
+            assert not ctr["tile_ordering_gave_up"], (ctr, m, faithful)
     finally:
         gidx.close()
         oidx.close()
@@ -628,6 +638,7 @@ def test_composite_ordering_puts_runs_right(monkeypatch):
     try:
         seqs = np.array([list(site)], dtype=np.uint8)
         pams = np.frombuffer(b"NGG", np.uint8).reshape(1, 3)
+        monkeypatch.setenv("GS_NO_TILE_ORDER", "1")
         monkeypatch.setenv("GS_BIG2_TWO_SORTS", "1")
         monkeypatch.setenv("GS_BIG2_NO_COMPOSITE", "1")
         ref_off, ref_hits, _ = gidx.enumerate(seqs, pams, mismatches=3)
