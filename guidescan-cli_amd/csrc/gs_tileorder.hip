@@ -56,18 +56,19 @@ struct gs_to_tab {
 __device__ __forceinline__ unsigned long long to_rank(const unsigned long long key, const uint32_t L, const uint32_t P,
                                                        const unsigned long long *nt, const unsigned long long pam_mul) {
   const unsigned long long path = key >> 8;
-  uint32_t j = 0;
-  for (uint32_t t = 0; t < L; t++) j += ((path >> (50u - 2u * t)) & 3ull) != 0ull;
-  if (j > 7u) j = 7u;
-  uint32_t r = j;
+  /* the guide's L two-bit fields, position 0 in the highest: only the substituted ones (at most seven) count */
+  const unsigned long long gb = path >> (52u - 2u * L);
+  unsigned long long nz = (gb | (gb >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
+  uint32_t r = (uint32_t)__popcll(nz);
+  if (r > 7u) r = 7u;
   unsigned long long rank = 0;
-  for (uint32_t t = 0; t < L && r != 0u; t++) {
-    const uint32_t c = (uint32_t)(path >> (50u - 2u * t)) & 3u;
-    if (c) {
-      const uint32_t a = L - 1u - t;
-      rank += nt[a * 8u + r] + (unsigned long long)(c - 1u) * nt[a * 8u + r - 1u];
-      r--;
-    }
+  while (nz != 0ull && r != 0u) {
+    const uint32_t hb = 63u - (uint32_t)__builtin_clzll(nz); /* = 2 x the positions behind this one */
+    const uint32_t c = (uint32_t)(gb >> hb) & 3u, a = hb >> 1;
+    /* smaller sequences with the same prefix: a 0 here (r substitutions behind), or one of the c-1 lower codes */
+    rank += nt[a * 8u + r] + (unsigned long long)(c - 1u) * nt[a * 8u + r - 1u];
+    r--;
+    nz &= ~(1ull << hb);
   }
   unsigned long long pr = 0;
   for (uint32_t u = 0; u < P; u++) {
