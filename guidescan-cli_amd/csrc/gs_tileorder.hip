@@ -32,9 +32,6 @@
 #define TO_NW (TO_NT / WAVE)       /* 8 waves */
 #define TO_KPT 8u                  /* keys per thread */
 #define TO_TILE (TO_NT * TO_KPT)   /* 4,096 records per tile */
-#define TO_CSTR (TO_NW + 1u)       /* counters of one digit: one per wave + a pad word (bank spread) */
-#define TO_NCNT (256u * TO_CSTR)
-#define TO_EP ((TO_NCNT + TO_NT - 1u) / TO_NT)
 #define TO_NBMAX 1024u             /* buckets of one item */
 #define TO_DIRECT 0x80000000u
 
@@ -84,128 +81,95 @@ __device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uin
   return (w << 32) | rec.z;
 }
 
-__device__ __forceinline__ uint32_t wave_or32(uint32_t x) {
-  for (int o = 32; o > 0; o >>= 1) x |= (uint32_t)__shfl_xor((int)x, o);
-  return x;
-}
-__device__ __forceinline__ uint32_t wave_and32(uint32_t x) {
-  for (int o = 32; o > 0; o >>= 1) x &= (uint32_t)__shfl_xor((int)x, o);
-  return x;
-}
-
-/* ---- LSD radix sort of n <= TO_TILE 64-bit words in LDS over the bits of V, by the whole workgroup ----------
- * keys[TO_TILE] (+ idx[TO_TILE]: a 16-bit payload that moves with its key), cnt[TO_NCNT] counters, wsum[TO_NW].
- * A pass takes the lowest bit of V still to do and the seven above it (the bits of that window that are in V):
- * each wave owns a contiguous piece of the array and goes through it 64 keys at a time - lanes with equal digits
- * find each other by one ballot per window bit, the first of them bumps the wave's counter of that digit, each
- * keeps counter + lanes before it as its rank in the wave's piece - keys and ranks stay in registers; a flat
- * exclusive scan over the counters (digit-major, wave-minor) turns them into each (digit, wave)'s first place;
- * every key goes there + its rank.  Stable.  Places n .. (padded size) hold words of all ones, which every pass
- * leaves behind the real ones. */
+/* ---- merge sort of n <= TO_TILE 64-bit words in LDS by the whole workgroup --------------------------------------
+ * keys[TO_TILE] (+ idx[TO_TILE]: a 16-bit payload that moves with its key).  Thread t owns places 8t .. 8t+7: it
+ * orders its eight words in registers (Batcher's network, 19 exchanges), then log2(n / 8) rounds merge neighbouring
+ * runs pairwise - the thread finds where its eight places of the merged run begin in either input (merge path: a
+ * binary search along its diagonal) and merges eight words from there, from LDS into registers; all write back after
+ * a barrier.  About 25 instructions per word and round whatever the words' bits - the radix passes this replaced (one
+ * ballot per key bit to rank a wave's keys stably) cost 90 per word and pass, eight passes on a repeat-rich tile.
+ * Places n .. 8 * ceil(n / 8) hold words of all ones. */
+#define TO_CE(i, j)                                  \
+  if (k[i] > k[j]) {                                 \
+    const unsigned long long tk = k[i];              \
+    k[i] = k[j];                                     \
+    k[j] = tk;                                       \
+    if constexpr (WITH_IDX) {                        \
+      const uint32_t tv = v[i];                      \
+      v[i] = v[j];                                   \
+      v[j] = tv;                                     \
+    }                                                \
+  }
 template <bool WITH_IDX>
-__device__ __forceinline__ void to_radix(unsigned long long *keys, uint16_t *idx, uint32_t *cnt, uint32_t *wsum, const uint32_t n,
-                                         unsigned long long V) {
-  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), w = tid / WAVE;
-  const uint32_t per = ((n + TO_NW * WAVE - 1u) / (TO_NW * WAVE)) * WAVE; /* keys per wave, a multiple of 64 */
-  const uint32_t rounds = per / WAVE;
-  while (V) {
-    const uint32_t sh = (uint32_t)__builtin_ctzll(V);
-    const uint32_t wmask = (uint32_t)((V >> sh) & 0xFFull);
-    V &= ~(0xFFull << sh);
-    for (uint32_t i = tid; i < TO_NCNT; i += TO_NT) cnt[i] = 0u;
-    __syncthreads();
-    unsigned long long kreg[TO_KPT];
-    uint32_t lrank[TO_KPT];
-    uint32_t ireg[TO_KPT];
+__device__ __forceinline__ void to_msort(unsigned long long *keys, uint16_t *idx, const uint32_t n) {
+  const uint32_t t = threadIdx.x;
+  const uint32_t nthr = (n + TO_KPT - 1u) / TO_KPT, ntot = nthr * TO_KPT;
+  const bool on = t < nthr;
+  unsigned long long k[TO_KPT];
+  uint32_t v[TO_KPT];
 #pragma unroll
-    for (uint32_t r = 0; r < TO_KPT; ++r) {
-      kreg[r] = ~0ull;
-      lrank[r] = 0u;
-      ireg[r] = 0u;
-      if (r < rounds) {
-        const uint32_t e = w * per + r * WAVE + lane;
-        const bool real = e < n;
-        const unsigned long long k = real ? keys[e] : ~0ull;
-        if constexpr (WITH_IDX) ireg[r] = real ? idx[e] : 0u;
-        const uint32_t d = (uint32_t)(k >> sh) & wmask;
-        unsigned long long same = ~0ull;
-        for (uint32_t bits = wmask; bits; bits &= bits - 1u) {
-          const uint32_t b = (uint32_t)__builtin_ctz(bits);
-          const bool one = ((d >> b) & 1u) != 0u;
-          const unsigned long long bal = __ballot(one);
-          same &= one ? bal : ~bal;
+  for (uint32_t j = 0; j < TO_KPT; ++j) {
+    const uint32_t e = t * TO_KPT + j;
+    k[j] = on && e < n ? keys[e] : ~0ull;
+    v[j] = 0u;
+    if constexpr (WITH_IDX) v[j] = on && e < n ? idx[e] : 0u;
+  }
+  TO_CE(0, 1) TO_CE(2, 3) TO_CE(4, 5) TO_CE(6, 7)
+  TO_CE(0, 2) TO_CE(1, 3) TO_CE(4, 6) TO_CE(5, 7)
+  TO_CE(1, 2) TO_CE(5, 6)
+  TO_CE(0, 4) TO_CE(1, 5) TO_CE(2, 6) TO_CE(3, 7)
+  TO_CE(2, 4) TO_CE(3, 5)
+  TO_CE(1, 2) TO_CE(3, 4) TO_CE(5, 6)
+  if (on) {
+#pragma unroll
+    for (uint32_t j = 0; j < TO_KPT; ++j) {
+      keys[t * TO_KPT + j] = k[j];
+      if constexpr (WITH_IDX) idx[t * TO_KPT + j] = (uint16_t)v[j];
+    }
+  }
+  __syncthreads();
+  for (uint32_t width = TO_KPT; width < ntot; width <<= 1) {
+    if (on) {
+      const uint32_t base = (t * TO_KPT) & ~(2u * width - 1u);
+      const uint32_t d = t * TO_KPT - base; /* this thread's first place on the merged run */
+      const uint32_t a0 = base, a1 = base + width < ntot ? base + width : ntot;
+      const uint32_t b1 = base + 2u * width < ntot ? base + 2u * width : ntot;
+      const uint32_t la = a1 - a0, lb = b1 - a1;
+      const unsigned long long *A = keys + a0, *B = keys + a1;
+      uint32_t lo = d > lb ? d - lb : 0u, hi = d < la ? d : la;
+      while (lo < hi) { /* how many of the first d merged words come from A */
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A[mid] <= B[d - 1u - mid])
+          lo = mid + 1u;
+        else
+          hi = mid;
+      }
+      uint32_t i = lo, j = d - lo;
+      unsigned long long ka = i < la ? A[i] : ~0ull, kb = j < lb ? B[j] : ~0ull;
+#pragma unroll
+      for (uint32_t o = 0; o < TO_KPT; ++o) {
+        const bool ta = j >= lb || (i < la && ka <= kb);
+        k[o] = ta ? ka : kb;
+        if constexpr (WITH_IDX) v[o] = idx[ta ? a0 + i : a1 + j];
+        if (ta) {
+          ++i;
+          ka = i < la ? A[i] : ~0ull;
+        } else {
+          ++j;
+          kb = j < lb ? B[j] : ~0ull;
         }
-        const uint32_t below = lanes_below(same), total = (uint32_t)__popcll(same);
-        const uint32_t c = cnt[d * TO_CSTR + w];
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (below == 0u) cnt[d * TO_CSTR + w] = c + total;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        kreg[r] = k;
-        lrank[r] = c + below;
       }
     }
     __syncthreads();
-    {
-      uint32_t v[TO_EP], s = 0;
+    if (on) {
 #pragma unroll
-      for (uint32_t j = 0; j < TO_EP; ++j) {
-        const uint32_t i = tid * TO_EP + j;
-        v[j] = i < TO_NCNT ? cnt[i] : 0u;
-        s += v[j];
-      }
-      const uint32_t incl = wave_incl_sum(s);
-      if (lane == WAVE - 1u) wsum[w] = incl;
-      __syncthreads();
-      uint32_t base = incl - s;
-      for (uint32_t q = 0; q < w; ++q) base += wsum[q];
-#pragma unroll
-      for (uint32_t j = 0; j < TO_EP; ++j) {
-        const uint32_t i = tid * TO_EP + j;
-        if (i < TO_NCNT) cnt[i] = base;
-        base += v[j];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t r = 0; r < TO_KPT; ++r) {
-      if (r < rounds) {
-        const uint32_t d = (uint32_t)(kreg[r] >> sh) & wmask;
-        const uint32_t pos = cnt[d * TO_CSTR + w] + lrank[r];
-        keys[pos] = kreg[r];
-        if constexpr (WITH_IDX) idx[pos] = (uint16_t)ireg[r];
+      for (uint32_t o = 0; o < TO_KPT; ++o) {
+        keys[t * TO_KPT + o] = k[o];
+        if constexpr (WITH_IDX) idx[t * TO_KPT + o] = (uint16_t)v[o];
       }
     }
     __syncthreads();
   }
-}
-
-/* the bits in which the words of the tile differ (all threads get the result) */
-__device__ __forceinline__ unsigned long long to_varying(const unsigned long long *keys, const uint32_t n, uint32_t *red /* [4] */) {
-  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
-  if (tid < 4u) red[tid] = tid < 2u ? 0u : 0xFFFFFFFFu;
-  __syncthreads();
-  uint32_t olo = 0, ohi = 0, alo = 0xFFFFFFFFu, ahi = 0xFFFFFFFFu;
-  for (uint32_t e = tid; e < n; e += TO_NT) {
-    const unsigned long long k = keys[e];
-    olo |= (uint32_t)k;
-    ohi |= (uint32_t)(k >> 32);
-    alo &= (uint32_t)k;
-    ahi &= (uint32_t)(k >> 32);
-  }
-  olo = wave_or32(olo);
-  ohi = wave_or32(ohi);
-  alo = wave_and32(alo);
-  ahi = wave_and32(ahi);
-  if (lane == 0u) {
-    atomicOr(&red[0], olo);
-    atomicOr(&red[1], ohi);
-    atomicAnd(&red[2], alo);
-    atomicAnd(&red[3], ahi);
-  }
-  __syncthreads();
-  const unsigned long long o = ((unsigned long long)red[1] << 32) | red[0], a = ((unsigned long long)red[3] << 32) | red[2];
-  __syncthreads();
-  return n ? (o ^ a) : 0ull;
 }
 
 /* ---- the plan ------------------------------------------------------------------------------------------- */
@@ -374,7 +338,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
   __shared__ unsigned long long s_keys[TO_TILE];
   __shared__ unsigned long long s_spl[TO_NBMAX];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
-  __shared__ uint32_t s_cnt[TO_NCNT], s_cur[TO_NBMAX], s_wsum[TO_NW], s_red[4];
+  __shared__ uint32_t s_cur[TO_NBMAX];
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
   for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
   if (tid < 8u) s_bs[tid] = a.tab->base[tid];
@@ -401,8 +365,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
     s_keys[j] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
   }
   __syncthreads();
-  const unsigned long long V = to_varying(s_keys, ns, s_red);
-  to_radix<false>(s_keys, nullptr, s_cnt, s_wsum, ns, V);
+  to_msort<false>(s_keys, nullptr, ns);
   unsigned long long spl_mine[2] = {0ull, 0ull};
   for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) spl_mine[q] = s_keys[(b + 1u) * per - 1u];
   __syncthreads();
@@ -423,10 +386,11 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
 #pragma unroll
     for (uint32_t u = 0; u < 4u; ++u) {
       if (i0 - tid + u * TO_NT >= c_pad) break; /* workgroup-uniform */
-      uint32_t b = 0;
+      uint32_t b = 0, kw = 0;
       if (on[u]) {
         multi = multi || rec[u].z != rec[u].w;
         const unsigned long long K = to_word(rec[u], a.L, a.P, s_nt, s_bs, pam_mul);
+        kw = (uint32_t)(K >> 32);
         uint32_t lo = 0, hi = nb - 1u; /* splitters below K */
         while (lo < hi) {
           const uint32_t mid = (lo + hi) >> 1;
@@ -450,7 +414,8 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
       } else {
         pos = on[u] ? atomicAdd(&s_cur[b], 1u) : 0u;
       }
-      if (on[u] && pos < TO_TILE) out[(size_t)b * TO_TILE + pos] = rec[u];
+      /* a bucket record carries its sequence word where the (equal) last row was: the tile does not rank it again */
+      if (on[u] && pos < TO_TILE) out[(size_t)b * TO_TILE + pos] = make_uint4(rec[u].x, rec[u].y, rec[u].z, kw);
     }
   }
   if (multi) atomicOr(a.flags, TO_F_MULTIROW);
@@ -486,14 +451,13 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   __shared__ unsigned long long s_keys[TO_TILE];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
   __shared__ uint16_t s_idx[TO_TILE];
-  __shared__ uint32_t s_cnt[TO_NCNT], s_wsum[TO_NW], s_red[4], s_flag;
+
   const uint32_t tid = threadIdx.x;
   const uint4 t = a.tiles[blockIdx.x];
   const uint32_t n = t.z;
   if (n == 0u) return;
   for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
   if (tid < 8u) s_bs[tid] = a.tab->base[tid];
-  if (tid == 0u) s_flag = 0u;
   const unsigned long long pam_mul = a.tab->pam_mul;
   const bool direct = (t.x & TO_DIRECT) != 0u;
   const uint32_t sb = t.x & ~TO_DIRECT;
@@ -505,34 +469,19 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   __syncthreads();
   bool multi = false;
   for (uint32_t i = tid; i < n; i += TO_NT) {
-    const uint4 rec = direct ? *to_addr(a.src, item, cb, i) : bucket[i];
-    multi = multi || rec.z != rec.w;
-    s_keys[i] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+    if (direct) {
+      const uint4 rec = *to_addr(a.src, item, cb, i);
+      multi = multi || rec.z != rec.w;
+      s_keys[i] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+    } else {
+      const uint2 zw = *(const uint2 *)&bucket[i].z; /* {row, sequence word}: k_to_partition ranked it */
+      s_keys[i] = ((unsigned long long)zw.y << 32) | zw.x;
+    }
     s_idx[i] = (uint16_t)i;
   }
   if (multi) atomicOr(a.flags, TO_F_MULTIROW);
   __syncthreads();
-  /* by the sequence word alone first: on a genome without repeat families every sequence of a tile occurs once and
-   * the rows never decide; only a tile that shows two rows of one sequence out of order is ordered by row, then by
-   * word again (there the words differ in few bits: a bucket of a long run holds one or two sequences) */
-  const unsigned long long V = to_varying(s_keys, n, s_red);
-  const unsigned long long Vw = V & 0xFFFFFFFF00000000ull, Vr = V & 0xFFFFFFFFull;
-  if (Vw) {
-    to_radix<true>(s_keys, s_idx, s_cnt, s_wsum, n, Vw);
-    bool bad = false;
-    for (uint32_t e = tid + 1u; e < n; e += TO_NT) {
-      const unsigned long long p = s_keys[e - 1u], q = s_keys[e];
-      bad = bad || ((p >> 32) == (q >> 32) && (uint32_t)q < (uint32_t)p);
-    }
-    if (bad) s_flag = 1u;
-  } else if (tid == 0u && Vr) {
-    s_flag = 1u;
-  }
-  __syncthreads();
-  if (s_flag) {
-    to_radix<true>(s_keys, s_idx, s_cnt, s_wsum, n, Vr);
-    if (Vw) to_radix<true>(s_keys, s_idx, s_cnt, s_wsum, n, Vw);
-  }
+  to_msort<true>(s_keys, s_idx, n);
   /* the hits: place = the guide's first + the class's start + rank in the item (process.hpp:100-115) */
   const uint32_t *sa = a.sa[strand];
   const uint32_t *rel = a.rel + (size_t)gset * 16u + strand;
@@ -693,9 +642,11 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.v_rem = in.v_rem;
   if (S.n_big) hipLaunchKernelGGL(k_to_partition, dim3(S.n_big), dim3(TO_NT), 0, st, ra);
   if (S.n_tiles) hipLaunchKernelGGL(k_to_sort, dim3(S.n_tiles), dim3(TO_NT), 0, st, ra);
-  uint32_t h[4] = {0, 0, 0, 0};
-  GS_HIP(hipMemcpyAsync(h, d_flags, 16, hipMemcpyDeviceToHost, st));
+  uint32_t h[16] = {0};
+  GS_HIP(hipMemcpyAsync(h, d_flags, 64, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
+  if (getenv("GS_DEBUG"))
+    fprintf(stderr, "[gs] tile ordering: %u items, %u of them partitioned into %u buckets, %u tiles\n", S.n_it, S.n_big, S.n_btiles, S.n_tiles);
   *violations = h[0];
   S.n_records = ((uint64_t)h[3] << 32) | h[2];
   GS_HIP(hipGetLastError());
