@@ -64,6 +64,19 @@ def main():
                          "from the reference's sources; its SDSL index files are written first, about "
                          "75 s at hg38 size) or the oracle port; auto = reference when oracle/_ref "
                          "was built, else port")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch guides per GPU per step (the default); strong: --batch guides per step in all, "
+                         "split over the ranks in contiguous shards (configs 4/5: a fixed guide set over 8 GPUs)")
+    ap.add_argument("--stream", type=int, default=0,
+                    help="a step goes through its guides in sub-batches of this many (config 5: 1 M guides at <= 6 "
+                         "mismatches as 50 batches of 20 k); 0 = one call per step")
+    ap.add_argument("--score", action="store_true", help="CFD + specificity of every hit inside the timed step (config 5)")
+    ap.add_argument("--cpu-threads", default="32,64,128,256",
+                    help="thread counts the reference CPU baseline is timed at (the best is reported)")
+    ap.add_argument("--hwpopcnt", action="store_true", help="also time the reference built with hardware POPCNT")
+    ap.add_argument("--extra-rows", choices=["auto", "on", "off"], default="auto",
+                    help="after the headline: the repeat-rich genome at <= 3 mismatches and <= 6 mismatches + CFD on this "
+                         "genome, 20 k guides each (auto: with the default hg38 workload on one GPU)")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, check full-size properties of the last batch (on-target found, order)")
     args = ap.parse_args()
@@ -112,16 +125,51 @@ def main():
     free_after_index = int(torch.cuda.mem_get_info()[0])
 
     nb = args.steps + args.warmup
-    # every step and every rank gets its own guides (seeded): shard r of the global batch
-    seqs, pams, _, _ = synth.sample_guides(text, batch * nb, seed=1000 + rank)
+    parallel = import_module("guidescan-cli_amd.parallel")
+    batch_all = batch * world   # guides per step over all ranks
+    if args.scaling == "strong":
+        # one seeded guide set per step for the whole job, rank r takes the contiguous shard r of every step
+        # (src/guidescan.cxx:226-251 deals guides to threads; here to GPUs, each with the whole index)
+        batch_all = batch
+        b = parallel.shard_bounds(batch_all, world)
+        lo, hi = b[rank], b[rank + 1]
+        batch = hi - lo
+        all_seqs, all_pams, _, _ = synth.sample_guides(text, batch_all * nb, seed=1000)
+        pick = np.concatenate([np.arange(i * batch_all + lo, i * batch_all + hi) for i in range(nb)])
+        seqs, pams = np.ascontiguousarray(all_seqs[pick]), np.ascontiguousarray(all_pams[pick])
+        del all_seqs, all_pams
+    else:
+        # every step and every rank gets its own guides (seeded): shard r of the global batch
+        seqs, pams, _, _ = synth.sample_guides(text, batch * nb, seed=1000 + rank)
     d_seqs = torch.from_numpy(seqs).cuda()
     d_pams = torch.from_numpy(pams).cuda()
     L, P = seqs.shape[1], pams.shape[1]
+    gs_struct = api.make_genome_structure(names, lengths) if args.score else None
+    score_buf = {}
+
+    def one_call(s, p, n):
+        d_off, d_hits, st = gidx.enumerate_device(s.data_ptr(), n, L, p.data_ptr(), P, mismatches=m)
+        if args.score:
+            # CFD of every hit + specificity per guide, in HBM (printer.hpp:98-170): part of the step for config 5
+            if score_buf.get("n", 0) < st["n_hits"] or score_buf.get("g", 0) < n:
+                score_buf.update(n=int(st["n_hits"] * 1.25) + 1, g=n)
+                score_buf["cfd"] = torch.empty(score_buf["n"], dtype=torch.float32, device="cuda")
+                score_buf["spec"] = torch.empty(n, dtype=torch.float32, device="cuda")
+            gidx.score_device(gs_struct, s.data_ptr(), n, L, P, d_off, d_hits, score_buf["cfd"].data_ptr(),
+                              score_buf["spec"].data_ptr())
+        return d_off, d_hits, st
 
     def step(i):
         s = d_seqs[i * batch:(i + 1) * batch]
         p = d_pams[i * batch:(i + 1) * batch]
-        return gidx.enumerate_device(s.data_ptr(), batch, L, p.data_ptr(), P, mismatches=m)
+        if not args.stream or args.stream >= batch:
+            return one_call(s, p, batch)
+        tot = None
+        for j in range(0, batch, args.stream):   # the step's guides as a stream of sub-batches
+            n = min(args.stream, batch - j)
+            d_off, d_hits, st = one_call(s[j:j + n], p[j:j + n], n)
+            tot = st if tot is None else {k: tot[k] + st[k] for k in st}
+        return d_off, d_hits, tot
 
     def fence():
         torch.cuda.synchronize()
@@ -133,7 +181,7 @@ def main():
     # rules.  The timed path skips the input-independent top of the tree through the prefix
     # table, so it is measured here, untimed, with the reference-order walk on a sample (sized so
     # that the walk stays around a second: it is ~10^5 extensions per guide at m = 3, 3.5e7 at m = 6).
-    ns = min(batch, {0: 20000, 1: 20000, 2: 20000, 3: 20000, 4: 4000}.get(m, 0))
+    ns = min(batch, args.stream or batch, {0: 20000, 1: 20000, 2: 20000, 3: 20000, 4: 4000}.get(m, 0))
     if ns:
         _, _, st_ref = gidx.enumerate_device(d_seqs.data_ptr(), ns, L, d_pams.data_ptr(), P, mismatches=m,
                                              faithful=True)
@@ -148,7 +196,9 @@ def main():
     # The bytes THIS algorithm asks the memory system for: one untimed pass of the first batch
     # through the counting instantiation of k_search (same code, plus a tally of the distinct
     # 64-byte lines every load instruction requests; include/guidescan_amd.h GS_FLAG_COUNT_REQUESTS)
-    _, _, st_cnt = gidx.enumerate_device(d_seqs.data_ptr(), batch, L, d_pams.data_ptr(), P, mismatches=m,
+    n_cnt = min(batch, args.stream) if args.stream else batch   # guides of one launch
+    launches_per_step = (batch + n_cnt - 1) // n_cnt if n_cnt else 1
+    _, _, st_cnt = gidx.enumerate_device(d_seqs.data_ptr(), n_cnt, L, d_pams.data_ptr(), P, mismatches=m,
                                          count_requests=True)
     req = gidx.last_counters()
 
@@ -168,6 +218,7 @@ def main():
         ms_total += st["ms_total"]
     fence()
     elapsed = time.perf_counter() - t0
+    last_ctr = gidx.last_counters()   # of the last timed call (the flags of the counting pass are in `req`)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -185,7 +236,7 @@ def main():
         except Exception as e:  # a side figure: never lose the bench line to it
             print(f"[bench] per-rank memory report not gathered: {e!r}", file=sys.stderr)
     K = args.steps
-    guides_total = batch * K * world
+    guides_total = batch_all * K
     value = guides_total / elapsed
 
     # Roofline of the dominant kernel (k_search), HBM bound.  Algorithmic bytes of the algorithm that
@@ -201,15 +252,15 @@ def main():
     # the recipe lists (a few KB, the same for every item) stay in the L2: their lines are reported, not priced
     n_lines = sum(v for k, v in lines.items() if k != "recipe_lines")
     alg_bytes_per_launch = 64.0 * n_lines + 16.0 * st_cnt["n_matches"]
-    search_s = (ms_search / K) / 1e3
+    search_s = (ms_search / (K * launches_per_step)) / 1e3   # one launch
     achieved = alg_bytes_per_launch / search_s / 1e9 if search_s > 0 else 0.0
-    traffic, traffic_src, issue = recorded_traffic(args.workload, batch, m)
+    traffic, traffic_src, issue = recorded_traffic(args.workload, n_cnt, m)
     if issue:
         # what binds the kernel when the bytes do not: VALU wave-instructions of the same dispatch (SQ_INSTS_VALU
         # of a separate --pmc pass) against the SIMDs' issue slots - 4 cycles per wave64 instruction, 1024 SIMDs, 2.4 GHz
         issue = dict(issue, valu_frac_of_issue_cycles=issue["valu_wave_instructions"] * 4.0 /
                      (1024 * 2.4e9 * issue["duration_ms"] * 1e-3), source=traffic_src.replace("fetch_size", "sq_wave_cycles").split(" + ")[0])
-    ref_bytes = 128.0 * n_ext_ref_per_guide * batch
+    ref_bytes = 128.0 * n_ext_ref_per_guide * n_cnt
     out = {
         "metric": f"guides/sec off-target enum, <={m} mismatches",
         "value": value,
@@ -221,14 +272,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}-sized synthetic genome ({sum(lengths)} bp, "
-                               f"{len(lengths)} chr, fwd+rev index in HBM), {batch} NGG 20-mers per GPU "
-                               f"per step, <={m} mismatches",
-                   "guides_per_step_per_gpu": batch, "mismatches": m,
+                               f"{len(lengths)} chr, fwd+rev index in HBM), "
+                               + (f"{batch_all} NGG 20-mers per step split over {world} GPU(s)" if args.scaling == "strong"
+                                  else f"{batch} NGG 20-mers per GPU per step")
+                               + f", <={m} mismatches"
+                               + (f", streamed in sub-batches of {args.stream}" if args.stream else "")
+                               + (", CFD + specificity in the step" if args.score else ""),
+                   "guides_per_step_per_gpu": batch, "guides_per_step": batch_all, "mismatches": m,
                    "parallelism": f"replicated index, guide batch sharded x{world}"},
         "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      # achieved / frac price the lines each load instruction asks for; on a repeat-rich batch
@@ -243,10 +298,11 @@ def main():
                      "traffic_measured_in_this_run": False,
                      "traffic_source": traffic_src, "instruction_issue": issue,
                      "alg_bytes_per_launch": alg_bytes_per_launch,
-                     "avg_launch_ms": ms_search / K,
-                     "requests_per_guide": {k: v / batch for k, v in lines.items()},
+                     "avg_launch_ms": ms_search / (K * launches_per_step),
+                     "guides_per_launch": n_cnt,
+                     "requests_per_guide": {k: v / n_cnt for k, v in lines.items()},
                      "random_requests": {
-                         "per_guide": n_lines / batch, "unit": "64-byte lines",
+                         "per_guide": n_lines / n_cnt, "unit": "64-byte lines",
                          "achieved_per_s": n_lines / search_s if search_s > 0 else None,
                          "ceiling_per_s": [5.0e10, 5.5e10],
                          "frac_of_ceiling": (n_lines / search_s / 5.5e10) if search_s > 0 else None,
@@ -269,13 +325,15 @@ def main():
                    "device_ms_total_per_step": ms_total / K, "index_build_s": t_index,
                    "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes,
                    "items_two_sided": req["items_two_sided"], "items_one_sided": req["items_one_sided"],
-                   "overflow_items_first_pass": req["overflow_items"], "guides_redone": req["guides_redone"],
+                   "overflow_items_first_pass": req["overflow_items"], "guides_redone": last_ctr["guides_redone"],
                    "slots_per_item": req["slots_per_item"], "matches_max_per_item": req["matches_max_per_item"],
-                   "ordered_device_wide": req["ordered_device_wide"],
-                   "redo_ordered_device_wide": req["redo_ordered_device_wide"],
-                   "overflow_from_arena": req["overflow_from_arena"],
-                   "ordered_by_one_composite_sort": req["ordered_by_one_composite_sort"],
-                   "runs_put_right_after_the_sort": req["runs_turned_round"], "per_rank_memory": per_rank},
+                   "ordered_device_wide": last_ctr["ordered_device_wide"],
+                   "redo_ordered_device_wide": last_ctr["redo_ordered_device_wide"],
+                   "overflow_from_arena": last_ctr["overflow_from_arena"],
+                   "ordered_by_one_composite_sort": last_ctr["ordered_by_one_composite_sort"],
+                   "runs_put_right_after_the_sort": last_ctr["runs_turned_round"],
+                   "ordered_per_guide_in_lds_tiles": last_ctr["ordered_in_tiles"],
+                   "tile_ordering_gave_up": last_ctr["tile_ordering_gave_up"], "per_rank_memory": per_rank},
     }
 
     if rank == 0:
@@ -295,7 +353,7 @@ def main():
         if kind == "reference":
             try:
                 out["cpu_baseline"] = cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m,
-                                                             args.cpu_sample)
+                                                             args.cpu_sample, args.cpu_threads, args.hwpopcnt)
                 if "hwpopcnt" in out["cpu_baseline"]:   # BASELINE.md section 3's second reference row
                     out["cpu_baseline_hwpopcnt"] = out["cpu_baseline"].pop("hwpopcnt")
             except Exception as e:  # the baseline is a side figure: never lose the bench line to it
@@ -306,9 +364,19 @@ def main():
                 kind = "port"
         if kind == "port":
             out["cpu_baseline"] = cpu_baseline(text, gidx, seqs, pams, m, args.cpu_sample)
+    want_rows = args.extra_rows == "on" or (args.extra_rows == "auto" and args.workload == "hg38" and m == 3 and world == 1
+                                            and not args.batch and not args.stream and args.cpu_sample != 0)
+    if rank == 0 and world == 1 and want_rows:
+        # the rows the headline does not show, under the same clock: the deep budget on this genome and the
+        # repeat-rich genome (24 k hits per guide: what real hg38's repeat half looks like) - never part of `value`
+        try:
+            out["detail"]["extra_rows"], gidx = extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P)
+        except Exception as e:
+            print(f"[bench] extra rows failed: {e!r}", file=sys.stderr)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    gidx.close()
+    if gidx is not None:
+        gidx.close()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -395,15 +463,26 @@ def stub_main(args):
     lengths = [synth.CHR1_LENGTH] if lens_name == "CHR1" else getattr(synth, lens_name)
     batch = args.batch or batch
     text, names, lengths = shared_genome(synth, args.workload, lengths, probs, dist, int(os.environ.get("LOCAL_RANK", "0")))
-    seqs, pams, _, _ = synth.sample_guides(text, batch, seed=1000 + rank)
+    batch_all = batch * world
+    if args.scaling == "strong":   # the same contiguous shards the GPU path takes
+        batch_all = batch
+        b = parallel.shard_bounds(batch_all, world)
+        all_seqs, all_pams, _, _ = synth.sample_guides(text, batch_all, seed=1000)
+        seqs, pams = all_seqs[b[rank]:b[rank + 1]], all_pams[b[rank]:b[rank + 1]]
+        batch = b[rank + 1] - b[rank]
+    else:
+        seqs, pams, _, _ = synth.sample_guides(text, batch, seed=1000 + rank)
     acc = []
     elapsed = parallel.timed_steps(lambda i: acc.append(int(seqs.sum()) + i), args.steps, args.warmup, lambda: None, dist)
     sums = [None] * world
-    dist.all_gather_object(sums, (int(text[::4097].astype(np.int64).sum()), len(acc)))
+    dist.all_gather_object(sums, (int(text[::4097].astype(np.int64).sum()), len(acc), int(seqs.shape[0]),
+                                  int(seqs.astype(np.int64).sum())))
     if rank == 0:
         print(json.dumps({"stub": True, "metric": "plumbing rehearsal (no GPU)", "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "value": batch * args.steps * world / max(elapsed, 1e-9),
-                          "unit": "guides/s", "text_checksums": [s[0] for s in sums],
+                          "warmup": args.warmup, "value": batch_all * args.steps / max(elapsed, 1e-9),
+                          "unit": "guides/s", "scaling": args.scaling, "guides_per_step": batch_all,
+                          "guides_per_rank": [s[2] for s in sums], "guide_checksums": [s[3] for s in sums],
+                          "text_checksums": [s[0] for s in sums],
                           "steps_run_per_rank": [s[1] for s in sums],
                           "shared_text": bool(os.environ.get("GS_BENCH_TEXT"))}), flush=True)
     dist.destroy_process_group()
@@ -494,6 +573,79 @@ def side_steps(torch, api, gidx, d_seqs, d_pams, batch, i, L, P, m, text, names,
                 "kmers_bp_per_s": n0 / dt})
     km.close()
     return out
+
+
+def timed_row(torch, api, gidx, text, names, lengths, L, P, m, n_guides, steps, score, seed):
+    """K steps of n_guides sampled guides at <= m mismatches on a resident index (one warm-up step first: derived
+    tables, workspace): guides/s and hits/s by the wall clock around the steps, k_search's share from the library's
+    own events; with `score`, CFD + specificity of every hit inside the step (gs_score_device)."""
+    synth = import_module("guidescan-cli_amd.synth")
+    seqs, pams, _, _ = synth.sample_guides(text, n_guides * (steps + 1), seed=seed)
+    d_s, d_p = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+    gs = api.make_genome_structure(names, lengths) if score else None
+    bufs = {}
+
+    def step(i):
+        s, p = d_s[i * n_guides:(i + 1) * n_guides], d_p[i * n_guides:(i + 1) * n_guides]
+        d_off, d_hits, st = gidx.enumerate_device(s.data_ptr(), n_guides, L, p.data_ptr(), P, mismatches=m)
+        t_sc = 0.0
+        if score:
+            if bufs.get("n", 0) < st["n_hits"]:
+                bufs.update(n=int(st["n_hits"] * 1.25) + 1, cfd=None)
+                bufs["cfd"] = torch.empty(bufs["n"], dtype=torch.float32, device="cuda")
+                bufs["spec"] = torch.empty(n_guides, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gidx.score_device(gs, s.data_ptr(), n_guides, L, P, d_off, d_hits, bufs["cfd"].data_ptr(), bufs["spec"].data_ptr())
+            torch.cuda.synchronize()
+            t_sc = time.perf_counter() - t0
+        return st, t_sc
+
+    step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hits = 0
+    ms_search = ms_enum = t_score = 0.0
+    for i in range(1, steps + 1):
+        st, t_sc = step(i)
+        hits += st["n_hits"]
+        ms_search += st["ms_search"]
+        ms_enum += st["ms_total"]
+        t_score += t_sc
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ctr = gidx.last_counters()
+    el_enum = el - t_score
+    return {"guides_per_step": n_guides, "mismatches": m, "steps": steps, "guides_per_s": n_guides * steps / el,
+            "hits_per_s": hits / el, "hits_per_guide": hits / (n_guides * steps), "ms_per_step": el / steps * 1e3,
+            "enumerate_ms_per_step": el_enum / steps * 1e3, "k_search_ms_per_step": ms_search / steps,
+            "score_ms_per_step": (t_score / steps * 1e3) if score else None,
+            # what of the enumerate step (prepare .. locate, wall clock) is not the search kernel
+            "non_search_share_of_enumerate": 1.0 - (ms_search / 1e3) / el_enum if el_enum > 0 else None,
+            "ordered_per_guide_in_lds_tiles": ctr["ordered_in_tiles"], "tile_ordering_gave_up": ctr["tile_ordering_gave_up"],
+            "guides_redone": ctr["guides_redone"], "matches_max_per_item": ctr["matches_max_per_item"]}
+
+
+def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P):
+    """(rows, index still open or None).  Row 1 on the resident index: 20,000 guides at <= 6 mismatches with CFD
+    (config 5's depth).  Row 2: the same index is closed, the repeat-rich genome of the same size is generated and
+    indexed, 20,000 guides at <= 3 mismatches (bench.py --workload hg38rep)."""
+    rows = {}
+    rows["hg38_20k_m6_cfd"] = timed_row(torch, api, gidx, text, names, lengths, L, P, 6, 20000, 3, True, 4242)
+    gidx.close()
+    t0 = time.time()
+    text2, names2, lengths2 = make_workload_genome(synth, "hg38rep", lengths, probs)
+    t_gen = time.time() - t0
+    t0 = time.time()
+    g2 = api.GenomeIndex.build(text2, device=torch.cuda.current_device())
+    torch.cuda.synchronize()
+    t_idx = time.time() - t0
+    try:
+        rows["hg38rep_20k_m3"] = dict(timed_row(torch, api, g2, text2, names2, lengths2, L, P, 3, 20000, 3, False, 1000),
+                                      genome_gen_s=round(t_gen, 1), index_build_s=round(t_idx, 1))
+    finally:
+        g2.close()
+    return rows, None
 
 
 def verify_last_batch(torch, gidx, d_seqs, d_pams, batch, i, L, P, m, text, seqs):
@@ -589,7 +741,25 @@ def cpu_baseline(text, gidx, seqs, pams, m, sample):
             "n_ext_per_guide": ctr.n_ext / sample, "rank_bwt_per_guide": ctr.n_rank / sample}
 
 
-def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample):
+def physical_cores():
+    """distinct (package, core) pairs of /proc/cpuinfo; None where that cannot be read"""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample, threads="", hwpopcnt=False):
     """The reference itself (oracle/_ref/gs_ref_enumerate: its index.hpp / process.hpp /
     printer.hpp / csa_wt compiled in place by oracle/Makefile) on this host's cores, timed by the
     same clock the reference prints ("Processed N kmers in S seconds", src/guidescan.cxx:239-256:
@@ -634,16 +804,29 @@ def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample):
                               [pams[i].tobytes().decode() for i in range(sample)], [names[0]] * sample,
                               [1] * sample, ["+"] * sample)
         t_files = time.time() - t0
-        env = dict(os.environ, GS_REF_THREADS=str(cores))
-        r = subprocess.run([str(shim), os.path.join(td, "g"), os.path.join(td, "k.csv"), os.path.join(td, "o.csv"),
-                            "csv", "complete", str(m), "0", "0", "-1", "-1", "0"], env=env, check=True,
-                           timeout=3600, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
-        dt = float(re.search(r"kmers in ([0-9.eE+-]+) s", r.stderr.decode()).group(1))
+        # the reference deals guide i to thread i mod n (src/guidescan.cxx:229-231) and is latency bound: the thread
+        # count that serves it best is found, not assumed - each count on the same guides, the best reported
+        tlist = sorted({min(cores, max(1, int(x))) for x in threads.split(",") if x.strip()} or {cores})
+        sweep = []
+        best_dt, best_t = None, None
+        for nthr in tlist:
+            env = dict(os.environ, GS_REF_THREADS=str(nthr))
+            r = subprocess.run([str(shim), os.path.join(td, "g"), os.path.join(td, "k.csv"), os.path.join(td, f"o{nthr}.csv"),
+                                "csv", "complete", str(m), "0", "0", "-1", "-1", "0"], env=env, check=True,
+                               timeout=3600, stderr=subprocess.PIPE, stdout=subprocess.DEVNULL)
+            dt_n = float(re.search(r"kmers in ([0-9.eE+-]+) s", r.stderr.decode()).group(1))
+            sweep.append({"threads": nthr, "guides_per_thread": sample // nthr, "seconds": round(dt_n, 2),
+                          "guides_per_s": sample / dt_n})
+            if best_dt is None or dt_n < best_dt:
+                best_dt, best_t = dt_n, nthr
+        dt = best_dt
+        os.replace(os.path.join(td, f"o{best_t}.csv"), os.path.join(td, "o.csv"))
+        env = dict(os.environ, GS_REF_THREADS=str(best_t))
         # the same run by the build with hardware POPCNT (oracle/Makefile: -march=x86-64-v3; the box's own
         # -march=native cannot be built there, the reference's sources do not travel)
         hw = None
         shim_hw = ol.ORACLE_DIR / "_ref" / "gs_ref_enumerate_hwpopcnt"
-        if shim_hw.exists():
+        if hwpopcnt and shim_hw.exists():
             try:
                 r2 = subprocess.run([str(shim_hw), os.path.join(td, "g"), os.path.join(td, "k.csv"), os.path.join(td, "o2.csv"),
                                      "csv", "complete", str(m), "0", "0", "-1", "-1", "0"], env=env, check=True,
@@ -651,9 +834,9 @@ def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample):
                 dt2 = float(re.search(r"kmers in ([0-9.eE+-]+) s", r2.stderr.decode()).group(1))
                 with open(os.path.join(td, "o.csv"), "rb") as f1, open(os.path.join(td, "o2.csv"), "rb") as f2:
                     same = sorted(f1.read().splitlines()) == sorted(f2.read().splitlines())
-                hw = {"value": sample / dt2, "unit": "guides/s", "cores": cores, "kind": "reference",
+                hw = {"value": sample / dt2, "unit": "guides/s", "cores": best_t, "kind": "reference",
                       "sample": f"the same {sample} guides through the reference built -O3 -DNDEBUG -march=x86-64-v3 "
-                                f"(hardware POPCNT in sdsl bits::cnt), {cores} threads, {dt2:.1f} s",
+                                f"(hardware POPCNT in sdsl bits::cnt), {best_t} threads, {dt2:.1f} s",
                       "same_lines_as_the_as_shipped_build": same}
             except Exception as e:   # a host CPU below x86-64-v3, or any failure of the side run: no second row
                 print(f"[bench] hardware-POPCNT reference row skipped: {e!r}", file=sys.stderr)
@@ -676,11 +859,13 @@ def cpu_baseline_reference(text, names, lengths, gidx, seqs, pams, m, sample):
             print(f"[bench] PARITY FAILURE: {len(want)} reference lines vs {len(got)} product lines", file=sys.stderr)
     finally:
         shutil.rmtree(td, ignore_errors=True)
-    out = {"value": sample / dt, "unit": "guides/s", "cores": cores, "kind": "reference",
+    out = {"value": sample / dt, "unit": "guides/s", "cores": best_t, "kind": "reference",
            "sample": f"first {sample} guides of rank 0's batch through the compiled reference "
-                     f"(process_kmers_to_stream, CSV out, built -O3 -DNDEBUG as its Release build), {cores} threads, "
-                     f"{dt:.1f} s; SDSL index files written in {t_files:.0f} s (untimed)",
-           "parity": parity}
+                     f"(process_kmers_to_stream, CSV out, built -O3 -DNDEBUG as its Release build), best of "
+                     f"{len(sweep)} thread counts: {best_t} threads, {dt:.1f} s; SDSL index files written in "
+                     f"{t_files:.0f} s (untimed)",
+           "host": {"logical_cpus": cores, "physical_cores": physical_cores()},
+           "thread_sweep": sweep, "parity": parity}
     if hw:
         out["hwpopcnt"] = hw
     return out

@@ -82,13 +82,19 @@ __device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uin
 }
 
 /* ---- merge sort of n <= TO_TILE 64-bit words in LDS by the whole workgroup --------------------------------------
- * keys[TO_TILE] (+ idx[TO_TILE]: a 16-bit payload that moves with its key).  Thread t owns places 8t .. 8t+7: it
- * orders its eight words in registers (Batcher's network, 19 exchanges), then log2(n / 8) rounds merge neighbouring
- * runs pairwise - the thread finds where its eight places of the merged run begin in either input (merge path: a
- * binary search along its diagonal) and merges eight words from there, from LDS into registers; all write back after
- * a barrier.  About 25 instructions per word and round whatever the words' bits - the radix passes this replaced (one
- * ballot per key bit to rank a wave's keys stably) cost 90 per word and pass, eight passes on a repeat-rich tile.
+ * keys (+ idx: a 16-bit payload that moves with its key), TO_LDS entries each: word e lives at TO_AT(e) - one pad
+ * entry after every eight, so that threads reading their own eight consecutive words hit different banks (blocked
+ * accesses at a 64-byte stride were a 32-way bank conflict: 65 % of the LDS cycles of the first version).
+ * Thread t owns places 8t .. 8t+7: it orders its eight words in registers (Batcher's network, 19 exchanges), then
+ * log2(n / 8) rounds merge neighbouring runs pairwise - the thread finds where its eight places of the merged run
+ * begin in either input (merge path: a binary search along its diagonal), loads the eight words that follow in each
+ * input (sixteen independent LDS reads, no read waits for a compare) and takes the eight smallest: min(A[x], B[7-x])
+ * is a bitonic sequence of them, three exchange stages put it in order; all write back after a barrier.  About 30
+ * instructions per word and round whatever the words' bits - the radix passes this replaced (one ballot per key bit
+ * to rank a wave's keys stably) cost 90 per word and pass, eight passes on a repeat-rich tile.
  * Places n .. 8 * ceil(n / 8) hold words of all ones. */
+#define TO_AT(e) ((e) + ((e) >> 3))
+#define TO_LDS (TO_TILE + TO_TILE / 8u)
 #define TO_CE(i, j)                                  \
   if (k[i] > k[j]) {                                 \
     const unsigned long long tk = k[i];              \
@@ -105,14 +111,15 @@ __device__ __forceinline__ void to_msort(unsigned long long *keys, uint16_t *idx
   const uint32_t t = threadIdx.x;
   const uint32_t nthr = (n + TO_KPT - 1u) / TO_KPT, ntot = nthr * TO_KPT;
   const bool on = t < nthr;
+  const uint32_t mine = t * (TO_KPT + 1u); /* = TO_AT(8 t) */
   unsigned long long k[TO_KPT];
   uint32_t v[TO_KPT];
 #pragma unroll
   for (uint32_t j = 0; j < TO_KPT; ++j) {
     const uint32_t e = t * TO_KPT + j;
-    k[j] = on && e < n ? keys[e] : ~0ull;
+    k[j] = on && e < n ? keys[mine + j] : ~0ull;
     v[j] = 0u;
-    if constexpr (WITH_IDX) v[j] = on && e < n ? idx[e] : 0u;
+    if constexpr (WITH_IDX) v[j] = on && e < n ? idx[mine + j] : 0u;
   }
   TO_CE(0, 1) TO_CE(2, 3) TO_CE(4, 5) TO_CE(6, 7)
   TO_CE(0, 2) TO_CE(1, 3) TO_CE(4, 6) TO_CE(5, 7)
@@ -123,8 +130,8 @@ __device__ __forceinline__ void to_msort(unsigned long long *keys, uint16_t *idx
   if (on) {
 #pragma unroll
     for (uint32_t j = 0; j < TO_KPT; ++j) {
-      keys[t * TO_KPT + j] = k[j];
-      if constexpr (WITH_IDX) idx[t * TO_KPT + j] = (uint16_t)v[j];
+      keys[mine + j] = k[j];
+      if constexpr (WITH_IDX) idx[mine + j] = (uint16_t)v[j];
     }
   }
   __syncthreads();
@@ -135,37 +142,45 @@ __device__ __forceinline__ void to_msort(unsigned long long *keys, uint16_t *idx
       const uint32_t a0 = base, a1 = base + width < ntot ? base + width : ntot;
       const uint32_t b1 = base + 2u * width < ntot ? base + 2u * width : ntot;
       const uint32_t la = a1 - a0, lb = b1 - a1;
-      const unsigned long long *A = keys + a0, *B = keys + a1;
       uint32_t lo = d > lb ? d - lb : 0u, hi = d < la ? d : la;
       while (lo < hi) { /* how many of the first d merged words come from A */
         const uint32_t mid = (lo + hi) >> 1;
-        if (A[mid] <= B[d - 1u - mid])
+        if (keys[TO_AT(a0 + mid)] <= keys[TO_AT(a1 + d - 1u - mid)])
           lo = mid + 1u;
         else
           hi = mid;
       }
-      uint32_t i = lo, j = d - lo;
-      unsigned long long ka = i < la ? A[i] : ~0ull, kb = j < lb ? B[j] : ~0ull;
+      const uint32_t i = lo, j = d - lo;
+      unsigned long long kb[TO_KPT];
+      uint32_t vb[TO_KPT];
 #pragma unroll
-      for (uint32_t o = 0; o < TO_KPT; ++o) {
-        const bool ta = j >= lb || (i < la && ka <= kb);
-        k[o] = ta ? ka : kb;
-        if constexpr (WITH_IDX) v[o] = idx[ta ? a0 + i : a1 + j];
-        if (ta) {
-          ++i;
-          ka = i < la ? A[i] : ~0ull;
-        } else {
-          ++j;
-          kb = j < lb ? B[j] : ~0ull;
+      for (uint32_t x = 0; x < TO_KPT; ++x) { /* A[i + x] and B[j + 7 - x]; beyond either run: all ones */
+        const bool ina = i + x < la, inb = j + (TO_KPT - 1u - x) < lb;
+        const uint32_t pa = TO_AT(a0 + i + x), pb = TO_AT(a1 + j + (TO_KPT - 1u - x));
+        k[x] = ina ? keys[pa] : ~0ull;
+        kb[x] = inb ? keys[pb] : ~0ull;
+        if constexpr (WITH_IDX) {
+          v[x] = ina ? idx[pa] : 0u;
+          vb[x] = inb ? idx[pb] : 0u;
         }
       }
+#pragma unroll
+      for (uint32_t x = 0; x < TO_KPT; ++x) {
+        if (kb[x] < k[x]) {
+          k[x] = kb[x];
+          if constexpr (WITH_IDX) v[x] = vb[x];
+        }
+      }
+      TO_CE(0, 4) TO_CE(1, 5) TO_CE(2, 6) TO_CE(3, 7)
+      TO_CE(0, 2) TO_CE(1, 3) TO_CE(4, 6) TO_CE(5, 7)
+      TO_CE(0, 1) TO_CE(2, 3) TO_CE(4, 5) TO_CE(6, 7)
     }
     __syncthreads();
     if (on) {
 #pragma unroll
       for (uint32_t o = 0; o < TO_KPT; ++o) {
-        keys[t * TO_KPT + o] = k[o];
-        if constexpr (WITH_IDX) idx[t * TO_KPT + o] = (uint16_t)v[o];
+        keys[mine + o] = k[o];
+        if constexpr (WITH_IDX) idx[mine + o] = (uint16_t)v[o];
       }
     }
     __syncthreads();
@@ -335,7 +350,7 @@ struct gs_to_run_args {
 
 /* ---- items beyond one tile: splitters from a sample, then one streaming pass into buckets ---------------------- */
 __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
-  __shared__ unsigned long long s_keys[TO_TILE];
+  __shared__ unsigned long long s_keys[TO_LDS];
   __shared__ unsigned long long s_spl[TO_NBMAX];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
   __shared__ uint32_t s_cur[TO_NBMAX];
@@ -362,12 +377,12 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
     h ^= h >> 13;
     const uint32_t pos = lo + h % (hi - lo); /* hi > lo: c > TO_TILE >= ns */
     const uint4 rec = *to_addr(a.src, item, cb, pos);
-    s_keys[j] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+    s_keys[TO_AT(j)] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
   }
   __syncthreads();
   to_msort<false>(s_keys, nullptr, ns);
   unsigned long long spl_mine[2] = {0ull, 0ull};
-  for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) spl_mine[q] = s_keys[(b + 1u) * per - 1u];
+  for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) spl_mine[q] = s_keys[TO_AT((b + 1u) * per - 1u)];
   __syncthreads();
   for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) s_spl[b] = spl_mine[q];
   for (uint32_t b = tid; b < nb; b += TO_NT) s_cur[b] = 0u;
@@ -448,9 +463,9 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
 
 /* ---- one tile: order its records in LDS and write its hits -------------------------------------------------------- */
 __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
-  __shared__ unsigned long long s_keys[TO_TILE];
+  __shared__ unsigned long long s_keys[TO_LDS];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
-  __shared__ uint16_t s_idx[TO_TILE];
+  __shared__ uint16_t s_idx[TO_LDS];
 
   const uint32_t tid = threadIdx.x;
   const uint4 t = a.tiles[blockIdx.x];
@@ -468,37 +483,70 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   const uint4 *bucket = a.buckets + (size_t)t.y * TO_TILE;
   __syncthreads();
   bool multi = false;
-  for (uint32_t i = tid; i < n; i += TO_NT) {
-    if (direct) {
-      const uint4 rec = *to_addr(a.src, item, cb, i);
-      multi = multi || rec.z != rec.w;
-      s_keys[i] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
-    } else {
-      const uint2 zw = *(const uint2 *)&bucket[i].z; /* {row, sequence word}: k_to_partition ranked it */
-      s_keys[i] = ((unsigned long long)zw.y << 32) | zw.x;
+  if (direct) {
+#pragma unroll
+    for (uint32_t u = 0; u < TO_KPT; ++u) { /* every load of the thread in flight at once */
+      const uint32_t i = tid + u * TO_NT;
+      if (i < n) {
+        const uint4 rec = *to_addr(a.src, item, cb, i);
+        multi = multi || rec.z != rec.w;
+        s_keys[TO_AT(i)] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+        s_idx[TO_AT(i)] = (uint16_t)i;
+      }
     }
-    s_idx[i] = (uint16_t)i;
+  } else {
+    uint2 zw[TO_KPT];
+#pragma unroll
+    for (uint32_t u = 0; u < TO_KPT; ++u) {
+      const uint32_t i = tid + u * TO_NT;
+      zw[u] = i < n ? *(const uint2 *)&bucket[i].z : make_uint2(0u, 0u); /* {row, sequence word}: k_to_partition ranked it */
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < TO_KPT; ++u) {
+      const uint32_t i = tid + u * TO_NT;
+      if (i < n) {
+        s_keys[TO_AT(i)] = ((unsigned long long)zw[u].y << 32) | zw[u].x;
+        s_idx[TO_AT(i)] = (uint16_t)i;
+      }
+    }
   }
   if (multi) atomicOr(a.flags, TO_F_MULTIROW);
   __syncthreads();
   to_msort<true>(s_keys, s_idx, n);
-  /* the hits: place = the guide's first + the class's start + rank in the item (process.hpp:100-115) */
+  /* the hits: place = the guide's first + the class's start + rank in the item (process.hpp:100-115); eight
+   * independent chains per thread (key re-read, suffix array gather), consecutive lanes on consecutive hits */
   const uint32_t *sa = a.sa[strand];
   const uint32_t *rel = a.rel + (size_t)gset * 16u + strand;
   gs_hit *out = a.hits + a.offsets[g] + t.w;
   bool dup = false;
-  for (uint32_t r = tid; r < n; r += TO_NT) {
-    const unsigned long long K = s_keys[r];
-    const uint32_t i = s_idx[r];
-    const uint2 kk = *(const uint2 *)(direct ? to_addr(a.src, item, cb, i) : bucket + i);
-    const unsigned long long key = ((unsigned long long)kk.y << 32) | kk.x;
-    dup = dup || (r > 0u && s_keys[r - 1u] == K);
-    const uint32_t row = (uint32_t)K;
-    const uint64_t sap = (uint64_t)sa[row] - ((key & 1ull) ? a.v_rem : 0u);
-    gs_hit o;
-    o.pos = strand == 0u ? -(int64_t)sap : (int64_t)(a.genome_length - (sap + 1ull));
-    o.key = key & ~1ull;
-    out[rel[2u * (uint32_t)(key >> 61)] + r] = o;
+  unsigned long long K[TO_KPT];
+  uint2 kk[TO_KPT];
+  uint32_t sav[TO_KPT];
+#pragma unroll
+  for (uint32_t u = 0; u < TO_KPT; ++u) {
+    const uint32_t r = tid + u * TO_NT;
+    K[u] = 0ull;
+    kk[u] = make_uint2(0u, 0u);
+    sav[u] = 0u;
+    if (r < n) {
+      K[u] = s_keys[TO_AT(r)];
+      const uint32_t i = s_idx[TO_AT(r)];
+      dup = dup || (r > 0u && s_keys[TO_AT(r - 1u)] == K[u]);
+      kk[u] = *(const uint2 *)(direct ? to_addr(a.src, item, cb, i) : bucket + i);
+      sav[u] = sa[(uint32_t)K[u]];
+    }
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < TO_KPT; ++u) {
+    const uint32_t r = tid + u * TO_NT;
+    if (r < n) {
+      const unsigned long long key = ((unsigned long long)kk[u].y << 32) | kk[u].x;
+      const uint64_t sap = (uint64_t)sav[u] - ((key & 1ull) ? a.v_rem : 0u);
+      gs_hit o;
+      o.pos = strand == 0u ? -(int64_t)sap : (int64_t)(a.genome_length - (sap + 1ull));
+      o.key = key & ~1ull;
+      out[rel[2u * (uint32_t)(key >> 61)] + r] = o;
+    }
   }
   if (dup) atomicOr(a.flags, TO_F_DUP);
 }
