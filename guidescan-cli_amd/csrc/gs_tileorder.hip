@@ -87,10 +87,8 @@ __device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uin
  * accesses at a 64-byte stride were a 32-way bank conflict: 65 % of the LDS cycles of the first version).
  * Thread t owns places 8t .. 8t+7: it orders its eight words in registers (Batcher's network, 19 exchanges), then
  * log2(n / 8) rounds merge neighbouring runs pairwise - the thread finds where its eight places of the merged run
- * begin in either input (merge path: a binary search along its diagonal), loads the eight words that follow in each
- * input (sixteen independent LDS reads, no read waits for a compare) and takes the eight smallest: min(A[x], B[7-x])
- * is a bitonic sequence of them, three exchange stages put it in order; all write back after a barrier.  About 30
- * instructions per word and round whatever the words' bits - the radix passes this replaced (one ballot per key bit
+ * begin in either input (merge path: a binary search along its diagonal) and merges eight words from there, from LDS
+ * into registers; all write back after a barrier.  About 30 instructions per word and round whatever the words' bits - the radix passes this replaced (one ballot per key bit
  * to rank a wave's keys stably) cost 90 per word and pass, eight passes on a repeat-rich tile.
  * Places n .. 8 * ceil(n / 8) hold words of all ones. */
 #define TO_AT(e) ((e) + ((e) >> 3))
@@ -150,30 +148,27 @@ __device__ __forceinline__ void to_msort(unsigned long long *keys, uint16_t *idx
         else
           hi = mid;
       }
-      const uint32_t i = lo, j = d - lo;
-      unsigned long long kb[TO_KPT];
-      uint32_t vb[TO_KPT];
+      /* eight words of the merged run from there, one at a time (a version that loaded the eight words that follow
+       * in either input at once and took the eight smallest through a bitonic network had no read waiting for a
+       * compare, and 85 % more instructions: the kernel was instruction bound with it) */
+      uint32_t i = lo, j = d - lo;
+      uint32_t pa = TO_AT(a0 + i), pb = TO_AT(a1 + j);
+      unsigned long long ka = i < la ? keys[pa] : ~0ull, kb = j < lb ? keys[pb] : ~0ull;
 #pragma unroll
-      for (uint32_t x = 0; x < TO_KPT; ++x) { /* A[i + x] and B[j + 7 - x]; beyond either run: all ones */
-        const bool ina = i + x < la, inb = j + (TO_KPT - 1u - x) < lb;
-        const uint32_t pa = TO_AT(a0 + i + x), pb = TO_AT(a1 + j + (TO_KPT - 1u - x));
-        k[x] = ina ? keys[pa] : ~0ull;
-        kb[x] = inb ? keys[pb] : ~0ull;
-        if constexpr (WITH_IDX) {
-          v[x] = ina ? idx[pa] : 0u;
-          vb[x] = inb ? idx[pb] : 0u;
+      for (uint32_t o = 0; o < TO_KPT; ++o) {
+        const bool ta = j >= lb || (i < la && ka <= kb);
+        k[o] = ta ? ka : kb;
+        if constexpr (WITH_IDX) v[o] = idx[ta ? pa : pb];
+        if (ta) {
+          ++i;
+          pa = TO_AT(a0 + i);
+          ka = i < la ? keys[pa] : ~0ull;
+        } else {
+          ++j;
+          pb = TO_AT(a1 + j);
+          kb = j < lb ? keys[pb] : ~0ull;
         }
       }
-#pragma unroll
-      for (uint32_t x = 0; x < TO_KPT; ++x) {
-        if (kb[x] < k[x]) {
-          k[x] = kb[x];
-          if constexpr (WITH_IDX) v[x] = vb[x];
-        }
-      }
-      TO_CE(0, 4) TO_CE(1, 5) TO_CE(2, 6) TO_CE(3, 7)
-      TO_CE(0, 2) TO_CE(1, 3) TO_CE(4, 6) TO_CE(5, 7)
-      TO_CE(0, 1) TO_CE(2, 3) TO_CE(4, 5) TO_CE(6, 7)
     }
     __syncthreads();
     if (on) {
@@ -466,89 +461,133 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   __shared__ unsigned long long s_keys[TO_LDS];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
   __shared__ uint16_t s_idx[TO_LDS];
+  __shared__ uint32_t s_rel[8];
+  __shared__ unsigned long long s_first;
 
   const uint32_t tid = threadIdx.x;
+  /* one workgroup per tile (persistent workgroups looping over the tiles were tried: the loop took the kernel from 71
+   * to 156 registers, one workgroup per CU instead of three, 22 ms instead of 9) */
   const uint4 t = a.tiles[blockIdx.x];
   const uint32_t n = t.z;
   if (n == 0u) return;
-  for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
-  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
-  const unsigned long long pam_mul = a.tab->pam_mul;
+#ifdef TO_PROFILE
+  const unsigned long long tp0 = wall_clock64();
+#endif
   const bool direct = (t.x & TO_DIRECT) != 0u;
   const uint32_t sb = t.x & ~TO_DIRECT;
   const uint32_t gset = sb >> 1, strand = sb & 1u;
   const uint32_t g = a.list ? a.list[gset] : gset;
   const uint32_t item = 2u * g + strand;
-  const uint32_t cb = a.cbase[sb];
   const uint4 *bucket = a.buckets + (size_t)t.y * TO_TILE;
-  __syncthreads();
-  bool multi = false;
+  /* every global read the tile needs is asked for before anything waits: the records (eight per thread), where the
+   * guide's classes start, the guide's first hit */
+  uint4 rec[TO_KPT];
   if (direct) {
+    const uint32_t cb = a.cbase[sb];
 #pragma unroll
-    for (uint32_t u = 0; u < TO_KPT; ++u) { /* every load of the thread in flight at once */
+    for (uint32_t u = 0; u < TO_KPT; ++u) {
       const uint32_t i = tid + u * TO_NT;
+      rec[u] = i < n ? *to_addr(a.src, item, cb, i) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  } else {
+#pragma unroll
+    for (uint32_t u = 0; u < TO_KPT; ++u) {
+      const uint32_t i = tid + u * TO_NT;
+      rec[u] = i < n ? bucket[i] : make_uint4(0u, 0u, 0u, 0u); /* {key, row, sequence word}: k_to_partition ranked it */
+    }
+  }
+  if (tid < 8u) s_rel[tid] = a.rel[(size_t)gset * 16u + 2u * tid + strand];
+  if (tid == 8u) s_first = a.offsets[g] + t.w;
+  bool multi = false;
+  uint2 kx[TO_KPT]; /* the records' keys, in load order: they wait in registers while the words are ordered */
+  if (direct) {
+    for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
+    if (tid < 8u) s_bs[tid] = a.tab->base[tid];
+    const unsigned long long pam_mul = a.tab->pam_mul;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < TO_KPT; ++u) {
+      const uint32_t i = tid + u * TO_NT;
+      kx[u] = make_uint2(rec[u].x, rec[u].y);
       if (i < n) {
-        const uint4 rec = *to_addr(a.src, item, cb, i);
-        multi = multi || rec.z != rec.w;
-        s_keys[TO_AT(i)] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+        multi = multi || rec[u].z != rec[u].w;
+        s_keys[TO_AT(i)] = to_word(rec[u], a.L, a.P, s_nt, s_bs, pam_mul);
         s_idx[TO_AT(i)] = (uint16_t)i;
       }
     }
   } else {
-    uint2 zw[TO_KPT];
 #pragma unroll
     for (uint32_t u = 0; u < TO_KPT; ++u) {
       const uint32_t i = tid + u * TO_NT;
-      zw[u] = i < n ? *(const uint2 *)&bucket[i].z : make_uint2(0u, 0u); /* {row, sequence word}: k_to_partition ranked it */
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < TO_KPT; ++u) {
-      const uint32_t i = tid + u * TO_NT;
+      kx[u] = make_uint2(rec[u].x, rec[u].y);
       if (i < n) {
-        s_keys[TO_AT(i)] = ((unsigned long long)zw[u].y << 32) | zw[u].x;
+        s_keys[TO_AT(i)] = ((unsigned long long)rec[u].w << 32) | rec[u].z;
         s_idx[TO_AT(i)] = (uint16_t)i;
       }
     }
   }
   if (multi) atomicOr(a.flags, TO_F_MULTIROW);
   __syncthreads();
+#ifdef TO_PROFILE
+  const unsigned long long tp1 = wall_clock64();
+#endif
   to_msort<true>(s_keys, s_idx, n);
-  /* the hits: place = the guide's first + the class's start + rank in the item (process.hpp:100-115); eight
-   * independent chains per thread (key re-read, suffix array gather), consecutive lanes on consecutive hits */
+#ifdef TO_PROFILE
+  const unsigned long long tp2 = wall_clock64();
+#endif
+  /* the hits: place = the guide's first + the class's start + rank in the item (process.hpp:100-115).  Consecutive
+   * lanes take consecutive places; the ordered words and the records they came from are read into registers, then
+   * the keys - still in registers in load order - take the words' place in LDS and are picked up from there: the
+   * only random global request left per hit is the suffix array's (the first version read each key again from the
+   * bucket: 10^9 random requests per batch, the rate the memory system serves them at was the kernel's bound) */
   const uint32_t *sa = a.sa[strand];
-  const uint32_t *rel = a.rel + (size_t)gset * 16u + strand;
-  gs_hit *out = a.hits + a.offsets[g] + t.w;
+  gs_hit *out = a.hits + s_first;
   bool dup = false;
-  unsigned long long K[TO_KPT];
-  uint2 kk[TO_KPT];
-  uint32_t sav[TO_KPT];
+  uint32_t row[TO_KPT], from[TO_KPT], sav[TO_KPT];
 #pragma unroll
   for (uint32_t u = 0; u < TO_KPT; ++u) {
     const uint32_t r = tid + u * TO_NT;
-    K[u] = 0ull;
-    kk[u] = make_uint2(0u, 0u);
-    sav[u] = 0u;
+    row[u] = from[u] = sav[u] = 0u;
     if (r < n) {
-      K[u] = s_keys[TO_AT(r)];
-      const uint32_t i = s_idx[TO_AT(r)];
-      dup = dup || (r > 0u && s_keys[TO_AT(r - 1u)] == K[u]);
-      kk[u] = *(const uint2 *)(direct ? to_addr(a.src, item, cb, i) : bucket + i);
-      sav[u] = sa[(uint32_t)K[u]];
+      const unsigned long long K = s_keys[TO_AT(r)];
+      from[u] = s_idx[TO_AT(r)];
+      dup = dup || (r > 0u && s_keys[TO_AT(r - 1u)] == K);
+      row[u] = (uint32_t)K;
+      sav[u] = sa[row[u]];
     }
   }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t u = 0; u < TO_KPT; ++u) {
+    const uint32_t i = tid + u * TO_NT;
+    if (i < n) s_keys[TO_AT(i)] = ((unsigned long long)kx[u].y << 32) | kx[u].x;
+  }
+  __syncthreads();
 #pragma unroll
   for (uint32_t u = 0; u < TO_KPT; ++u) {
     const uint32_t r = tid + u * TO_NT;
     if (r < n) {
-      const unsigned long long key = ((unsigned long long)kk[u].y << 32) | kk[u].x;
+      const unsigned long long key = s_keys[TO_AT(from[u])];
       const uint64_t sap = (uint64_t)sav[u] - ((key & 1ull) ? a.v_rem : 0u);
       gs_hit o;
       o.pos = strand == 0u ? -(int64_t)sap : (int64_t)(a.genome_length - (sap + 1ull));
       o.key = key & ~1ull;
-      out[rel[2u * (uint32_t)(key >> 61)] + r] = o;
+      out[s_rel[(uint32_t)(key >> 61)] + r] = o;
     }
   }
   if (dup) atomicOr(a.flags, TO_F_DUP);
+#ifdef TO_PROFILE
+  __syncthreads();
+  if (tid == 0u) { /* 100 MHz ticks per phase: load, order, write; tiles; records */
+    unsigned long long *dbg = (unsigned long long *)(a.flags + 4);
+    const unsigned long long tp3 = wall_clock64();
+    atomicAdd(&dbg[0], tp1 - tp0);
+    atomicAdd(&dbg[1], tp2 - tp1);
+    atomicAdd(&dbg[2], tp3 - tp2);
+    atomicAdd(&dbg[3], 1ull);
+    atomicAdd(&dbg[4], (unsigned long long)n);
+  }
+#endif
 }
 
 /* ---- host side ------------------------------------------------------------------------------------------------ */
@@ -693,6 +732,13 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   uint32_t h[16] = {0};
   GS_HIP(hipMemcpyAsync(h, d_flags, 64, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
+#ifdef TO_PROFILE
+  {
+    const unsigned long long *d = (const unsigned long long *)(h + 4);
+    fprintf(stderr, "[gs] k_to_sort phases (wall-clock ticks per tile, 100 MHz): load %.0f, order %.0f, write %.0f; %llu tiles, %.0f records each\n",
+            (double)d[0] / d[3], (double)d[1] / d[3], (double)d[2] / d[3], d[3], (double)d[4] / d[3]);
+  }
+#endif
   if (getenv("GS_DEBUG"))
     fprintf(stderr, "[gs] tile ordering: %u items, %u of them partitioned into %u buckets, %u tiles\n", S.n_it, S.n_big, S.n_btiles, S.n_tiles);
   *violations = h[0];

@@ -102,3 +102,23 @@ def test_bench_under_the_drivers_torchrun_command():
                          "--steps", "2", "--warmup", "1", "--workload", "saccer3", "--batch", "64"], {})
     assert j["n_gpus"] == 2 and j["shared_text"] is False
     assert len(set(j["text_checksums"])) == 1
+
+
+def test_bench_strong_scaling_splits_one_guide_set():
+    """`--scaling strong`: --batch is the whole job's guides per step, dealt to the ranks in contiguous shards of ONE
+    seeded set (configs 4 and 5: a fixed candidate set over 8 GPUs).  Two ranks on gloo: uneven shards, the union is
+    the set a single rank would have taken, the line says strong."""
+    j2 = _run_bench_stub([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--workload", "saccer3", "--batch", "65", "--scaling", "strong"], {})
+    assert j2["scaling"] == "strong" and j2["n_gpus"] == 2 and j2["guides_per_step"] == 65
+    assert j2["guides_per_rank"] == [33, 32]
+    port = 25000 + os.getpid() % 2000
+    j1 = _run_bench_stub([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "1",
+                          "--steps", "2", "--warmup", "1", "--workload", "saccer3", "--batch", "65", "--scaling", "strong"], {})
+    assert j1["guides_per_rank"] == [65]
+    assert sum(j2["guide_checksums"]) == j1["guide_checksums"][0]     # the same guides, split
+    # weak scaling keeps --batch per rank
+    jw = _run_bench_stub([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--workload", "saccer3", "--batch", "65"], {})
+    assert jw["scaling"] == "weak" and jw["guides_per_rank"] == [65, 65] and jw["guides_per_step"] == 130
