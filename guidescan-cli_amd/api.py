@@ -122,6 +122,10 @@ def lib():
     L.gs_index_copy_sa.argtypes = [vp, i32, vp]
     L.gs_index_last_counters.restype = i32
     L.gs_index_last_counters.argtypes = [vp, vp]
+    L.gs_index_lock.restype = i32
+    L.gs_index_lock.argtypes = [vp]
+    L.gs_index_unlock.restype = i32
+    L.gs_index_unlock.argtypes = [vp]
     L.gs_index_verify_sa.restype = i32
     L.gs_index_verify_sa.argtypes = [vp, i32, vp, u64, u64, u64, C.POINTER(GsSaReport)]
     L.gs_calculate_cfd.restype = C.c_float
@@ -187,7 +191,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
            "gs_index_last_guide_flags", "gs_enumerate_general_pams", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
-           "gs_debug_seed_recipes", "gs_debug_choose_thresholds"]
+           "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_index_lock", "gs_index_unlock"]
 
 
 def _check(rc):
@@ -551,6 +555,20 @@ class GenomeIndex:
         finally:
             lib().gs_result_ex_free(r)
         return offsets, hits
+
+    def locked(self):
+        """context manager: hold the handle across several device-pointer calls (gs_index_lock / gs_index_unlock);
+        calls on this handle from other threads wait meanwhile"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def hold():
+            _check(lib().gs_index_lock(self._h))
+            try:
+                yield self
+            finally:
+                _check(lib().gs_index_unlock(self._h))
+        return hold()
 
     def last_counters(self):
         """k_search's counters of the last enumerate_device call (see gs_index_last_counters)"""

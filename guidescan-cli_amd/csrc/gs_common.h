@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -149,6 +150,12 @@ struct gs_recipe_set {
 };
 
 struct gs_index {
+  /* One batch at a time per handle: the workspace, the lazily built tables and the result buffers belong to the handle,
+   * while the reference's seam is called from N host threads on one const index (src/guidescan.cxx:240-247).  Every
+   * entry point that takes a handle holds this lock for its whole call (host-pointer entry points copy their
+   * results out under it: they are safe from any number of threads); recursive because the host-pointer entry points
+   * call the device ones.  gs_index_lock / gs_index_unlock hold it across several device-pointer calls. */
+  mutable std::recursive_mutex mtx;
   int device = 0;
   uint64_t genome_length = 0;
   gs_strand strand[2];
@@ -233,6 +240,10 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
 /* partition + order + write the hits; *violations != 0: an assumption did not hold (multi-row records, a sequence at
  * one row twice, a bucket beyond its space) - the hits of the set are then not valid and the caller orders it the other way */
 gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder_state &S, hipStream_t st, uint32_t *violations);
+
+#define GS_HANDLE_LOCK(ix)                               \
+  std::unique_lock<std::recursive_mutex> handle_lock__; \
+  if (ix) handle_lock__ = std::unique_lock<std::recursive_mutex>((ix)->mtx)
 
 #define GS_HIP(expr)                                                              \
   do {                                                                            \

@@ -585,6 +585,7 @@ extern "C" gs_status gs_enumerate_general(gs_index *ix, const char *guides, uint
                                           const char *guide_pams, uint32_t P, const char *alt_pams, uint32_t n_alt,
                                           uint32_t mismatches, uint32_t rna_bulges, uint32_t dna_bulges,
                                           uint32_t flags, gs_result_ex **out) {
+  GS_HANDLE_LOCK(ix);
   try {
     return enumerate_general(ix, guides, n, L, guide_pams, P, alt_pams, n_alt, mismatches, rna_bulges, dna_bulges,
                              flags, out);
@@ -598,6 +599,7 @@ extern "C" gs_status gs_enumerate_general_pams(gs_index *ix, const char *guides,
                                                const uint32_t *alt_lens, uint32_t n_alt, uint32_t mismatches,
                                                uint32_t rna_bulges, uint32_t dna_bulges, uint32_t flags,
                                                gs_result_ex **out) {
+  GS_HANDLE_LOCK(ix);
   if (n_alt && !alt_lens) return GS_ERR_ARG;
   try {
     return enumerate_general(ix, guides, n, L, guide_pams, P, alt_pams, n_alt, mismatches, rna_bulges, dna_bulges,

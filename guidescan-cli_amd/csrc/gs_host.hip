@@ -139,6 +139,7 @@ extern "C" gs_status gs_enumerate(gs_index *ix, const char *guides, uint64_t n, 
                                   const char *guide_pams, uint32_t P, const char *alt_pams,
                                   uint32_t n_alt, uint32_t mismatches, uint32_t flags,
                                   gs_result **out) {
+  GS_HANDLE_LOCK(ix);
   try { /* nothing may throw across the C boundary */
     return enumerate_host(ix, guides, n, L, guide_pams, P, alt_pams, n_alt, mismatches, flags, out);
   } catch (const std::bad_alloc &) {

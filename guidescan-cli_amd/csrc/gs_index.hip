@@ -859,6 +859,7 @@ static uint64_t text_fingerprint(const uint8_t *text, uint64_t len) {
   return h;
 }
 extern "C" gs_status gs_index_save_sa(gs_index *ix, const uint8_t *text, uint64_t len, const char *path) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || !text || !path || len != ix->genome_length) return GS_ERR_ARG;
   GS_HIP(hipSetDevice(ix->device));
   FILE *f = fopen(path, "wb");
@@ -968,13 +969,27 @@ extern "C" void gs_index_close(gs_index *ix) {
   gs_pairtab_free(ix, 1);
   delete ix;
 }
+/* hold the handle across several device-pointer calls (enumerate, score, copies of the results they leave in HBM):
+ * other threads' calls on the handle wait */
+extern "C" gs_status gs_index_lock(gs_index *ix) {
+  if (!ix) return GS_ERR_ARG;
+  ix->mtx.lock();
+  return GS_OK;
+}
+extern "C" gs_status gs_index_unlock(gs_index *ix) {
+  if (!ix) return GS_ERR_ARG;
+  ix->mtx.unlock();
+  return GS_OK;
+}
 extern "C" gs_status gs_index_last_guide_flags(const gs_index *ix, const void **d_flags, uint64_t *n_unsupported) {
+  GS_HANDLE_LOCK(ix);
   if (!ix) return GS_ERR_ARG;
   if (d_flags) *d_flags = ix->w_flags.p;
   if (n_unsupported) *n_unsupported = ix->last_unsupported;
   return GS_OK;
 }
 extern "C" gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || !out) return GS_ERR_ARG;
   for (int i = 0; i < 16; i++) out[i] = ix->last_counters[i];
   return GS_OK;
@@ -992,6 +1007,7 @@ extern "C" gs_status gs_index_meta(const gs_index *ix, int strand, uint64_t C_ac
   return GS_OK;
 }
 extern "C" gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || strand < 0 || strand > 1 || !out) return GS_ERR_ARG;
   GS_HIP(hipSetDevice(ix->device));
   GS_HIP(hipMemcpy(out, ix->strand[strand].sa, 4 * ix->strand[strand].n, hipMemcpyDeviceToHost));

@@ -239,6 +239,7 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
                                      uint32_t flags, int64_t max_off_targets, const gs_genome_structure *gs,
                                      const void *d_offsets, const void *d_hits, void *stream, void *d_cfd,
                                      void *d_specificity) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || !gs || (n && (!d_guides || !d_offsets || !d_specificity)) || (gs->n_chr && !gs->chr_lengths))
     return GS_ERR_ARG;
   if (n >= (1ull << 31) || max_off_targets < -1) return GS_ERR_ARG;
@@ -305,6 +306,7 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
 extern "C" gs_status gs_score(gs_index *ix, const char *guides, uint64_t n, uint32_t L, uint32_t P,
                               uint32_t flags, int64_t max_off_targets, const gs_genome_structure *gs,
                               const uint64_t *offsets, const gs_hit *hits, float *cfd, float *specificity) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || !gs || (n && (!guides || !offsets || !specificity))) return GS_ERR_ARG;
   if (n == 0) return GS_OK;
   const uint64_t nh = offsets[n];

@@ -2102,14 +2102,21 @@ __global__ __launch_bounds__(256) void k_big2_fixruns(uint4 *S2, uint4 *tmp, con
     __syncthreads();
     const uint32_t hmin = s_lo, hmax = s_hi;
     uint64_t base = 0;
-    for (uint32_t v = hmin; v <= hmax; ++v) {
+    /* one pass per value the high part TAKES (the next one is found during the pass), not per integer between
+     * the least and the greatest: with few row bits a run's rows can span thousands of multiples of 2^row_bits */
+    for (uint32_t v = hmin;;) {
+      if (tid == 0) s_lo = 0xFFFFFFFFu; /* least high part above v */
+      __syncthreads();
+      uint32_t nxt = 0xFFFFFFFFu;
       for (uint64_t c = 0; c < len; c += blockDim.x) {
         const uint64_t i = c + tid;
         uint4 rec = make_uint4(0u, 0u, 0u, 0u);
         bool f = false;
         if (i < len) {
           rec = S2[start + i];
-          f = (uint32_t)(((unsigned long long)rec.z + row_off) >> row_bits) == v;
+          const uint32_t h = (uint32_t)(((unsigned long long)rec.z + row_off) >> row_bits);
+          f = h == v;
+          if (h > v && h < nxt) nxt = h;
         }
         const uint64_t b = __ballot(f);
         if (lane == 0) s_w[wave] = (uint32_t)__popcll(b);
@@ -2123,7 +2130,12 @@ __global__ __launch_bounds__(256) void k_big2_fixruns(uint4 *S2, uint4 *tmp, con
         base += total;
         __syncthreads();
       }
-      if (v == 0xFFFFFFFFu) break;
+      if (nxt != 0xFFFFFFFFu) atomicMin(&s_lo, nxt);
+      __syncthreads();
+      const uint32_t nv = s_lo;
+      __syncthreads();
+      if (nv == 0xFFFFFFFFu || v == hmax) break;
+      v = nv;
     }
     __threadfence();
     __syncthreads();
@@ -2521,6 +2533,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
                                          uint32_t n_alt, uint32_t mismatches, uint32_t flags,
                                          void *stream, const void **d_offsets, const void **d_hits,
                                          gs_result_view *stats) {
+  GS_HANDLE_LOCK(ix);
   try { /* the plans and lists built per batch live in std containers: nothing may throw across the C boundary */
     gs_status rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream,
                                          d_offsets, d_hits, stats);
@@ -3835,6 +3848,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
 
 extern "C" gs_status gs_rank_bwt4(gs_index *ix, int strand, const uint64_t *rows, uint64_t n,
                                   uint64_t *out) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || strand < 0 || strand > 1 || (n && (!rows || !out))) return GS_ERR_ARG;
   for (uint64_t j = 0; j < n; j++)
     if (rows[j] > ix->strand[strand].n) return GS_ERR_ARG;
@@ -3854,6 +3868,7 @@ extern "C" gs_status gs_rank_bwt4(gs_index *ix, int strand, const uint64_t *rows
 
 extern "C" gs_status gs_resolve(gs_index *ix, int strand, const uint64_t *rows, uint64_t n,
                                 uint64_t *out) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || strand < 0 || strand > 1 || (n && (!rows || !out))) return GS_ERR_ARG;
   for (uint64_t j = 0; j < n; j++)
     if (rows[j] >= ix->strand[strand].n) return GS_ERR_ARG;

@@ -146,6 +146,7 @@ __global__ void k_v_order(gs_vorder_args a) {
 
 extern "C" gs_status gs_index_verify_sa(gs_index *ix, int strand, const uint8_t *text, uint64_t len,
                                         uint64_t n_samples, uint64_t seed, gs_sa_report *rep) {
+  GS_HANDLE_LOCK(ix);
   if (!ix || strand < 0 || strand > 1 || !text || !rep || len != ix->genome_length) return GS_ERR_ARG;
   GS_HIP(hipSetDevice(ix->device));
   const gs_strand &s = ix->strand[strand];

@@ -148,6 +148,9 @@ inline bool record(const char *line, size_t len, const std::map<std::string, int
   }
   const bool has_seq = seq != "*";
   const uint32_t l_seq = has_seq ? (uint32_t)seq.size() : 0u;
+  /* what BAM's fixed-width fields cannot hold is an error, not a truncated byte: l_read_name counts the NUL in
+   * eight bits, MAPQ is one byte */
+  if (qname.size() > 254 || mapq > 255) return false;
   std::string body;
   put32(body, (uint32_t)rid);
   put32(body, (uint32_t)(int32_t)pos);
@@ -187,6 +190,7 @@ inline bool record(const char *line, size_t len, const std::map<std::string, int
     switch (t[3]) {
       case 'i': {
         const long long v = strtoll(val.c_str(), nullptr, 10);
+        if (v < -2147483648ll || v > 4294967295ll) return false; /* no integer tag type is wider than 32 bits */
         if (v >= 0 && v <= 255) {
           body.push_back('C');
           body.push_back((char)v);

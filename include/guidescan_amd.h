@@ -35,8 +35,16 @@ typedef enum {
 
 /* Opaque handle: both strand indexes of one genome resident in one GPU's HBM.
  * Replaces the two `genome_index<wt_huff<>,64,8192>` objects built in
- * src/guidescan.cxx:198-211 (include/genomics/index.hpp:23-123).  Immutable after
- * creation; one in-flight enumerate per handle. */
+ * src/guidescan.cxx:198-211 (include/genomics/index.hpp:23-123).
+ * Threads: the reference calls its seam from N std::threads on one const index
+ * (src/guidescan.cxx:240-247).  A handle owns its workspace, its lazily built tables and the
+ * device buffers its results are left in, so it runs ONE call at a time: every entry point that
+ * takes a handle holds the handle's lock for the whole call and other threads' calls wait.  The
+ * host-pointer entry points (gs_enumerate, gs_enumerate_general*, gs_score, ...) copy their
+ * results out under the lock: any number of threads may call them on one handle and each gets
+ * the bytes a single thread would.  The device-pointer entry points leave their results in the
+ * handle's buffers "until the next call": a thread that wants to read or score them holds the
+ * handle with gs_index_lock ... gs_index_unlock around its calls (the lock is recursive). */
 typedef struct gs_index gs_index;
 
 /* One off-target hit, 16 bytes.
@@ -155,6 +163,12 @@ void gs_index_close(gs_index *ix);
  * [12] Occ block lines, [3] lines of the seed recipe lists.  (the bytes the
  * roofline is priced on.)  [7] >> 8: items whose seeds went through PAM-pair tables. */
 gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]);
+/* Hold / release the handle's lock (see gs_index above): between the two, calls on this handle
+ * from other threads wait, and the device buffers a gs_enumerate_device call returned stay as
+ * they are.  Stands where the reference needs nothing (its index is const and its per-call state
+ * lives on the caller's stack, include/genomics/index.hpp:102-110). */
+gs_status gs_index_lock(gs_index *ix);
+gs_status gs_index_unlock(gs_index *ix);
 uint64_t gs_index_genome_length(const gs_index *ix); /* sum of chromosome lengths (no sentinel) */
 uint64_t gs_index_device_bytes(const gs_index *ix);
 

@@ -47,10 +47,6 @@ int main(int argc, char **argv) {
   opts.start = std::atoi(argv[11]) != 0;
   opts.nthreads = 1;
   for (int i = 12; i < argc; i++) opts.alt_pams.push_back(argv[i]);
-  if (opts.rna_bulges || opts.dna_bulges) {
-    std::cerr << "the stub covers the bulge-free path (gs_enumerate); see INTEGRATION.md for gs_enumerate_bulges\n";
-    return 2;
-  }
 
   genomics::genome_structure gs;
   if (!genomics::seq_io::load_from_file(gs, opts.index_file_prefix + ".gs")) return 1;

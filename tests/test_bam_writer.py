@@ -40,3 +40,25 @@ def test_large_blocks_and_odd_fields(tmp_path):
     sizes, eof = bam_reader.bgzf_blocks((tmp_path / "o.bam").read_bytes())
     assert eof and len(sizes) >= 4
     assert bam_reader.to_sam(tmp_path / "o.bam") == (tmp_path / "i.sam").read_text()
+
+
+def test_values_bam_cannot_hold_are_errors(tmp_path):
+    """l_read_name is one byte (name + NUL <= 255), MAPQ is one byte, integer tags are at most 32 bits wide: a SAM
+    line beyond that is refused (exit code 1, 'malformed SAM line'), not written with a truncated field"""
+    head = "@HD\tVN:1.0\tSO:unknown\n@SQ\tSN:c1\tLN:5000\n"
+    ok = "q\t0\tc1\t10\t100\t23M\t*\t0\t0\tACGTNACGTACGTACGTACGTAC\t*\tk0:i:1\n"
+    bad = {
+        "long-name": "n" * 255 + "\t0\tc1\t10\t100\t23M\t*\t0\t0\tACGTNACGTACGTACGTACGTAC\t*\tk0:i:1\n",
+        "mapq": "q\t0\tc1\t10\t256\t23M\t*\t0\t0\tACGTNACGTACGTACGTACGTAC\t*\tk0:i:1\n",
+        "tag-high": "q\t0\tc1\t10\t100\t23M\t*\t0\t0\tACGTNACGTACGTACGTACGTAC\t*\tk0:i:4294967296\n",
+        "tag-low": "q\t0\tc1\t10\t100\t23M\t*\t0\t0\tACGTNACGTACGTACGTACGTAC\t*\tk0:i:-2147483649\n",
+    }
+    (tmp_path / "ok.sam").write_text(head + "n" * 254 + ok[1:] + ok)
+    subprocess.run([str(CLI), "sam2bam", str(tmp_path / "ok.sam"), str(tmp_path / "ok.bam")], check=True, timeout=60)
+    assert bam_reader.to_sam(tmp_path / "ok.bam") == (tmp_path / "ok.sam").read_text()
+    for name, line in bad.items():
+        (tmp_path / "b.sam").write_text(head + ok + line)
+        r = subprocess.run([str(CLI), "sam2bam", str(tmp_path / "b.sam"), str(tmp_path / "b.bam")], timeout=60,
+                           capture_output=True, text=True)
+        assert r.returncode != 0, name
+        assert "malformed" in r.stderr.lower() or "error" in r.stderr.lower(), (name, r.stderr)

@@ -194,6 +194,8 @@ def test_a_failing_batch_ends_the_run(tmp_path):
                            timeout=120, capture_output=True, text=True)
         assert r.returncode == 1, r.stderr
         assert "error:" in r.stderr
+        # and leaves no file behind that looks like a database with a hole in it
+        assert not (tmp_path / "o.csv").exists()
 
 
 def test_cli_fans_batches_out_over_several_workers(tmp_path):

@@ -377,7 +377,7 @@ def test_config5_hg38_m6_2048_guides_properties_and_paths(hg38):
     hip = _hip()
     d_off, d_hits, st = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=6)
     ctr = hg38.gidx.last_counters()
-    assert ctr["ordered_device_wide"], ctr
+    assert ctr["ordered_device_wide"] and ctr["ordered_in_tiles"] and not ctr["tile_ordering_gave_up"], ctr
     off, hits = device_result_to_host(hip, d_off, d_hits, n, st["n_hits"])
     assert st["n_hits"] > n * 5000
     check_batch_properties(hg38.text, seqs, pos, strands, off, hits[:, 0], hits[:, 1].view(np.uint64))
