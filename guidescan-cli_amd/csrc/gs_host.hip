@@ -170,14 +170,14 @@ static char comp(char c) {
 
 extern "C" gs_status gs_decode_sequence(const char *guide, uint32_t L, uint32_t P, uint32_t flags,
                                         uint64_t key, char *out) {
-  if (!guide || !out || L < 1 || 2 * L + 3 * P > 52) return GS_ERR_ARG;
-  const uint64_t path = (key >> 8) & ((1ull << 52) - 1);
+  if (!guide || !out || L < 1 || 2 * L + 3 * P > 59) return GS_ERR_ARG;
+  const uint64_t path = (key >> 1) & ((1ull << 59) - 1); /* key bits 59:1, position 0 at the top */
   const bool start = flags & GS_FLAG_PAM_AT_START;
   static const char B[4] = {'A', 'C', 'G', 'T'};
   for (uint32_t t = 0; t < L; t++) {
     /* query char consumed at step t (process.hpp:63, index.hpp:218) */
     const char qc = start ? guide[L - 1 - t] : comp(guide[t]);
-    const uint32_t code = (uint32_t)(path >> (50 - 2 * t)) & 3u;
+    const uint32_t code = (uint32_t)(path >> (57 - 2 * t)) & 3u;
     if (code == 0) {
       out[t] = qc;
     } else {
@@ -191,7 +191,7 @@ extern "C" gs_status gs_decode_sequence(const char *guide, uint32_t L, uint32_t 
   }
   static const char PB[5] = {'A', 'C', 'G', 'N', 'T'};
   for (uint32_t u = 0; u < P; u++) {
-    const uint32_t code = (uint32_t)(path >> (49 - 2 * L - 3 * u)) & 7u;
+    const uint32_t code = (uint32_t)(path >> (56 - 2 * L - 3 * u)) & 7u;
     if (code > 4) return GS_ERR_ARG;
     out[L + u] = PB[code];
   }

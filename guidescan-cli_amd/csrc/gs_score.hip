@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t sc_seq_at(const uint8_t *guide, uint32_t L, 
   lower = false;
   if (i < L) {
     const uint32_t qc = start ? guide[L - 1u - i] : sc_comp_upper(guide[i]);
-    const uint32_t code = (uint32_t)(path >> (50u - 2u * i)) & 3u;
+    const uint32_t code = (uint32_t)(path >> (57u - 2u * i)) & 3u;
     if (code == 0u) return qc;
     const int q = sc_bidx(qc);
     int a = (int)code - 1;
@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t sc_seq_at(const uint8_t *guide, uint32_t L, 
     lower = true; /* index.hpp:243 */
     return a == 0 ? 'A' : a == 1 ? 'C' : a == 2 ? 'G' : 'T';
   }
-  const uint32_t code = (uint32_t)(path >> (49u - 2u * L - 3u * (i - L))) & 7u;
+  const uint32_t code = (uint32_t)(path >> (56u - 2u * L - 3u * (i - L))) & 7u;
   return code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : code == 3 ? 'N' : 'T';
 }
 
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, uint64_t n_
     while (lo + 1u < a.n && a.offsets[lo + 1u] <= h) lo++;
     const uint8_t *gd = a.guides + (size_t)lo * L;
     const gs_hit hit = a.hits[h];
-    const uint64_t path = (hit.key >> 8) & ((1ull << 52) - 1ull);
+    const uint64_t path = (hit.key >> 1) & ((1ull << 59) - 1ull); /* key bits 59:1: position 0 at the top */
     const uint32_t d = (uint32_t)(hit.key >> 61);
     float c = 1.0f;
     uint32_t pgg = 0u;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, uint64_t n_
        * given, while with --start the two strings are compared as the reference compares them */
       uint64_t todo = a.start ? 0xFFFFFull : 0ull;
       if (!a.start)
-        for (uint32_t i = 0; i < 20u; ++i) todo |= (uint64_t)(((path >> (50u - 2u * i)) & 3ull) != 0ull) << i;
+        for (uint32_t i = 0; i < 20u; ++i) todo |= (uint64_t)(((path >> (57u - 2u * i)) & 3ull) != 0ull) << i;
       while (todo) {
         const uint32_t i = (uint32_t)__builtin_ctzll(todo);
         todo &= todo - 1ull;
@@ -243,8 +243,8 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   if (!ix || !gs || (n && (!d_guides || !d_offsets || !d_specificity)) || (gs->n_chr && !gs->chr_lengths))
     return GS_ERR_ARG;
   if (n >= (1ull << 31) || max_off_targets < -1) return GS_ERR_ARG;
-  if (L < 1 || L > 31 || P > 8 || 2 * L + 3 * P > 52) {
-    gs_set_error("device path supports 1<=L<=31, P<=8, 2L+3P<=52");
+  if (L < 1 || L > 31 || P > 8 || 2 * L + 3 * P > 59) {
+    gs_set_error("device path supports 1<=L<=31, P<=8, 2L+3P<=59");
     return GS_ERR_UNSUPPORTED;
   }
   if (n == 0) return GS_OK;

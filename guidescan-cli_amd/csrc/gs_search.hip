@@ -175,6 +175,15 @@ __device__ __forceinline__ const T *own_sgprs(const T *p) {
 template <bool CNT, bool WALK, bool SPEC = false>
 __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk) {
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
+  /* Where a path lives in the 64-bit word the search carries next to a seed or a hit.  The walking variant packs
+   * the node's step, PAM pattern and fan-out flag above it (node meta, top of the file): 52 path bits, key = path << 8.
+   * The table-only variants carry nothing but the mismatch count: 59 path bits - 2L + 3P <= 59 covers 23-mers with
+   * a four-symbol PAM (Cas12a) - in the SAME key layout (position 0 at key bits 59:58, bit 0 = the record's
+   * row is v_rem symbols into the site): a path of at most 52 bits gives the key it always gave. */
+  constexpr uint32_t PB = WALK ? 0u : 7u;           /* path bias: field shifts are those of the 52-bit layout + PB */
+  constexpr uint32_t KSH = WALK ? 56u : 61u;        /* mismatch count above the path */
+  constexpr uint32_t PSG = 50u + PB, PSP = 49u + PB; /* guide symbol t at PSG - 2t, PAM symbol u at PSP - 2L - 3u */
+  constexpr uint64_t PMASK = (1ull << (52u + PB)) - 1ull;
   const uint32_t lane = lane_id();
   unsigned long long n_ext = 0, n_ovf = 0;
   uint32_t n_fail = 0; /* items that needed more overflow chunks than the arena had left */
@@ -302,7 +311,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         const uint32_t hi = n_match + (uint32_t)__popcll(be); /* one past the last record of this emission */
         if (a.arena != nullptr) {
           /* matches per mismatch count: lane d adds this emission's share of class d (one LDS add, distinct words) */
-          const uint32_t kk = META_K(cmeta);
+          const uint32_t kk = (uint32_t)((cmeta >> KSH) & 7ull);
           uint32_t add = 0;
           for (uint32_t d = 0; d <= m; ++d) {
             const uint32_t c = (uint32_t)__popcll(__ballot(em && kk == d));
@@ -336,8 +345,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint32_t idx = n_match + lanes_below(be);
           /* bit 0: the record is a single row at the table depth whose text position still
            * has to move left by v_rem symbols (k_locate) */
-          const uint64_t key = ((uint64_t)META_K(cmeta) << 61) | ((uint64_t)strand << 60) |
-                               ((cmeta & PATH_MASK) << 8) | vflag;
+          const uint64_t key = ((uint64_t)((cmeta >> KSH) & 7ull) << 61) | ((uint64_t)strand << 60) |
+                               ((cmeta & PMASK) << (8u - PB)) | vflag;
           const uint4 rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
           if (idx < item_cap) {
             out[idx] = rec;
@@ -523,11 +532,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
           const bool gok = has && !excbad && kv + mmv <= m && mmv >= ((dd.y >> DSC_LO) & 7u);
           if (!__ballot(gok)) continue;
-          const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PATH_MASK;
+          const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PMASK;
           if (modeB) {
             /* word symbol j is guide symbol g-1-j, complemented: the bases as this strand reads them against
              * the guide's own; code j belongs at path bit 50 - 2 (g-1-j) */
-            const uint64_t gpath = (uint64_t)path_codes16(~w & gmask, ~qrem & gmask) << (52u - 2u * g);
+            const uint64_t gpath = (uint64_t)path_codes16(~w & gmask, ~qrem & gmask) << (52u + PB - 2u * g);
             uint32_t rowA = 0;
             if (gok) {
               /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
@@ -536,7 +545,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               rowA = sd.isa[sA];
             }
             if constexpr (CNT) c_isa += 2u * (uint32_t)__popcll(__ballot(gok));
-            const uint64_t mmeta = ((uint64_t)(kv + mmv) << 56) | spath | gpath;
+            const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath;
             route(gok, true, false, rowA, rowA, mmeta, 0u);
             continue;
           }
@@ -554,12 +563,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               const uint32_t tb = (w >> (2u * (g + u))) & 3u;
               const bool isn = ((nmask >> u) & 1u) != 0u;
               ok = ok && (isn ? pc == 4u : (pc == 4u || pc == tb));
-              ppath |= (uint64_t)(isn ? 3u : (tb < 3u ? tb : 4u)) << (49u - 2u * L - 3u * u);
+              ppath |= (uint64_t)(isn ? 3u : (tb < 3u ? tb : 4u)) << (PSP - 2u * L - 3u * u);
             }
             if (!__ballot(ok)) continue;
             /* word symbol v is guide symbol k+v: code v belongs at path bit 50 - 2 (k+v), the fields in reverse order */
-            const uint64_t gpath = ((uint64_t)rev_fields16(path_codes16(w & gmask, qrem)) << 32) >> (12u + 2u * k);
-            const uint64_t mmeta = ((uint64_t)(kv + mmv) << 56) | spath | gpath | ppath;
+            const uint64_t gpath = ((uint64_t)rev_fields16(path_codes16(w & gmask, qrem)) << 32) >> (12u - PB + 2u * k);
+            const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath | ppath;
             route(ok, true, false, orow, orow, mmeta, 1u);
           }
         }
@@ -583,7 +592,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u;
         const uint32_t sym = (qc + 1u + d) & 3u;               /* one of the three other bases */
         const uint32_t code = 1u + sym - (sym > qc ? 1u : 0u); /* its rank among them, A<C<G<T */
-        const uint64_t pb = (uint64_t)code << (50u - 2u * t);
+        const uint64_t pb = (uint64_t)code << (PSG - 2u * t);
         /* the other strand's k-mer holds the complements: complementing both keeps the xor */
         const uint32_t sh = 2u * (sideB ? nYb - 1u - s : k - 1u - s);
         dtab[e] = d == 3u ? make_uint4(0u, 0u, 0u, 0u) : make_uint4((qc ^ sym) << sh, (uint32_t)pb, (uint32_t)(pb >> 32), 0u);
@@ -726,7 +735,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           for (uint32_t t = 0; t < L; ++t) {
             const uint32_t qc = (uint32_t)(gr_q >> (2u * t)) & 3u, tb = (uint32_t)(cq >> (2u * t)) & 3u;
             const uint32_t code = tb == qc ? 0u : 1u + tb - (tb > qc ? 1u : 0u);
-            gpath |= (uint64_t)code << (50u - 2u * t);
+            gpath |= (uint64_t)code << (PSG - 2u * t);
           }
           uint32_t rowA = 0;
           if (mine) rowA = sd.isa[ce.w];
@@ -738,9 +747,9 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             for (uint32_t u = 0; u < P; ++u) {
               const uint32_t pc = (pw >> (3u * u)) & 7u, tb = (ce.z >> (3u * u)) & 7u;
               ok = ok && (tb == 4u ? pc == 4u : (pc == 4u || pc == tb));
-              ppath |= (uint64_t)(tb == 4u ? 3u : (tb < 3u ? tb : 4u)) << (49u - 2u * L - 3u * u);
+              ppath |= (uint64_t)(tb == 4u ? 3u : (tb < 3u ? tb : 4u)) << (PSP - 2u * L - 3u * u);
             }
-            route(ok, true, false, rowA, rowA, ((uint64_t)tot << 56) | gpath | ppath, 0u);
+            route(ok, true, false, rowA, rowA, ((uint64_t)tot << KSH) | gpath | ppath, 0u);
           }
         }
         /* context mask for the other strand's seeds: the symbols it consumes next are the complemented
@@ -802,7 +811,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
                 bxset = cn == 4u ? 15u : 1u << (3u - cn);
                 bnn = 0;
                 for (uint32_t u = 1; u < P; ++u)
-                  ppath |= (uint64_t)(((pw >> (3u * u)) & 7u) < 3u ? ((pw >> (3u * u)) & 7u) : 4u) << (49u - 2u * L - 3u * u);
+                  ppath |= (uint64_t)(((pw >> (3u * u)) & 7u) < 3u ? ((pw >> (3u * u)) & 7u) : 4u) << (PSP - 2u * L - 3u * u);
               } else {
                 for (uint32_t u = 0; u < P; ++u) {
                   const uint32_t pc = (pw >> (3u * u)) & 7u;
@@ -811,7 +820,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
                     base = ee & 3u;
                     ee >>= 2;
                   }
-                  ppath |= (uint64_t)(base < 3u ? base : 4u) << (49u - 2u * L - 3u * u);
+                  ppath |= (uint64_t)(base < 3u ? base : 4u) << (PSP - 2u * L - 3u * u);
                   pidxb |= (3u - base) << (2u * (k - P + u));
                 }
               }
@@ -842,7 +851,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             if (deep) {
               ep += bx;
               act = act && ((bxset >> bx) & 1u) != 0u;
-              path |= (uint64_t)(bx != 0u ? 3u - bx : 4u) << (49u - 2u * L); /* that base: 3 - bx (T = 3 is coded 4) */
+              path |= (uint64_t)(bx != 0u ? 3u - bx : 4u) << (PSP - 2u * L); /* that base: 3 - bx (T = 3 is coded 4) */
             }
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
             if (act) ent = *ep;
@@ -858,7 +867,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               const uint32_t intact = (uint32_t)__popc(mz & bsel_z) + (uint32_t)__popc(mw & bsel_w);
               if (intact + bl < n_bpairs) live = false;
             }
-            cmeta = ((uint64_t)k << 59) | ((uint64_t)jb << 56) | path;
+            cmeta = (WALK ? ((uint64_t)k << 59) | ((uint64_t)jb << 56) : 0ull) | path; /* (the queue keeps the count in .y) */
             rem = (live && !(a.dbg_skip & 1u)) ? ecnt : 0u;
           }
           /* the surviving seeds wait in the queue (it is this phase's alone: one-sided seeding has not
@@ -1018,7 +1027,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           }
         }
         const bool live = act && ecnt != 0u && !hopeless && !(a.dbg_skip & 2u);
-        const uint64_t cmeta = ((uint64_t)k << 59) | ((uint64_t)kk << 56) | path;
+        const uint64_t cmeta = (WALK ? ((uint64_t)k << 59) | ((uint64_t)kk << 56) : 0ull) | path;
         /* every interval is resolved right here against ctx[] (exception rows included, large
          * ones in pieces); without the context arrays the seeds continue as ordinary nodes
          * (k < L: never terminal) */
@@ -1093,7 +1102,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint32_t pw =
               pamid == 0 ? gr_pam0 : pamid == 1 ? gr_pam1 : pamid == 2 ? gr_pam2 : gr_pam3;
           c = (pw >> (3u * (t - L))) & 3u; /* fixed PAM base (code < 4 by construction) */
-          path |= (uint64_t)(c < 3u ? c : 4u) << (49u - 2u * L - 3u * (t - L));
+          path |= (uint64_t)(c < 3u ? c : 4u) << (PSP - 2u * L - 3u * (t - L));
         }
         uint32_t oa = 0, ob = 0;
         if (active) {
@@ -1162,8 +1171,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t t2 = t + 1u;
       const bool term = (t2 == T_end);
       const bool needfan = (t2 == L) && fanning;
-      const uint32_t sh_g = 50u - 2u * t;                                    /* guide step: 2-bit code */
-      const uint32_t sh_p = inpam ? 49u - 2u * L - 3u * (t - L) : 0u; /* PAM step: 3-bit code */
+      const uint32_t sh_g = PSG - 2u * t;                                    /* guide step: 2-bit code */
+      const uint32_t sh_p = inpam ? PSP - 2u * L - 3u * (t - L) : 0u; /* PAM step: 3-bit code */
 
 #pragma unroll
       for (uint32_t c = 0; c < MAX_FANOUT; ++c) {
@@ -2569,10 +2578,11 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   if (!ix || (!d_guides && n) || (P && !d_guide_pams && n) || (n_alt && !alt_pams))
     return GS_ERR_ARG;
   if (n >= (1ull << 31)) return GS_ERR_ARG;
-  if (L < 1 || L > 31 || P > 8 || 2 * L + 3 * P > 52 || mismatches > 7 || n_alt > 31) {
-    gs_set_error("device path supports 1<=L<=31, P<=8, 2L+3P<=52, mismatches<=7, <=31 alt PAMs");
+  if (L < 1 || L > 31 || P > 8 || 2 * L + 3 * P > 59 || mismatches > 7 || n_alt > 31) {
+    gs_set_error("device path supports 1<=L<=31, P<=8, 2L+3P<=59, mismatches<=7, <=31 alt PAMs");
     return GS_ERR_UNSUPPORTED;
   }
+  const bool wide_key = 2 * L + 3 * P > 52; /* beyond what the walking kernel and the device-wide ordering carry */
   hipStream_t st = (hipStream_t)stream;
   GS_HIP(hipSetDevice(ix->device));
   ix->last_unsupported = 0;
@@ -2671,6 +2681,11 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       ix->strand[1].ctx && ix->strand[0].ctx16 && ix->strand[1].ctx16 && L + P - ix->pt_k <= 16)
     v_rem = L + P - ix->pt_k;
   uint32_t *d_nlist = d_work + 2;
+  if (wide_key && v_rem == 0) {
+    gs_set_error("match sequences beyond 52 key bits (2L+3P > 52) need the table-seeded search: this index's prefix table is too "
+                 "shallow for them (or the reference-order walk was asked for) - gs_enumerate_general carries such sequences as bytes");
+    return GS_ERR_UNSUPPORTED;
+  }
 
   /* two-sided seeding (k_search): possible when set X (the first consumed guide symbols, which only
    * this strand's table covers) lies inside the recipes' positions, the PAM fits the table depth and
@@ -3531,7 +3546,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
    * 16-byte records in LDS costs more than nine radix passes (m <= 4, 512 slots: 32.9 against 35.1, LDS kept) */
   uint32_t wide_from = 1024;
   if (const char *e = getenv("GS_ORDER_WIDE_FROM")) wide_from = (uint32_t)atol(e);
-  const bool big_batch = cap > LDS_CAP_MAX || (cap >= wide_from && big_fits_v2(n32));
+  const bool big_batch = cap > LDS_CAP_MAX || (cap >= wide_from && (wide_key ? gs_tileorder_fits(L, P, mismatches) : big_fits_v2(n32)));
   if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
   unsigned long long h_stats[2] = {0, 0};
   if ((rc = run_search((const gs_guide_rec *)ix->w_grec.p, n32, (uint4 *)ix->w_slots.p,
@@ -3706,6 +3721,11 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       bool usable = false;
       if ((rc = gs_tileorder_plan(ix, ti, st, ts, &usable)) != GS_OK) return rc;
       if (!usable) tile = false;
+    }
+    if (set_exists && !tile && wide_key) {
+      gs_set_error("a guide with more matches than LDS orders and a match sequence beyond 52 key bits: the device-wide ordering "
+                   "does not carry such keys and the per-guide tile ordering could not take the batch (gs_enumerate_general does)");
+      return GS_ERR_UNSUPPORTED;
     }
     if (set_exists && !tile) {
       if (!big_batch) {

@@ -324,7 +324,7 @@ static gs_status format_csv_fast(const gs_genome_structure *gs, const uint64_t *
                                  uint32_t flags, int64_t max_off_targets, float spec, outbuf &o) {
   const bool start = flags & GS_FLAG_PAM_AT_START, complete = flags & GS_TEXT_COMPLETE;
   const size_t L = strlen(k->sequence), P = strlen(k->pam), idl = strlen(k->id);
-  if (L < 1 || 2 * L + 3 * P > 52) return GS_ERR_ARG;
+  if (L < 1 || 2 * L + 3 * P > 59) return GS_ERR_ARG;
   if (!o.need(idl + L + P + 64)) return GS_ERR_NOMEM;
   if (n_hits == 0) { /* printer.hpp:189-199 */
     o.put(k->id, idl);
@@ -397,11 +397,11 @@ static gs_status format_csv_fast(const gs_genome_structure *gs, const uint64_t *
     if (complete) {
       o.ch(',');
       /* complement(match.sequence), decoded from the key (gs_decode_sequence + printer.hpp:232,264) */
-      const uint64_t path = (key >> 8) & ((1ull << 52) - 1);
+      const uint64_t path = (key >> 1) & ((1ull << 59) - 1); /* key bits 59:1 */
       for (uint32_t t = 0; t < L; t++) {
         const char gq = start ? k->sequence[L - 1 - t] : k->sequence[t]; /* guide base under this step */
         const char qc = start ? gq : comp(gq);                            /* the query char (index.hpp:218) */
-        const uint32_t code = (uint32_t)(path >> (50 - 2 * t)) & 3u;
+        const uint32_t code = (uint32_t)(path >> (57 - 2 * t)) & 3u;
         if (code == 0) {
           o.ch(comp(qc));
         } else {
@@ -413,7 +413,7 @@ static gs_status format_csv_fast(const gs_genome_structure *gs, const uint64_t *
         }
       }
       for (uint32_t u = 0; u < P; u++) {
-        const uint32_t code = (uint32_t)(path >> (49 - 2 * L - 3 * u)) & 7u;
+        const uint32_t code = (uint32_t)(path >> (56 - 2 * L - 3 * u)) & 7u;
         if (code > 4) return GS_ERR_ARG;
         o.ch(PBC[code]);
       }

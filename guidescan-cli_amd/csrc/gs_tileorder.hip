@@ -52,9 +52,9 @@ struct gs_to_tab {
  * the key's own bits order them (the same number gs_search.hip's big2_rank computes) */
 __device__ __forceinline__ unsigned long long to_rank(const unsigned long long key, const uint32_t L, const uint32_t P,
                                                        const unsigned long long *nt, const unsigned long long pam_mul) {
-  const unsigned long long path = key >> 8;
+  const unsigned long long path = (key >> 1) & ((1ull << 59) - 1ull); /* key bits 59:1 */
   /* the guide's L two-bit fields, position 0 in the highest: only the substituted ones (at most seven) count */
-  const unsigned long long gb = path >> (52u - 2u * L);
+  const unsigned long long gb = path >> (59u - 2u * L);
   unsigned long long nz = (gb | (gb >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
   uint32_t r = (uint32_t)__popcll(nz);
   if (r > 7u) r = 7u;
@@ -69,7 +69,7 @@ __device__ __forceinline__ unsigned long long to_rank(const unsigned long long k
   }
   unsigned long long pr = 0;
   for (uint32_t u = 0; u < P; u++) {
-    const uint32_t c = (uint32_t)(path >> (49u - 2u * L - 3u * u)) & 7u;
+    const uint32_t c = (uint32_t)(path >> (56u - 2u * L - 3u * u)) & 7u;
     pr = pr * 5ull + (c < 4u ? c : 4u);
   }
   return rank * pam_mul + pr;
@@ -615,7 +615,7 @@ static bool to_make_tab(uint32_t L, uint32_t P, uint32_t m, gs_to_tab &tab) {
       c64 += tab.n[L][j] * tab.pam_mul;
     }
   }
-  return L >= 1 && L <= 31 && m <= 7 && cum < 4294967295.0L; /* the words stay below 2^32 - 1: all ones marks padding */
+  return L >= 1 && 2 * L + 3 * P <= 59 && m <= 7 && cum < 4294967295.0L; /* the words stay below 2^32 - 1: all ones marks padding */
 }
 bool gs_tileorder_fits(uint32_t L, uint32_t P, uint32_t m) {
   gs_to_tab tab;

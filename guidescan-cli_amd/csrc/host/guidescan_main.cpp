@@ -360,7 +360,24 @@ static void format_batch(enumerate_job &job, batch &b) {
 
 /* the device side of one batch: threshold filter, search (fast path; general path for the guides it
  * flags, or for all of them with bulges), scoring */
+static std::string search_batch_as(enumerate_job &job, gs_index *ix, batch &b, bool all_general, gs_status &rc);
 static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
+  const uint32_t L = (uint32_t)job.kmers[b.lo].sequence.size(), P = (uint32_t)job.kmers[b.lo].pam.size();
+  /* Match sequences beyond the fast path's key: up to 59 bits (23-mers with a four-symbol PAM: 58) the table-seeded
+   * kernels carry them; the reference-order walk (small genomes whose table is too shallow for the context arrays)
+   * stops at 52 and says GS_ERR_UNSUPPORTED - then, and beyond 59 bits, the general path carries sequences as bytes */
+  const uint32_t bits = 2 * L + 3 * P;
+  gs_status rc = GS_OK;
+  std::string err = search_batch_as(job, ix, b, bits > 59, rc);
+  if (!err.empty() && rc == GS_ERR_UNSUPPORTED && bits > 52 && bits <= 59) {
+    if (b.res) gs_result_free(b.res);
+    b.res = nullptr;
+    b.skip.clear();
+    err = search_batch_as(job, ix, b, true, rc);
+  }
+  return err;
+}
+static std::string search_batch_as(enumerate_job &job, gs_index *ix, batch &b, bool all_general, gs_status &rc) {
   const size_t n = b.hi - b.lo;
   const uint32_t L = (uint32_t)job.kmers[b.lo].sequence.size(), P = (uint32_t)job.kmers[b.lo].pam.size();
   const uint32_t n_alt = P ? job.n_alt : 0;
@@ -369,10 +386,7 @@ static std::string search_batch(enumerate_job &job, gs_index *ix, batch &b) {
    * general path searches every pattern at its own length, as the reference does */
   bool mixed = false;
   for (uint32_t j = 0; j < n_alt; j++) mixed = mixed || job.alt_lens[j] != P;
-  /* a match sequence beyond the 52 bits of the fast path's key (23-mers with a four-symbol PAM): the general
-   * path carries sequences as bytes */
-  if (2 * L + 3 * P > 52) mixed = true;
-  gs_status rc;
+  if (all_general) mixed = true;
   /* --threshold t (process.hpp:66-76): a guide with more than one hit within t mismatches (both
    * indexes, bulges off; counted per PAM pattern, before duplicate sequences collapse) is dropped
    * before the real search */

@@ -748,3 +748,74 @@ def test_search_iteration_bound_fails_cleanly(toy_gpu, monkeypatch):
         monkeypatch.delenv("GS_SEARCH_MAX_ITER")
         got = gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
         assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes()
+
+
+def cas12a_genome(seed, n_copies, size):
+    """PAM at the 5' end: sites are TTTN + a 23-nt protospacer.  A family of near-copies of one site (0..4 substitutions
+    in the protospacer, the PAM's N any base, a few with another PAM), on both strands"""
+    rng = np.random.default_rng(seed)
+    text, names, lengths = synth.make_genome(size, seed=seed, n_blocks=False)
+    text = text.copy()
+    fam = text[2000:2023].copy()
+    text[1996:2000] = np.frombuffer(b"TTTA", np.uint8)
+    for c in range(n_copies):
+        site = fam.copy()
+        for j in rng.choice(23, size=int(rng.integers(0, 5)), replace=False):
+            site[j] = rng.choice([x for x in b"ACGT" if x != site[j]])
+        pam = bytes(rng.choice([b"TTTA", b"TTTC", b"TTTG", b"TTTT", b"TTTA", b"TCTA", b"CTTA", b"TTTN"]))
+        w = np.concatenate([np.frombuffer(pam, np.uint8), site])
+        if c % 2:
+            w = synth.reverse_complement_bytes(w)
+        at = int(rng.integers(3000, text.shape[0] - 100))
+        text[at:at + 27] = w
+    for _ in range(4):
+        at = int(rng.integers(3000, text.shape[0] - 3000))
+        text[at:at + int(rng.integers(1, 40))] = ord("N")
+    return text, fam
+
+
+def test_wide_keys_23mers_with_a_four_symbol_pam(monkeypatch):
+    """Cas12a: 23-mers behind TTTN (--start).  2L + 3P = 58 bits of match sequence: beyond the 52 bits the hit key
+    carried until round 4, inside the 59 it carries now (key bits 59:1) - the table-seeded kernels take the batch
+    (one-sided seeding at this shape), LDS orders it, and on the second genome - 30,000 near-copies of one site - the
+    guide's thousands of records overflow into the arena and are ordered per guide in LDS tiles.  Every hit list
+    equals the oracle's: positions, distances, index, match.sequence as gs_decode_sequence rebuilds it from the key."""
+    monkeypatch.setenv("GS_PREFIX_K", "13")
+    for seed, n_copies, size, ms in ((21, 150, [150_000, 90_000], (1, 2, 3, 4)), (22, 30000, [3_000_000], (3,))):
+        text, fam = cas12a_genome(seed, n_copies, size)
+        oidx = ol.OracleIndex(text)
+        gidx = api.GenomeIndex.build(text, device=0)
+        try:
+            t = text.tobytes()
+            guides, at = [fam.tobytes().decode(), synth.reverse_complement_bytes(fam).tobytes().decode()], 0
+            while len(guides) < 26:   # guides read off the genome behind TTT sites: they hit
+                at = t.find(b"TTT", at + 1)
+                assert at >= 0
+                w = t[at:at + 27]
+                if len(w) == 27 and set(w) <= set(b"ACGT"):
+                    guides.append(w[4:].decode())
+                    at += 5000
+            seqs = np.array([list(g.encode()) for g in guides], dtype=np.uint8)
+            pams = np.tile(np.frombuffer(b"TTTN", np.uint8), (len(guides), 1))
+            for m in ms:
+                for alt in ((), ("TCTN",)):
+                    opts = ol.make_opts(mismatches=m, alt_pams=alt, start=True)
+                    offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=True)
+                    ctr = gidx.last_counters()
+                    total = 0
+                    for i, g in enumerate(guides):
+                        exp, _ = oracle_hits_as_records(oidx, g, "TTTN", opts, 4, True)
+                        assert gpu_hits_as_records(offsets, hits, i, g, 4, True) == exp, (seed, i, m, alt)
+                        total += len(exp)
+                    assert total > len(guides)
+                    if n_copies >= 5000:
+                        pick = {k: ctr[k] for k in ("guides_redone", "ordered_in_tiles", "tile_ordering_gave_up", "matches_max_per_item",
+                                                    "overflow_from_arena", "redo_ordered_device_wide")}
+                        assert ctr["guides_redone"] >= 1 and ctr["ordered_in_tiles"] and ctr["matches_max_per_item"] > 4096, pick
+            # the reference-order walk carries 52 path bits: it says so instead of returning a truncated key
+            with pytest.raises(api.GsError) as e:
+                gidx.enumerate(seqs[:2], pams[:2], mismatches=1, start=True, faithful=True)
+            assert e.value.status == 3
+        finally:
+            gidx.close()
+            oidx.close()
