@@ -20,7 +20,8 @@
 
 #include <rocprim/rocprim.hpp>
 
-#define GSTACK 1024 /* 48-byte nodes per wave */
+#define GSTACK 1024 /* 48-byte nodes per wave: 48 KB, three single-wave workgroups per CU.  (512 nodes, six per CU: the room a pop of
+                        64 nodes needs - 11 children each - is never there, pops shrink to 17 lanes and the batch takes 3 x as long) */
 #define GFAN 12     /* children one node can push: 4 DNA-bulge + exact + 4 substitutions + RNA bulge + PAM hop (+1) */
 
 /* state word: t[5:0] mm[8:6] dna[11:9] rna[14:12] bulge_type[16:15] curr[17] slen[23:18] pamid[28:24] inpam[29] hop[30] */
@@ -69,6 +70,11 @@ struct gs_gsearch_args {
   const gs_gen_guide *guides;
   gs_grec *recs;             /* item s writes at recs[slot_off[s] ...]; nullptr = count only */
   const uint64_t *slot_off;
+  /* slot_off == nullptr with recs: ONE pass - records go to recs[] in emission order through the counter pool_next
+   * (the device-wide sort that follows orders by guide first, so an item's records need not be neighbours);
+   * records beyond pool_cap are counted, not written: the host then runs the pass again with room for all */
+  unsigned long long *pool_next;
+  unsigned long long pool_cap;
   uint32_t *counts;
   uint32_t *work;   /* [0] work-queue head, [1] error flag (iteration bound hit) */
   uint8_t alt[32][8]; /* alt PAM patterns in consumption order */
@@ -105,8 +111,9 @@ __global__ __launch_bounds__(WAVE) void k_search_general(gs_gsearch_args a) {
     const gs_gen_guide *gg = a.guides + guide;
     const gs_strand_dev &sd = a.sd[strand];
     const uint4 *__restrict__ blocks = sd.blocks;
-    gs_grec *out = a.recs ? a.recs + a.slot_off[slot] : nullptr;
-    const uint32_t item_cap = a.recs ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : 0u;
+    const bool pooled = a.recs != nullptr && a.slot_off == nullptr;
+    gs_grec *out = a.recs && !pooled ? a.recs + a.slot_off[slot] : a.recs;
+    const uint32_t item_cap = a.recs && !pooled ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : 0u;
     uint32_t n_match = 0, size = 1;
     if (lane == 0) {
       stk[0] = make_uint4(0u, sd.n - 1u, 0u, 0u);
@@ -130,9 +137,15 @@ __global__ __launch_bounds__(WAVE) void k_search_general(gs_gsearch_args a) {
       }
       const uint64_t be = __ballot(em);
       if (be) {
+        unsigned long long pbase = 0;
+        if (pooled) { /* one atomic per emission of the wave */
+          if (lane == (uint32_t)__builtin_ctzll(be)) pbase = atomicAdd(a.pool_next, (unsigned long long)__popcll(be));
+          pbase = ((unsigned long long)__shfl((int)(pbase >> 32), (int)__builtin_ctzll(be)) << 32) |
+                  (uint32_t)__shfl((int)(uint32_t)pbase, (int)__builtin_ctzll(be));
+        }
         if (em) {
-          const uint32_t idx = n_match + lanes_below(be);
-          if (idx < item_cap) {
+          const unsigned long long idx = pooled ? pbase + lanes_below(be) : (unsigned long long)(n_match + lanes_below(be));
+          if (idx < (pooled ? a.pool_cap : (unsigned long long)item_cap)) {
             gs_grec r;
             for (int i = 0; i < 8; i++) r.seq[i] = sq[i];
             r.sp = csp;
@@ -460,24 +473,40 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
   sa.max_rna = rna_bulges;
   sa.max_dna = dna_bulges;
   sa.max_iter = getenv("GS_BULGE_MAX_ITER") ? (uint32_t)atol(getenv("GS_BULGE_MAX_ITER")) : (1u << 26);
-  const uint32_t grid_max = (uint32_t)gs_num_cus(ix->device) * 3u;
+  const uint32_t grid_max = (uint32_t)gs_num_cus(ix->device) * 3u; /* 48 KB of LDS per single-wave workgroup */
   uint32_t grid = 2 * n32;
   if (grid > grid_max) grid = grid_max;
-  /* pass 1: count matches per (guide, strand) */
-  hipLaunchKernelGGL(k_search_general, dim3(grid), dim3(WAVE), 0, st, sa);
-  std::vector<uint32_t> cnt(2 * n);
-  GS_HIP(hipMemcpy(cnt.data(), d_cnt.p, 8 * n, hipMemcpyDeviceToHost));
-  {
-    uint32_t flag = 0;
-    GS_HIP(hipMemcpy(&flag, (uint32_t *)d_misc.p + 1, 4, hipMemcpyDeviceToHost));
-    if (flag) {
+  /* ONE search pass: records go to a pool through an atomic counter (the sort below orders by guide first).  The pool
+   * is sized by a guess - 256 records per guide - and what does not fit is only counted: the pass then runs again with
+   * room for all (the first version always searched twice: a counting pass, then a filling pass at exact offsets) */
+  uint64_t T = 0, cap = std::max<uint64_t>((uint64_t)n * 256u, 1u << 16);
+  if (const char *e = getenv("GS_GENERAL_POOL")) cap = (uint64_t)std::max(1ll, atoll(e));
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if (d_a.p) {
+      hipFree(d_a.p);
+      d_a.p = nullptr;
+    }
+    GS_TRY(d_a.get(sizeof(gs_grec) * cap));
+    GS_HIP(hipMemset(d_misc.p, 0, 64));
+    sa.recs = (gs_grec *)d_a.p;
+    sa.slot_off = nullptr;
+    sa.pool_next = (unsigned long long *)((char *)d_misc.p + 16);
+    sa.pool_cap = cap;
+    hipLaunchKernelGGL(k_search_general, dim3(grid), dim3(WAVE), 0, st, sa);
+    uint32_t h_misc[8] = {0};
+    GS_HIP(hipMemcpy(h_misc, d_misc.p, 32, hipMemcpyDeviceToHost));
+    if (h_misc[1]) {
       gs_set_error("internal: general search exceeded its iteration bound");
       return GS_ERR_DEVICE;
     }
+    T = ((uint64_t)h_misc[5] << 32) | h_misc[4];
+    if (T <= cap) break;
+    if (attempt == 1) {
+      gs_set_error("internal: general search found more records the second time");
+      return GS_ERR_DEVICE;
+    }
+    cap = T;
   }
-  std::vector<uint64_t> soff(2 * n + 1, 0);
-  for (size_t i = 0; i < 2 * n; i++) soff[i + 1] = soff[i] + cnt[i];
-  const uint64_t T = soff.back();
   if (T >= (1ull << 31)) {
     gs_set_error("more than 2^31 match records in one batch of the general path: use smaller batches");
     return GS_ERR_UNSUPPORTED;
@@ -487,15 +516,7 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
     *out = res;
     return GS_OK;
   }
-  GS_TRY(d_off.get(8 * soff.size()));
-  GS_TRY(d_a.get(sizeof(gs_grec) * T));
   GS_TRY(d_b.get(sizeof(gs_grec) * T));
-  GS_HIP(hipMemcpy(d_off.p, soff.data(), 8 * soff.size(), hipMemcpyHostToDevice));
-  /* pass 2: fill at exact offsets */
-  GS_HIP(hipMemset(d_misc.p, 0, 8));
-  sa.recs = (gs_grec *)d_a.p;
-  sa.slot_off = (const uint64_t *)d_off.p;
-  hipLaunchKernelGGL(k_search_general, dim3(grid), dim3(WAVE), 0, st, sa);
   {
     dbuf d_raw;
     GS_TRY(d_raw.get(8 * n));
