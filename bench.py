@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--extra-rows", choices=["auto", "on", "off"], default="auto",
                     help="after the headline: the repeat-rich genome at <= 3 mismatches and <= 6 mismatches + CFD on this "
                          "genome, 20 k guides each (auto: with the default hg38 workload on one GPU)")
+    ap.add_argument("--n-gaps", type=int, default=0,
+                    help="overwrite this many random stretches of the genome with N runs (a scaffold-level assembly: "
+                         "three literal-N windows per run and strand for k_search to look through)")
     ap.add_argument("--verify", action="store_true",
                     help="after timing, check full-size properties of the last batch (on-target found, order)")
     args = ap.parse_args()
@@ -115,6 +118,11 @@ def main():
     m = args.mismatches
     t0 = time.time()
     text, names, lengths = shared_genome(synth, args.workload, lengths, probs, dist, local_rank)
+    if args.n_gaps:
+        text = np.array(text, copy=True)
+        rng = np.random.Generator(np.random.PCG64(4321))
+        for at in np.sort(rng.integers(1_000_000, text.shape[0] - 1_000_000, size=args.n_gaps)):
+            text[at:at + int(rng.integers(100, 50_000))] = ord("N")
     t_gen = time.time() - t0
     t0 = time.time()
     gidx = api.GenomeIndex.build(text, device=local_rank)

@@ -114,6 +114,11 @@ struct gs_search_args {
    * reported straight from this list. */
   const uint4 *cand[2];
   uint32_t n_cand[2];
+  /* an assembly with thousands of N runs: the windows bucketed by each of the first four 5-symbol chunks of their
+   * guide part (cand_off[s][1025 c + v] .. [+1] = the places in cand_ids[s] of the windows whose chunk c spells v):
+   * within m <= 3 substitutions one of the four chunks is intact, so an item reads the four buckets of its own
+   * chunks instead of the whole list; nullptr: the list is scanned in order */
+  const uint32_t *cand_off[2], *cand_ids[2];
 };
 #define DSC_LO 27u  /* descriptor.y bits 29:27: fewest substitutions allowed among the remaining guide symbols */
 #define DSC_EXC 30u /* descriptor.y bit 30: the interval holds exception rows (gs_strand_dev::exc_row) */
@@ -180,8 +185,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
    * The table-only variants carry nothing but the mismatch count: 59 path bits - 2L + 3P <= 59 covers 23-mers with
    * a four-symbol PAM (Cas12a) - in the SAME key layout (position 0 at key bits 59:58, bit 0 = the record's
    * row is v_rem symbols into the site): a path of at most 52 bits gives the key it always gave. */
-  constexpr uint32_t PB = WALK ? 0u : 7u;           /* path bias: field shifts are those of the 52-bit layout + PB */
-  constexpr uint32_t KSH = WALK ? 56u : 61u;        /* mismatch count above the path */
+#ifndef GS_X_PB
+#define GS_X_PB 7u
+#endif
+  constexpr uint32_t PB = WALK ? 0u : GS_X_PB;           /* path bias: field shifts are those of the 52-bit layout + PB */
+  constexpr uint32_t KSH = (WALK || GS_X_PB == 0u) ? 56u : 61u;        /* mismatch count above the path */
   constexpr uint32_t PSG = 50u + PB, PSP = 49u + PB; /* guide symbol t at PSG - 2t, PAM symbol u at PSP - 2L - 3u */
   constexpr uint64_t PMASK = (1ull << (52u + PB)) - 1ull;
   const uint32_t lane = lane_id();
@@ -309,6 +317,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint64_t be = __ballot(em);
       if (be) {
         const uint32_t hi = n_match + (uint32_t)__popcll(be); /* one past the last record of this emission */
+#ifndef GS_X_NO_CLS
         if (a.arena != nullptr) {
           /* matches per mismatch count: lane d adds this emission's share of class d (one LDS add, distinct words) */
           const uint32_t kk = (uint32_t)((cmeta >> KSH) & 7ull);
@@ -319,6 +328,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           }
           if (add) atomicAdd(&wmisc[4u + lane], add);
         }
+#endif
         if (hi > item_cap && a.arena != nullptr) {
           /* the emission reaches beyond the item's slots: take overflow chunks up to its last record
            * (wave-uniform; at most two per emission, almost always none) */
@@ -721,12 +731,27 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         const uint32_t ncand = a.n_cand[strand];
         const uint64_t lmask = (1ull << (2u * L)) - 1ull;
         const uint64_t xmask = (1ull << (2u * sx)) - 1ull, komask = (1ull << (2u * k)) - 1ull;
-        for (uint32_t c0 = 0; c0 < ncand; c0 += WAVE) {
-          const bool in = c0 + lane < ncand;
+#ifdef GS_X_NO_BUCKETS
+        const uint32_t *cids = nullptr;
+#else
+        const uint32_t *cids = a.cand_ids[strand];
+#endif
+        const uint32_t nseg = cids != nullptr ? 4u : 1u;
+        for (uint32_t sg = 0; sg < nseg; ++sg) {
+        uint32_t s0 = 0, s1 = ncand;
+        if (cids != nullptr) { /* the bucket of this item's chunk sg */
+          const uint32_t *off = a.cand_off[strand] + 1025u * sg + ((uint32_t)(gr_q >> (10u * sg)) & 1023u);
+          s0 = __builtin_amdgcn_readfirstlane(off[0]);
+          s1 = __builtin_amdgcn_readfirstlane(off[1]);
+        }
+        for (uint32_t c0 = s0; c0 < s1; c0 += WAVE) {
+          bool in = c0 + lane < s1;
           uint4 ce = make_uint4(0u, 0u, 0u, 0u);
-          if (in) ce = a.cand[strand][c0 + lane];
+          if (in) ce = a.cand[strand][cids != nullptr ? cids[(size_t)sg * ncand + c0 + lane] : c0 + lane];
           const uint64_t cq = ((uint64_t)ce.y << 32) | ce.x;
           const uint64_t x = cq ^ gr_q;
+          /* a window that an earlier chunk spells too was reported from that chunk's bucket */
+          for (uint32_t e = 0; e < sg; ++e) in = in && ((uint32_t)(x >> (10u * e)) & 1023u) != 0u;
           const uint64_t nz = (x | (x >> 1)) & 0x5555555555555555ull & lmask;
           const uint32_t tot = __popcll(nz), jx = __popcll(nz & xmask), jo = __popcll(nz & komask & ~xmask);
           const bool mine = in && tot <= m && (pslots != 0u || jx >= ((a.astar >> (4u * (jo < 7u ? jo : 7u))) & 15u));
@@ -751,6 +776,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             }
             route(ok, true, false, rowA, rowA, ((uint64_t)tot << KSH) | gpath | ppath, 0u);
           }
+        }
         }
         /* context mask for the other strand's seeds: the symbols it consumes next are the complemented
          * X symbols, last first - all guide symbols: up to four pairs, each broken by at most one
@@ -2694,6 +2720,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   uint32_t astar_packed = 0xFFFFFFFFu, astar[8] = {15, 15, 15, 15, 15, 15, 15, 15};
   uint32_t n_cand[2] = {0, 0};
   const uint4 *d_cand[2] = {nullptr, nullptr};
+  const uint32_t *d_cand_off[2] = {nullptr, nullptr}, *d_cand_ids[2] = {nullptr, nullptr};
   uint32_t x_len = v_rem;
   uint32_t n_pt = 0, pt_slot[2] = {0, 0};
   const bool table_seeding = ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK);
@@ -2929,17 +2956,44 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     n_cand[0] = (uint32_t)cand[0].size();
     n_cand[1] = (uint32_t)cand[1].size();
     if (n_cand[0] + n_cand[1]) {
-      if ((rc = gs_reserve(ix->w_cand, 16 * (size_t)(n_cand[0] + n_cand[1]))) != GS_OK) return rc;
+      /* behind the windows: per strand with many of them, the bucket index (4 x 1025 offsets, 4 x n places) */
+      std::vector<uint32_t> bidx[2];
+      for (uint32_t s = 0; s < 2; s++) {
+        uint32_t from = 256;
+        if (const char *e = getenv("GS_CAND_BUCKETS_FROM")) from = (uint32_t)atol(e);
+        if (n_cand[s] <= from || mismatches > 3 || L < 20 || getenv("GS_NO_CAND_BUCKETS")) continue;
+        const uint32_t nc = n_cand[s];
+        bidx[s].assign(4u * 1025u + 4u * (size_t)nc, 0u);
+        for (uint32_t c = 0; c < 4; c++) {
+          uint32_t *off = bidx[s].data() + 1025u * c, *ids = bidx[s].data() + 4u * 1025u + (size_t)c * nc;
+          auto val = [&](uint32_t i) { return (uint32_t)((((uint64_t)cand[s][i].y << 32) | cand[s][i].x) >> (10u * c)) & 1023u; };
+          for (uint32_t i = 0; i < nc; i++) off[val(i) + 1u]++;
+          for (uint32_t v = 0; v < 1024; v++) off[v + 1u] += off[v];
+          std::vector<uint32_t> cur(off, off + 1024);
+          for (uint32_t i = 0; i < nc; i++) ids[cur[val(i)]++] = i;
+        }
+      }
+      const size_t b_w = 16 * (size_t)(n_cand[0] + n_cand[1]);
+      if ((rc = gs_reserve(ix->w_cand, b_w + 4 * (bidx[0].size() + bidx[1].size()) + 16)) != GS_OK) return rc;
       uint4 *dc = (uint4 *)ix->w_cand.p;
       if (n_cand[0]) GS_HIP(hipMemcpy(dc, cand[0].data(), 16 * (size_t)n_cand[0], hipMemcpyHostToDevice));
       if (n_cand[1]) GS_HIP(hipMemcpy(dc + n_cand[0], cand[1].data(), 16 * (size_t)n_cand[1], hipMemcpyHostToDevice));
       d_cand[0] = dc;
       d_cand[1] = dc + n_cand[0];
+      uint32_t *di = (uint32_t *)((char *)ix->w_cand.p + b_w);
+      for (uint32_t s = 0; s < 2; s++) {
+        if (bidx[s].empty()) continue;
+        GS_HIP(hipMemcpy(di, bidx[s].data(), 4 * bidx[s].size(), hipMemcpyHostToDevice));
+        d_cand_off[s] = di;
+        d_cand_ids[s] = di + 4u * 1025u; /* chunk c's places: from c * n_cand[s] on */
+        di += bidx[s].size();
+      }
     }
     if (getenv("GS_DEBUG"))
       fprintf(stderr, "[gs] two-sided seeding: astar %u,%u,%u,%u,%u,%u,%u,%u over |X|=%u |O|=%u |R|=%u, "
-              "literal-N windows %u + %u, PAM-pair tables %u%s\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
-              astar[6], astar[7], x_len, ix->pt_k - x_len, L - ix->pt_k, n_cand[0], n_cand[1], n_pt, deep ? " with deep tables" : "");
+              "literal-N windows %u + %u%s, PAM-pair tables %u%s\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
+              astar[6], astar[7], x_len, ix->pt_k - x_len, L - ix->pt_k, n_cand[0], n_cand[1],
+              d_cand_off[0] || d_cand_off[1] ? " (bucketed by 5-symbol chunks)" : "", n_pt, deep ? " with deep tables" : "");
   }
 
 
@@ -3055,6 +3109,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         sa.cand[1] = d_cand[1];
         sa.n_cand[0] = n_cand[0];
         sa.n_cand[1] = n_cand[1];
+        for (uint32_t s = 0; s < 2; s++) {
+          sa.cand_off[s] = d_cand_off[s];
+          sa.cand_ids[s] = d_cand_ids[s];
+        }
       }
     }
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as their

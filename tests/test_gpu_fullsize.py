@@ -177,6 +177,72 @@ def test_config2_chr1_sized_100k_guides_m3():
         gidx.close()
 
 
+def test_chr1_sized_assembly_with_5000_n_runs(monkeypatch, capfd):
+    """A scaffold-level assembly: 5,000 N runs in a chr1-sized genome (3 x 10^4 literal-N windows per strand), 3,000 of
+    them single Ns planted where an NGG site has its N on them (the reference matches a PAM N against the genome's
+    literal N, index.hpp:139-149).  The window list is indexed by 5-symbol chunks (one bucket read per chunk and
+    item instead of 470 passes over the list): 4,000 guides - half of them at the planted sites - return the same
+    bytes as the plain scan of the list, and 96 of them the oracle's hit lists."""
+    import torch
+    rng = np.random.default_rng(19)
+    text, names, lengths = synth.make_genome([synth.CHR1_LENGTH], seed=1)
+    text = text.copy()
+    n_total = text.shape[0]
+    ok = np.frombuffer(b"ACGT", np.uint8)
+    planted = []
+    at = 2_000_000
+    for r in range(5000):
+        at += int(rng.integers(20_000, 45_000))
+        if r < 3000:   # 20-mer N GG on the + strand, or CC N 20-mer (a - strand site)
+            text[at - 30:at + 30] = rng.choice(ok, 60)
+            text[at] = ord("N")
+            if r % 2 == 0:
+                text[at + 1:at + 3] = np.frombuffer(b"GG", np.uint8)
+                planted.append(text[at - 20:at].copy())
+            else:
+                text[at - 2:at] = np.frombuffer(b"CC", np.uint8)
+                planted.append(synth.reverse_complement_bytes(text[at + 1:at + 21]).copy())
+        else:
+            text[at:at + int(rng.integers(2, 3000))] = ord("N")
+    assert at < n_total - 10_000
+    monkeypatch.setenv("GS_DEBUG", "1")
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        sampled, _, _, _ = synth.sample_guides(text, 2000, seed=4)
+        pick = rng.choice(len(planted), 2000, replace=False)
+        seqs = np.concatenate([np.stack([planted[i] for i in pick]), sampled])
+        for i in range(0, 2000, 3):   # some of the planted guides one or two substitutions away from their site
+            for q in rng.choice(20, size=int(rng.integers(1, 3)), replace=False):
+                seqs[i, q] = rng.choice([x for x in b"ACGT" if x != seqs[i, q]])
+        pams = np.tile(NGG, (seqs.shape[0], 1))
+        capfd.readouterr()
+        off, hits, st = gidx.enumerate(seqs, pams, mismatches=3)
+        err = capfd.readouterr().err
+        assert "bucketed by 5-symbol chunks" in err, err[-400:]
+        monkeypatch.setenv("GS_NO_CAND_BUCKETS", "1")
+        off2, hits2, st2 = gidx.enumerate(seqs, pams, mismatches=3)
+        monkeypatch.delenv("GS_NO_CAND_BUCKETS")
+        assert "bucketed" not in capfd.readouterr().err
+        assert np.array_equal(off, off2) and hits.tobytes() == hits2.tobytes()
+        lit = 0
+        oidx = ol.OracleIndex(text, sa_provider=lambda s: gidx.suffix_array(s), nthreads=16)
+        try:
+            opts = ol.make_opts(mismatches=3)
+            for i in list(range(0, 2000, 42)) + list(range(2000, 4000, 42)):
+                g = seqs[i].tobytes().decode()
+                exp, ctr, raw = oidx.enumerate(g, "NGG", opts)
+                ol.lib().gso_free(raw[0])
+                got = [(int(h["pos"]), int(h["key"]) >> 61, (int(h["key"]) >> 60) & 1,
+                        api.decode_sequence(g, 3, int(h["key"]))) for h in hits[off[i]:off[i + 1]]]
+                assert got == [(e[0], e[1], e[2], e[3]) for e in exp], i
+                lit += sum(1 for e in exp if e[3][20:].startswith("N"))
+        finally:
+            oidx.close()
+        assert lit >= 40, lit   # the planted sites are found with the genome's N in their match sequence
+    finally:
+        gidx.close()
+
+
 # ---- configs 3, 4, 5: one hg38-sized index for the whole group -------------------------------------
 
 class Hg38:

@@ -412,14 +412,20 @@ def test_two_sided_pieces_exceptions_and_windows(monkeypatch, capfd):
         oidx.close()
 
 
-def test_many_literal_n_windows(monkeypatch, capfd):
+@pytest.mark.parametrize("buckets", [False, True], ids=["list", "buckets"])
+def test_many_literal_n_windows(monkeypatch, capfd, buckets):
     """hundreds of windows with a literal N under the PAM (a scaffold-level assembly has thousands of N
     runs): the window list is scanned in several passes of 64, by both kinds of item - through the
     PAM-pair tables every such site comes from the list, with the strand tables only the other strand's
-    share does - and every site is found exactly once"""
+    share does - and every site is found exactly once.  buckets: the list indexed by the four 5-symbol chunks of
+    the windows' guide part (what a list beyond 256 windows gets at <= 3 mismatches), forced on this short one"""
     import re
     monkeypatch.setenv("GS_PREFIX_K", "13")
     monkeypatch.setenv("GS_DEBUG", "1")
+    if buckets:
+        monkeypatch.setenv("GS_CAND_BUCKETS_FROM", "0")
+    else:
+        monkeypatch.setenv("GS_NO_CAND_BUCKETS", "1")
     rng = np.random.default_rng(77)
     text, names, lengths = synth.make_genome([260_000, 140_000], seed=21, n_blocks=False)
     text = text.copy()
@@ -454,8 +460,10 @@ def test_many_literal_n_windows(monkeypatch, capfd):
             capfd.readouterr()
             offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt)
             monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
-            mt = re.search(r"literal-N windows (\d+) \+ (\d+)", capfd.readouterr().err)
+            err = capfd.readouterr().err
+            mt = re.search(r"literal-N windows (\d+) \+ (\d+)", err)
             assert mt and int(mt.group(1)) > 128 and int(mt.group(2)) > 128, mt   # more than two passes of 64 per strand
+            assert ("bucketed" in err) == (buckets and m <= 3), (m, err)
             opts = ol.make_opts(mismatches=m, alt_pams=alt)
             n_lit = 0
             for i, g in enumerate(guides):
