@@ -101,6 +101,11 @@ struct gs_search_args {
   uint32_t v_rem;
   uint32_t v_max; /* rows per queued descriptor (<= 1023): larger intervals are verified in pieces */
   uint32_t dbg_skip; /* timing experiments only (GS_DBG_SKIP): 1 = no verification, 2 = no seeds kept */
+  /* the counting instantiation tallies distinct aligned blocks of 2^cnt_shift bytes per load instruction: 6 = the
+   * 64-byte lines the roofline's bytes are priced on, 7 (GS_COUNT_SHIFT=7) = 128-byte blocks - what the memory
+   * system serves as ONE random request (tools/gather_bench: a 128-byte block read by one instruction costs what a
+   * 64-byte one does, 4.8 x 10^10 per second at 12-40 GB) */
+  uint32_t cnt_shift;
   /* two-sided seeding.  X = the first v_rem consumed guide symbols (only
    * this strand's table covers them), O = the next pt_k - v_rem (both tables), R = the rest of the
    * guide (only the other strand's table, with the PAM).  A site with (a, o, b) substitutions in
@@ -203,7 +208,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
    * previous active lane's (the access patterns here are runs of neighbouring lanes) */
   auto count_lines = [&](uint32_t &acc, bool act, const void *p) __attribute__((always_inline)) {
     if constexpr (CNT) {
-      const uint32_t line = (uint32_t)((uintptr_t)p >> 6);
+      const uint32_t line = (uint32_t)((uintptr_t)p >> a.cnt_shift);
       const uint32_t prev = (uint32_t)__shfl_up((int)line, 1);
       const int pact = __shfl_up((int)act, 1);
       const bool fresh = act && (lane == 0u || !pact || prev != line);
@@ -3080,6 +3085,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       sa.v_max = v < 1 ? 1u : v > 1023 ? 1023u : (uint32_t)v;
     }
     sa.dbg_skip = getenv("GS_DBG_SKIP") ? (uint32_t)atol(getenv("GS_DBG_SKIP")) : 0u;
+    sa.cnt_shift = getenv("GS_COUNT_SHIFT") ? (uint32_t)std::min(12l, std::max(4l, atol(getenv("GS_COUNT_SHIFT")))) : 6u;
     sa.astar = 0xFFFFFFFFu;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m

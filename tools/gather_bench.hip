@@ -78,6 +78,48 @@ static void run_quad(const uint4* tab, uint64_t bytes, int grid, uint32_t iters,
   }
 }
 
+// group-cooperative variant, general: G adjacent lanes read ONE random block of G x W bytes (W bytes each) with one
+// load instruction, and every lane takes part in 4 blocks per iteration.  (4, 16) is the quad pattern above;
+// (8, 16) one 128-byte block per instruction as eight 16-byte pieces; (16, 8) a 128-byte block of sixteen 8-byte
+// entries - k_search's read of a PAM-pair block; (16, 4) a 64-byte block of sixteen 4-byte words.  The question
+// DESIGN 9.2 turns on: does a 128-byte block cost the memory system one random request or two?
+template <int G, int W>
+__global__ __launch_bounds__(256) void k_gather_group(const uint8_t* __restrict__ tab, uint64_t nblocks, uint32_t iters,
+                                                      uint32_t* out) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t s = (uint64_t)(tid / G) * 0x9E3779B97F4A7C15ull + 4242;
+  const uint32_t piece = tid % G;
+  uint32_t acc = 0;
+  for (uint32_t it = 0; it < iters; it++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+      const uint64_t b = (uint64_t)(((unsigned __int128)s * nblocks) >> 64);
+      const uint8_t* p = tab + b * (uint64_t)(G * W) + piece * W;
+      if (W == 16) { const uint4 v = *(const uint4*)p; acc += v.x ^ v.y ^ v.z ^ v.w; }
+      else if (W == 8) { const uint2 v = *(const uint2*)p; acc += v.x ^ v.y; }
+      else { acc += *(const uint32_t*)p; }
+    }
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+template <int G, int W>
+static void run_group(const uint4* tab, uint64_t bytes, int grid, uint32_t iters, uint32_t* out) {
+  const uint64_t nblocks = bytes / (G * W);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k_gather_group<G, W>), dim3(grid), dim3(256), 0, 0, (const uint8_t*)tab, nblocks, iters, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    const double blocks = (double)grid * 256 * iters * 4 / G;
+    const double lines = blocks * ((G * W + 63) / 64);
+    if (rep == 1)
+      printf("group  %2d lanes x %2d B = %3d-byte blocks table=%6.0f MiB : %8.3f ms  %7.2f Gblocks/s  %7.2f G 64-byte lines/s  %8.1f GB/s\n",
+             G, W, G * W, bytes / 1048576.0, ms, blocks / ms / 1e6, lines / ms / 1e6, blocks * G * W / ms / 1e6);
+  }
+}
+
 template <int B>
 static void run(const uint4* tab, uint64_t bytes, int grid, uint32_t iters, uint32_t* out, bool chase) {
   const uint64_t nblocks = bytes / B;
@@ -103,7 +145,7 @@ int main(int argc, char** argv) {
   hipMalloc(&out, 64);
   hipMemset(tab, 0, max_bytes);
   hipDeviceSynchronize();
-  const uint64_t sizes[] = {3200ull << 20, 8000ull << 20, 16000ull << 20, max_bytes};
+  const uint64_t sizes[] = {3200ull << 20, 12000ull << 20, max_bytes};
   for (uint64_t sz : sizes) {
     if (sz > max_bytes) continue;
     for (int grid : {5120}) {
@@ -112,6 +154,10 @@ int main(int argc, char** argv) {
       run<64>(tab, sz, grid, 256, out, false);
       run<128>(tab, sz, grid, 128, out, false);
       run_quad(tab, sz, grid, 256, out);
+      run_group<8, 16>(tab, sz, grid, 128, out);
+      run_group<16, 8>(tab, sz, grid, 128, out);
+      run_group<16, 4>(tab, sz, grid, 128, out);
+      run_group<8, 8>(tab, sz, grid, 128, out);
     }
 
   }
