@@ -209,6 +209,15 @@ def main():
     _, _, st_cnt = gidx.enumerate_device(d_seqs.data_ptr(), n_cnt, L, d_pams.data_ptr(), P, mismatches=m,
                                          count_requests=True)
     req = gidx.last_counters()
+    # the same pass once more tallying 128-byte blocks: what the memory system serves as ONE random request (a 128-byte
+    # block read by one instruction costs what a 64-byte one does: tools/gather_bench, profiles/r04_gather_calibration_groups.txt)
+    os.environ["GS_COUNT_SHIFT"] = "7"
+    try:
+        gidx.enumerate_device(d_seqs.data_ptr(), n_cnt, L, d_pams.data_ptr(), P, mismatches=m, count_requests=True)
+        req128 = gidx.last_counters()
+    finally:
+        del os.environ["GS_COUNT_SHIFT"]
+    n_req128 = sum(req128[k] for k in ("table_lines", "ctx16_lines", "ctx_words", "sa_isa_gathers", "occ_lines"))
 
     for i in range(args.warmup):
         step(i)
@@ -310,13 +319,20 @@ def main():
                      "guides_per_launch": n_cnt,
                      "requests_per_guide": {k: v / n_cnt for k, v in lines.items()},
                      "random_requests": {
-                         "per_guide": n_lines / n_cnt, "unit": "64-byte lines",
-                         "achieved_per_s": n_lines / search_s if search_s > 0 else None,
-                         "ceiling_per_s": [5.0e10, 5.5e10],
-                         "frac_of_ceiling": (n_lines / search_s / 5.5e10) if search_s > 0 else None,
-                         "note": "the memory system's measured rate of random 64-byte line requests "
-                                 "(tools/gather_bench, profiles/r01_gather_calibration.txt) is what binds "
-                                 "this kernel before bytes do"},
+                         # requests as the memory system counts them: distinct 128-byte aligned blocks per load
+                         # instruction (a PAM-pair block of sixteen 8-byte entries is ONE, not two lines)
+                         "per_guide": n_req128 / n_cnt, "unit": "128-byte aligned blocks per load instruction",
+                         "achieved_per_s": n_req128 / search_s if search_s > 0 else None,
+                         "ceiling_per_s": [4.7e10, 5.2e10],
+                         "frac_of_ceiling": (n_req128 / search_s / 4.8e10) if search_s > 0 else None,
+                         # the same from the memory side (blocks the L2 serves are not in it): HBM lines of the recorded
+                         # PMC pass against the 64-byte lines per second a pure 128-byte-block gather reaches (9.6e10)
+                         "hbm_side": ({"lines_per_s": traffic / 64.0 / search_s, "ceiling_lines_per_s": 9.6e10,
+                                       "frac": traffic / 64.0 / search_s / 9.6e10} if traffic and search_s > 0 else None),
+                         "lines_64_per_guide": n_lines / n_cnt,
+                         "note": "the memory system serves random blocks at ~4.8e10 per second whether they are 16, 64 "
+                                 "or 128 bytes (tools/gather_bench, profiles/r04_gather_calibration_groups.txt, 12-40 GB "
+                                 "tables): that rate binds this kernel before bytes do"},
                      # SURVEY 8d's figure, kept for comparison: the bytes the REFERENCE'S traversal
                      # (128 B per extended node, N_ext from the reference-order walk on a sample) would
                      # need for this batch.  Not what this kernel does: table, context mask, context
