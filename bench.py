@@ -330,6 +330,8 @@ def main():
                          "hbm_side": ({"lines_per_s": traffic / 64.0 / search_s, "ceiling_lines_per_s": 9.6e10,
                                        "frac": traffic / 64.0 / search_s / 9.6e10} if traffic and search_s > 0 else None),
                          "lines_64_per_guide": n_lines / n_cnt,
+                         "by_kind_per_guide": {k: req128[k] / n_cnt for k in ("table_lines", "ctx16_lines", "ctx_words",
+                                                                               "sa_isa_gathers", "occ_lines")},
                          "note": "the memory system serves random blocks at ~4.8e10 per second whether they are 16, 64 "
                                  "or 128 bytes (tools/gather_bench, profiles/r04_gather_calibration_groups.txt, 12-40 GB "
                                  "tables): that rate binds this kernel before bytes do"},
