@@ -9,5 +9,5 @@ for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INST
   i=$((i+1))
   rocprofv3 --pmc $pass -f csv --kernel-include-regex 'k_search|k_to_' -d $OUT/p$i -- python3 bench.py $ARGS > $OUT/p$i.json 2> $OUT/p$i.err
   echo "pass $i rc=$?"
-  python3 tools/pmc_summary.py $OUT/p$i k_search k_to_ > $SUM/r04a_hg38rep_pmc_p$i.json
+  python3 tools/pmc_summary.py $OUT/p$i k_search k_to_ > $SUM/r04_hg38rep_m3_pmc_pass$i.json
 done
