@@ -105,7 +105,7 @@ __device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uin
     }                                                \
   }
 template <bool WITH_IDX>
-__device__ __forceinline__ void to_msort(unsigned long long *keys, uint16_t *idx, const uint32_t n) {
+__device__ __forceinline__ void to_msort(unsigned long long *keys, uint16_t *idx, const uint32_t n) { /* (any workgroup size: thread t owns places 8t ..) */
   const uint32_t t = threadIdx.x;
   const uint32_t nthr = (n + TO_KPT - 1u) / TO_KPT, ntot = nthr * TO_KPT;
   const bool on = t < nthr;
@@ -341,6 +341,7 @@ struct gs_to_run_args {
   uint64_t genome_length;
   uint32_t *flags;
   uint32_t L, P, v_rem;
+  uint32_t sample_per; /* 0, or GS_TILE_SAMPLE_PER (tests) */
 };
 
 /* ---- items beyond one tile: splitters from a sample, then one streaming pass into buckets ---------------------- */
@@ -360,7 +361,9 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
   const uint32_t bb = a.bbase[sb], tb = a.tbase[sb], cb = a.cbase[sb];
   /* stratified sample: one record from each of `ns` equal stretches of the item (emission order is seed by seed,
    * so a stretch is a few neighbouring sequences: no worse than independent draws) */
-  const uint32_t per = TO_TILE / nb < 64u ? TO_TILE / nb : 64u; /* samples per bucket */
+  uint32_t per = TO_TILE / nb < 64u ? TO_TILE / nb : 64u; /* samples per bucket */
+  if (a.sample_per != 0u && a.sample_per < per) per = a.sample_per; /* tests: a sample too small to keep the buckets within their slots */
+  const uint32_t slots = a.sample_per == 1u ? TO_TILE / 4u : TO_TILE; /* ... and, at one word per splitter, a quarter of the slots: certain to overflow */
   const uint32_t ns = per * nb;
   __syncthreads();
   bool multi = false;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
         pos = on[u] ? atomicAdd(&s_cur[b], 1u) : 0u;
       }
       /* a bucket record carries its sequence word where the (equal) last row was: the tile does not rank it again */
-      if (on[u] && pos < TO_TILE) out[(size_t)b * TO_TILE + pos] = make_uint4(rec[u].x, rec[u].y, rec[u].z, kw);
+      if (on[u] && pos < slots) out[(size_t)b * TO_TILE + pos] = make_uint4(rec[u].x, rec[u].y, rec[u].z, kw);
     }
   }
   if (multi) atomicOr(a.flags, TO_F_MULTIROW);
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
       const uint32_t b = tid * each + q;
       if (b < nb) {
         s += s_cur[b];
-        over = over || s_cur[b] > TO_TILE;
+        over = over || s_cur[b] > slots;
       }
     }
     uint32_t run = wave_incl_sum(s) - s;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
       const uint32_t b = tid * each + q;
       if (b < nb) {
         const uint32_t n = s_cur[b];
-        a.tiles[tb + b].z = n < TO_TILE ? n : TO_TILE;
+        a.tiles[tb + b].z = n < slots ? n : slots;
         a.tiles[tb + b].w = run;
         run += n;
       }
@@ -457,10 +460,16 @@ __global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
 }
 
 /* ---- one tile: order its records in LDS and write its hits -------------------------------------------------------- */
-__global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
-  __shared__ unsigned long long s_keys[TO_LDS];
+/* NT threads, tiles of NT x 8 records at most: 512 for the tiles proper, 128 for the many small ones (an m <= 5 batch is
+ * 2 x 10^5 items of ~700 records: in a workgroup of 512 a merge round keeps 90 threads busy and seven waves wait at its
+ * barriers; 12 KB of LDS instead of 47: twelve workgroups per CU).  Both are launched over the whole tile list, each
+ * takes its size class (lo < n <= NT x 8). */
+template <uint32_t NT>
+__global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t lo) {
+  constexpr uint32_t CAP = NT * TO_KPT, LDSN = CAP + CAP / 8u;
+  __shared__ unsigned long long s_keys[LDSN];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
-  __shared__ uint16_t s_idx[TO_LDS];
+  __shared__ uint16_t s_idx[LDSN];
   __shared__ uint32_t s_rel[8];
   __shared__ unsigned long long s_first;
 
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
    * to 156 registers, one workgroup per CU instead of three, 22 ms instead of 9) */
   const uint4 t = a.tiles[blockIdx.x];
   const uint32_t n = t.z;
-  if (n == 0u) return;
+  if (n <= lo || n > CAP) return;
 #ifdef TO_PROFILE
   const unsigned long long tp0 = wall_clock64();
 #endif
@@ -486,13 +495,13 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
     const uint32_t cb = a.cbase[sb];
 #pragma unroll
     for (uint32_t u = 0; u < TO_KPT; ++u) {
-      const uint32_t i = tid + u * TO_NT;
+      const uint32_t i = tid + u * NT;
       rec[u] = i < n ? *to_addr(a.src, item, cb, i) : make_uint4(0u, 0u, 0u, 0u);
     }
   } else {
 #pragma unroll
     for (uint32_t u = 0; u < TO_KPT; ++u) {
-      const uint32_t i = tid + u * TO_NT;
+      const uint32_t i = tid + u * NT;
       rec[u] = i < n ? bucket[i] : make_uint4(0u, 0u, 0u, 0u); /* {key, row, sequence word}: k_to_partition ranked it */
     }
   }
@@ -501,13 +510,13 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   bool multi = false;
   uint2 kx[TO_KPT]; /* the records' keys, in load order: they wait in registers while the words are ordered */
   if (direct) {
-    for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
+    for (uint32_t i = tid; i < 32u * 8u; i += NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
     if (tid < 8u) s_bs[tid] = a.tab->base[tid];
     const unsigned long long pam_mul = a.tab->pam_mul;
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < TO_KPT; ++u) {
-      const uint32_t i = tid + u * TO_NT;
+      const uint32_t i = tid + u * NT;
       kx[u] = make_uint2(rec[u].x, rec[u].y);
       if (i < n) {
         multi = multi || rec[u].z != rec[u].w;
@@ -518,7 +527,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   } else {
 #pragma unroll
     for (uint32_t u = 0; u < TO_KPT; ++u) {
-      const uint32_t i = tid + u * TO_NT;
+      const uint32_t i = tid + u * NT;
       kx[u] = make_uint2(rec[u].x, rec[u].y);
       if (i < n) {
         s_keys[TO_AT(i)] = ((unsigned long long)rec[u].w << 32) | rec[u].z;
@@ -546,7 +555,7 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   uint32_t row[TO_KPT], from[TO_KPT], sav[TO_KPT];
 #pragma unroll
   for (uint32_t u = 0; u < TO_KPT; ++u) {
-    const uint32_t r = tid + u * TO_NT;
+    const uint32_t r = tid + u * NT;
     row[u] = from[u] = sav[u] = 0u;
     if (r < n) {
       const unsigned long long K = s_keys[TO_AT(r)];
@@ -559,13 +568,13 @@ __global__ __launch_bounds__(TO_NT) void k_to_sort(gs_to_run_args a) {
   __syncthreads();
 #pragma unroll
   for (uint32_t u = 0; u < TO_KPT; ++u) {
-    const uint32_t i = tid + u * TO_NT;
+    const uint32_t i = tid + u * NT;
     if (i < n) s_keys[TO_AT(i)] = ((unsigned long long)kx[u].y << 32) | kx[u].x;
   }
   __syncthreads();
 #pragma unroll
   for (uint32_t u = 0; u < TO_KPT; ++u) {
-    const uint32_t r = tid + u * TO_NT;
+    const uint32_t r = tid + u * NT;
     if (r < n) {
       const unsigned long long key = s_keys[TO_AT(from[u])];
       const uint64_t sap = (uint64_t)sav[u] - ((key & 1ull) ? a.v_rem : 0u);
@@ -727,8 +736,12 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.L = in.L;
   ra.P = in.P;
   ra.v_rem = in.v_rem;
+  ra.sample_per = getenv("GS_TILE_SAMPLE_PER") ? (uint32_t)std::max(1l, atol(getenv("GS_TILE_SAMPLE_PER"))) : 0u;
   if (S.n_big) hipLaunchKernelGGL(k_to_partition, dim3(S.n_big), dim3(TO_NT), 0, st, ra);
-  if (S.n_tiles) hipLaunchKernelGGL(k_to_sort, dim3(S.n_tiles), dim3(TO_NT), 0, st, ra);
+  if (S.n_tiles) {
+    hipLaunchKernelGGL(k_to_sort<128u>, dim3(S.n_tiles), dim3(128), 0, st, ra, 0u);
+    hipLaunchKernelGGL(k_to_sort<TO_NT>, dim3(S.n_tiles), dim3(TO_NT), 0, st, ra, 128u * TO_KPT);
+  }
   uint32_t h[16] = {0};
   GS_HIP(hipMemcpyAsync(h, d_flags, 64, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));

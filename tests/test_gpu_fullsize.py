@@ -26,6 +26,7 @@ import ctypes as C
 import os
 import shutil
 import subprocess
+import sys
 import tempfile
 import threading
 import time
@@ -464,6 +465,42 @@ def test_config5_hg38_m6_2048_guides_properties_and_paths(hg38):
     assert hits64.tobytes() == np.ascontiguousarray(hits[:int(off[64])]).tobytes()
     _, spec64 = hg38.gidx.score(hg38.gs, seqs[:64], 3, off64, hits64, want_cfd=False)
     assert np.array_equal(np.asarray(spec64, dtype=np.float32), spec[:64])
+
+
+def test_hg38_cas12a_and_the_general_path_equal_the_compiled_reference(hg38):
+    """What runs beside the NGG headline, pinned at hg38 size against the compiled reference (tools/general_bench.py
+    is the same comparison with larger batches and rates): (1) Cas12a - TTTN at the 5' end (--start) - 20-mers
+    (two-sided seeding through a four-symbol PAM's pair table) and 23-mers (58 key bits: the wide key, one-sided), 1,024
+    guides each; (2) the general path: 256 guides at -m 1 --rna-bulges 1 --dna-bulges 1 (index.hpp:250-375) and 256
+    guides with an N in them at -m 3 (index.hpp:218-247).  Every CSV line equals the reference's."""
+    sys.path.insert(0, str(ol.ROOT / "tools"))
+    gb = import_module("general_bench")
+    for L in (20, 23):
+        n = 1024
+        seqs, pams = gb.cas_guides(synth, hg38.text, n, L, 60 + L)
+        ids = [f"c{L}_{i}" for i in range(n)]
+        want, _ = gb.ref_lines(hg38, f"tcas{L}", [(ids[i], seqs[i].tobytes().decode(), "TTTN") for i in range(n)], 3, start=True)
+        off, hits, st = hg38.gidx.enumerate(seqs, pams, mismatches=3, start=True)
+        _, spec = hg38.gidx.score(hg38.gs, seqs, 4, off, hits, want_cfd=False, start=True)
+        got = []
+        for i in range(n):
+            got += api.format_guide(hg38.gs, ids[i], seqs[i].tobytes().decode(), "TTTN", True, hits[off[i]:off[i + 1]], 3,
+                                    specificity=spec[i], start=True).splitlines()
+        assert len(want) >= n and sorted(got) == want, L
+    n = 256
+    seqs, pams, _, _ = synth.sample_guides(hg38.text, n, seed=77)
+    odd = seqs.copy()
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        odd[i, int(rng.integers(0, 20))] = ord("N")
+    for tag, s, m, rna, dna in (("tbul", seqs, 1, 1, 1), ("todd", odd, 3, 0, 0)):
+        ids = [f"{tag}{i}" for i in range(n)]
+        want, _ = gb.ref_lines(hg38, tag, [(ids[i], s[i].tobytes().decode(), "NGG") for i in range(n)], m, rna, dna)
+        off, hx = hg38.gidx.enumerate_general(s, pams, mismatches=m, rna_bulges=rna, dna_bulges=dna)
+        got = []
+        for i in range(n):
+            got += api.format_guide_ex(hg38.gs, ids[i], s[i].tobytes().decode(), "NGG", True, hx[off[i]:off[i + 1]], m).splitlines()
+        assert len(want) >= n // 2 and sorted(got) == want, tag
 
 
 def test_hg38_alt_pam_through_two_pair_tables_equals_the_compiled_reference(hg38):

@@ -623,6 +623,55 @@ def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
         oidx.close()
 
 
+def test_tile_ordering_gives_up_and_the_device_wide_form_takes_over(monkeypatch):
+    """The per-guide tile ordering writes final hits on two assumptions and checks them tile by tile: no (sequence, row)
+    twice in an item - overlapping PAM patterns break it: NGG listed again as an alt PAM, every site found twice, the
+    per-distance std::set keeps one (process.hpp:21-23) - and no bucket beyond its slots (forced here by a sample of
+    one word per splitter).  A tile that sees either raises a flag and the call orders the batch with the device-wide
+    form: the counters say so and the hit lists still equal the oracle's.  A handle that met duplicates does not try
+    the tiles again for that batch shape; another shape it does."""
+    rng = np.random.default_rng(7)
+    site = np.frombuffer(b"GATTACAGATTACAGATTAC", np.uint8)
+    chunks = []
+    for i in range(16000):
+        s = site.copy()
+        for j in rng.choice(20, size=int(rng.integers(0, 4)), replace=False):
+            s[j] = rng.choice([c for c in b"ACGT" if c != s[j]])
+        pam = np.frombuffer(rng.choice([b"AGG", b"CGG", b"GGG", b"TGG"]), np.uint8)
+        filler = rng.choice(np.frombuffer(b"ACGT", np.uint8), int(rng.integers(30, 60)))
+        chunks += [filler, s, pam]
+    text = np.concatenate(chunks)
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        others, _, _, _ = synth.sample_guides(text, 3, seed=4)
+        seqs = np.concatenate([others[:1], np.array([list(site)], dtype=np.uint8), others[1:]])
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
+
+        def check(alt, want_tiles, want_gave_up):
+            offsets, hits, _ = gidx.enumerate(seqs, pams, mismatches=3, alt_pams=alt)
+            ctr = gidx.last_counters()
+            pick = {k: ctr[k] for k in ("ordered_in_tiles", "tile_ordering_gave_up", "matches_max_per_item", "guides_redone")}
+            assert ctr["matches_max_per_item"] > 4096 and ctr["ordered_in_tiles"] == want_tiles and \
+                ctr["tile_ordering_gave_up"] == want_gave_up, (alt, pick)
+            opts = ol.make_opts(3, alt_pams=alt)
+            for i in range(seqs.shape[0]):
+                g = seqs[i].tobytes().decode()
+                exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
+                assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, (i, alt)
+
+        check((), True, False)
+        monkeypatch.setenv("GS_TILE_SAMPLE_PER", "1")     # buckets outgrow their slots: gives up, same hits
+        check((), False, True)
+        monkeypatch.delenv("GS_TILE_SAMPLE_PER")
+        check(("NGG",), False, True)                       # every site twice: gives up, the device-wide form drops the copies
+        check(("NGG",), False, False)                      # ... and this shape is not tried again on this handle
+        check(("NAG",), True, False)                       # another shape is
+    finally:
+        gidx.close()
+        oidx.close()
+
+
 def test_composite_ordering_puts_runs_right(monkeypatch):
     """the device-wide ordering as ONE sort of (sort word, low bits of the first row): the rows of a run of equal
     words are scattered over their k-mer's suffix array interval, and where that reaches across a multiple of
