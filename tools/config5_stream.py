@@ -57,7 +57,7 @@ def main():
     min_free = free0
     n_guides = n_hits = 0
     t_enum = t_score = ms_search = 0.0
-    slots, redone, from_arena, wide = [], 0, 0, 0
+    slots, redone, from_arena, wide, tiles_n = [], 0, 0, 0, 0
     batch_ms = []
     own_found = 0
     csum = 0
@@ -79,6 +79,7 @@ def main():
         redone += int(ctr["guides_redone"])
         from_arena += int(ctr["overflow_from_arena"])
         wide += int(ctr["ordered_device_wide"])
+        tiles_n += int(ctr.get("ordered_in_tiles", False))
         d_spec = torch.empty(n, dtype=torch.float32, device="cuda")
         t0 = time.perf_counter()
         gidx.score_device(gs, d_seqs.data_ptr() + lo * 20, n, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
@@ -131,6 +132,7 @@ def main():
             "slots_per_item_distinct": sorted(set(slots)),
             "guides_overflowed": int(tot[2]), "batches_served_from_arena": int(tot[3]),
             "batches_ordered_device_wide": int(tot[4]),
+            "batches_ordered_per_guide_in_lds_tiles_rank0": tiles_n,
             "mean_specificity": float(tot[5]) / g if g else None,
             "checksum": f"{csum:016x}" if a.checksum else None}))
     gidx.close()
