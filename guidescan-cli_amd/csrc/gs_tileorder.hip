@@ -15,9 +15,10 @@
  *                   streaming pass deals the records into buckets of at most TO_TILE records (sample sort:
  *                   the full word decides, so a run of 10^4 equal sequences is split by row)
  *   k_to_sort       one workgroup per tile (a small item where k_search left it, or a bucket): K of every
- *                   record, LSD radix sort in LDS over the bits that vary inside the tile (eight-bit digits,
- *                   wave64 ballot match for the stable rank inside a wave), then the hits - suffix array
- *                   gather + coordinate rule (process.hpp:104, 111) - straight to their final place
+ *                   record, a merge sort in LDS (eight words per thread ordered in registers, then merge-path
+ *                   rounds), then the hits - suffix array gather + coordinate rule (process.hpp:104, 111) -
+ *                   straight to their final place; 512 threads for tiles of up to 4,096 records, 128 for
+ *                   those of up to 1,024
  *
  * Two passes of HBM traffic for partitioned items (16 B read + 16 B written, twice), one for the rest.
  * The path writes final hits on two assumptions it checks as it goes: every record is a single row, and no

@@ -54,12 +54,15 @@ typedef struct gs_index gs_index;
  *         (include/genomics/structures.hpp:33-43):
  *           bits 63..61  match.mismatches
  *           bit  60      0 = found in the forward index, 1 = reverse index
- *           bits 59..8   match.sequence as per-position codes, position 0 first:
+ *           bits 59..1   match.sequence as per-position codes, position 0 first (2L + 3P <= 59 bits,
+ *                        from bit 59 down; what a sequence does not use stays zero):
  *                        guide positions (2 bits): 0 = equals the query base
  *                          (upper case), 1..3 = mismatch, the matched base's rank
  *                          among the three other bases in A<C<G<T order (lower case);
  *                        PAM positions (3 bits): A=0 C=1 G=2 N=3 T=4 (upper case).
- *           bits 7..0    zero
+ *           bit  0       zero
+ *         (Sequences of up to 52 bits - 20-mers with a PAM of up to four symbols - leave bits 7..1 zero: the
+ *         layout of earlier versions.  23-mers with a four-symbol PAM use 58.)
  *         Ascending key == the reference's order of (distance, index, std::set<match>
  *         ordered by sequence string) because 'A'<'C'<'G'<'N'<'T'<'a'<'c'<'g'<'t'.
  * gs_decode_sequence() rebuilds match.sequence from (guide, key). */
@@ -78,7 +81,8 @@ typedef struct {
  * n_ext counts only the extensions actually executed below the table depth. */
 #define GS_FLAG_FAITHFUL_WALK 2u
 /* Measurement only: run the counting instantiation of the search kernel, which tallies the distinct
- * 64-byte lines each of its load instructions asks for (gs_index_last_counters).  Same results,
+ * 64-byte lines each of its load instructions asks for (gs_index_last_counters; with GS_COUNT_SHIFT=7 in the
+ * environment: 128-byte blocks, what the memory system serves as one random request).  Same results,
  * slower; never set in a timed call. */
 #define GS_FLAG_COUNT_REQUESTS 4u
 /* Also return, per guide, the number of hits BEFORE duplicate sequences are dropped
@@ -156,7 +160,9 @@ void gs_index_close(gs_index *ix);
  * redone because their matches overflowed the first pass's slots, [7] bit 0: the whole batch was ordered
  * device-wide, bit 1: the redone guides were, bit 2: the overflowing guides' records came out of the arena,
  * bit 3: the device-wide ordering ran as one sort of (sort word, low bits of the first row), bit 4: it had runs
- * to put right afterwards, [13] slots per item of the first pass, [14] / [15] sum and
+ * to put right afterwards, bit 5: the guides beyond LDS were ordered per guide in LDS tiles (gs_tileorder.hip),
+ * bit 6: that form gave up (overlapping PAM patterns, a bucket beyond its slots) and the device-wide one ran
+ * (DESIGN.md section 5.3), [13] slots per item of the first pass, [14] / [15] sum and
  * maximum of the per-item match counts; with
  * GS_FLAG_COUNT_REQUESTS also the 64-byte lines requested by the search kernel: [8] prefix-table
  * lines, [9] 16-bit context lines, [10] 32-bit context words, [11] SA/ISA gathers of the search,

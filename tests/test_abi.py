@@ -49,10 +49,11 @@ def encode_key(guide, sequence, k, index, P, start=False):
         else:
             others = [b for b in "ACGT" if b != qc]
             code = 1 + others.index(ch.upper())
-        path |= code << (50 - 2 * t)
+        path |= code << (57 - 2 * t)
     for u in range(P):
-        path |= "ACGNT".index(sequence[L + u]) << (49 - 2 * L - 3 * u)
-    return (k << 61) | (index << 60) | (path << 8)
+        path |= "ACGNT".index(sequence[L + u]) << (56 - 2 * L - 3 * u)
+    assert 2 * L + 3 * P <= 59 and path < (1 << 59)
+    return (k << 61) | (index << 60) | (path << 1)      # key bits 59..1 (bits 7..1 stay zero up to 52 sequence bits)
 
 
 def test_decode_sequence_roundtrip_and_order(toy):
@@ -75,6 +76,33 @@ def test_decode_sequence_roundtrip_and_order(toy):
                 assert keys == sorted(keys), k.id
     finally:
         oidx.close()
+
+
+def test_decode_sequence_of_wide_keys():
+    """23-mers with a four-symbol PAM (Cas12a): 58 bits of match.sequence in key bits 59..1 - every position and
+    every code decodes back, keys order as the strings do, and 60 bits are refused"""
+    rng = np.random.default_rng(11)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    L, P = 23, 4
+    for start in (False, True):
+        guide = "".join(rng.choice(list("ACGT"), L))
+        seqs = []
+        for _ in range(300):
+            seq = []
+            for t in range(L):
+                qc = guide[L - 1 - t] if start else comp[guide[t]]
+                seq.append(qc if rng.random() < 0.8 else rng.choice([b for b in "ACGT" if b != qc]).lower())
+            seq += list(rng.choice(list("ACGNT"), P))
+            seqs.append("".join(seq))
+        keys = []
+        for sq in seqs:
+            key = encode_key(guide, sq, sum(c.islower() for c in sq) & 7, 0, P, start)
+            assert key & 1 == 0
+            assert api.decode_sequence(guide, P, key, 1 if start else 0) == sq
+            keys.append((key & ((1 << 60) - 1), sq))
+        assert [s for _, s in sorted(keys)] == sorted(s for _, s in keys)   # 'A'<'C'<'G'<'N'<'T'<'a'<'c'<'g'<'t'
+    buf = C.create_string_buffer(64)
+    assert api.lib().gs_decode_sequence(b"A" * 24, 24, 4, 0, 0, buf) != 0   # 2L + 3P = 60
 
 
 def test_calculate_cfd_matches_oracle():
