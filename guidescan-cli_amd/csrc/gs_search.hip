@@ -2413,6 +2413,31 @@ static void build_recipes_a(std::vector<uint64_t> &out, uint32_t k, uint32_t m, 
       if ((uint32_t)__builtin_popcount(mk) != j) continue;
       const uint32_t ax = (uint32_t)__builtin_popcount(mk & xmask), o0 = j - ax;
       if (!mine(ax, o0)) continue;
+      if (astar && nX > kp) {
+        /* X reaches into the two-symbol extension (27-symbol sites at k = 14: X = steps 0 .. 12): a substitution at step
+         * k-2 counts for X, one at step k-1 for O - every (e2, e1) is taken or left by itself, from the plain table */
+        uint32_t steps[8], ns = 0;
+        for (uint32_t t = 0; t < kp; t++)
+          if ((mk >> t) & 1u) steps[ns++] = t;
+        uint32_t ndig = 1;
+        for (uint32_t i = 0; i < j; i++) ndig *= 3;
+        for (uint32_t dc = 0; dc < ndig; dc++) {
+          uint32_t f[10], x = dc;
+          for (uint32_t i = j; i-- > 0;) {
+            f[i] = (steps[i] << 2) | (x % 3);
+            x /= 3;
+          }
+          for (uint32_t e2 = 0; e2 < 4; e2++)
+            for (uint32_t e1 = 0; e1 < 4; e1++) {
+              uint32_t n = j;
+              if (e2) f[n++] = ((k - 2) << 2) | (e2 - 1);
+              if (e1) f[n++] = ((k - 1) << 2) | (e1 - 1);
+              if (n > m || n > 7 || !mine(ax + (e2 ? 1u : 0u), o0 + (e1 ? 1u : 0u))) continue;
+              out.push_back(recipe_word(n, 0, false, 0, f));
+            }
+        }
+        continue;
+      }
       uint32_t eb = 0; /* substitutions the extension may add */
       while (eb < 2 && j + eb + 1 <= m && mine(ax, o0 + eb + 1)) eb++;
       uint32_t steps[8], ns = 0, plast = 0;
@@ -2484,7 +2509,7 @@ static void build_recipes_b(std::vector<uint64_t> &out, uint32_t k, uint32_t L, 
 extern "C" gs_status gs_debug_seed_recipes(uint32_t k, uint32_t L, uint32_t P, uint32_t m, uint32_t n_x,
                                            const uint32_t *astar, uint32_t deep, uint64_t *out, uint64_t cap,
                                            uint64_t counts[3]) {
-  if (k < 4 || k > 16 || L < k || L > 31 || m > 7 || n_x + 2 > k || !counts) return GS_ERR_ARG;
+  if (k < 4 || k > 16 || L < k || L > 31 || m > 7 || n_x + 1 > k || !counts) return GS_ERR_ARG;
   try {
     std::vector<uint64_t> all;
     build_recipes_a(all, k, m, n_x, nullptr, true);
@@ -2733,7 +2758,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     gs_set_error("more than 7 mismatches");
     return GS_ERR_UNSUPPORTED;
   }
-  const bool two_ok = v_rem != 0 && mismatches >= 1 && v_rem + 2 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
+  const bool two_ok = v_rem != 0 && mismatches >= 1 && v_rem + 1 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
                       L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !getenv("GS_NO_BIDIR");
   /* the pairs of bases the batch's patterns end in (k_prepare's tally), most frequent first */
   uint32_t want[2] = {16, 16}, n_codes = 0;

@@ -831,13 +831,15 @@ def cas12a_genome(seed, n_copies, size):
     return text, fam
 
 
-def test_wide_keys_23mers_with_a_four_symbol_pam(monkeypatch):
+@pytest.mark.parametrize("table_k", [13, 14])
+def test_wide_keys_23mers_with_a_four_symbol_pam(monkeypatch, table_k):
     """Cas12a: 23-mers behind TTTN (--start).  2L + 3P = 58 bits of match sequence: beyond the 52 bits the hit key
     carried until round 4, inside the 59 it carries now (key bits 59:1) - the table-seeded kernels take the batch
-    (one-sided seeding at this shape), LDS orders it, and on the second genome - 30,000 near-copies of one site - the
+    (one-sided seeding with 13-symbol tables; two-sided with 14: X, 13 symbols, then reaches step k-2 of the table's
+    two-symbol extension), LDS orders it, and on the second genome - 30,000 near-copies of one site - the
     guide's thousands of records overflow into the arena and are ordered per guide in LDS tiles.  Every hit list
     equals the oracle's: positions, distances, index, match.sequence as gs_decode_sequence rebuilds it from the key."""
-    monkeypatch.setenv("GS_PREFIX_K", "13")
+    monkeypatch.setenv("GS_PREFIX_K", str(table_k))
     for seed, n_copies, size, ms in ((21, 150, [150_000, 90_000], (1, 2, 3, 4)), (22, 30000, [3_000_000], (3,))):
         text, fam = cas12a_genome(seed, n_copies, size)
         oidx = ol.OracleIndex(text)
@@ -865,6 +867,7 @@ def test_wide_keys_23mers_with_a_four_symbol_pam(monkeypatch):
                         assert gpu_hits_as_records(offsets, hits, i, g, 4, True) == exp, (seed, i, m, alt)
                         total += len(exp)
                     assert total > len(guides)
+                    assert (ctr["items_two_sided"] > 0) == (table_k == 14 and m >= 1), (m, ctr["items_two_sided"])
                     if n_copies >= 5000:
                         pick = {k: ctr[k] for k in ("guides_redone", "ordered_in_tiles", "tile_ordering_gave_up", "matches_max_per_item",
                                                     "overflow_from_arena", "redo_ordered_device_wide")}

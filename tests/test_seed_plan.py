@@ -59,6 +59,9 @@ GEOM = [  # k, L, P, m, |X|, thresholds, deep
     (11, 16, 3, 2, 8, (2, 1, 1), False),
     (12, 20, 0, 3, 8, (2, 2, 1, 1), False),
     (14, 20, 3, 6, 8, (4, 3, 3, 2, 2, 1, 1), True),
+    (14, 23, 4, 3, 13, (2, 2, 1, 1), False),   # X reaches the table's two-symbol extension (step k-2)
+    (14, 23, 4, 4, 13, (3, 2, 2, 1, 1), False),
+    (12, 20, 3, 3, 11, (2, 2, 1, 1), False),
 ]
 
 
