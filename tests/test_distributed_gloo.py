@@ -122,3 +122,41 @@ def test_bench_strong_scaling_splits_one_guide_set():
     jw = _run_bench_stub([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0",
                           "--workload", "saccer3", "--batch", "65"], {})
     assert jw["scaling"] == "weak" and jw["guides_per_rank"] == [65, 65] and jw["guides_per_step"] == 130
+
+
+def _run_tool_stub(tool, world, extra):
+    import json
+    import subprocess
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GS_TOOLS_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    port = 21000 + (os.getpid() * 7 + world * 131 + len(tool)) % 4000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), f"tools/{tool}", "--workload", "saccer3"] + extra
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout        # ONE JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["stub"] is True
+    return j
+
+
+def test_genomewide_and_config5_tools_under_world2_gloo():
+    """tools/genomewide_enumerate.py (config 4) and tools/config5_stream.py (config 5) as the driver would start them on a
+    node: torch.distributed.run, rank r takes the batches b with b % world == r, totals summed and times MAX-reduced, one
+    line from rank 0.  Rehearsed on gloo with tools/_stub.py standing in for the index (its numbers depend on the guides
+    alone): two ranks report the totals one rank reports - no batch dropped, none taken twice."""
+    g1 = _run_tool_stub("genomewide_enumerate.py", 1, ["--batch", "50000", "--max-guides", "0", "--score"])
+    g2 = _run_tool_stub("genomewide_enumerate.py", 2, ["--batch", "50000", "--max-guides", "0", "--score"])
+    assert g1["n_gpus"] == 1 and g2["n_gpus"] == 2
+    assert g1["guides_enumerated"] == g1["candidates_scanned"] > 300_000
+    for k in ("candidates_scanned", "guides_enumerated", "hits"):
+        assert g1[k] == g2[k], k
+    assert abs(g1["mean_specificity"] - g2["mean_specificity"]) < 1e-6   # float32 partial sums per batch
+    c1 = _run_tool_stub("config5_stream.py", 1, ["--guides", "10007", "--batch", "1000"])
+    c2 = _run_tool_stub("config5_stream.py", 2, ["--guides", "10007", "--batch", "1000"])
+    assert c1["guides"] == c2["guides"] == 10007 and c1["hits"] == c2["hits"] > 10007
+    assert abs(c1["mean_specificity"] - c2["mean_specificity"]) < 1e-9

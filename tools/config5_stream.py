@@ -9,7 +9,8 @@ Reports guides/s and hits/s over the whole stream (search + ordering + locate + 
 k_search, peak HBM in use, and what the slot sizing did per batch (slots per item, guides that overflowed
 into the arena / were searched again).  A checksum over every batch's CSR offsets, hit records and
 specificities makes two runs comparable.  Multi-GPU: launch with torch.distributed.run; rank r takes the
-batches b with b % world == r (independent units, no data-path collective)."""
+batches b with b % world == r (independent units, no data-path collective).  GS_TOOLS_STUB=1 rehearses exactly that
+plumbing on gloo without a GPU (tools/_stub.py; not a measurement)."""
 import argparse
 import ctypes as C
 import json
@@ -38,22 +39,34 @@ def main():
     synth = import_module("guidescan-cli_amd.synth")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    stub = None
+    if os.environ.get("GS_TOOLS_STUB") == "1":
+        import _stub as stub
+        a.checksum = False
+    dev = "cpu" if stub else "cuda"
+    sync = (lambda: None) if stub else torch.cuda.synchronize
+    mem_info = (lambda: (0, 0)) if stub else torch.cuda.mem_get_info
+    if not stub:
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     lengths = {"chr1": [synth.CHR1_LENGTH], "hg38": synth.GRCH38_LENGTHS, "saccer3": synth.SACCER3_LENGTHS}[a.workload]
     text, names, lengths = synth.make_genome(lengths, seed=1)
     t0 = time.time()
-    gidx = api.GenomeIndex.build(text, device=local)
+    gidx = stub.StubIndex(text) if stub else api.GenomeIndex.build(text, device=local)
     t_index = time.time() - t0
     gs = api.make_genome_structure(names, lengths)
     seqs, pams, pos, strands = synth.sample_guides(text, a.guides, seed=1000)
-    d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    free0, total_mem = torch.cuda.mem_get_info()
+    d_seqs, d_pams = torch.from_numpy(seqs).to(dev), torch.from_numpy(pams).to(dev)
+    if not stub:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    free0, total_mem = mem_info()
     min_free = free0
     n_guides = n_hits = 0
     t_enum = t_score = ms_search = 0.0
@@ -62,7 +75,7 @@ def main():
     own_found = 0
     csum = 0
     spec_sum = 0.0
-    torch.cuda.synchronize()
+    sync()
     t_start = time.perf_counter()
     for b, lo in enumerate(range(0, a.guides, a.batch)):
         if b % world != rank:
@@ -80,11 +93,11 @@ def main():
         from_arena += int(ctr["overflow_from_arena"])
         wide += int(ctr["ordered_device_wide"])
         tiles_n += int(ctr.get("ordered_in_tiles", False))
-        d_spec = torch.empty(n, dtype=torch.float32, device="cuda")
+        d_spec = torch.empty(n, dtype=torch.float32, device=dev)
         t0 = time.perf_counter()
         gidx.score_device(gs, d_seqs.data_ptr() + lo * 20, n, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
         t_score += time.perf_counter() - t0
-        min_free = min(min_free, torch.cuda.mem_get_info()[0])
+        min_free = min(min_free, mem_info()[0])
         n_guides += n
         n_hits += st["n_hits"]
         spec_sum += float(d_spec.double().sum().item())
@@ -107,10 +120,10 @@ def main():
                     int(d_spec.view(torch.int32).long().sum().item())) & 0xFFFFFFFFFFFFFFFF
             del off
         del d_spec
-    torch.cuda.synchronize()
+    sync()
     wall = time.perf_counter() - t_start
-    tot = torch.tensor([n_guides, n_hits, redone, from_arena, wide, spec_sum], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([wall, t_enum, t_score, ms_search, float(total_mem - min_free)], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([n_guides, n_hits, redone, from_arena, wide, spec_sum], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([wall, t_enum, t_score, ms_search, float(total_mem - min_free)], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tot)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -118,6 +131,7 @@ def main():
         g, h = float(tot[0]), float(tot[1])
         w = float(tmax[0])
         print(json.dumps({
+            **({"stub": True} if stub else {}),
             "config": f"{a.workload}-sized synthetic genome, {a.guides} sampled NGG 20-mers, <= {a.mismatches} mismatches + CFD, "
                       f"batches of {a.batch}, {world} GPU(s)",
             "guides": int(g), "hits": int(h), "hits_per_guide": h / g if g else None,
@@ -127,7 +141,7 @@ def main():
             "index_build_s": t_index, "index_bytes": gidx.device_bytes,
             "peak_hbm_in_use_bytes": int(tmax[4]), "hbm_total_bytes": int(total_mem),
             "enumerate_ms_per_batch": {"first5": [round(x, 1) for x in batch_ms[:5]], "median": round(float(np.median(batch_ms)), 1),
-                                       "min": round(min(batch_ms), 1), "max": round(max(batch_ms), 1)},
+                                       "min": round(min(batch_ms), 1), "max": round(max(batch_ms), 1)} if batch_ms else None,
             "slots_per_item_first_last": [slots[0], slots[-1]] if slots else None,
             "slots_per_item_distinct": sorted(set(slots)),
             "guides_overflowed": int(tot[2]), "batches_served_from_arena": int(tot[3]),

@@ -7,7 +7,8 @@ by chromosome (gs_kmers_generate) and enumerated in batches straight from HBM
         [--batch 1000000] [--max-guides 4000000] [--score]
 
 Multi-GPU: launch with torch.distributed.run; rank r takes the batches b with b % world == r of
-every chromosome (independent units, no data-path collective), totals are summed at the end."""
+every chromosome (independent units, no data-path collective), totals are summed at the end.
+GS_TOOLS_STUB=1 rehearses exactly that plumbing on gloo without a GPU (tools/_stub.py; not a measurement)."""
 import argparse
 import json
 import os
@@ -36,14 +37,25 @@ def main():
     synth = import_module("guidescan-cli_amd.synth")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    stub = None
+    if os.environ.get("GS_TOOLS_STUB") == "1":
+        import _stub as stub
+        if a.sorted:
+            raise SystemExit("--sorted is a single-GPU mode: nothing to rehearse")
+    dev = "cpu" if stub else "cuda"
+    sync = (lambda: None) if stub else torch.cuda.synchronize
+    if not stub:
+        torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     lengths = {"chr1": [synth.CHR1_LENGTH], "hg38": synth.GRCH38_LENGTHS, "saccer3": synth.SACCER3_LENGTHS}[a.workload]
     text, names, lengths = synth.make_genome(lengths, seed=1)
-    gidx = api.GenomeIndex.build(text, device=local)
+    gidx = stub.StubIndex(text) if stub else api.GenomeIndex.build(text, device=local)
     gs = api.make_genome_structure(names, lengths)
     n_guides = n_hits = n_cand = 0
     t_gen = t_enum = t_score = 0.0
@@ -114,11 +126,14 @@ def main():
     for name, ln in zip(names, lengths):
         if a.max_guides and n_guides >= a.max_guides:
             break
-        d_chr = torch.from_numpy(text[off:off + ln]).cuda()
-        off += ln
-        torch.cuda.synchronize()
+        d_chr = torch.from_numpy(text[off:off + ln]).to(dev)
+        sync()
         t0 = time.perf_counter()
-        km = api.generate_kmers(None, "NGG", 20, device=local, chrm_device_ptr=d_chr.data_ptr(), chrm_len=ln)
+        if stub:
+            km = stub.generate_kmers(text[off:off + ln])
+        else:
+            km = api.generate_kmers(None, "NGG", 20, device=local, chrm_device_ptr=d_chr.data_ptr(), chrm_len=ln)
+        off += ln
         t_gen += time.perf_counter() - t0
         n_cand += km.n
         for b, lo in enumerate(range(0, km.n, a.batch)):
@@ -134,26 +149,26 @@ def main():
             n_guides += n
             n_hits += st["n_hits"]
             if a.score:
-                d_spec = torch.empty(n, dtype=torch.float32, device="cuda")
+                d_spec = torch.empty(n, dtype=torch.float32, device=dev)
                 t0 = time.perf_counter()
                 gidx.score_device(gs, km.seqs_ptr + lo * 20, n, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
                 t_score += time.perf_counter() - t0
                 spec_sum += float(d_spec.sum().item())
         km.close()
         del d_chr
-    tot = torch.tensor([n_guides, n_hits], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([t_enum], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([n_guides, n_hits, spec_sum], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([t_enum], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tot)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
         g, h = float(tot[0]), float(tot[1])
-        print(json.dumps({"workload": a.workload, "mismatches": a.mismatches, "n_gpus": world,
+        print(json.dumps({"workload": a.workload, "mismatches": a.mismatches, "n_gpus": world, **({"stub": True} if stub else {}),
                           "candidates_scanned": n_cand, "guides_enumerated": int(g), "hits": int(h),
                           "kmers_generate_s": t_gen, "enumerate_s": float(tmax[0]),
                           "guides_per_s": g / float(tmax[0]) if float(tmax[0]) > 0 else None,
                           "score_s": t_score if a.score else None,
-                          "mean_specificity": spec_sum / n_guides if a.score and n_guides else None}))
+                          "mean_specificity": float(tot[2]) / g if a.score and g else None}))
     gidx.close()
     if dist is not None:
         dist.destroy_process_group()
