@@ -229,7 +229,7 @@ struct gs_tileorder_in {
   uint32_t L, P, m, v_rem;
 };
 struct gs_tileorder_state {
-  uint32_t n_it = 0, n_tiles = 0, n_btiles = 0, n_chunks = 0, n_big = 0;
+  uint32_t n_it = 0, n_tiles = 0, n_btiles = 0, n_chunks = 0, n_big = 0, n_deal = 0;
   uint64_t n_records = 0; /* records of the set (set by gs_tileorder_run) */
 };
 /* does the sort word (class base + rank of the sequence, then the row) fit 64 bits? */

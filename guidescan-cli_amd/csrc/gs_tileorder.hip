@@ -11,7 +11,7 @@
  *   k_to_plan       one workgroup: per set item the tiles, bucket space and arena chunks it needs; four scans
  *   k_to_fill       tile descriptors, the chunk index of every item, per guide where each (mismatches, index)
  *                   class starts in its hit list (from k_search's per-class counts), hits per guide
- *   k_to_partition  items beyond one tile: a sample of their records ordered in LDS gives splitters; one
+ *   k_to_splitters, k_to_deal, k_to_bucketsum  items beyond one tile: a sample of their records ordered in LDS gives splitters; one
  *                   streaming pass deals the records into buckets of at most TO_TILE records (sample sort:
  *                   the full word decides, so a run of 10^4 equal sequences is split by row)
  *   k_to_sort       one workgroup per tile (a small item where k_search left it, or a bucket): K of every
@@ -34,6 +34,8 @@
 #define TO_KPT 8u                  /* keys per thread */
 #define TO_TILE (TO_NT * TO_KPT)   /* 4,096 records per tile */
 #define TO_NBMAX 1024u             /* buckets of one item */
+#define TO_BU 128u                 /* bucket slots are handed out in units of 128 records */
+#define TO_DEAL 2048u              /* records one workgroup of k_to_deal deals into buckets */
 #define TO_DIRECT 0x80000000u
 
 /* flags raised by the kernels (gs_tileorder_run) */
@@ -80,6 +82,51 @@ __device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uin
   const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
   const unsigned long long w = bs[(uint32_t)(key >> 61)] + to_rank(key, L, P, nt, pam_mul);
   return (w << 32) | rec.z;
+}
+
+/* four records at once, step by step: the rank loop reads its table through a chain of LDS reads, each waiting for
+ * the one before - four chains side by side hide three quarters of that wait (the dealing pass was bound by it) */
+__device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L, const uint32_t P, const unsigned long long *nt,
+                                         const unsigned long long *bs, const unsigned long long pam_mul, unsigned long long (&K)[4]) {
+  unsigned long long gb[4], nz[4], rank[4], path[4];
+  uint32_t r[4];
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u) {
+    const unsigned long long key = ((unsigned long long)rec[u].y << 32) | rec[u].x;
+    path[u] = (key >> 1) & ((1ull << 59) - 1ull);
+    gb[u] = path[u] >> (59u - 2u * L);
+    nz[u] = (gb[u] | (gb[u] >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
+    r[u] = (uint32_t)__popcll(nz[u]);
+    if (r[u] > 7u) r[u] = 7u;
+    rank[u] = 0ull;
+  }
+  for (;;) {
+    bool any = false;
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const bool go = nz[u] != 0ull && r[u] != 0u;
+      const uint32_t hb = go ? 63u - (uint32_t)__builtin_clzll(nz[u]) : 0u;
+      const uint32_t c = (uint32_t)(gb[u] >> hb) & 3u, a = hb >> 1;
+      const unsigned long long n1 = nt[a * 8u + (go ? r[u] : 1u)], n0 = nt[a * 8u + (go ? r[u] : 1u) - 1u];
+      if (go) {
+        rank[u] += n1 + (unsigned long long)(c - 1u) * n0;
+        r[u]--;
+        nz[u] &= ~(1ull << hb);
+      }
+      any = any || go;
+    }
+    if (!any) break;
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u) {
+    unsigned long long pr = 0;
+    for (uint32_t q = 0; q < P; q++) {
+      const uint32_t c = (uint32_t)(path[u] >> (56u - 2u * L - 3u * q)) & 7u;
+      pr = pr * 5ull + (c < 4u ? c : 4u);
+    }
+    const unsigned long long w = bs[rec[u].y >> 29] + rank[u] * pam_mul + pr;
+    K[u] = (w << 32) | rec[u].z;
+  }
 }
 
 /* ---- merge sort of n <= TO_TILE 64-bit words in LDS by the whole workgroup --------------------------------------
@@ -188,48 +235,66 @@ struct gs_to_plan_args {
   const uint32_t *counts; /* per item of the batch: records (exact) */
   const uint32_t *list;   /* set guide -> guide of the batch, or nullptr: the whole batch */
   uint32_t n_it, cap;
-  uint32_t *tbase, *bbase, *cbase, *gbase; /* [n_it + 1] first tile / first bucket slot / first chunk-index entry / place on the list of partitioned items */
+  uint32_t *tbase, *bbase, *cbase, *gbase, *dbase; /* [n_it + 1] first tile / first bucket slot / first chunk-index entry / place on the list of partitioned
+                                                      items / first stretch of TO_DEAL records the dealing kernel takes */
   uint32_t *flags;
 };
-/* buckets of an item of c > TO_TILE records and the records each is meant to hold: the fewer samples per
- * splitter a large item can afford (TO_TILE samples in all), the more room its buckets get */
-__device__ __host__ __forceinline__ uint32_t to_buckets(const uint32_t c) {
+/* buckets of an item of c > TO_TILE records: how many, and the slot each gets (su units of TO_BU records).  The
+ * buckets aim below the 512 records one wave orders in registers (k_to_wsort); what a splitter's luck makes larger is a
+ * tile of the workgroup kernels.  An item affords TO_TILE samples in all: the fewer per splitter, the wider a bucket's
+ * size spreads (a gamma distribution of that shape) and the more room its slot has over the aim - every row keeps the
+ * chance of one bucket outgrowing its slot below 10^-10 (32 samples: 2.9 x the aim; 16: 4; 8: 6.2; 4: 8).  No more than 32
+ * samples per splitter: ordering the sample is itself a sort of ns words per item (64 per splitter, 4,096 for an item of
+ * 24,000 records, cost a third of what ordering the records costs). */
+__device__ __host__ __forceinline__ uint32_t to_buckets(const uint32_t c, uint32_t &su) {
+  su = 0u;
   if (c <= TO_TILE) return 0u;
-  const uint32_t target = c <= 64u * (TO_TILE / 2u) ? TO_TILE / 2u : c <= 128u * (TO_TILE / 3u) ? TO_TILE / 3u : c <= 256u * (TO_TILE / 4u) ? TO_TILE / 4u
-                          : c <= 512u * (TO_TILE / 6u) ? TO_TILE / 6u : TO_TILE / 8u;
+  uint32_t target;
+  if (c <= 128u * 400u)
+    target = 400u, su = 9u; /* 32 samples per splitter: one bucket in twenty grows past 512 */
+  else if (c <= 256u * 320u)
+    target = 320u, su = 10u; /* 16 */
+  else if (c <= 512u * 288u)
+    target = 288u, su = 14u; /* 8 */
+  else if (c <= 1024u * 256u)
+    target = 256u, su = 16u; /* 4 */
+  else
+    target = 512u, su = 32u; /* (to half a million records: 1,024 buckets) */
   return (c + target - 1u) / target;
 }
 __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
-  __shared__ uint32_t s_w[4][16], s_carry[4];
+  __shared__ uint32_t s_w[5][16], s_carry[5];
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), w = tid / WAVE;
-  if (tid < 4u) s_carry[tid] = 0u;
+  if (tid < 5u) s_carry[tid] = 0u;
   __syncthreads();
   for (uint32_t i0 = 0; i0 < a.n_it + 1u; i0 += 1024u) {
     const uint32_t sb = i0 + tid;
-    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    uint32_t v[5] = {0u, 0u, 0u, 0u, 0u};
     if (sb < a.n_it) {
       const uint32_t item = a.list ? 2u * a.list[sb >> 1] + (sb & 1u) : sb;
       const uint32_t c = a.counts[item];
-      uint32_t nb = to_buckets(c);
+      uint32_t su;
+      uint32_t nb = to_buckets(c, su);
       if (nb > TO_NBMAX) { /* an item beyond half a million records: the device-wide form orders this batch */
         atomicOr(a.flags, TO_F_BIG);
         nb = 0u;
       }
       v[0] = c == 0u ? 0u : nb ? nb : 1u;
-      v[1] = nb;
+      v[1] = nb * su;
       v[2] = c > a.cap ? (c - a.cap + ARENA_CHUNK - 1u) / ARENA_CHUNK : 0u;
       v[3] = nb ? 1u : 0u;
+      v[4] = nb ? (c + TO_DEAL - 1u) / TO_DEAL : 0u;
     }
-    uint32_t ex[4];
+    uint32_t ex[5];
 #pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q) {
+    for (uint32_t q = 0; q < 5u; ++q) {
       const uint32_t incl = wave_incl_sum(v[q]);
       if (lane == WAVE - 1u) s_w[q][w] = incl;
       ex[q] = incl - v[q];
     }
     __syncthreads();
 #pragma unroll
-    for (uint32_t q = 0; q < 4u; ++q) {
+    for (uint32_t q = 0; q < 5u; ++q) {
       uint32_t b = s_carry[q];
       for (uint32_t u = 0; u < w; ++u) b += s_w[q][u];
       ex[q] += b;
@@ -239,11 +304,12 @@ __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
       a.bbase[sb] = ex[1];
       a.cbase[sb] = ex[2];
       a.gbase[sb] = ex[3];
+      a.dbase[sb] = ex[4];
     }
     __syncthreads();
     if (tid == 1023u) {
 #pragma unroll
-      for (uint32_t q = 0; q < 4u; ++q) s_carry[q] = ex[q] + v[q];
+      for (uint32_t q = 0; q < 5u; ++q) s_carry[q] = ex[q] + v[q];
     }
     __syncthreads();
   }
@@ -253,8 +319,11 @@ __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
 struct gs_to_fill_args {
   const uint32_t *counts, *cls, *list;
   uint32_t n_it, cap;
-  const uint32_t *tbase, *bbase, *gbase;
-  uint4 *tiles;     /* {set item | TO_DIRECT, bucket slot, records, records of the item in the buckets before} */
+  const uint32_t *tbase, *bbase, *gbase, *dbase;
+  uint4 *dealmap;    /* per stretch of TO_DEAL records, two words: {set item, first record, records of the item, first tile},
+                        {first bucket unit, first chunk-index entry, item of the batch, 0} - all k_to_deal needs to start */
+  const uint32_t *cbase;
+  uint4 *tiles;     /* {set item | TO_DIRECT, bucket slot (unit), records, records of the item in the buckets before} */
   uint32_t *biglist; /* set items that are partitioned */
   uint32_t *rel;    /* [n_set][16]: where class (mismatches d, index s) of the guide starts in its hit list, less the
                        records of item s in classes before d: a record's place = rel[2d + s] + its rank in the item */
@@ -267,12 +336,19 @@ __global__ __launch_bounds__(256) void k_to_fill(gs_to_fill_args a) {
   const uint32_t g = a.list ? a.list[sb >> 1] : (sb >> 1);
   const uint32_t item = 2u * g + (sb & 1u);
   const uint32_t c = a.counts[item];
-  const uint32_t nb = to_buckets(c), tb = a.tbase[sb];
+  uint32_t su;
+  const uint32_t nb = to_buckets(c, su), tb = a.tbase[sb];
   if (c != 0u && nb == 0u) a.tiles[tb] = make_uint4(sb | TO_DIRECT, 0u, c, 0u);
   if (nb != 0u && nb <= TO_NBMAX) {
     const uint32_t bb = a.bbase[sb];
-    for (uint32_t b = 0; b < nb; ++b) a.tiles[tb + b] = make_uint4(sb, bb + b, 0u, 0u);
+    for (uint32_t b = 0; b < nb; ++b) a.tiles[tb + b] = make_uint4(sb, bb + b * su, 0u, 0u);
     a.biglist[a.gbase[sb]] = sb;
+    const uint32_t d0 = a.dbase[sb], nd = (c + TO_DEAL - 1u) / TO_DEAL;
+    const uint32_t cbi = a.cbase[sb];
+    for (uint32_t q = 0; q < nd; ++q) {
+      a.dealmap[2u * (d0 + q)] = make_uint4(sb, q * TO_DEAL, c, tb);
+      a.dealmap[2u * (d0 + q) + 1u] = make_uint4(bb, cbi, item, 0u);
+    }
   }
   if ((sb & 1u) == 0u) {
     const uint32_t *c0 = a.cls + (size_t)item * 8u, *c1 = c0 + 8u;
@@ -332,6 +408,8 @@ struct gs_to_run_args {
   const uint32_t *counts, *list;
   const uint32_t *tbase, *bbase, *cbase;
   const uint32_t *biglist;
+  const uint4 *dealmap;
+  unsigned long long *spl; /* [n_tiles]: entry tbase + b = splitter b of the item */
   uint4 *tiles;
   uint4 *buckets;
   const gs_to_tab *tab;
@@ -345,119 +423,190 @@ struct gs_to_run_args {
   uint32_t sample_per; /* 0, or GS_TILE_SAMPLE_PER (tests) */
 };
 
-/* ---- items beyond one tile: splitters from a sample, then one streaming pass into buckets ---------------------- */
-__global__ __launch_bounds__(TO_NT) void k_to_partition(gs_to_run_args a) {
+/* ---- items beyond one tile: splitters from a sample, then one streaming pass into buckets ----------------------
+ * Three kernels.  k_to_splitters: one workgroup per item orders a sample of it and leaves the splitters in memory.
+ * k_to_deal: one workgroup per stretch of TO_DEAL records - counts its records per bucket in LDS, reserves that many
+ * places in each bucket with one atomic on the bucket's tile descriptor (tiles[].z is the cursor), writes the records.
+ * k_to_bucketsum: records of the item before each bucket.  (One workgroup per ITEM doing all of it - the first form -
+ * left the chip to 10,482 workgroups on the repeat-rich batch, 46,000 records each and the largest 219,515: 280 us of
+ * every item's 336 went into its own stream loop, twenty-two passes of chained LDS reads with three workgroups per
+ * CU to hide them, and the kernel ended when the largest item did.) */
+__device__ __forceinline__ uint32_t to_sample_per(const gs_to_run_args &a, const uint32_t nb) {
+  uint32_t per = TO_TILE / nb < 32u ? TO_TILE / nb : 32u; /* samples per bucket */
+  if (a.sample_per != 0u && a.sample_per < per) per = a.sample_per; /* tests: a sample too small to keep the buckets within their slots */
+  return per;
+}
+__device__ __forceinline__ uint32_t to_slots(const gs_to_run_args &a, const uint32_t su) {
+  return a.sample_per == 1u ? su * TO_BU / 4u : su * TO_BU; /* tests: at one word per splitter, a quarter of the slots - certain to overflow */
+}
+__global__ __launch_bounds__(TO_NT) void k_to_splitters(gs_to_run_args a) {
   __shared__ unsigned long long s_keys[TO_LDS];
-  __shared__ unsigned long long s_spl[TO_NBMAX];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
-  __shared__ uint32_t s_cur[TO_NBMAX];
-  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
+  const uint32_t tid = threadIdx.x;
   for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
   if (tid < 8u) s_bs[tid] = a.tab->base[tid];
   const unsigned long long pam_mul = a.tab->pam_mul;
   const uint32_t sb = a.biglist[blockIdx.x];
   const uint32_t g = a.list ? a.list[sb >> 1] : (sb >> 1);
   const uint32_t item = 2u * g + (sb & 1u);
-  const uint32_t c = a.counts[item], nb = to_buckets(c);
-  const uint32_t bb = a.bbase[sb], tb = a.tbase[sb], cb = a.cbase[sb];
+  uint32_t su;
+  const uint32_t c = a.counts[item], nb = to_buckets(c, su);
+  const uint32_t tb = a.tbase[sb], cb = a.cbase[sb];
   /* stratified sample: one record from each of `ns` equal stretches of the item (emission order is seed by seed,
    * so a stretch is a few neighbouring sequences: no worse than independent draws) */
-  uint32_t per = TO_TILE / nb < 64u ? TO_TILE / nb : 64u; /* samples per bucket */
-  if (a.sample_per != 0u && a.sample_per < per) per = a.sample_per; /* tests: a sample too small to keep the buckets within their slots */
-  const uint32_t slots = a.sample_per == 1u ? TO_TILE / 4u : TO_TILE; /* ... and, at one word per splitter, a quarter of the slots: certain to overflow */
-  const uint32_t ns = per * nb;
+  const uint32_t per = to_sample_per(a, nb), ns = per * nb;
   __syncthreads();
-  bool multi = false;
-  for (uint32_t j = tid; j < ns; j += TO_NT) {
-    const uint32_t lo = (uint32_t)(((unsigned long long)j * c) / ns), hi = (uint32_t)(((unsigned long long)(j + 1u) * c) / ns);
-    uint32_t h = j * 2654435761u ^ (sb * 40503u + 0x9E3779B9u);
-    h ^= h >> 15;
-    h *= 2246822519u;
-    h ^= h >> 13;
-    const uint32_t pos = lo + h % (hi - lo); /* hi > lo: c > TO_TILE >= ns */
-    const uint4 rec = *to_addr(a.src, item, cb, pos);
-    s_keys[TO_AT(j)] = to_word(rec, a.L, a.P, s_nt, s_bs, pam_mul);
+  {
+    uint4 srec[TO_KPT]; /* (ns <= TO_TILE: eight per thread, all asked for before the first is ranked) */
+#pragma unroll
+    for (uint32_t q = 0; q < TO_KPT; ++q) {
+      const uint32_t j = tid + q * TO_NT;
+      srec[q] = make_uint4(0u, 0u, 0u, 0u);
+      if (j < ns) {
+        const uint32_t lo = (uint32_t)(((unsigned long long)j * c) / ns), hi = (uint32_t)(((unsigned long long)(j + 1u) * c) / ns);
+        uint32_t h = j * 2654435761u ^ (sb * 40503u + 0x9E3779B9u);
+        h ^= h >> 15;
+        h *= 2246822519u;
+        h ^= h >> 13;
+        const uint32_t pos = lo + h % (hi - lo); /* hi > lo: c > TO_TILE >= ns */
+        srec[q] = *to_addr(a.src, item, cb, pos);
+      }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < TO_KPT; ++q) {
+      const uint32_t j = tid + q * TO_NT;
+      if (j < ns) s_keys[TO_AT(j)] = to_word(srec[q], a.L, a.P, s_nt, s_bs, pam_mul);
+    }
   }
   __syncthreads();
   to_msort<false>(s_keys, nullptr, ns);
-  unsigned long long spl_mine[2] = {0ull, 0ull};
-  for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) spl_mine[q] = s_keys[TO_AT((b + 1u) * per - 1u)];
+  for (uint32_t b = tid; b + 1u < nb; b += TO_NT) a.spl[tb + b] = s_keys[TO_AT((b + 1u) * per - 1u)];
+}
+
+__global__ __launch_bounds__(TO_NT) void k_to_deal(gs_to_run_args a) {
+  __shared__ unsigned long long s_spl[TO_NBMAX];
+  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+  __shared__ uint32_t s_cnt[TO_NBMAX];
+  __shared__ uint32_t s_chunk[4];
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
+  for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
+  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
+  const unsigned long long pam_mul = a.tab->pam_mul;
+  const uint4 d0 = a.dealmap[2u * blockIdx.x], d1 = a.dealmap[2u * blockIdx.x + 1u]; /* (one read, then everything else at once) */
+  const uint32_t i_lo = d0.y, c = d0.z, tb = d0.w, bb = d1.x, cb = d1.y, item = d1.z;
+  uint32_t su;
+  const uint32_t nb = to_buckets(c, su);
+  const uint32_t cap = a.src.cap;
+  /* the arena chunks the stretch touches (TO_DEAL / ARENA_CHUNK + 1 at most), by number from the first */
+  const uint32_t e_lo = i_lo > cap ? (i_lo - cap) >> ARENA_SHIFT : 0u;
+  const uint32_t nch = c > cap ? (c - cap + ARENA_CHUNK - 1u) >> ARENA_SHIFT : 0u;
+  if (tid < 4u && e_lo + tid < nch) s_chunk[tid] = a.src.chunk_of[cb + e_lo + tid];
+  for (uint32_t b = tid; b < nb; b += TO_NT) {
+    s_cnt[b] = 0u;
+    if (b + 1u < nb) s_spl[b] = a.spl[tb + b];
+  }
+  const uint32_t slots0 = su * TO_BU, slots = to_slots(a, su);
+  const uint32_t nsteps = 32u - (uint32_t)__builtin_clz(nb - 1u); /* probes of a search among nb - 1 splitters (nb >= 2) */
+  const uint4 *slots_of = a.src.slots + (size_t)item * cap;
   __syncthreads();
-  for (uint32_t b = tid, q = 0; b + 1u < nb; b += TO_NT, ++q) s_spl[b] = spl_mine[q];
-  for (uint32_t b = tid; b < nb; b += TO_NT) s_cur[b] = 0u;
-  __syncthreads();
-  uint4 *out = a.buckets + (size_t)bb * TO_TILE;
-  const uint32_t c_pad = ((c + TO_NT - 1u) / TO_NT) * TO_NT;
-  for (uint32_t i0 = tid; i0 < c_pad; i0 += 4u * TO_NT) {
-    uint4 rec[4];
-    bool on[4];
+  uint4 rec[4];
+  bool on[4];
 #pragma unroll
-    for (uint32_t u = 0; u < 4u; ++u) { /* four loads in flight */
-      const uint32_t i = i0 + u * TO_NT;
-      on[u] = i < c;
-      rec[u] = on[u] ? *to_addr(a.src, item, cb, i) : make_uint4(0u, 0u, 0u, 0u);
-    }
+  for (uint32_t u = 0; u < 4u; ++u) {
+    const uint32_t i = i_lo + tid + u * TO_NT;
+    on[u] = i < c;
+    rec[u] = make_uint4(0u, 0u, 0u, 0u);
+    if (on[u])
+      rec[u] = i < cap ? slots_of[i] : a.src.arena[((size_t)s_chunk[((i - cap) >> ARENA_SHIFT) - e_lo] << ARENA_SHIFT) | ((i - cap) & (ARENA_CHUNK - 1u))];
+  }
+  /* the four records go through every stage together: their words, then the splitters below each (a search of
+   * `nsteps` probes, the same for all) - four chains of LDS reads side by side */
+  unsigned long long K[4];
+  to_word4(rec, a.L, a.P, s_nt, s_bs, pam_mul, K);
+  uint32_t blo[4], bhi[4], lp[4];
+  bool multi = false;
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u) {
+    multi = multi || (on[u] && rec[u].z != rec[u].w);
+    blo[u] = 0u;
+    bhi[u] = nb - 1u;
+  }
+  for (uint32_t st = 0; st < nsteps; ++st) {
 #pragma unroll
     for (uint32_t u = 0; u < 4u; ++u) {
-      if (i0 - tid + u * TO_NT >= c_pad) break; /* workgroup-uniform */
-      uint32_t b = 0, kw = 0;
-      if (on[u]) {
-        multi = multi || rec[u].z != rec[u].w;
-        const unsigned long long K = to_word(rec[u], a.L, a.P, s_nt, s_bs, pam_mul);
-        kw = (uint32_t)(K >> 32);
-        uint32_t lo = 0, hi = nb - 1u; /* splitters below K */
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_spl[mid] < K)
-            lo = mid + 1u;
-          else
-            hi = mid;
-        }
-        b = lo;
+      const uint32_t mid = (blo[u] + bhi[u]) >> 1;
+      const bool below = s_spl[mid < nb - 1u ? mid : 0u] < K[u];
+      if (blo[u] < bhi[u]) {
+        if (below)
+          blo[u] = mid + 1u;
+        else
+          bhi[u] = mid;
       }
-      /* one LDS atomic per wave when its records go to one bucket (the stretches of a long run), else one per lane */
-      const unsigned long long act = __ballot(on[u]);
-      if (act == 0ull) continue;
-      const uint32_t b0 = (uint32_t)__shfl((int)b, (int)__builtin_ctzll(act));
-      uint32_t pos;
-      if (__ballot(on[u] && b != b0) == 0ull) {
-        uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(act)) base = atomicAdd(&s_cur[b0], (uint32_t)__popcll(act));
-        base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(act));
-        pos = base + lanes_below(act);
-      } else {
-        pos = on[u] ? atomicAdd(&s_cur[b], 1u) : 0u;
-      }
-      /* a bucket record carries its sequence word where the (equal) last row was: the tile does not rank it again */
-      if (on[u] && pos < slots) out[(size_t)b * TO_TILE + pos] = make_uint4(rec[u].x, rec[u].y, rec[u].z, kw);
+    }
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u) {
+    /* place among the workgroup's records of the bucket: one LDS atomic per wave when its records go to one bucket
+     * (the stretches of a long run), else one per lane */
+    const unsigned long long act = __ballot(on[u]);
+    lp[u] = 0u;
+    if (act == 0ull) continue;
+    const uint32_t b0 = (uint32_t)__shfl((int)blo[u], (int)__builtin_ctzll(act));
+    if (__ballot(on[u] && blo[u] != b0) == 0ull) {
+      uint32_t base = 0;
+      if (lane == (uint32_t)__builtin_ctzll(act)) base = atomicAdd(&s_cnt[b0], (uint32_t)__popcll(act));
+      lp[u] = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(act)) + lanes_below(act);
+    } else if (on[u]) {
+      lp[u] = atomicAdd(&s_cnt[blo[u]], 1u);
     }
   }
   if (multi) atomicOr(a.flags, TO_F_MULTIROW);
   __syncthreads();
-  /* records per bucket and before it (the first wave: nb <= 1,024 = 16 per lane) */
-  if (tid < WAVE) {
-    const uint32_t each = (nb + WAVE - 1u) / WAVE;
-    uint32_t s = 0;
-    bool over = false;
-    for (uint32_t q = 0; q < each; ++q) {
-      const uint32_t b = tid * each + q;
-      if (b < nb) {
-        s += s_cur[b];
-        over = over || s_cur[b] > slots;
-      }
-    }
-    uint32_t run = wave_incl_sum(s) - s;
-    for (uint32_t q = 0; q < each; ++q) {
-      const uint32_t b = tid * each + q;
-      if (b < nb) {
-        const uint32_t n = s_cur[b];
-        a.tiles[tb + b].z = n < slots ? n : slots;
-        a.tiles[tb + b].w = run;
-        run += n;
-      }
-    }
-    if (over) atomicOr(a.flags, TO_F_BUCKET);
+  for (uint32_t b = tid; b < nb; b += TO_NT) { /* that many places in the bucket, from its cursor */
+    const uint32_t n = s_cnt[b];
+    s_cnt[b] = n ? atomicAdd(&a.tiles[tb + b].z, n) : 0u;
   }
+  __syncthreads();
+  uint4 *out = a.buckets + (size_t)bb * TO_BU;
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u) {
+    const uint32_t pos = s_cnt[blo[u]] + lp[u];
+    /* a bucket record carries its sequence word where the (equal) last row was: the tile does not rank it again */
+    if (on[u] && pos < slots) out[(size_t)blo[u] * slots0 + pos] = make_uint4(rec[u].x, rec[u].y, rec[u].z, (uint32_t)(K[u] >> 32));
+  }
+}
+
+/* records per bucket (cut to the slot; more raise TO_F_BUCKET) and before it: one wave per item, nb <= 1,024 = 16 per lane */
+__global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const uint32_t n_big) {
+  const uint32_t w = (blockIdx.x * 256u + threadIdx.x) / WAVE, lane = threadIdx.x & (WAVE - 1u);
+  if (w >= n_big) return;
+  const uint32_t sb = a.biglist[w];
+  const uint32_t g = a.list ? a.list[sb >> 1] : (sb >> 1);
+  uint32_t su;
+  const uint32_t nb = to_buckets(a.counts[2u * g + (sb & 1u)], su);
+  const uint32_t tb = a.tbase[sb], slots = to_slots(a, su);
+  const uint32_t each = (nb + WAVE - 1u) / WAVE;
+  uint32_t s = 0;
+  bool over = false;
+  for (uint32_t q = 0; q < each; ++q) {
+    const uint32_t b = lane * each + q;
+    if (b < nb) {
+      const uint32_t n = a.tiles[tb + b].z;
+      s += n;
+      over = over || n > slots;
+    }
+  }
+  uint32_t run = wave_incl_sum(s) - s;
+  for (uint32_t q = 0; q < each; ++q) {
+    const uint32_t b = lane * each + q;
+    if (b < nb) {
+      const uint32_t n = a.tiles[tb + b].z;
+      a.tiles[tb + b].z = n < slots ? n : slots;
+      a.tiles[tb + b].w = run;
+      run += n;
+    }
+  }
+  if (over) atomicOr(a.flags, TO_F_BUCKET);
 }
 
 /* ---- one tile: order its records in LDS and write its hits -------------------------------------------------------- */
@@ -488,7 +637,7 @@ __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t
   const uint32_t gset = sb >> 1, strand = sb & 1u;
   const uint32_t g = a.list ? a.list[gset] : gset;
   const uint32_t item = 2u * g + strand;
-  const uint4 *bucket = a.buckets + (size_t)t.y * TO_TILE;
+  const uint4 *bucket = a.buckets + (size_t)t.y * TO_BU;
   /* every global read the tile needs is asked for before anything waits: the records (eight per thread), where the
    * guide's classes start, the guide's first hit */
   uint4 rec[TO_KPT];
@@ -503,7 +652,7 @@ __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t
 #pragma unroll
     for (uint32_t u = 0; u < TO_KPT; ++u) {
       const uint32_t i = tid + u * NT;
-      rec[u] = i < n ? bucket[i] : make_uint4(0u, 0u, 0u, 0u); /* {key, row, sequence word}: k_to_partition ranked it */
+      rec[u] = i < n ? bucket[i] : make_uint4(0u, 0u, 0u, 0u); /* {key, row, sequence word}: k_to_deal ranked it */
     }
   }
   if (tid < 8u) s_rel[tid] = a.rel[(size_t)gset * 16u + 2u * tid + strand];
@@ -600,8 +749,250 @@ __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t
 #endif
 }
 
+/* ---- one tile of at most 512 records per WAVE: ordered in registers ------------------------------------------------
+ * Lane l holds places 8l .. 8l+7 of the tile (word, key: four registers per record, 32 in all).  A bitonic network
+ * over the 512 places: partners whose places differ in bits 0..2 are the lane's own registers, partners whose places
+ * differ in bit 3 + b sit in lane l ^ 2^b and arrive by DPP (b = 0, 1, 3: quad_perm, row_ror:8; b = 2: row_shl:4 and
+ * row_shr:4 under bank masks), ds_swizzle (b = 4) or ds_bpermute (b = 5).  21 of the 45 steps cross lanes, eight
+ * independent records each - no LDS array, no barrier, no read that waits for a compare: the workgroup form above
+ * spends its time in the merge rounds' chains of dependent LDS reads (nine rounds of up to twenty) with three tiles
+ * resident per CU; this one keeps eight tiles per SIMD going.  Padding places hold words of all ones. */
+#define TO_WTILE 512u
+template <uint32_t D>
+__device__ __forceinline__ uint32_t to_xl(const uint32_t v) { /* v of lane ^ D */
+  if constexpr (D == 1u)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); /* quad_perm [1,0,3,2] */
+  else if constexpr (D == 2u)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); /* quad_perm [2,3,0,1] */
+  else if constexpr (D == 4u) {
+    const int r = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0x5, false);   /* row_shl:4 into lanes 0-3, 8-11 of a row */
+    return (uint32_t)__builtin_amdgcn_update_dpp(r, (int)v, 0x114, 0xF, 0xA, false); /* row_shr:4 into lanes 4-7, 12-15 */
+  } else if constexpr (D == 8u)
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xF, 0xF, true); /* row_ror:8 */
+  else if constexpr (D == 16u)
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F); /* bit mode: and 0x1F, or 0, xor 0x10 */
+  else
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ 32u) << 2), (int)v);
+}
+struct to_wregs {
+  unsigned long long K[8];
+  uint32_t x[8], y[8];
+};
+/* places i < j of the lane: the smaller word to i when asc, the larger when not (one compare and a mask flip: equal
+ * words then trade places when not asc, which changes nothing) */
+#define TO_WCE(i, j)                                              \
+  {                                                               \
+    const bool sw = (r.K[i] > r.K[j]) != desc;                    \
+    const unsigned long long tk = sw ? r.K[j] : r.K[i];           \
+    r.K[j] = sw ? r.K[i] : r.K[j];                                \
+    r.K[i] = tk;                                                  \
+    if constexpr (!PACKED) {                                      \
+      const uint32_t tx = sw ? r.x[j] : r.x[i];                   \
+      r.x[j] = sw ? r.x[i] : r.x[j];                              \
+      r.x[i] = tx;                                                \
+      const uint32_t ty = sw ? r.y[j] : r.y[i];                   \
+      r.y[j] = sw ? r.y[i] : r.y[j];                              \
+      r.y[i] = ty;                                                \
+    }                                                             \
+  }
+template <uint32_t D, bool PACKED>
+__device__ __forceinline__ void to_wcross(to_wregs &r, const bool asc) {
+  /* the lane keeps the smaller of the two words when it is the lower lane of an ascending pair (or the upper of a
+   * descending one).  One compare: of two EQUAL words the lane that keeps the larger takes its partner's record and the
+   * other keeps its own - one record twice, one lost.  Equal words are padding (identical records) or the duplicate
+   * (sequence, row) that TO_F_DUP reports from the words, which stay what they were: the batch is then ordered again. */
+  const bool keep_max = ((lane_id() & D) == 0u) != asc;
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) {
+    const uint32_t pl = to_xl<D>((uint32_t)r.K[u]), ph = to_xl<D>((uint32_t)(r.K[u] >> 32));
+    const unsigned long long pK = ((unsigned long long)ph << 32) | pl;
+    const bool take = (pK < r.K[u]) != keep_max;
+    if constexpr (!PACKED) {
+      const uint32_t px = to_xl<D>(r.x[u]), py = to_xl<D>(r.y[u]);
+      r.x[u] = take ? px : r.x[u];
+      r.y[u] = take ? py : r.y[u];
+    }
+    r.K[u] = take ? pK : r.K[u];
+  }
+}
+template <bool PACKED>
+__device__ __forceinline__ void to_wlocal(to_wregs &r, const bool asc) { /* the steps at distances 4, 2, 1 */
+  const bool desc = !asc;
+  TO_WCE(0, 4) TO_WCE(1, 5) TO_WCE(2, 6) TO_WCE(3, 7)
+  TO_WCE(0, 2) TO_WCE(1, 3) TO_WCE(4, 6) TO_WCE(5, 7)
+  TO_WCE(0, 1) TO_WCE(2, 3) TO_WCE(4, 5) TO_WCE(6, 7)
+}
+template <bool PACKED>
+__device__ __forceinline__ void to_wsort(to_wregs &r) {
+  const uint32_t lane = lane_id();
+  {
+    const bool desc = (lane & 1u) != 0u; /* the lane's eight: Batcher's network, up in even lanes and down in odd ones */
+    TO_WCE(0, 1) TO_WCE(2, 3) TO_WCE(4, 5) TO_WCE(6, 7)
+    TO_WCE(0, 2) TO_WCE(1, 3) TO_WCE(4, 6) TO_WCE(5, 7)
+    TO_WCE(1, 2) TO_WCE(5, 6)
+    TO_WCE(0, 4) TO_WCE(1, 5) TO_WCE(2, 6) TO_WCE(3, 7)
+    TO_WCE(2, 4) TO_WCE(3, 5)
+    TO_WCE(1, 2) TO_WCE(3, 4) TO_WCE(5, 6)
+  }
+  bool asc = (lane & 2u) == 0u; /* runs of 16 */
+  to_wcross<1u, PACKED>(r, asc);
+  to_wlocal<PACKED>(r, asc);
+  asc = (lane & 4u) == 0u; /* 32 */
+  to_wcross<2u, PACKED>(r, asc);
+  to_wcross<1u, PACKED>(r, asc);
+  to_wlocal<PACKED>(r, asc);
+  asc = (lane & 8u) == 0u; /* 64 */
+  to_wcross<4u, PACKED>(r, asc);
+  to_wcross<2u, PACKED>(r, asc);
+  to_wcross<1u, PACKED>(r, asc);
+  to_wlocal<PACKED>(r, asc);
+  asc = (lane & 16u) == 0u; /* 128 */
+  to_wcross<8u, PACKED>(r, asc);
+  to_wcross<4u, PACKED>(r, asc);
+  to_wcross<2u, PACKED>(r, asc);
+  to_wcross<1u, PACKED>(r, asc);
+  to_wlocal<PACKED>(r, asc);
+  asc = (lane & 32u) == 0u; /* 256 */
+  to_wcross<16u, PACKED>(r, asc);
+  to_wcross<8u, PACKED>(r, asc);
+  to_wcross<4u, PACKED>(r, asc);
+  to_wcross<2u, PACKED>(r, asc);
+  to_wcross<1u, PACKED>(r, asc);
+  to_wlocal<PACKED>(r, asc);
+  asc = true; /* 512 */
+  to_wcross<32u, PACKED>(r, asc);
+  to_wcross<16u, PACKED>(r, asc);
+  to_wcross<8u, PACKED>(r, asc);
+  to_wcross<4u, PACKED>(r, asc);
+  to_wcross<2u, PACKED>(r, asc);
+  to_wcross<1u, PACKED>(r, asc);
+  to_wlocal<PACKED>(r, asc);
+}
+#define TO_WNW 4u /* waves (tiles) per workgroup */
+#define TO_WPACK_BITS 23u /* PACKED: sequence words below 2^23 (20-mers + NGG to three mismatches: 4.07 x 10^6) */
+/* PACKED: word << 41 | row << 9 | the record's place in load order - nothing travels with the 64 bits: five instructions
+ * per record and step instead of nine.  The keys wait in LDS (4 KB per wave) and are picked up by that place. */
+template <bool PACKED>
+__global__ __launch_bounds__(TO_WNW *WAVE) void k_to_wsort(gs_to_run_args a, const uint32_t n_tiles) {
+  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+  __shared__ uint2 s_key[TO_WNW * TO_WTILE]; /* 4 KB per wave: the keys while their words are ordered (PACKED), then the way to the stores' layout */
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
+  const uint32_t tile = blockIdx.x * TO_WNW + tid / WAVE;
+  uint4 t = make_uint4(0u, 0u, 0u, 0u);
+  if (tile < n_tiles) t = a.tiles[tile];
+  for (uint32_t i = tid; i < 32u * 8u; i += TO_WNW * WAVE) s_nt[i] = a.tab->n[i >> 3][i & 7u];
+  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
+  const unsigned long long pam_mul = a.tab->pam_mul;
+  __syncthreads(); /* (the only one: from here on each wave is by itself) */
+  const uint32_t n = t.z;
+  if (n == 0u || n > TO_WTILE) return;
+  const bool direct = (t.x & TO_DIRECT) != 0u;
+  const uint32_t sb = t.x & ~TO_DIRECT;
+  const uint32_t gset = sb >> 1, strand = sb & 1u;
+  const uint32_t g = a.list ? a.list[gset] : gset;
+  uint4 rec[8];
+  if (direct) {
+    const uint32_t item = 2u * g + strand, cb = a.cbase[sb];
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) {
+      const uint32_t i = lane + u * WAVE;
+      rec[u] = i < n ? *to_addr(a.src, item, cb, i) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  } else {
+    const uint4 *bucket = a.buckets + (size_t)t.y * TO_BU;
+#pragma unroll
+    for (uint32_t u = 0; u < 8u; ++u) {
+      const uint32_t i = lane + u * WAVE;
+      rec[u] = i < n ? bucket[i] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  const uint32_t relv = lane < 8u ? a.rel[(size_t)gset * 16u + 2u * lane + strand] : 0u;
+  const uint64_t first = a.offsets[g] + t.w;
+  uint2 *keys = s_key + (tid / WAVE) * TO_WTILE;
+  to_wregs r;
+  bool multi = false;
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) {
+    const uint32_t i = lane + u * WAVE;
+    const bool on = i < n;
+    r.x[u] = rec[u].x;
+    r.y[u] = rec[u].y;
+    if (direct) {
+      multi = multi || (on && rec[u].z != rec[u].w);
+      r.K[u] = on ? to_word(rec[u], a.L, a.P, s_nt, s_bs, pam_mul) : ~0ull;
+    } else {
+      r.K[u] = on ? ((unsigned long long)rec[u].w << 32) | rec[u].z : ~0ull; /* k_to_deal ranked it */
+    }
+    if constexpr (PACKED) {
+      keys[i] = make_uint2(rec[u].x, rec[u].y);
+      if (on) r.K[u] = ((r.K[u] >> 32) << 41) | ((r.K[u] & 0xFFFFFFFFull) << 9) | i;
+    }
+  }
+  if (multi) atomicOr(a.flags, TO_F_MULTIROW);
+  to_wsort<PACKED>(r);
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) { /* (the ordered records, in registers, before anything below starts: left to itself the compiler
+                                         sinks the network's last exchanges into the code that follows and keeps both sides of each) */
+    if constexpr (PACKED)
+      asm volatile("" : "+v"(r.K[u]));
+    else
+      asm volatile("" : "+v"(r.K[u]), "+v"(r.x[u]), "+v"(r.y[u]));
+  }
+  /* place 8 lane + u of the tile is in register u of lane `lane` */
+  constexpr uint32_t SH = PACKED ? 9u : 0u; /* word and row from here up */
+  const uint32_t p_lo = (uint32_t)__shfl_up((int)(uint32_t)r.K[7], 1), p_hi = (uint32_t)__shfl_up((int)(uint32_t)(r.K[7] >> 32), 1);
+  bool dup = lane != 0u && 8u * lane < n && ((((unsigned long long)p_hi << 32) | p_lo) >> SH) == (r.K[0] >> SH);
+  uint32_t row[8];
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) {
+    if (u != 0u) dup = dup || (8u * lane + u < n && (r.K[u] >> SH) == (r.K[u - 1u] >> SH));
+    row[u] = (uint32_t)(r.K[u] >> SH);
+    if constexpr (PACKED) {
+      const uint2 k = keys[(uint32_t)r.K[u] & (TO_WTILE - 1u)];
+      r.x[u] = k.x;
+      r.y[u] = k.y;
+    }
+  }
+  /* ... and goes to register q >> 6 of lane q & 63, through the wave's 4 KB of LDS (rows and low key words, then the
+   * high words), so that a store instruction writes 64 neighbouring hits: with each lane writing its own eight - 64
+   * sixteen-byte pieces 128 bytes apart per instruction - the kernel took 6.3 ms instead of 4.6 */
+  uint32_t *T = (uint32_t *)keys;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  *(uint4 *)(T + 8u * lane) = make_uint4(row[0], row[1], row[2], row[3]);
+  *(uint4 *)(T + 8u * lane + 4u) = make_uint4(row[4], row[5], row[6], row[7]);
+  *(uint4 *)(T + TO_WTILE + 8u * lane) = make_uint4(r.x[0], r.x[1], r.x[2], r.x[3]);
+  *(uint4 *)(T + TO_WTILE + 8u * lane + 4u) = make_uint4(r.x[4], r.x[5], r.x[6], r.x[7]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) {
+    row[u] = T[u * WAVE + lane];
+    r.x[u] = T[TO_WTILE + u * WAVE + lane];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  *(uint4 *)(T + 8u * lane) = make_uint4(r.y[0], r.y[1], r.y[2], r.y[3]);
+  *(uint4 *)(T + 8u * lane + 4u) = make_uint4(r.y[4], r.y[5], r.y[6], r.y[7]);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) r.y[u] = T[u * WAVE + lane];
+  const uint32_t *sa = a.sa[strand];
+  gs_hit *out = a.hits + first + lane;
+  uint32_t sav[8];
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) sav[u] = sa[u * WAVE + lane < n ? row[u] : 0u]; /* eight gathers in flight (padding reads entry 0) */
+#pragma unroll
+  for (uint32_t u = 0; u < 8u; ++u) {
+    const uint32_t rel = (uint32_t)__shfl((int)relv, (int)(r.y[u] >> 29));
+    const uint64_t sap = (uint64_t)sav[u] - ((r.x[u] & 1u) ? a.v_rem : 0u);
+    gs_hit o;
+    o.pos = strand == 0u ? -(int64_t)sap : (int64_t)(a.genome_length - (sap + 1ull));
+    o.key = (((unsigned long long)r.y[u] << 32) | r.x[u]) & ~1ull;
+    if (u * WAVE + lane < n) out[rel + u * WAVE] = o;
+  }
+  if (dup) atomicOr(a.flags, TO_F_DUP);
+}
+
 /* ---- host side ------------------------------------------------------------------------------------------------ */
-static bool to_make_tab(uint32_t L, uint32_t P, uint32_t m, gs_to_tab &tab) {
+static bool to_make_tab(uint32_t L, uint32_t P, uint32_t m, gs_to_tab &tab, unsigned long long *words = nullptr) {
   memset(&tab, 0, sizeof(tab));
   for (uint32_t a = 0; a < 32; a++)
     for (uint32_t r = 0; r < 8; r++) {
@@ -625,6 +1016,7 @@ static bool to_make_tab(uint32_t L, uint32_t P, uint32_t m, gs_to_tab &tab) {
       c64 += tab.n[L][j] * tab.pam_mul;
     }
   }
+  if (words) *words = c64; /* (exact when the function returns true) */
   return L >= 1 && 2 * L + 3 * P <= 59 && m <= 7 && cum < 4294967295.0L; /* the words stay below 2^32 - 1: all ones marks padding */
 }
 bool gs_tileorder_fits(uint32_t L, uint32_t P, uint32_t m) {
@@ -640,13 +1032,14 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   const uint32_t n_it = 2u * in.n_set;
   S = gs_tileorder_state();
   S.n_it = n_it;
-  if ((rc = gs_reserve(ix->w_t_plan, 4 * 4 * ((size_t)n_it + 1) + 64)) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_t_tab, sizeof(gs_to_tab) + 64)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_plan, 5 * 4 * ((size_t)n_it + 1) + 64)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_tab, sizeof(gs_to_tab) + 128)) != GS_OK) return rc;
   if ((rc = gs_reserve(ix->w_t_rel, 64 * ((size_t)in.n_set + 1))) != GS_OK) return rc;
   uint32_t *tbase = (uint32_t *)ix->w_t_plan.p, *bbase = tbase + (n_it + 1), *cbase = bbase + (n_it + 1), *gbase = cbase + (n_it + 1);
+  uint32_t *dbase = gbase + (n_it + 1);
   uint32_t *d_flags = (uint32_t *)((char *)ix->w_t_tab.p + sizeof(gs_to_tab));
   GS_HIP(hipMemcpyAsync(ix->w_t_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice, st));
-  GS_HIP(hipMemsetAsync(d_flags, 0, 64, st));
+  GS_HIP(hipMemsetAsync(d_flags, 0, 128, st));
   gs_to_plan_args pa;
   pa.counts = in.counts;
   pa.list = in.list;
@@ -656,13 +1049,15 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   pa.bbase = bbase;
   pa.cbase = cbase;
   pa.gbase = gbase;
+  pa.dbase = dbase;
   pa.flags = d_flags;
   hipLaunchKernelGGL(k_to_plan, dim3(1), dim3(1024), 0, st, pa);
-  uint32_t tot[4] = {0, 0, 0, 0}, h_flags = 0;
+  uint32_t tot[5] = {0, 0, 0, 0, 0}, h_flags = 0;
   GS_HIP(hipMemcpyAsync(&tot[0], tbase + n_it, 4, hipMemcpyDeviceToHost, st));
   GS_HIP(hipMemcpyAsync(&tot[1], bbase + n_it, 4, hipMemcpyDeviceToHost, st));
   GS_HIP(hipMemcpyAsync(&tot[2], cbase + n_it, 4, hipMemcpyDeviceToHost, st));
   GS_HIP(hipMemcpyAsync(&tot[3], gbase + n_it, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(&tot[4], dbase + n_it, 4, hipMemcpyDeviceToHost, st));
   GS_HIP(hipMemcpyAsync(&h_flags, d_flags, 4, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st)); /* (tab is a local, too) */
   if (h_flags) return GS_OK;
@@ -670,10 +1065,12 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   S.n_btiles = tot[1];
   S.n_chunks = tot[2];
   S.n_big = tot[3];
-  if ((rc = gs_reserve(ix->w_t_tiles, 16 * ((size_t)S.n_tiles + 1))) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_t_buckets, 16 * (size_t)TO_TILE * S.n_btiles + 16)) != GS_OK) return rc;
+  S.n_deal = tot[4];
+  if ((rc = gs_reserve(ix->w_t_tiles, (16 + 8) * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* descriptors, then the splitters */
+  if ((rc = gs_reserve(ix->w_t_buckets, 16 * (size_t)TO_BU * S.n_btiles + 16)) != GS_OK) return rc;
   if ((rc = gs_reserve(ix->w_t_chunkof, 4 * ((size_t)S.n_chunks + 1))) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_t_big, 4 * ((size_t)S.n_big + 1))) != GS_OK) return rc;
+  const size_t deal_at = (4 * ((size_t)S.n_big + 1) + 31) & ~(size_t)31; /* the list, then the deal map */
+  if ((rc = gs_reserve(ix->w_t_big, deal_at + 32 * ((size_t)S.n_deal + 1))) != GS_OK) return rc;
   gs_to_fill_args fa;
   fa.counts = in.counts;
   fa.cls = in.cls;
@@ -683,6 +1080,9 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   fa.tbase = tbase;
   fa.bbase = bbase;
   fa.gbase = gbase;
+  fa.dbase = dbase;
+  fa.dealmap = (uint4 *)((char *)ix->w_t_big.p + deal_at);
+  fa.cbase = cbase;
   fa.tiles = (uint4 *)ix->w_t_tiles.p;
   fa.biglist = (uint32_t *)ix->w_t_big.p;
   fa.rel = (uint32_t *)ix->w_t_rel.p;
@@ -724,6 +1124,8 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.bbase = bbase;
   ra.cbase = cbase;
   ra.biglist = (const uint32_t *)ix->w_t_big.p;
+  ra.dealmap = (const uint4 *)((const char *)ix->w_t_big.p + ((4 * ((size_t)S.n_big + 1) + 31) & ~(size_t)31));
+  ra.spl = (unsigned long long *)((char *)ix->w_t_tiles.p + 16 * ((size_t)S.n_tiles + 1));
   ra.tiles = (uint4 *)ix->w_t_tiles.p;
   ra.buckets = (uint4 *)ix->w_t_buckets.p;
   ra.tab = (const gs_to_tab *)ix->w_t_tab.p;
@@ -738,13 +1140,25 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.P = in.P;
   ra.v_rem = in.v_rem;
   ra.sample_per = getenv("GS_TILE_SAMPLE_PER") ? (uint32_t)std::max(1l, atol(getenv("GS_TILE_SAMPLE_PER"))) : 0u;
-  if (S.n_big) hipLaunchKernelGGL(k_to_partition, dim3(S.n_big), dim3(TO_NT), 0, st, ra);
+  if (S.n_big) {
+    hipLaunchKernelGGL(k_to_splitters, dim3(S.n_big), dim3(TO_NT), 0, st, ra);
+    hipLaunchKernelGGL(k_to_deal, dim3(S.n_deal), dim3(TO_NT), 0, st, ra);
+    hipLaunchKernelGGL(k_to_bucketsum, dim3((S.n_big + 3u) / 4u), dim3(256), 0, st, ra, S.n_big);
+  }
   if (S.n_tiles) {
-    hipLaunchKernelGGL(k_to_sort<128u>, dim3(S.n_tiles), dim3(128), 0, st, ra, 0u);
+    /* (the table's words count both indexes' classes: tab.base[7] + the last class = every word of the batch) */
+    gs_to_tab tab;
+    unsigned long long words = ~0ull;
+    to_make_tab(in.L, in.P, in.m, tab, &words);
+    if (words < (1ull << TO_WPACK_BITS) && !getenv("GS_TILE_NO_PACK"))
+      hipLaunchKernelGGL(k_to_wsort<true>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
+    else
+      hipLaunchKernelGGL(k_to_wsort<false>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
+    hipLaunchKernelGGL(k_to_sort<128u>, dim3(S.n_tiles), dim3(128), 0, st, ra, TO_WTILE);
     hipLaunchKernelGGL(k_to_sort<TO_NT>, dim3(S.n_tiles), dim3(TO_NT), 0, st, ra, 128u * TO_KPT);
   }
-  uint32_t h[16] = {0};
-  GS_HIP(hipMemcpyAsync(h, d_flags, 64, hipMemcpyDeviceToHost, st));
+  uint32_t h[32] = {0};
+  GS_HIP(hipMemcpyAsync(h, d_flags, sizeof(h), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
 #ifdef TO_PROFILE
   {
