@@ -36,6 +36,7 @@
 #define TO_NBMAX 1024u             /* buckets of one item */
 #define TO_BU 128u                 /* bucket slots are handed out in units of 128 records */
 #define TO_DEAL 2048u              /* records one workgroup of k_to_deal deals into buckets */
+#define TO_WTILE 512u              /* records one wave orders in registers (k_to_wsort) */
 #define TO_DIRECT 0x80000000u
 
 /* flags raised by the kernels (gs_tileorder_run) */
@@ -320,6 +321,7 @@ struct gs_to_fill_args {
   const uint32_t *counts, *cls, *list;
   uint32_t n_it, cap;
   const uint32_t *tbase, *bbase, *gbase, *dbase;
+  uint32_t *slow[2], *slow_n; /* tiles beyond one wave's 512 records: lists (to 1,024 records; beyond) and their lengths */
   uint4 *dealmap;    /* per stretch of TO_DEAL records, two words: {set item, first record, records of the item, first tile},
                         {first bucket unit, first chunk-index entry, item of the batch, 0} - all k_to_deal needs to start */
   const uint32_t *cbase;
@@ -338,7 +340,13 @@ __global__ __launch_bounds__(256) void k_to_fill(gs_to_fill_args a) {
   const uint32_t c = a.counts[item];
   uint32_t su;
   const uint32_t nb = to_buckets(c, su), tb = a.tbase[sb];
-  if (c != 0u && nb == 0u) a.tiles[tb] = make_uint4(sb | TO_DIRECT, 0u, c, 0u);
+  if (c != 0u && nb == 0u) {
+    a.tiles[tb] = make_uint4(sb | TO_DIRECT, 0u, c, 0u);
+    if (c > TO_WTILE) {
+      const uint32_t k = c > 128u * TO_KPT ? 1u : 0u;
+      a.slow[k][atomicAdd(&a.slow_n[k], 1u)] = tb;
+    }
+  }
   if (nb != 0u && nb <= TO_NBMAX) {
     const uint32_t bb = a.bbase[sb];
     for (uint32_t b = 0; b < nb; ++b) a.tiles[tb + b] = make_uint4(sb, bb + b * su, 0u, 0u);
@@ -410,6 +418,7 @@ struct gs_to_run_args {
   const uint32_t *biglist;
   const uint4 *dealmap;
   unsigned long long *spl; /* [n_tiles]: entry tbase + b = splitter b of the item */
+  uint32_t *slow[2], *slow_n;
   uint4 *tiles;
   uint4 *buckets;
   const gs_to_tab *tab;
@@ -604,6 +613,10 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
       a.tiles[tb + b].z = n < slots ? n : slots;
       a.tiles[tb + b].w = run;
       run += n;
+      if (n > TO_WTILE) { /* (one bucket in twenty) */
+        const uint32_t k = n > 128u * TO_KPT ? 1u : 0u;
+        a.slow[k][atomicAdd(&a.slow_n[k], 1u)] = tb + b;
+      }
     }
   }
   if (over) atomicOr(a.flags, TO_F_BUCKET);
@@ -612,10 +625,11 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
 /* ---- one tile: order its records in LDS and write its hits -------------------------------------------------------- */
 /* NT threads, tiles of NT x 8 records at most: 512 for the tiles proper, 128 for the many small ones (an m <= 5 batch is
  * 2 x 10^5 items of ~700 records: in a workgroup of 512 a merge round keeps 90 threads busy and seven waves wait at its
- * barriers; 12 KB of LDS instead of 47: twelve workgroups per CU).  Both are launched over the whole tile list, each
- * takes its size class (lo < n <= NT x 8). */
+ * barriers; 12 KB of LDS instead of 47: twelve workgroups per CU).  Since k_to_wsort they take the tiles of more than 512
+ * records only, each from its list (k_to_fill and k_to_bucketsum write them; launched over all tiles to pick their own,
+ * 1.7 x 10^6 workgroups that leave at once cost 1.5 ms). */
 template <uint32_t NT>
-__global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t lo) {
+__global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t *list) {
   constexpr uint32_t CAP = NT * TO_KPT, LDSN = CAP + CAP / 8u;
   __shared__ unsigned long long s_keys[LDSN];
   __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
@@ -626,9 +640,9 @@ __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t
   const uint32_t tid = threadIdx.x;
   /* one workgroup per tile (persistent workgroups looping over the tiles were tried: the loop took the kernel from 71
    * to 156 registers, one workgroup per CU instead of three, 22 ms instead of 9) */
-  const uint4 t = a.tiles[blockIdx.x];
+  const uint4 t = a.tiles[list[blockIdx.x]];
   const uint32_t n = t.z;
-  if (n <= lo || n > CAP) return;
+  if (n > CAP) return; /* (cannot happen: the lists are made by size) */
 #ifdef TO_PROFILE
   const unsigned long long tp0 = wall_clock64();
 #endif
@@ -757,7 +771,6 @@ __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t
  * independent records each - no LDS array, no barrier, no read that waits for a compare: the workgroup form above
  * spends its time in the merge rounds' chains of dependent LDS reads (nine rounds of up to twenty) with three tiles
  * resident per CU; this one keeps eight tiles per SIMD going.  Padding places hold words of all ones. */
-#define TO_WTILE 512u
 template <uint32_t D>
 __device__ __forceinline__ uint32_t to_xl(const uint32_t v) { /* v of lane ^ D */
   if constexpr (D == 1u)
@@ -1033,13 +1046,13 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   S = gs_tileorder_state();
   S.n_it = n_it;
   if ((rc = gs_reserve(ix->w_t_plan, 5 * 4 * ((size_t)n_it + 1) + 64)) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_t_tab, sizeof(gs_to_tab) + 128)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_tab, sizeof(gs_to_tab) + 192)) != GS_OK) return rc; /* the table, flags (128 bytes), list lengths */
   if ((rc = gs_reserve(ix->w_t_rel, 64 * ((size_t)in.n_set + 1))) != GS_OK) return rc;
   uint32_t *tbase = (uint32_t *)ix->w_t_plan.p, *bbase = tbase + (n_it + 1), *cbase = bbase + (n_it + 1), *gbase = cbase + (n_it + 1);
   uint32_t *dbase = gbase + (n_it + 1);
   uint32_t *d_flags = (uint32_t *)((char *)ix->w_t_tab.p + sizeof(gs_to_tab));
   GS_HIP(hipMemcpyAsync(ix->w_t_tab.p, &tab, sizeof(tab), hipMemcpyHostToDevice, st));
-  GS_HIP(hipMemsetAsync(d_flags, 0, 128, st));
+  GS_HIP(hipMemsetAsync(d_flags, 0, 192, st));
   gs_to_plan_args pa;
   pa.counts = in.counts;
   pa.list = in.list;
@@ -1068,7 +1081,7 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   S.n_deal = tot[4];
   if ((rc = gs_reserve(ix->w_t_tiles, (16 + 8) * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* descriptors, then the splitters */
   if ((rc = gs_reserve(ix->w_t_buckets, 16 * (size_t)TO_BU * S.n_btiles + 16)) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_t_chunkof, 4 * ((size_t)S.n_chunks + 1))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_chunkof, 4 * ((size_t)S.n_chunks + 1) + 8 * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* the chunk index, then the two lists */
   const size_t deal_at = (4 * ((size_t)S.n_big + 1) + 31) & ~(size_t)31; /* the list, then the deal map */
   if ((rc = gs_reserve(ix->w_t_big, deal_at + 32 * ((size_t)S.n_deal + 1))) != GS_OK) return rc;
   gs_to_fill_args fa;
@@ -1082,6 +1095,9 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   fa.gbase = gbase;
   fa.dbase = dbase;
   fa.dealmap = (uint4 *)((char *)ix->w_t_big.p + deal_at);
+  fa.slow[0] = (uint32_t *)ix->w_t_chunkof.p + (S.n_chunks + 1);
+  fa.slow[1] = fa.slow[0] + (S.n_tiles + 1);
+  fa.slow_n = d_flags + 32;
   fa.cbase = cbase;
   fa.tiles = (uint4 *)ix->w_t_tiles.p;
   fa.biglist = (uint32_t *)ix->w_t_big.p;
@@ -1126,6 +1142,9 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.biglist = (const uint32_t *)ix->w_t_big.p;
   ra.dealmap = (const uint4 *)((const char *)ix->w_t_big.p + ((4 * ((size_t)S.n_big + 1) + 31) & ~(size_t)31));
   ra.spl = (unsigned long long *)((char *)ix->w_t_tiles.p + 16 * ((size_t)S.n_tiles + 1));
+  ra.slow[0] = (uint32_t *)ix->w_t_chunkof.p + (S.n_chunks + 1);
+  ra.slow[1] = ra.slow[0] + (S.n_tiles + 1);
+  ra.slow_n = d_flags + 32;
   ra.tiles = (uint4 *)ix->w_t_tiles.p;
   ra.buckets = (uint4 *)ix->w_t_buckets.p;
   ra.tab = (const gs_to_tab *)ix->w_t_tab.p;
@@ -1146,7 +1165,13 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
     hipLaunchKernelGGL(k_to_bucketsum, dim3((S.n_big + 3u) / 4u), dim3(256), 0, st, ra, S.n_big);
   }
   if (S.n_tiles) {
-    /* (the table's words count both indexes' classes: tab.base[7] + the last class = every word of the batch) */
+    /* the tiles one wave cannot take: how many is known once the buckets are counted - the host waits for that number
+     * alone (an event behind its copy) while k_to_wsort runs */
+    uint32_t n_slow[2] = {0u, 0u};
+    hipEvent_t ev;
+    GS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    GS_HIP(hipMemcpyAsync(n_slow, ra.slow_n, 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipEventRecord(ev, st));
     gs_to_tab tab;
     unsigned long long words = ~0ull;
     to_make_tab(in.L, in.P, in.m, tab, &words);
@@ -1154,8 +1179,11 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
       hipLaunchKernelGGL(k_to_wsort<true>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
     else
       hipLaunchKernelGGL(k_to_wsort<false>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
-    hipLaunchKernelGGL(k_to_sort<128u>, dim3(S.n_tiles), dim3(128), 0, st, ra, TO_WTILE);
-    hipLaunchKernelGGL(k_to_sort<TO_NT>, dim3(S.n_tiles), dim3(TO_NT), 0, st, ra, 128u * TO_KPT);
+    const hipError_t ee = hipEventSynchronize(ev);
+    (void)hipEventDestroy(ev);
+    GS_HIP(ee);
+    if (n_slow[0]) hipLaunchKernelGGL(k_to_sort<128u>, dim3(n_slow[0]), dim3(128), 0, st, ra, (const uint32_t *)ra.slow[0]);
+    if (n_slow[1]) hipLaunchKernelGGL(k_to_sort<TO_NT>, dim3(n_slow[1]), dim3(TO_NT), 0, st, ra, (const uint32_t *)ra.slow[1]);
   }
   uint32_t h[32] = {0};
   GS_HIP(hipMemcpyAsync(h, d_flags, sizeof(h), hipMemcpyDeviceToHost, st));
