@@ -1016,12 +1016,16 @@ extern "C" gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out) {
 
 gs_status gs_reserve(gs_buffer &b, size_t bytes) {
   if (b.cap >= bytes && b.p) return GS_OK;
+  if (bytes > ((size_t)1 << 30) && getenv("GS_DEBUG"))
+    fprintf(stderr, "[gs] workspace buffer grows from %.2f to %.2f GiB\n", (double)b.cap / (1 << 30), (double)bytes / (1 << 30));
+  const bool again = b.p != nullptr && b.cap > ((size_t)1 << 30);
   if (b.p) hipFree(b.p);
   b.p = nullptr;
   b.cap = 0;
   /* room to grow without another allocation: a quarter on top, a sixteenth for buffers beyond 1 GiB
-   * (the workspace of a repeat-rich batch is tens of GB next to a 220 GB index) */
-  size_t want = bytes + (bytes > ((size_t)1 << 30) ? bytes / 16 : bytes / 4) + 256;
+   * (the workspace of a repeat-rich batch is tens of GB next to a 220 GB index) - and an eighth when such a buffer grows
+   * a second time: batches of one kind differ by several per cent, and freeing and allocating 30 GB takes a second */
+  size_t want = bytes + (bytes > ((size_t)1 << 30) ? (again ? bytes / 8 : bytes / 16) : bytes / 4) + 256;
   if (hipMalloc(&b.p, want) != hipSuccess) {
     (void)hipGetLastError(); /* or the next call that reports the last error (rocPRIM does) fails with this one */
     if (hipMalloc(&b.p, bytes) != hipSuccess) {

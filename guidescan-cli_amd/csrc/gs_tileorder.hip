@@ -35,6 +35,8 @@
 #define TO_TILE (TO_NT * TO_KPT)   /* 4,096 records per tile */
 #define TO_NBMAX 1024u             /* buckets of one item */
 #define TO_BU 128u                 /* bucket slots are handed out in units of 128 records */
+#define TO_SNT 1024u               /* threads of k_to_splitters */
+#define TO_SAMPLE (TO_SNT * TO_KPT) /* 8,192: the largest sample of an item */
 #define TO_DEAL 2048u              /* records one workgroup of k_to_deal deals into buckets */
 #define TO_WTILE 512u              /* records one wave orders in registers (k_to_wsort) */
 #define TO_DIRECT 0x80000000u
@@ -53,44 +55,46 @@ struct gs_to_tab {
 };
 
 /* rank of a key's match.sequence among the sequences of its mismatch class: position 0 most significant, as
- * the key's own bits order them (the same number gs_search.hip's big2_rank computes) */
-__device__ __forceinline__ unsigned long long to_rank(const unsigned long long key, const uint32_t L, const uint32_t P,
-                                                       const unsigned long long *nt, const unsigned long long pam_mul) {
+ * the key's own bits order them (the same number gs_search.hip's big2_rank computes).  32-bit arithmetic: the path is
+ * only taken when every word of the batch is below 2^32 - 1 (to_make_tab), so are the table entries a record within
+ * the batch's mismatch limit can reach - the kernels keep the table's low words. */
+__device__ __forceinline__ uint32_t to_rank(const unsigned long long key, const uint32_t L, const uint32_t P, const uint32_t *nt,
+                                            const uint32_t pam_mul) {
   const unsigned long long path = (key >> 1) & ((1ull << 59) - 1ull); /* key bits 59:1 */
   /* the guide's L two-bit fields, position 0 in the highest: only the substituted ones (at most seven) count */
   const unsigned long long gb = path >> (59u - 2u * L);
   unsigned long long nz = (gb | (gb >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
   uint32_t r = (uint32_t)__popcll(nz);
   if (r > 7u) r = 7u;
-  unsigned long long rank = 0;
+  uint32_t rank = 0;
   while (nz != 0ull && r != 0u) {
     const uint32_t hb = 63u - (uint32_t)__builtin_clzll(nz); /* = 2 x the positions behind this one */
     const uint32_t c = (uint32_t)(gb >> hb) & 3u, a = hb >> 1;
     /* smaller sequences with the same prefix: a 0 here (r substitutions behind), or one of the c-1 lower codes */
-    rank += nt[a * 8u + r] + (unsigned long long)(c - 1u) * nt[a * 8u + r - 1u];
+    const uint32_t n0 = nt[a * 8u + r - 1u];
+    rank += nt[a * 8u + r] + (c == 2u ? n0 : c == 3u ? 2u * n0 : 0u);
     r--;
     nz &= ~(1ull << hb);
   }
-  unsigned long long pr = 0;
+  uint32_t pr = 0;
   for (uint32_t u = 0; u < P; u++) {
     const uint32_t c = (uint32_t)(path >> (56u - 2u * L - 3u * u)) & 7u;
-    pr = pr * 5ull + (c < 4u ? c : 4u);
+    pr = pr * 5u + (c < 4u ? c : 4u);
   }
   return rank * pam_mul + pr;
 }
-__device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uint32_t L, const uint32_t P, const unsigned long long *nt,
-                                                       const unsigned long long *bs, const unsigned long long pam_mul) {
+__device__ __forceinline__ unsigned long long to_word(const uint4 rec, const uint32_t L, const uint32_t P, const uint32_t *nt,
+                                                       const uint32_t *bs, const uint32_t pam_mul) {
   const unsigned long long key = ((unsigned long long)rec.y << 32) | rec.x;
-  const unsigned long long w = bs[(uint32_t)(key >> 61)] + to_rank(key, L, P, nt, pam_mul);
-  return (w << 32) | rec.z;
+  const uint32_t w = bs[rec.y >> 29] + to_rank(key, L, P, nt, pam_mul);
+  return ((unsigned long long)w << 32) | rec.z;
 }
-
 /* four records at once, step by step: the rank loop reads its table through a chain of LDS reads, each waiting for
  * the one before - four chains side by side hide three quarters of that wait (the dealing pass was bound by it) */
-__device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L, const uint32_t P, const unsigned long long *nt,
-                                         const unsigned long long *bs, const unsigned long long pam_mul, unsigned long long (&K)[4]) {
-  unsigned long long gb[4], nz[4], rank[4], path[4];
-  uint32_t r[4];
+__device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L, const uint32_t P, const uint32_t *nt, const uint32_t *bs,
+                                         const uint32_t pam_mul, unsigned long long (&K)[4]) {
+  unsigned long long gb[4], nz[4], path[4];
+  uint32_t r[4], rank[4];
 #pragma unroll
   for (uint32_t u = 0; u < 4u; ++u) {
     const unsigned long long key = ((unsigned long long)rec[u].y << 32) | rec[u].x;
@@ -99,7 +103,7 @@ __device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L
     nz[u] = (gb[u] | (gb[u] >> 1)) & 0x5555555555555555ull & ((1ull << (2u * L)) - 1ull);
     r[u] = (uint32_t)__popcll(nz[u]);
     if (r[u] > 7u) r[u] = 7u;
-    rank[u] = 0ull;
+    rank[u] = 0u;
   }
   for (;;) {
     bool any = false;
@@ -108,9 +112,9 @@ __device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L
       const bool go = nz[u] != 0ull && r[u] != 0u;
       const uint32_t hb = go ? 63u - (uint32_t)__builtin_clzll(nz[u]) : 0u;
       const uint32_t c = (uint32_t)(gb[u] >> hb) & 3u, a = hb >> 1;
-      const unsigned long long n1 = nt[a * 8u + (go ? r[u] : 1u)], n0 = nt[a * 8u + (go ? r[u] : 1u) - 1u];
+      const uint32_t n1 = nt[a * 8u + (go ? r[u] : 1u)], n0 = nt[a * 8u + (go ? r[u] : 1u) - 1u];
       if (go) {
-        rank[u] += n1 + (unsigned long long)(c - 1u) * n0;
+        rank[u] += n1 + (c == 2u ? n0 : c == 3u ? 2u * n0 : 0u);
         r[u]--;
         nz[u] &= ~(1ull << hb);
       }
@@ -120,13 +124,13 @@ __device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L
   }
 #pragma unroll
   for (uint32_t u = 0; u < 4u; ++u) {
-    unsigned long long pr = 0;
+    uint32_t pr = 0;
     for (uint32_t q = 0; q < P; q++) {
       const uint32_t c = (uint32_t)(path[u] >> (56u - 2u * L - 3u * q)) & 7u;
-      pr = pr * 5ull + (c < 4u ? c : 4u);
+      pr = pr * 5u + (c < 4u ? c : 4u);
     }
-    const unsigned long long w = bs[rec[u].y >> 29] + rank[u] * pam_mul + pr;
-    K[u] = (w << 32) | rec[u].z;
+    const uint32_t w = bs[rec[u].y >> 29] + rank[u] * pam_mul + pr;
+    K[u] = ((unsigned long long)w << 32) | rec[u].z;
   }
 }
 
@@ -242,25 +246,23 @@ struct gs_to_plan_args {
 };
 /* buckets of an item of c > TO_TILE records: how many, and the slot each gets (su units of TO_BU records).  The
  * buckets aim below the 512 records one wave orders in registers (k_to_wsort); what a splitter's luck makes larger is a
- * tile of the workgroup kernels.  An item affords TO_TILE samples in all: the fewer per splitter, the wider a bucket's
+ * tile of the workgroup kernels.  An item affords TO_SAMPLE samples in all: the fewer per splitter, the wider a bucket's
  * size spreads (a gamma distribution of that shape) and the more room its slot has over the aim - every row keeps the
- * chance of one bucket outgrowing its slot below 10^-10 (32 samples: 2.9 x the aim; 16: 4; 8: 6.2; 4: 8).  No more than 32
+ * chance of one bucket outgrowing its slot below 10^-10 (32 samples: 2.9 x the aim; 16: 4; 8: 6.2).  No more than 32
  * samples per splitter: ordering the sample is itself a sort of ns words per item (64 per splitter, 4,096 for an item of
  * 24,000 records, cost a third of what ordering the records costs). */
 __device__ __host__ __forceinline__ uint32_t to_buckets(const uint32_t c, uint32_t &su) {
   su = 0u;
   if (c <= TO_TILE) return 0u;
   uint32_t target;
-  if (c <= 128u * 400u)
+  if (c <= 256u * 400u)
     target = 400u, su = 9u; /* 32 samples per splitter: one bucket in twenty grows past 512 */
-  else if (c <= 256u * 320u)
+  else if (c <= 512u * 320u)
     target = 320u, su = 10u; /* 16 */
-  else if (c <= 512u * 288u)
+  else if (c <= 1024u * 288u)
     target = 288u, su = 14u; /* 8 */
-  else if (c <= 1024u * 256u)
-    target = 256u, su = 16u; /* 4 */
   else
-    target = 512u, su = 32u; /* (to half a million records: 1,024 buckets) */
+    target = 512u, su = 25u; /* 8 (to half a million records: 1,024 buckets) */
   return (c + target - 1u) / target;
 }
 __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
@@ -441,20 +443,20 @@ struct gs_to_run_args {
  * every item's 336 went into its own stream loop, twenty-two passes of chained LDS reads with three workgroups per
  * CU to hide them, and the kernel ended when the largest item did.) */
 __device__ __forceinline__ uint32_t to_sample_per(const gs_to_run_args &a, const uint32_t nb) {
-  uint32_t per = TO_TILE / nb < 32u ? TO_TILE / nb : 32u; /* samples per bucket */
+  uint32_t per = TO_SAMPLE / nb < 32u ? TO_SAMPLE / nb : 32u; /* samples per bucket */
   if (a.sample_per != 0u && a.sample_per < per) per = a.sample_per; /* tests: a sample too small to keep the buckets within their slots */
   return per;
 }
 __device__ __forceinline__ uint32_t to_slots(const gs_to_run_args &a, const uint32_t su) {
   return a.sample_per == 1u ? su * TO_BU / 4u : su * TO_BU; /* tests: at one word per splitter, a quarter of the slots - certain to overflow */
 }
-__global__ __launch_bounds__(TO_NT) void k_to_splitters(gs_to_run_args a) {
-  __shared__ unsigned long long s_keys[TO_LDS];
-  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+__global__ __launch_bounds__(TO_SNT) void k_to_splitters(gs_to_run_args a) {
+  __shared__ unsigned long long s_keys[TO_SAMPLE + TO_SAMPLE / 8u];
+  __shared__ uint32_t s_nt[32 * 8], s_bs[8];
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
-  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
-  const unsigned long long pam_mul = a.tab->pam_mul;
+  for (uint32_t i = tid; i < 32u * 8u; i += TO_SNT) s_nt[i] = (uint32_t)a.tab->n[i >> 3][i & 7u];
+  if (tid < 8u) s_bs[tid] = (uint32_t)a.tab->base[tid];
+  const uint32_t pam_mul = (uint32_t)a.tab->pam_mul;
   const uint32_t sb = a.biglist[blockIdx.x];
   const uint32_t g = a.list ? a.list[sb >> 1] : (sb >> 1);
   const uint32_t item = 2u * g + (sb & 1u);
@@ -466,10 +468,10 @@ __global__ __launch_bounds__(TO_NT) void k_to_splitters(gs_to_run_args a) {
   const uint32_t per = to_sample_per(a, nb), ns = per * nb;
   __syncthreads();
   {
-    uint4 srec[TO_KPT]; /* (ns <= TO_TILE: eight per thread, all asked for before the first is ranked) */
+    uint4 srec[TO_KPT]; /* (ns <= TO_SAMPLE: eight per thread, all asked for before the first is ranked) */
 #pragma unroll
     for (uint32_t q = 0; q < TO_KPT; ++q) {
-      const uint32_t j = tid + q * TO_NT;
+      const uint32_t j = tid + q * TO_SNT;
       srec[q] = make_uint4(0u, 0u, 0u, 0u);
       if (j < ns) {
         const uint32_t lo = (uint32_t)(((unsigned long long)j * c) / ns), hi = (uint32_t)(((unsigned long long)(j + 1u) * c) / ns);
@@ -477,30 +479,30 @@ __global__ __launch_bounds__(TO_NT) void k_to_splitters(gs_to_run_args a) {
         h ^= h >> 15;
         h *= 2246822519u;
         h ^= h >> 13;
-        const uint32_t pos = lo + h % (hi - lo); /* hi > lo: c > TO_TILE >= ns */
+        const uint32_t pos = lo + h % (hi - lo); /* hi > lo: c > TO_TILE, ns <= 32 (c / 400 + 1) */
         srec[q] = *to_addr(a.src, item, cb, pos);
       }
     }
 #pragma unroll
     for (uint32_t q = 0; q < TO_KPT; ++q) {
-      const uint32_t j = tid + q * TO_NT;
+      const uint32_t j = tid + q * TO_SNT;
       if (j < ns) s_keys[TO_AT(j)] = to_word(srec[q], a.L, a.P, s_nt, s_bs, pam_mul);
     }
   }
   __syncthreads();
   to_msort<false>(s_keys, nullptr, ns);
-  for (uint32_t b = tid; b + 1u < nb; b += TO_NT) a.spl[tb + b] = s_keys[TO_AT((b + 1u) * per - 1u)];
+  for (uint32_t b = tid; b + 1u < nb; b += TO_SNT) a.spl[tb + b] = s_keys[TO_AT((b + 1u) * per - 1u)];
 }
 
 __global__ __launch_bounds__(TO_NT) void k_to_deal(gs_to_run_args a) {
   __shared__ unsigned long long s_spl[TO_NBMAX];
-  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+  __shared__ uint32_t s_nt[32 * 8], s_bs[8];
   __shared__ uint32_t s_cnt[TO_NBMAX];
   __shared__ uint32_t s_chunk[4];
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
-  for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
-  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
-  const unsigned long long pam_mul = a.tab->pam_mul;
+  for (uint32_t i = tid; i < 32u * 8u; i += TO_NT) s_nt[i] = (uint32_t)a.tab->n[i >> 3][i & 7u];
+  if (tid < 8u) s_bs[tid] = (uint32_t)a.tab->base[tid];
+  const uint32_t pam_mul = (uint32_t)a.tab->pam_mul;
   const uint4 d0 = a.dealmap[2u * blockIdx.x], d1 = a.dealmap[2u * blockIdx.x + 1u]; /* (one read, then everything else at once) */
   const uint32_t i_lo = d0.y, c = d0.z, tb = d0.w, bb = d1.x, cb = d1.y, item = d1.z;
   uint32_t su;
@@ -576,6 +578,8 @@ __global__ __launch_bounds__(TO_NT) void k_to_deal(gs_to_run_args a) {
     s_cnt[b] = n ? atomicAdd(&a.tiles[tb + b].z, n) : 0u;
   }
   __syncthreads();
+  /* (staged through LDS first, so that neighbouring threads write neighbouring records of a bucket - sixteen in a row on
+   * average -, the kernel took 5.2 ms instead of 4.2: three more barriers, and 256 bytes are still a short row) */
   uint4 *out = a.buckets + (size_t)bb * TO_BU;
 #pragma unroll
   for (uint32_t u = 0; u < 4u; ++u) {
@@ -632,7 +636,7 @@ template <uint32_t NT>
 __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t *list) {
   constexpr uint32_t CAP = NT * TO_KPT, LDSN = CAP + CAP / 8u;
   __shared__ unsigned long long s_keys[LDSN];
-  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+  __shared__ uint32_t s_nt[32 * 8], s_bs[8];
   __shared__ uint16_t s_idx[LDSN];
   __shared__ uint32_t s_rel[8];
   __shared__ unsigned long long s_first;
@@ -674,9 +678,9 @@ __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t
   bool multi = false;
   uint2 kx[TO_KPT]; /* the records' keys, in load order: they wait in registers while the words are ordered */
   if (direct) {
-    for (uint32_t i = tid; i < 32u * 8u; i += NT) s_nt[i] = a.tab->n[i >> 3][i & 7u];
-    if (tid < 8u) s_bs[tid] = a.tab->base[tid];
-    const unsigned long long pam_mul = a.tab->pam_mul;
+    for (uint32_t i = tid; i < 32u * 8u; i += NT) s_nt[i] = (uint32_t)a.tab->n[i >> 3][i & 7u];
+    if (tid < 8u) s_bs[tid] = (uint32_t)a.tab->base[tid];
+    const uint32_t pam_mul = (uint32_t)a.tab->pam_mul;
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < TO_KPT; ++u) {
@@ -887,15 +891,15 @@ __device__ __forceinline__ void to_wsort(to_wregs &r) {
  * per record and step instead of nine.  The keys wait in LDS (4 KB per wave) and are picked up by that place. */
 template <bool PACKED>
 __global__ __launch_bounds__(TO_WNW *WAVE) void k_to_wsort(gs_to_run_args a, const uint32_t n_tiles) {
-  __shared__ unsigned long long s_nt[32 * 8], s_bs[8];
+  __shared__ uint32_t s_nt[32 * 8], s_bs[8];
   __shared__ uint2 s_key[TO_WNW * TO_WTILE]; /* 4 KB per wave: the keys while their words are ordered (PACKED), then the way to the stores' layout */
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
   const uint32_t tile = blockIdx.x * TO_WNW + tid / WAVE;
   uint4 t = make_uint4(0u, 0u, 0u, 0u);
   if (tile < n_tiles) t = a.tiles[tile];
-  for (uint32_t i = tid; i < 32u * 8u; i += TO_WNW * WAVE) s_nt[i] = a.tab->n[i >> 3][i & 7u];
-  if (tid < 8u) s_bs[tid] = a.tab->base[tid];
-  const unsigned long long pam_mul = a.tab->pam_mul;
+  for (uint32_t i = tid; i < 32u * 8u; i += TO_WNW * WAVE) s_nt[i] = (uint32_t)a.tab->n[i >> 3][i & 7u];
+  if (tid < 8u) s_bs[tid] = (uint32_t)a.tab->base[tid];
+  const uint32_t pam_mul = (uint32_t)a.tab->pam_mul;
   __syncthreads(); /* (the only one: from here on each wave is by itself) */
   const uint32_t n = t.z;
   if (n == 0u || n > TO_WTILE) return;
@@ -1160,7 +1164,7 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.v_rem = in.v_rem;
   ra.sample_per = getenv("GS_TILE_SAMPLE_PER") ? (uint32_t)std::max(1l, atol(getenv("GS_TILE_SAMPLE_PER"))) : 0u;
   if (S.n_big) {
-    hipLaunchKernelGGL(k_to_splitters, dim3(S.n_big), dim3(TO_NT), 0, st, ra);
+    hipLaunchKernelGGL(k_to_splitters, dim3(S.n_big), dim3(TO_SNT), 0, st, ra);
     hipLaunchKernelGGL(k_to_deal, dim3(S.n_deal), dim3(TO_NT), 0, st, ra);
     hipLaunchKernelGGL(k_to_bucketsum, dim3((S.n_big + 3u) / 4u), dim3(256), 0, st, ra, S.n_big);
   }
