@@ -617,10 +617,17 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
       a.tiles[tb + b].z = n < slots ? n : slots;
       a.tiles[tb + b].w = run;
       run += n;
-      if (n > TO_WTILE) { /* (one bucket in twenty) */
-        const uint32_t k = n > 128u * TO_KPT ? 1u : 0u;
-        a.slow[k][atomicAdd(&a.slow_n[k], 1u)] = tb + b;
-      }
+    }
+    /* (one bucket in twenty: a place on its list, one atomic per wave and list) */
+    const uint32_t n = b < nb ? a.tiles[tb + b].z : 0u;
+    for (uint32_t k = 0; k < 2u; ++k) {
+      const bool mine = n > TO_WTILE && (n > 128u * TO_KPT) == (k == 1u);
+      const unsigned long long m = __ballot(mine);
+      if (m == 0ull) continue;
+      uint32_t base = 0;
+      if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&a.slow_n[k], (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m));
+      if (mine) a.slow[k][base + lanes_below(m)] = tb + b;
     }
   }
   if (over) atomicOr(a.flags, TO_F_BUCKET);
