@@ -336,19 +336,25 @@ struct gs_to_fill_args {
 };
 __global__ __launch_bounds__(256) void k_to_fill(gs_to_fill_args a) {
   const uint32_t sb = blockIdx.x * blockDim.x + threadIdx.x;
-  if (sb >= a.n_it) return;
-  const uint32_t g = a.list ? a.list[sb >> 1] : (sb >> 1);
+  const bool in = sb < a.n_it;
+  const uint32_t g = in ? (a.list ? a.list[sb >> 1] : (sb >> 1)) : 0u;
   const uint32_t item = 2u * g + (sb & 1u);
-  const uint32_t c = a.counts[item];
+  const uint32_t c = in ? a.counts[item] : 0u;
   uint32_t su;
-  const uint32_t nb = to_buckets(c, su), tb = a.tbase[sb];
-  if (c != 0u && nb == 0u) {
-    a.tiles[tb] = make_uint4(sb | TO_DIRECT, 0u, c, 0u);
-    if (c > TO_WTILE) {
-      const uint32_t k = c > 128u * TO_KPT ? 1u : 0u;
-      a.slow[k][atomicAdd(&a.slow_n[k], 1u)] = tb;
-    }
+  const uint32_t nb = to_buckets(c, su), tb = in ? a.tbase[sb] : 0u;
+  if (c != 0u && nb == 0u) a.tiles[tb] = make_uint4(sb | TO_DIRECT, 0u, c, 0u);
+  /* an item of 513 .. 4,096 records is a tile of the workgroup kernels: a place on its list (one atomic per wave and
+   * list - an m <= 5 batch has 10^5 of them) */
+  for (uint32_t k = 0; k < 2u; ++k) {
+    const bool mine = nb == 0u && c > TO_WTILE && (c > 128u * TO_KPT) == (k == 1u);
+    const unsigned long long m = __ballot(mine);
+    if (m == 0ull) continue;
+    uint32_t base = 0;
+    if (lane_id() == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&a.slow_n[k], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m));
+    if (mine) a.slow[k][base + lanes_below(m)] = tb;
   }
+  if (!in) return;
   if (nb != 0u && nb <= TO_NBMAX) {
     const uint32_t bb = a.bbase[sb];
     for (uint32_t b = 0; b < nb; ++b) a.tiles[tb + b] = make_uint4(sb, bb + b * su, 0u, 0u);

@@ -556,6 +556,8 @@ def test_config1_saccer3_sized_1k_guides_m1():
 
 
 ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
+               # the tiles' waves order (word, key) records instead of packed words (what serves sequence words of 2^23 and more)
+               ("GS_TILE_NO_PACK", "1"),
                # the device-wide ordering (what serves batches the per-guide tile ordering does not take):
                ("GS_NO_TILE_ORDER", "1"),
                # ... in the form that serves sort words beyond 64 bits (raw keys)
@@ -567,7 +569,7 @@ ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                # and the two stable sorts it replaces
                ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1"),
                ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1", "GS_BIG2_NO_COMPOSITE", "1")]
-ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "device-wide", "raw-key-order", "one-sort-and-runs", "composite-sort",
+ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "tiles-unpacked", "device-wide", "raw-key-order", "one-sort-and-runs", "composite-sort",
              "two-sorts"]
 
 
