@@ -191,7 +191,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
            "gs_index_last_guide_flags", "gs_enumerate_general_pams", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
-           "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_index_lock", "gs_index_unlock"]
+           "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_debug_tile_plan", "gs_index_lock", "gs_index_unlock"]
 
 
 def _check(rc):
@@ -225,6 +225,17 @@ def choose_thresholds(m, n_x, n_o, n_r, pam_expansions=4.0, verify_a=1.5, verify
     out = (C.c_uint32 * 8)()
     L_.gs_debug_choose_thresholds(m, n_x, n_o, n_r, pam_expansions, verify_a, verify_b, out)
     return list(out)
+
+
+def tile_plan(records):
+    """the tile ordering's plan for an item of `records` match records (gs_debug_tile_plan; host only):
+    dict(buckets, slot, per, wave_tile, max_buckets)"""
+    L_ = lib()
+    L_.gs_debug_tile_plan.restype = None
+    L_.gs_debug_tile_plan.argtypes = [C.c_uint32, C.c_void_p]
+    out = (C.c_uint32 * 5)()
+    L_.gs_debug_tile_plan(records, out)
+    return dict(buckets=out[0], slot=out[1], per=out[2], wave_tile=out[3], max_buckets=out[4])
 
 
 def make_genome_structure(names, lengths):

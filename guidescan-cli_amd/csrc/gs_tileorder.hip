@@ -256,7 +256,7 @@ __device__ __host__ __forceinline__ uint32_t to_buckets(const uint32_t c, uint32
   if (c <= TO_TILE) return 0u;
   uint32_t target;
   if (c <= 256u * 400u)
-    target = 400u, su = 9u; /* 32 samples per splitter: one bucket in twenty grows past 512 */
+    target = 400u, su = 9u; /* 32 samples per splitter: one bucket in fifteen grows past 512 */
   else if (c <= 512u * 320u)
     target = 320u, su = 10u; /* 16 */
   else if (c <= 1024u * 288u)
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
       a.tiles[tb + b].w = run;
       run += n;
     }
-    /* (one bucket in twenty: a place on its list, one atomic per wave and list) */
+    /* (one bucket in fifteen: a place on its list, one atomic per wave and list) */
     const uint32_t n = b < nb ? a.tiles[tb + b].z : 0u;
     for (uint32_t k = 0; k < 2u; ++k) {
       const bool mine = n > TO_WTILE && (n > 128u * TO_KPT) == (k == 1u);
@@ -1048,6 +1048,15 @@ static bool to_make_tab(uint32_t L, uint32_t P, uint32_t m, gs_to_tab &tab, unsi
   }
   if (words) *words = c64; /* (exact when the function returns true) */
   return L >= 1 && 2 * L + 3 * P <= 59 && m <= 7 && cum < 4294967295.0L; /* the words stay below 2^32 - 1: all ones marks padding */
+}
+extern "C" void gs_debug_tile_plan(uint32_t records, uint32_t out[5]) {
+  uint32_t su = 0;
+  const uint32_t nb = to_buckets(records, su);
+  out[0] = nb;
+  out[1] = su * TO_BU;
+  out[2] = nb ? (TO_SAMPLE / nb < 32u ? TO_SAMPLE / nb : 32u) : 0u;
+  out[3] = TO_WTILE;
+  out[4] = TO_NBMAX;
 }
 bool gs_tileorder_fits(uint32_t L, uint32_t P, uint32_t m) {
   gs_to_tab tab;

@@ -237,6 +237,10 @@ gs_status gs_debug_seed_recipes(uint32_t k, uint32_t L, uint32_t P, uint32_t m, 
                                 uint32_t deep, uint64_t *out, uint64_t cap, uint64_t counts[3]);
 void gs_debug_choose_thresholds(uint32_t m, uint32_t n_x, uint32_t n_o, uint32_t n_r, double pam_expansions,
                                 double verify_a, double verify_b, uint32_t astar[8]);
+/* The tile ordering's plan for one (guide, index) item of `records` match records, as data (host only; tests pin it):
+ * out = {buckets the item is dealt into (0: the item is one tile), records a bucket's slot holds, sample words per
+ * splitter, records one wave orders, buckets an item may have at most (more: the batch is ordered device-wide)}. */
+void gs_debug_tile_plan(uint32_t records, uint32_t out[5]);
 
 /* Self-check of a resident index from the genome text alone (no suffix-array builder involved):
  * the suffix array of `strand` is a permutation of [0, n) (all rows), n_samples evenly spread

@@ -1,0 +1,51 @@
+"""The tile ordering's bucket plan as data (host only; gs_tileorder.hip: to_buckets).  An item of more than 4,096 match
+records is dealt into buckets by splitters taken from a sample; a bucket's size is then a gamma variate of the shape
+"sample words per splitter", and three things must hold whatever the item's size: the sample fits the 8,192 words one
+workgroup orders, a bucket's slot is so far above the aim that none outgrows it (a bucket that does sends the whole batch
+to the device-wide ordering: correct, and ten times slower), and most buckets fit the 512 records one wave orders."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+from scipy.stats import gamma
+
+api = import_module("guidescan-cli_amd.api")
+
+SIZES = sorted(set([1, 511, 512, 513, 4096, 4097, 5000, 51_200, 51_201, 102_400, 102_401, 163_840, 163_841, 294_912, 294_913,
+                    524_288] + [int(x) for x in np.geomspace(4097, 524_288, 200)]))
+
+
+def test_small_items_are_one_tile():
+    for c in (0, 1, 512, 4096):
+        assert api.tile_plan(c)["buckets"] == 0
+
+
+@pytest.mark.parametrize("c", SIZES)
+def test_bucket_plan_invariants(c):
+    p = api.tile_plan(c)
+    if c <= 4096:
+        assert p["buckets"] == 0
+        return
+    nb, slot, per = p["buckets"], p["slot"], p["per"]
+    assert 2 <= nb <= p["max_buckets"]
+    assert 4 <= per <= 32 and per * nb <= 8192 and per * nb <= c        # one sample word per stretch of the item
+    aim = c / nb
+    assert aim <= 512 and slot % 128 == 0 and slot <= 4096               # the workgroup kernels take tiles of up to 4,096
+    # one bucket outgrowing its slot: below 10^-10 (a batch has 10^6 buckets)
+    assert gamma.sf(slot / aim * per, per) < 1e-10, (c, nb, slot, per)
+    # buckets beyond one wave's 512 records are served, by the slower kernels: few of them where the sample allows
+    if per >= 16:
+        assert gamma.sf(512 / aim * per, per) < 0.07
+
+
+def test_items_beyond_the_plan_are_refused():
+    p = api.tile_plan(600_000)
+    assert p["buckets"] > p["max_buckets"]     # k_to_plan raises TO_F_BIG: the batch is ordered device-wide
+
+
+def test_bucket_space_stays_within_a_small_multiple_of_the_records():
+    for c in (10_000, 46_000, 100_000, 150_000, 219_515, 438_204):
+        p = api.tile_plan(c)
+        assert p["buckets"] * p["slot"] <= 8.2 * c
+    p = api.tile_plan(46_000)     # the repeat-rich batch's average item
+    assert p["buckets"] * p["slot"] <= 3.0 * 46_000
