@@ -625,6 +625,47 @@ def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
         oidx.close()
 
 
+@pytest.mark.parametrize("unpacked", [False, True], ids=["packed-words", "word-key-records"])
+def test_tile_sizes_either_side_of_every_kernel_boundary(monkeypatch, unpacked):
+    """One batch whose guides have exactly 300, 511, 512, 513, 1,023, 1,024, 1,025, 4,095, 4,096, 4,097 and 9,000 copies of
+    their site (a third of them on the - strand): the items on the overflow list are tiles of one wave (<= 512 records),
+    of the 128- and 512-thread workgroup kernels (<= 1,024, <= 4,096) and, beyond, dealt into buckets - every boundary
+    from both sides, with equal sequences throughout (the row alone orders a family).  Hit lists equal the oracle's."""
+    if unpacked:
+        monkeypatch.setenv("GS_TILE_NO_PACK", "1")
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    counts = [300, 511, 512, 513, 1023, 1024, 1025, 4095, 4096, 4097, 9000]
+    sites = [rng.choice(acgt, 20) for _ in counts]
+    chunks = []
+    for site, n in zip(sites, counts):
+        for i in range(n):
+            unit = np.concatenate([site, np.frombuffer(rng.choice([b"AGG", b"CGG", b"GGG", b"TGG"]), np.uint8)])
+            if i % 3 == 2:
+                unit = synth.reverse_complement_bytes(unit)
+            chunks += [rng.choice(acgt, int(rng.integers(9, 19))), unit]
+    order = rng.permutation(len(chunks) // 2)
+    text = np.concatenate([np.concatenate(chunks[2 * i:2 * i + 2]) for i in order] + [rng.choice(acgt, 64)])
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        seqs = np.array([list(s) for s in sites], dtype=np.uint8)
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (len(sites), 1))
+        for m in (0, 2):
+            offsets, hits, _ = gidx.enumerate(seqs, pams, mismatches=m)
+            ctr = gidx.last_counters()
+            assert ctr["ordered_in_tiles"] and not ctr["tile_ordering_gave_up"] and ctr["guides_redone"] >= len(counts) - 1, ctr
+            opts = ol.make_opts(m)
+            for i, n in enumerate(counts):
+                g = seqs[i].tobytes().decode()
+                exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
+                assert len(exp) >= n
+                assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, (n, m)
+    finally:
+        gidx.close()
+        oidx.close()
+
+
 def test_tile_ordering_gives_up_and_the_device_wide_form_takes_over(monkeypatch):
     """The per-guide tile ordering writes final hits on two assumptions and checks them tile by tile: no (sequence, row)
     twice in an item - overlapping PAM patterns break it: NGG listed again as an alt PAM, every site found twice, the
