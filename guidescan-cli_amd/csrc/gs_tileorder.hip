@@ -8,19 +8,21 @@
  * Instead of eight device-wide radix passes over (guide | rank | row bits) and five more passes to gather, flag,
  * scan and locate, every item is ordered by itself:
  *
- *   k_to_plan       one workgroup: per set item the tiles, bucket space and arena chunks it needs; four scans
- *   k_to_fill       tile descriptors, the chunk index of every item, per guide where each (mismatches, index)
+ *   k_to_plan       one workgroup: per set item the tiles, bucket space, arena chunks and dealing stretches it needs;
+ *                   five scans
+ *   k_to_fill       tile descriptors, a descriptor per dealing stretch, per guide where each (mismatches, index)
  *                   class starts in its hit list (from k_search's per-class counts), hits per guide
- *   k_to_splitters, k_to_deal, k_to_bucketsum  items beyond one tile: a sample of their records ordered in LDS gives splitters; one
- *                   streaming pass deals the records into buckets of at most TO_TILE records (sample sort:
- *                   the full word decides, so a run of 10^4 equal sequences is split by row)
- *   k_to_sort       one workgroup per tile (a small item where k_search left it, or a bucket): K of every
- *                   record, a merge sort in LDS (eight words per thread ordered in registers, then merge-path
- *                   rounds), then the hits - suffix array gather + coordinate rule (process.hpp:104, 111) -
- *                   straight to their final place; 512 threads for tiles of up to 4,096 records, 128 for
- *                   those of up to 1,024
+ *   k_to_splitters  items of more than 4,096 records: a sample of their records ordered in LDS gives splitters
+ *   k_to_deal       ... one streaming pass, a workgroup per 2,048 records, deals the records into buckets that aim at
+ *                   400 (sample sort: the full word decides, so a run of 10^4 equal sequences is split by row)
+ *   k_to_bucketsum  ... records before each bucket; the buckets beyond 512 records go on the workgroup kernels' lists
+ *   k_to_wsort      ONE WAVE per tile of at most 512 records (a small item where k_search left it, or a bucket): K of
+ *                   every record, a bitonic network over the wave's registers (DPP), then the hits - suffix array
+ *                   gather + coordinate rule (process.hpp:104, 111) - straight to their final place
+ *   k_to_sort       one workgroup per tile of 513 .. 4,096 records: a merge sort in LDS (eight words per thread ordered
+ *                   in registers, then merge-path rounds); 128 threads for tiles of up to 1,024 records, 512 beyond
  *
- * Two passes of HBM traffic for partitioned items (16 B read + 16 B written, twice), one for the rest.
+ * Two passes of HBM traffic for dealt items (16 B read + 16 B written, twice), one for the rest.
  * The path writes final hits on two assumptions it checks as it goes: every record is a single row, and no
  * (sequence, row) occurs twice in an item (overlapping PAM patterns).  A tile that sees otherwise - or a bucket
  * that outgrows its space - raises a flag; the caller then orders the batch with the device-wide form.
@@ -29,10 +31,10 @@
 
 #include <algorithm>
 
-#define TO_NT 512u                 /* threads of the sort and partition workgroups */
+#define TO_NT 512u                 /* threads of the workgroup-tile and dealing kernels */
 #define TO_NW (TO_NT / WAVE)       /* 8 waves */
 #define TO_KPT 8u                  /* keys per thread */
-#define TO_TILE (TO_NT * TO_KPT)   /* 4,096 records per tile */
+#define TO_TILE (TO_NT * TO_KPT)   /* 4,096 records: the largest tile (one workgroup); items beyond are dealt into buckets */
 #define TO_NBMAX 1024u             /* buckets of one item */
 #define TO_BU 128u                 /* bucket slots are handed out in units of 128 records */
 #define TO_SNT 1024u               /* threads of k_to_splitters */
