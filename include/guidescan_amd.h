@@ -160,7 +160,7 @@ void gs_index_close(gs_index *ix);
  * redone because their matches overflowed the first pass's slots, [7] bit 0: the whole batch was ordered
  * device-wide, bit 1: the redone guides were, bit 2: the overflowing guides' records came out of the arena,
  * bit 3: the device-wide ordering ran as one sort of (sort word, low bits of the first row), bit 4: it had runs
- * to put right afterwards, bit 5: the guides beyond LDS were ordered per guide in LDS tiles (gs_tileorder.hip),
+ * to put right afterwards, bit 5: the guides beyond LDS were ordered per guide in tiles (gs_tileorder.hip),
  * bit 6: that form gave up (overlapping PAM patterns, a bucket beyond its slots) and the device-wide one ran
  * (DESIGN.md section 5.3), [13] slots per item of the first pass, [14] / [15] sum and
  * maximum of the per-item match counts; with
