@@ -476,7 +476,7 @@ def test_many_literal_n_windows(monkeypatch, capfd, buckets):
         oidx.close()
 
 
-@pytest.mark.parametrize("pk,L", [("13", 20), ("11", 16), ("12", 18)])
+@pytest.mark.parametrize("pk,L", [("13", 20), ("11", 16), ("12", 18), ("12", 20)])
 def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
     """the table depth that makes k_search seed from both strands (sites with >= 2 substitutions
     among the first consumed symbols come from the other strand's table): a genome with a repeat
@@ -513,7 +513,15 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
             monkeypatch.delenv("GS_PAIRTABS", raising=False)
             monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
             err = capfd.readouterr().err
-            assert "two-sided seeding" in err, cfg
+            # (12, 20): X = L + P - k = 11 symbols reaches step k - 2 of the table's two-symbol extension (round 4); a
+            # four-symbol PAM there leaves 12 > k - 1 and the batch is seeded from one side
+            two_sided = L + len(own) - int(pk) + 1 <= int(pk)
+            assert ("two-sided seeding" in err) == two_sided, cfg
+            if not two_sided:
+                for i, g in enumerate(guides):
+                    exp, _ = oracle_hits_as_records(oidx, g, own, opts, len(own), start)
+                    assert gpu_hits_as_records(offsets, hits, i, g, len(own), start) == exp, (i, cfg, pk)
+                continue
             # PAM-pair tables serve the items whose patterns all end in (at most two) pairs of concrete bases
             cnt = gidx.last_counters()
             pairs = {p[-2:] if not start else p[:2][::-1] for p in (own,) + tuple(alt)}
