@@ -264,7 +264,7 @@ __device__ __host__ __forceinline__ uint32_t to_buckets(const uint32_t c, uint32
   else if (c <= 1024u * 288u)
     target = 288u, su = 14u; /* 8 */
   else
-    target = 512u, su = 25u; /* 8 (to half a million records: 1,024 buckets) */
+    target = 1024u, su = 50u; /* 8 (to a million records: 1,024 buckets, ordered by the workgroup kernels - the 1,024-thread form takes 8,192) */
   return (c + target - 1u) / target;
 }
 __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
       const uint32_t c = a.counts[item];
       uint32_t su;
       uint32_t nb = to_buckets(c, su);
-      if (nb > TO_NBMAX) { /* an item beyond half a million records: the device-wide form orders this batch */
+      if (nb > TO_NBMAX) { /* an item beyond a million records: the device-wide form orders this batch */
         atomicOr(a.flags, TO_F_BIG);
         nb = 0u;
       }
@@ -325,7 +325,7 @@ struct gs_to_fill_args {
   const uint32_t *counts, *cls, *list;
   uint32_t n_it, cap;
   const uint32_t *tbase, *bbase, *gbase, *dbase;
-  uint32_t *slow[2], *slow_n; /* tiles beyond one wave's 512 records: lists (to 1,024 records; beyond) and their lengths */
+  uint32_t *slow[3], *slow_n; /* tiles beyond one wave's 512 records: lists (to 1,024 records; to 4,096; beyond) and their lengths */
   uint4 *dealmap;    /* per stretch of TO_DEAL records, two words: {set item, first record, records of the item, first tile},
                         {first bucket unit, first chunk-index entry, item of the batch, 0} - all k_to_deal needs to start */
   const uint32_t *cbase;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_to_fill(gs_to_fill_args a) {
   /* an item of 513 .. 4,096 records is a tile of the workgroup kernels: a place on its list (one atomic per wave and
    * list - an m <= 5 batch has 10^5 of them) */
   for (uint32_t k = 0; k < 2u; ++k) {
-    const bool mine = nb == 0u && c > TO_WTILE && (c > 128u * TO_KPT) == (k == 1u);
+    const bool mine = nb == 0u && c > TO_WTILE && (c > 128u * TO_KPT) == (k == 1u); /* (an item is a tile up to 4,096 records) */
     const unsigned long long m = __ballot(mine);
     if (m == 0ull) continue;
     uint32_t base = 0;
@@ -428,7 +428,7 @@ struct gs_to_run_args {
   const uint32_t *biglist;
   const uint4 *dealmap;
   unsigned long long *spl; /* [n_tiles]: entry tbase + b = splitter b of the item */
-  uint32_t *slow[2], *slow_n;
+  uint32_t *slow[3], *slow_n;
   uint4 *tiles;
   uint4 *buckets;
   const gs_to_tab *tab;
@@ -440,6 +440,7 @@ struct gs_to_run_args {
   uint32_t *flags;
   uint32_t L, P, v_rem;
   uint32_t sample_per; /* 0, or GS_TILE_SAMPLE_PER (tests) */
+  uint32_t big_from;   /* tiles of more records go to the 1,024-thread kernel: TO_TILE (tests: GS_TILE_BIG_FROM) */
 };
 
 /* ---- items beyond one tile: splitters from a sample, then one streaming pass into buckets ----------------------
@@ -628,8 +629,8 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
     }
     /* (one bucket in fifteen: a place on its list, one atomic per wave and list) */
     const uint32_t n = b < nb ? a.tiles[tb + b].z : 0u;
-    for (uint32_t k = 0; k < 2u; ++k) {
-      const bool mine = n > TO_WTILE && (n > 128u * TO_KPT) == (k == 1u);
+    for (uint32_t k = 0; k < 3u; ++k) {
+      const bool mine = n > TO_WTILE && (n > 128u * TO_KPT ? (n > a.big_from ? 2u : 1u) : 0u) == k;
       const unsigned long long m = __ballot(mine);
       if (m == 0ull) continue;
       uint32_t base = 0;
@@ -647,14 +648,18 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
  * barriers; 12 KB of LDS instead of 47: twelve workgroups per CU).  Since k_to_wsort they take the tiles of more than 512
  * records only, each from its list (k_to_fill and k_to_bucketsum write them; launched over all tiles to pick their own,
  * 1.7 x 10^6 workgroups that leave at once cost 1.5 ms). */
+static constexpr size_t to_sort_lds(uint32_t nt) { /* words + s_first, tables and class starts, 16-bit places */
+  return (size_t)(nt * TO_KPT + nt) * 8u + 8u + (32u * 8u + 8u + 8u) * 4u + (size_t)(nt * TO_KPT + nt) * 2u;
+}
 template <uint32_t NT>
 __global__ __launch_bounds__(NT) void k_to_sort(gs_to_run_args a, const uint32_t *list) {
   constexpr uint32_t CAP = NT * TO_KPT, LDSN = CAP + CAP / 8u;
-  __shared__ unsigned long long s_keys[LDSN];
-  __shared__ uint32_t s_nt[32 * 8], s_bs[8];
-  __shared__ uint16_t s_idx[LDSN];
-  __shared__ uint32_t s_rel[8];
-  __shared__ unsigned long long s_first;
+  /* dynamic LDS (to_sort_lds(NT) bytes; the 1,024-thread form needs 94 KB - beyond what a kernel may declare) */
+  extern __shared__ unsigned long long to_sort_smem[];
+  unsigned long long *s_keys = to_sort_smem;
+  unsigned long long &s_first = to_sort_smem[LDSN];
+  uint32_t *s_nt = (uint32_t *)(to_sort_smem + LDSN + 1u), *s_bs = s_nt + 32u * 8u, *s_rel = s_bs + 8u;
+  uint16_t *s_idx = (uint16_t *)(s_rel + 8u);
 
   const uint32_t tid = threadIdx.x;
   /* one workgroup per tile (persistent workgroups looping over the tiles were tried: the loop took the kernel from 71
@@ -1109,7 +1114,7 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   S.n_deal = tot[4];
   if ((rc = gs_reserve(ix->w_t_tiles, (16 + 8) * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* descriptors, then the splitters */
   if ((rc = gs_reserve(ix->w_t_buckets, 16 * (size_t)TO_BU * S.n_btiles + 16)) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_t_chunkof, 4 * ((size_t)S.n_chunks + 1) + 8 * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* the chunk index, then the two lists */
+  if ((rc = gs_reserve(ix->w_t_chunkof, 4 * ((size_t)S.n_chunks + 1) + 12 * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* the chunk index, then the three lists */
   const size_t deal_at = (4 * ((size_t)S.n_big + 1) + 31) & ~(size_t)31; /* the list, then the deal map */
   if ((rc = gs_reserve(ix->w_t_big, deal_at + 32 * ((size_t)S.n_deal + 1))) != GS_OK) return rc;
   gs_to_fill_args fa;
@@ -1125,6 +1130,7 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   fa.dealmap = (uint4 *)((char *)ix->w_t_big.p + deal_at);
   fa.slow[0] = (uint32_t *)ix->w_t_chunkof.p + (S.n_chunks + 1);
   fa.slow[1] = fa.slow[0] + (S.n_tiles + 1);
+  fa.slow[2] = fa.slow[1] + (S.n_tiles + 1);
   fa.slow_n = d_flags + 32;
   fa.cbase = cbase;
   fa.tiles = (uint4 *)ix->w_t_tiles.p;
@@ -1172,6 +1178,7 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.spl = (unsigned long long *)((char *)ix->w_t_tiles.p + 16 * ((size_t)S.n_tiles + 1));
   ra.slow[0] = (uint32_t *)ix->w_t_chunkof.p + (S.n_chunks + 1);
   ra.slow[1] = ra.slow[0] + (S.n_tiles + 1);
+  ra.slow[2] = ra.slow[1] + (S.n_tiles + 1);
   ra.slow_n = d_flags + 32;
   ra.tiles = (uint4 *)ix->w_t_tiles.p;
   ra.buckets = (uint4 *)ix->w_t_buckets.p;
@@ -1187,6 +1194,7 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.P = in.P;
   ra.v_rem = in.v_rem;
   ra.sample_per = getenv("GS_TILE_SAMPLE_PER") ? (uint32_t)std::max(1l, atol(getenv("GS_TILE_SAMPLE_PER"))) : 0u;
+  ra.big_from = getenv("GS_TILE_BIG_FROM") ? (uint32_t)std::max(1024l, atol(getenv("GS_TILE_BIG_FROM"))) : TO_TILE;
   if (S.n_big) {
     hipLaunchKernelGGL(k_to_splitters, dim3(S.n_big), dim3(TO_SNT), 0, st, ra);
     hipLaunchKernelGGL(k_to_deal, dim3(S.n_deal), dim3(TO_NT), 0, st, ra);
@@ -1195,10 +1203,10 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   if (S.n_tiles) {
     /* the tiles one wave cannot take: how many is known once the buckets are counted - the host waits for that number
      * alone (an event behind its copy) while k_to_wsort runs */
-    uint32_t n_slow[2] = {0u, 0u};
+    uint32_t n_slow[3] = {0u, 0u, 0u};
     hipEvent_t ev;
     GS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    GS_HIP(hipMemcpyAsync(n_slow, ra.slow_n, 8, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipMemcpyAsync(n_slow, ra.slow_n, 12, hipMemcpyDeviceToHost, st));
     GS_HIP(hipEventRecord(ev, st));
     gs_to_tab tab;
     unsigned long long words = ~0ull;
@@ -1210,8 +1218,14 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
     const hipError_t ee = hipEventSynchronize(ev);
     (void)hipEventDestroy(ev);
     GS_HIP(ee);
-    if (n_slow[0]) hipLaunchKernelGGL(k_to_sort<128u>, dim3(n_slow[0]), dim3(128), 0, st, ra, (const uint32_t *)ra.slow[0]);
-    if (n_slow[1]) hipLaunchKernelGGL(k_to_sort<TO_NT>, dim3(n_slow[1]), dim3(TO_NT), 0, st, ra, (const uint32_t *)ra.slow[1]);
+    if (getenv("GS_DEBUG"))
+      fprintf(stderr, "[gs] tile ordering: tiles beyond one wave: %u of up to 1024 records, %u of up to 4096, %u beyond\n", n_slow[0], n_slow[1], n_slow[2]);
+    if (n_slow[0]) hipLaunchKernelGGL(k_to_sort<128u>, dim3(n_slow[0]), dim3(128), to_sort_lds(128u), st, ra, (const uint32_t *)ra.slow[0]);
+    if (n_slow[1]) hipLaunchKernelGGL(k_to_sort<TO_NT>, dim3(n_slow[1]), dim3(TO_NT), to_sort_lds(TO_NT), st, ra, (const uint32_t *)ra.slow[1]);
+    if (n_slow[2]) { /* buckets of an item beyond 3 x 10^5 records (they aim at 1,024) that came out beyond 4,096 */
+      GS_HIP(hipFuncSetAttribute((const void *)k_to_sort<1024u>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)to_sort_lds(1024u)));
+      hipLaunchKernelGGL(k_to_sort<1024u>, dim3(n_slow[2]), dim3(1024), to_sort_lds(1024u), st, ra, (const uint32_t *)ra.slow[2]);
+    }
   }
   uint32_t h[32] = {0};
   GS_HIP(hipMemcpyAsync(h, d_flags, sizeof(h), hipMemcpyDeviceToHost, st));

@@ -674,6 +674,53 @@ def test_tile_sizes_either_side_of_every_kernel_boundary(monkeypatch, unpacked):
         oidx.close()
 
 
+def test_an_item_of_more_than_half_a_million_records(monkeypatch, capfd):
+    """700,000 exact copies of one site on the + strand (and 1,000 on the -): the item is dealt into 684 buckets that
+    aim at 1,024 records, ordered by the workgroup kernels (128, 512 and 1,024 threads) - the plan's last size class,
+    beyond which (10^6 records) a batch is ordered device-wide.  Every hit in row order, as the oracle has them; a
+    second time with every bucket beyond 1,024 records handed to the 1,024-thread kernel (GS_TILE_BIG_FROM: its tiles
+    proper, beyond 4,096 records, take a splitter's bad luck)."""
+    rng = np.random.default_rng(5)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    site = rng.choice(acgt, 20)
+    n_copies = 700_000
+    unit = 32
+    text = rng.choice(acgt, n_copies * unit + 40_000).astype(np.uint8)
+    body = text[:n_copies * unit].reshape(n_copies, unit)
+    body[:, 4:24] = site
+    body[:, 24] = rng.choice(acgt, n_copies)
+    body[:, 25:27] = ord("G")
+    tail = text[n_copies * unit:n_copies * unit + 1000 * unit].reshape(1000, unit)
+    tail[:, 2:25] = synth.reverse_complement_bytes(np.concatenate([site, np.frombuffer(b"AGG", np.uint8)]))
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        other, _, _, _ = synth.sample_guides(text[n_copies * unit + 1000 * unit:], 2, seed=9)
+        seqs = np.concatenate([other[:1], np.array([list(site)], dtype=np.uint8), other[1:]])
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (3, 1))
+        import re
+        monkeypatch.setenv("GS_DEBUG", "1")
+        opts = ol.make_opts(1)
+        want = [oracle_hits_as_records(oidx, seqs[i].tobytes().decode(), "NGG", opts, 3)[0] for i in range(3)]
+        assert len(want[1]) >= n_copies + 1000
+        for per in (None, "1024"):
+            if per:
+                monkeypatch.setenv("GS_TILE_BIG_FROM", per)
+            capfd.readouterr()
+            offsets, hits, _ = gidx.enumerate(seqs, pams, mismatches=1)
+            err = capfd.readouterr().err
+            ctr = gidx.last_counters()
+            assert ctr["ordered_in_tiles"] and not ctr["tile_ordering_gave_up"] and ctr["matches_max_per_item"] >= n_copies, ctr
+            beyond = [int(x) for x in re.findall(r"tiles beyond one wave: (\d+) of up to 1024 records, (\d+) of up to 4096, (\d+) beyond", err)[-1]]
+            assert beyond[0] + beyond[1] > 300 and (per is None or beyond[2] > 0), (per, beyond)
+            for i in range(3):
+                got = gpu_hits_as_records(offsets, hits, i, seqs[i].tobytes().decode(), 3)
+                assert len(got) == len(want[i]) and got == want[i], (i, per)
+    finally:
+        gidx.close()
+        oidx.close()
+
+
 def test_tile_ordering_gives_up_and_the_device_wide_form_takes_over(monkeypatch):
     """The per-guide tile ordering writes final hits on two assumptions and checks them tile by tile: no (sequence, row)
     twice in an item - overlapping PAM patterns break it: NGG listed again as an alt PAM, every site found twice, the
