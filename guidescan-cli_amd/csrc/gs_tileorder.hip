@@ -823,13 +823,10 @@ struct to_wregs {
     const unsigned long long tk = sw ? r.K[j] : r.K[i];           \
     r.K[j] = sw ? r.K[i] : r.K[j];                                \
     r.K[i] = tk;                                                  \
-    if constexpr (!PACKED) {                                      \
+    if constexpr (!PACKED) { /* (the record's place in load order travels with its word) */ \
       const uint32_t tx = sw ? r.x[j] : r.x[i];                   \
       r.x[j] = sw ? r.x[i] : r.x[j];                              \
       r.x[i] = tx;                                                \
-      const uint32_t ty = sw ? r.y[j] : r.y[i];                   \
-      r.y[j] = sw ? r.y[i] : r.y[j];                              \
-      r.y[i] = ty;                                                \
     }                                                             \
   }
 template <uint32_t D, bool PACKED>
@@ -845,9 +842,8 @@ __device__ __forceinline__ void to_wcross(to_wregs &r, const bool asc) {
     const unsigned long long pK = ((unsigned long long)ph << 32) | pl;
     const bool take = (pK < r.K[u]) != keep_max;
     if constexpr (!PACKED) {
-      const uint32_t px = to_xl<D>(r.x[u]), py = to_xl<D>(r.y[u]);
+      const uint32_t px = to_xl<D>(r.x[u]);
       r.x[u] = take ? px : r.x[u];
-      r.y[u] = take ? py : r.y[u];
     }
     r.K[u] = take ? pK : r.K[u];
   }
@@ -907,12 +903,14 @@ __device__ __forceinline__ void to_wsort(to_wregs &r) {
 }
 #define TO_WNW 4u /* waves (tiles) per workgroup */
 #define TO_WPACK_BITS 23u /* PACKED: sequence words below 2^23 (20-mers + NGG to three mismatches: 4.07 x 10^6) */
-/* PACKED: word << 41 | row << 9 | the record's place in load order - nothing travels with the 64 bits: five instructions
- * per record and step instead of nine.  The keys wait in LDS (4 KB per wave) and are picked up by that place. */
+/* The keys wait in LDS (4 KB per wave) while their words are ordered and are picked up by the record's place in load
+ * order.  PACKED: word << 41 | row << 9 | that place - nothing travels with the 64 bits: five instructions per record and
+ * crossing step (two moves, a compare, two selects).  Otherwise the place is a third register: seven (with the key's
+ * two words travelling instead, the first form: nine - 7.9 ms against 6.3 on the repeat-rich batch). */
 template <bool PACKED>
 __global__ __launch_bounds__(TO_WNW *WAVE) void k_to_wsort(gs_to_run_args a, const uint32_t n_tiles) {
   __shared__ uint32_t s_nt[32 * 8], s_bs[8];
-  __shared__ uint2 s_key[TO_WNW * TO_WTILE]; /* 4 KB per wave: the keys while their words are ordered (PACKED), then the way to the stores' layout */
+  __shared__ uint2 s_key[TO_WNW * TO_WTILE]; /* 4 KB per wave: the keys while their words are ordered, then the way to the stores' layout */
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u);
   const uint32_t tile = blockIdx.x * TO_WNW + tid / WAVE;
   uint4 t = make_uint4(0u, 0u, 0u, 0u);
@@ -952,7 +950,8 @@ __global__ __launch_bounds__(TO_WNW *WAVE) void k_to_wsort(gs_to_run_args a, con
   for (uint32_t u = 0; u < 8u; ++u) {
     const uint32_t i = lane + u * WAVE;
     const bool on = i < n;
-    r.x[u] = rec[u].x;
+    r.x[u] = PACKED ? rec[u].x : i; /* (x unused when PACKED, y always, until the keys come back - but left unset, the
+                                       compiler's allocation of the kernel goes from 62 registers to 82) */
     r.y[u] = rec[u].y;
     if (direct) {
       multi = multi || (on && rec[u].z != rec[u].w);
@@ -960,8 +959,8 @@ __global__ __launch_bounds__(TO_WNW *WAVE) void k_to_wsort(gs_to_run_args a, con
     } else {
       r.K[u] = on ? ((unsigned long long)rec[u].w << 32) | rec[u].z : ~0ull; /* k_to_deal ranked it */
     }
+    keys[i] = make_uint2(rec[u].x, rec[u].y);
     if constexpr (PACKED) {
-      keys[i] = make_uint2(rec[u].x, rec[u].y);
       if (on) r.K[u] = ((r.K[u] >> 32) << 41) | ((r.K[u] & 0xFFFFFFFFull) << 9) | i;
     }
   }
@@ -973,7 +972,7 @@ __global__ __launch_bounds__(TO_WNW *WAVE) void k_to_wsort(gs_to_run_args a, con
     if constexpr (PACKED)
       asm volatile("" : "+v"(r.K[u]));
     else
-      asm volatile("" : "+v"(r.K[u]), "+v"(r.x[u]), "+v"(r.y[u]));
+      asm volatile("" : "+v"(r.K[u]), "+v"(r.x[u]));
   }
   /* place 8 lane + u of the tile is in register u of lane `lane` */
   constexpr uint32_t SH = PACKED ? 9u : 0u; /* word and row from here up */
@@ -984,11 +983,9 @@ __global__ __launch_bounds__(TO_WNW *WAVE) void k_to_wsort(gs_to_run_args a, con
   for (uint32_t u = 0; u < 8u; ++u) {
     if (u != 0u) dup = dup || (8u * lane + u < n && (r.K[u] >> SH) == (r.K[u - 1u] >> SH));
     row[u] = (uint32_t)(r.K[u] >> SH);
-    if constexpr (PACKED) {
-      const uint2 k = keys[(uint32_t)r.K[u] & (TO_WTILE - 1u)];
-      r.x[u] = k.x;
-      r.y[u] = k.y;
-    }
+    const uint2 k = keys[(PACKED ? (uint32_t)r.K[u] : r.x[u]) & (TO_WTILE - 1u)];
+    r.x[u] = k.x;
+    r.y[u] = k.y;
   }
   /* ... and goes to register q >> 6 of lane q & 63, through the wave's 4 KB of LDS (rows and low key words, then the
    * high words), so that a store instruction writes 64 neighbouring hits: with each lane writing its own eight - 64
