@@ -137,7 +137,7 @@ __device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L
 }
 
 /* ---- merge sort of n <= TO_TILE 64-bit words in LDS by the whole workgroup --------------------------------------
- * keys (+ idx: a 16-bit payload that moves with its key), TO_LDS entries each: word e lives at TO_AT(e) - one pad
+ * keys (+ idx: a 16-bit payload that moves with its key), n + n / 8 entries each: word e lives at TO_AT(e) - one pad
  * entry after every eight, so that threads reading their own eight consecutive words hit different banks (blocked
  * accesses at a 64-byte stride were a 32-way bank conflict: 65 % of the LDS cycles of the first version).
  * Thread t owns places 8t .. 8t+7: it orders its eight words in registers (Batcher's network, 19 exchanges), then
@@ -147,7 +147,6 @@ __device__ __forceinline__ void to_word4(const uint4 (&rec)[4], const uint32_t L
  * to rank a wave's keys stably) cost 90 per word and pass, eight passes on a repeat-rich tile.
  * Places n .. 8 * ceil(n / 8) hold words of all ones. */
 #define TO_AT(e) ((e) + ((e) >> 3))
-#define TO_LDS (TO_TILE + TO_TILE / 8u)
 #define TO_CE(i, j)                                  \
   if (k[i] > k[j]) {                                 \
     const unsigned long long tk = k[i];              \
@@ -242,7 +241,7 @@ struct gs_to_plan_args {
   const uint32_t *counts; /* per item of the batch: records (exact) */
   const uint32_t *list;   /* set guide -> guide of the batch, or nullptr: the whole batch */
   uint32_t n_it, cap;
-  uint32_t *tbase, *bbase, *cbase, *gbase, *dbase; /* [n_it + 1] first tile / first bucket slot / first chunk-index entry / place on the list of partitioned
+  uint32_t *tbase, *bbase, *cbase, *gbase, *dbase; /* [n_it + 1] first tile / first bucket slot / first chunk-index entry / place on the list of dealt
                                                       items / first stretch of TO_DEAL records the dealing kernel takes */
   uint32_t *flags;
 };
@@ -330,7 +329,7 @@ struct gs_to_fill_args {
                         {first bucket unit, first chunk-index entry, item of the batch, 0} - all k_to_deal needs to start */
   const uint32_t *cbase;
   uint4 *tiles;     /* {set item | TO_DIRECT, bucket slot (unit), records, records of the item in the buckets before} */
-  uint32_t *biglist; /* set items that are partitioned */
+  uint32_t *biglist; /* set items that are dealt into buckets */
   uint32_t *rel;    /* [n_set][16]: where class (mismatches d, index s) of the guide starts in its hit list, less the
                        records of item s in classes before d: a record's place = rel[2d + s] + its rank in the item */
   uint32_t *nhits;  /* of the batch: hits per guide */
@@ -1235,7 +1234,7 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   }
 #endif
   if (getenv("GS_DEBUG"))
-    fprintf(stderr, "[gs] tile ordering: %u items, %u of them partitioned into %u buckets, %u tiles\n", S.n_it, S.n_big, S.n_btiles, S.n_tiles);
+    fprintf(stderr, "[gs] tile ordering: %u items, %u of them dealt into %u bucket units of 128 records, %u tiles\n", S.n_it, S.n_big, S.n_btiles, S.n_tiles);
   *violations = h[0];
   S.n_records = ((uint64_t)h[3] << 32) | h[2];
   GS_HIP(hipGetLastError());
