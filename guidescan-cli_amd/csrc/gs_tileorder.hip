@@ -458,11 +458,15 @@ __device__ __forceinline__ uint32_t to_sample_per(const gs_to_run_args &a, const
 __device__ __forceinline__ uint32_t to_slots(const gs_to_run_args &a, const uint32_t su) {
   return a.sample_per == 1u ? su * TO_BU / 4u : su * TO_BU; /* tests: at one word per splitter, a quarter of the slots - certain to overflow */
 }
-__global__ __launch_bounds__(TO_SNT) void k_to_splitters(gs_to_run_args a) {
-  __shared__ unsigned long long s_keys[TO_SAMPLE + TO_SAMPLE / 8u];
+/* SNT threads order a sample of up to SNT x 8 words: 1,024 for the large items, 128 for the items whose sample is at most
+ * 1,024 words (an m <= 6 batch has 27,000 items of ~5,000 records, 450 sample words each: in workgroups of 1,024, two per
+ * CU, their samples took 1.0 ms; 9 KB of LDS instead of 74).  Both are launched over the list, each takes its own. */
+template <uint32_t SNT>
+__global__ __launch_bounds__(SNT) void k_to_splitters(gs_to_run_args a) {
+  __shared__ unsigned long long s_keys[SNT * TO_KPT + SNT];
   __shared__ uint32_t s_nt[32 * 8], s_bs[8];
   const uint32_t tid = threadIdx.x;
-  for (uint32_t i = tid; i < 32u * 8u; i += TO_SNT) s_nt[i] = (uint32_t)a.tab->n[i >> 3][i & 7u];
+  for (uint32_t i = tid; i < 32u * 8u; i += SNT) s_nt[i] = (uint32_t)a.tab->n[i >> 3][i & 7u];
   if (tid < 8u) s_bs[tid] = (uint32_t)a.tab->base[tid];
   const uint32_t pam_mul = (uint32_t)a.tab->pam_mul;
   const uint32_t sb = a.biglist[blockIdx.x];
@@ -474,12 +478,13 @@ __global__ __launch_bounds__(TO_SNT) void k_to_splitters(gs_to_run_args a) {
   /* stratified sample: one record from each of `ns` equal stretches of the item (emission order is seed by seed,
    * so a stretch is a few neighbouring sequences: no worse than independent draws) */
   const uint32_t per = to_sample_per(a, nb), ns = per * nb;
+  if ((ns <= 128u * TO_KPT) != (SNT == 128u)) return; /* (workgroup-uniform) */
   __syncthreads();
   {
     uint4 srec[TO_KPT]; /* (ns <= TO_SAMPLE: eight per thread, all asked for before the first is ranked) */
 #pragma unroll
     for (uint32_t q = 0; q < TO_KPT; ++q) {
-      const uint32_t j = tid + q * TO_SNT;
+      const uint32_t j = tid + q * SNT;
       srec[q] = make_uint4(0u, 0u, 0u, 0u);
       if (j < ns) {
         const uint32_t lo = (uint32_t)(((unsigned long long)j * c) / ns), hi = (uint32_t)(((unsigned long long)(j + 1u) * c) / ns);
@@ -493,13 +498,13 @@ __global__ __launch_bounds__(TO_SNT) void k_to_splitters(gs_to_run_args a) {
     }
 #pragma unroll
     for (uint32_t q = 0; q < TO_KPT; ++q) {
-      const uint32_t j = tid + q * TO_SNT;
+      const uint32_t j = tid + q * SNT;
       if (j < ns) s_keys[TO_AT(j)] = to_word(srec[q], a.L, a.P, s_nt, s_bs, pam_mul);
     }
   }
   __syncthreads();
   to_msort<false>(s_keys, nullptr, ns);
-  for (uint32_t b = tid; b + 1u < nb; b += TO_SNT) a.spl[tb + b] = s_keys[TO_AT((b + 1u) * per - 1u)];
+  for (uint32_t b = tid; b + 1u < nb; b += SNT) a.spl[tb + b] = s_keys[TO_AT((b + 1u) * per - 1u)];
 }
 
 __global__ __launch_bounds__(TO_NT) void k_to_deal(gs_to_run_args a) {
@@ -1192,7 +1197,8 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.sample_per = getenv("GS_TILE_SAMPLE_PER") ? (uint32_t)std::max(1l, atol(getenv("GS_TILE_SAMPLE_PER"))) : 0u;
   ra.big_from = getenv("GS_TILE_BIG_FROM") ? (uint32_t)std::max(1024l, atol(getenv("GS_TILE_BIG_FROM"))) : TO_TILE;
   if (S.n_big) {
-    hipLaunchKernelGGL(k_to_splitters, dim3(S.n_big), dim3(TO_SNT), 0, st, ra);
+    hipLaunchKernelGGL(k_to_splitters<128u>, dim3(S.n_big), dim3(128), 0, st, ra);
+    hipLaunchKernelGGL(k_to_splitters<TO_SNT>, dim3(S.n_big), dim3(TO_SNT), 0, st, ra);
     hipLaunchKernelGGL(k_to_deal, dim3(S.n_deal), dim3(TO_NT), 0, st, ra);
     hipLaunchKernelGGL(k_to_bucketsum, dim3((S.n_big + 3u) / 4u), dim3(256), 0, st, ra, S.n_big);
   }
