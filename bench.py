@@ -211,12 +211,12 @@ def main():
     req = gidx.last_counters()
     # the same pass once more tallying 128-byte blocks: what the memory system serves as ONE random request (a 128-byte
     # block read by one instruction costs what a 64-byte one does: tools/gather_bench, profiles/r04_gather_calibration_groups.txt)
-    os.environ["GS_COUNT_SHIFT"] = "7"
+    gidx.set_option("GS_COUNT_SHIFT", "7")
     try:
         gidx.enumerate_device(d_seqs.data_ptr(), n_cnt, L, d_pams.data_ptr(), P, mismatches=m, count_requests=True)
         req128 = gidx.last_counters()
     finally:
-        del os.environ["GS_COUNT_SHIFT"]
+        gidx.set_option("GS_COUNT_SHIFT", None)
     n_req128 = sum(req128[k] for k in ("table_lines", "ctx16_lines", "ctx_words", "sa_isa_gathers", "occ_lines"))
 
     for i in range(args.warmup):
@@ -736,11 +736,11 @@ def verify_last_batch(torch, gidx, d_seqs, d_pams, batch, i, L, P, m, text, seqs
         assert hip.hipMemcpy(h2.data_ptr(), d_h, 16 * st2["n_hits"], 3) == 0
         return o2, h2, st2
 
-    os.environ["GS_NO_BIDIR"] = "1"
+    gidx.set_option("GS_NO_BIDIR", "1")
     try:
         o2, h2, st2 = fetch(batch)
     finally:
-        del os.environ["GS_NO_BIDIR"]
+        gidx.set_option("GS_NO_BIDIR", None)
     assert torch.equal(o2, off_d) and torch.equal(h2, hits_d), "one-sided and two-sided seeding differ"
     out["one_sided_identical_bytes"] = {"guides": int(batch), "hits": int(st2["n_hits"]),
                                         "k_search_ms": round(st2["ms_search"], 1)}

@@ -122,6 +122,12 @@ def lib():
     L.gs_index_copy_sa.argtypes = [vp, i32, vp]
     L.gs_index_last_counters.restype = i32
     L.gs_index_last_counters.argtypes = [vp, vp]
+    L.gs_index_last_sharing.restype = i32
+    L.gs_index_last_sharing.argtypes = [vp, vp]
+    L.gs_index_set_option.restype = i32
+    L.gs_index_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.gs_index_get_option.restype = i32
+    L.gs_index_get_option.argtypes = [vp, C.c_char_p, C.c_char_p, u64]
     L.gs_index_lock.restype = i32
     L.gs_index_lock.argtypes = [vp]
     L.gs_index_unlock.restype = i32
@@ -191,7 +197,8 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
            "gs_index_last_guide_flags", "gs_enumerate_general_pams", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
-           "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_debug_tile_plan", "gs_index_lock", "gs_index_unlock"]
+           "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_debug_tile_plan", "gs_index_lock", "gs_index_unlock",
+           "gs_index_last_sharing", "gs_index_set_option", "gs_index_get_option"]
 
 
 def _check(rc):
@@ -580,6 +587,26 @@ class GenomeIndex:
             finally:
                 _check(lib().gs_index_unlock(self._h))
         return hold()
+
+    def set_option(self, key, value):
+        """a switch of this handle (gs_index_set_option): value None removes it.  The environment's GS_* variables are
+        read once, when the handle is made; afterwards this is the only way to change one."""
+        _check(lib().gs_index_set_option(self._h, key.encode(), None if value is None else str(value).encode()))
+
+    def set_options(self, **kv):
+        for k, v in kv.items():
+            self.set_option(k, v)
+
+    def get_option(self, key):
+        buf = C.create_string_buffer(256)
+        rc = lib().gs_index_get_option(self._h, key.encode(), buf, 256)
+        return buf.value.decode() if rc == 0 else None
+
+    def last_sharing(self):
+        """heavy items shared among waves in the last search launch (gs_index_last_sharing)"""
+        out = (C.c_uint64 * 4)()
+        _check(lib().gs_index_last_sharing(self._h, out))
+        return dict(shared_items=int(out[0]), packages=int(out[1]), queue_packages=int(out[2]), tickets=int(out[3]))
 
     def last_counters(self):
         """k_search's counters of the last enumerate_device call (see gs_index_last_counters)"""

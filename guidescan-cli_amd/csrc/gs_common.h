@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -150,6 +152,10 @@ struct gs_recipe_set {
 };
 
 struct gs_index {
+  /* Switches of the library (tuning experiments, the forms the tests force): the process environment's GS_* variables
+   * as they were when the handle was made, then whatever gs_index_set_option changed.  No entry point reads the
+   * environment after that (a multithreaded host may setenv at any time): gs_opt() is the only reader. */
+  std::map<std::string, std::string> opts;
   /* One batch at a time per handle: the workspace, the lazily built tables and the result buffers belong to the handle,
    * while the reference's seam is called from N host threads on one const index (src/guidescan.cxx:240-247).  Every
    * entry point that takes a handle holds this lock for its whole call (host-pointer entry points copy their
@@ -168,9 +174,14 @@ struct gs_index {
       w_score, w_score_io, w_score_tmp, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
       /* overflow arena of k_search (gs_search.hip): records, chunk owners + sequence numbers, chunks per item */
       w_arena, w_arena_meta, w_nchunk,
+      /* heavy items shared among waves (gs_search_args::shq): the package queue; counters, flags, shared-item list, sums, directory bases */
+      w_shq, w_sh_meta,
       /* per-guide ordering in LDS tiles (gs_tileorder.hip): k_search's per-class counts, the plan's scans, tile
        * descriptors, bucket space, chunk index, partitioned items, class starts, rank tables + flags */
       w_cls, w_t_plan, w_t_tiles, w_t_buckets, w_t_chunkof, w_t_big, w_t_rel, w_t_tab;
+  uint32_t opt_share_min = 512, opt_share_max = 2048; /* groups of eight rows: a verification pass of share_min or more is handed out, in packages of at most share_max (0: items are never shared) */
+  unsigned long long last_share[4] = {0, 0, 0, 0}; /* the last search launch: shared items, packages reserved, queue capacity, tickets handed out */
+  uint64_t shq_packages = 16384; /* packages the next batch's queue holds (1,152 bytes each): grown when a batch reserved more */
   uint64_t arena_chunks = 4096; /* chunks of 1,024 records the next batch's arena holds: grown when a batch needed more */
   /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
   double seen_mean[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
@@ -255,6 +266,10 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   } while (0)
 
 void gs_set_error(const std::string &s);
+/* value of switch `key` on this handle, or nullptr (gs_index::opts) */
+const char *gs_opt(const gs_index *ix, const char *key);
+void gs_opts_from_env(gs_index *ix);
+extern std::atomic<int> gs_debug_any; /* some handle has GS_DEBUG set: the allocator reports large growth */
 gs_status gs_reserve(gs_buffer &b, size_t bytes);
 
 /* GPU suffix array: d_text (n bytes incl. sentinel) -> d_sa (n uint32) */

@@ -472,7 +472,7 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
   sa.n_alt = P ? n_alt : 0; /* empty guide PAM drops the alt PAMs: process.hpp:52-53 */
   sa.max_rna = rna_bulges;
   sa.max_dna = dna_bulges;
-  sa.max_iter = getenv("GS_BULGE_MAX_ITER") ? (uint32_t)atol(getenv("GS_BULGE_MAX_ITER")) : (1u << 26);
+  sa.max_iter = gs_opt(ix, "GS_BULGE_MAX_ITER") ? (uint32_t)atol(gs_opt(ix, "GS_BULGE_MAX_ITER")) : (1u << 26);
   const uint32_t grid_max = (uint32_t)gs_num_cus(ix->device) * 3u; /* 48 KB of LDS per single-wave workgroup */
   uint32_t grid = 2 * n32;
   if (grid > grid_max) grid = grid_max;
@@ -480,7 +480,7 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
    * is sized by a guess - 256 records per guide - and what does not fit is only counted: the pass then runs again with
    * room for all (the first version always searched twice: a counting pass, then a filling pass at exact offsets) */
   uint64_t T = 0, cap = std::max<uint64_t>((uint64_t)n * 256u, 1u << 16);
-  if (const char *e = getenv("GS_GENERAL_POOL")) cap = (uint64_t)std::max(1ll, atoll(e));
+  if (const char *e = gs_opt(ix, "GS_GENERAL_POOL")) cap = (uint64_t)std::max(1ll, atoll(e));
   for (int attempt = 0; attempt < 2; attempt++) {
     if (d_a.p) {
       hipFree(d_a.p);

@@ -12,6 +12,58 @@
 static thread_local std::string g_last_error;
 void gs_set_error(const std::string &s) { g_last_error = s; }
 
+/* ---- switches of a handle (gs_index::opts) ---- */
+extern char **environ;
+std::atomic<int> gs_debug_any{0};
+const char *gs_opt(const gs_index *ix, const char *key) {
+  if (!ix) return nullptr;
+  const auto it = ix->opts.find(key);
+  return it == ix->opts.end() ? nullptr : it->second.c_str();
+}
+void gs_opts_from_env(gs_index *ix) {
+  /* the one place that looks at the environment: when a handle is made */
+  for (char **e = environ; e && *e; ++e) {
+    if (strncmp(*e, "GS_", 3) != 0) continue;
+    const char *eq = strchr(*e, '=');
+    if (!eq) continue;
+    ix->opts[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+  }
+  if (ix->opts.count("GS_DEBUG")) gs_debug_any.store(1);
+}
+extern "C" gs_status gs_index_set_option(gs_index *ix, const char *key, const char *value) {
+  GS_HANDLE_LOCK(ix);
+  if (!ix || !key || strncmp(key, "GS_", 3) != 0) return GS_ERR_ARG;
+  try {
+    if (value)
+      ix->opts[key] = value;
+    else
+      ix->opts.erase(key);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
+  if (value && strcmp(key, "GS_DEBUG") == 0) gs_debug_any.store(1);
+  return GS_OK;
+}
+extern "C" gs_status gs_index_get_option(const gs_index *ix, const char *key, char *out, uint64_t cap) {
+  GS_HANDLE_LOCK(ix);
+  if (!ix || !key || !out || cap == 0) return GS_ERR_ARG;
+  const char *v = gs_opt(ix, key);
+  if (!v) {
+    out[0] = 0;
+    return GS_ERR_ARG; /* not set */
+  }
+  const size_t n = strlen(v);
+  if (n + 1 > cap) return GS_ERR_ARG;
+  memcpy(out, v, n + 1);
+  return GS_OK;
+}
+extern "C" gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[4]) {
+  GS_HANDLE_LOCK(ix);
+  if (!ix || !out) return GS_ERR_ARG;
+  for (int i = 0; i < 4; i++) out[i] = ix->last_share[i];
+  return GS_OK;
+}
+
 extern "C" const char *gs_status_string(gs_status s) {
   switch (s) {
     case GS_OK: return "ok";

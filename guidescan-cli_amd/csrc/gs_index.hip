@@ -748,6 +748,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
   if (!ix) return GS_ERR_NOMEM;
   ix->device = device;
   ix->genome_length = len;
+  gs_opts_from_env(ix);
   hipStream_t st = nullptr;
   uint8_t *d_fwd = nullptr, *d_rev = nullptr;
   /* every early return below (GS_HIP) releases what was allocated so far */
@@ -959,7 +960,7 @@ extern "C" void gs_index_close(gs_index *ix) {
                        &ix->w_nhits2, &ix->w_h_off, &ix->w_h_tmp, &ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix,
                        &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx, &ix->w_b_idxb,
                        &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_redo_pos, &ix->w_b_s, &ix->w_b_tab,
-                       &ix->w_cand, &ix->rec[0].buf, &ix->rec[1].buf, &ix->w_score, &ix->w_score_io, &ix->w_score_tmp, &ix->w_arena, &ix->w_arena_meta, &ix->w_nchunk,
+                       &ix->w_cand, &ix->rec[0].buf, &ix->rec[1].buf, &ix->w_score, &ix->w_score_io, &ix->w_score_tmp, &ix->w_arena, &ix->w_arena_meta, &ix->w_nchunk, &ix->w_shq, &ix->w_sh_meta,
                        &ix->w_cls, &ix->w_t_plan, &ix->w_t_tiles, &ix->w_t_buckets, &ix->w_t_chunkof, &ix->w_t_big, &ix->w_t_rel, &ix->w_t_tab};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
@@ -1016,7 +1017,7 @@ extern "C" gs_status gs_index_copy_sa(gs_index *ix, int strand, uint32_t *out) {
 
 gs_status gs_reserve(gs_buffer &b, size_t bytes) {
   if (b.cap >= bytes && b.p) return GS_OK;
-  if (bytes > ((size_t)1 << 30) && getenv("GS_DEBUG"))
+  if (bytes > ((size_t)1 << 30) && gs_debug_any.load(std::memory_order_relaxed))
     fprintf(stderr, "[gs] workspace buffer grows from %.2f to %.2f GiB\n", (double)b.cap / (1 << 30), (double)bytes / (1 << 30));
   const bool again = b.p != nullptr && b.cap > ((size_t)1 << 30);
   if (b.p) hipFree(b.p);

@@ -250,7 +250,7 @@ static gs_status build_one(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k, 
   d.rot_first = nrot ? rot_from : 31u;
   d.code = p.code;
   p.bytes += sizeof(uint2) * entries * (1 + nrot) + 10 * rows;
-  if (getenv("GS_DEBUG"))
+  if (gs_opt(ix, "GS_DEBUG"))
     fprintf(stderr, "[gs] PAM-pair table: strand %d, pair %u at context depth %u: %llu of %llu rows, %u rotated copies, %.2f GB\n",
             s, p.code, p.v_rem, (unsigned long long)rows, (unsigned long long)S.n, nrot,
             1e-9 * (double)(sizeof(uint2) * entries * (1 + nrot) + 10 * rows));
@@ -280,7 +280,7 @@ static gs_status build_deep(gs_index *ix, gs_pairtab_host &p, int s, uint32_t k,
   GS_HIP(hipGetLastError());
   p.d[s].deep = (const uint4 *)m[5];
   p.bytes += 64 * entries;
-  if (getenv("GS_DEBUG"))
+  if (gs_opt(ix, "GS_DEBUG"))
     fprintf(stderr, "[gs] deep table: strand %d, pair %u: %llu lines of four entries, %.2f GB\n", s, p.code,
             (unsigned long long)entries, 1e-9 * (double)(64 * entries));
   return GS_OK;
@@ -300,12 +300,12 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
   GS_HIP(hipMemGetInfo(&free_b, &total_b));
   const double entry_bytes = 8.0 * (double)(1ull << (2 * k));
   double reserve = 64e9; /* slots, sort buffers and hits of a large batch at a high budget */
-  if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
+  if (const char *e = gs_opt(ix, "GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
   if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
   const double rows_bytes = 10.0 * ((double)ix->strand[0].n + (double)ix->strand[1].n) / 16.0 * 1.5;
   const double tmp_bytes = 8.0 * (double)(1ull << (2 * k)) + 64e6;
   double room = (double)free_b - reserve;
-  if (const char *e = getenv("GS_INDEX_BUDGET_GB")) { /* the cap on the whole index covers its derived tables too */
+  if (const char *e = gs_opt(ix, "GS_INDEX_BUDGET_GB")) { /* the cap on the whole index covers its derived tables too */
     const double left = atof(e) * 1e9 - (double)gs_index_device_bytes(ix);
     if (left < room) room = left;
   }
@@ -314,7 +314,7 @@ gs_status gs_pairtab_ensure(gs_index *ix, uint32_t slot, uint32_t v_rem, uint32_
     const double need = 2.0 * entry_bytes * (1 + nrot) + rows_bytes + tmp_bytes;
     if (need <= room * share) break; /* share < 1: another pair's tables are still to come */
     if (nrot == 0) {
-      if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] PAM-pair table %u: not enough free memory (%.1f GB), skipped\n", code, 1e-9 * (double)free_b);
+      if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] PAM-pair table %u: not enough free memory (%.1f GB), skipped\n", code, 1e-9 * (double)free_b);
       return GS_OK;
     }
     rot_first = nrot == 1 ? 31 : rot_first + 1;
@@ -354,7 +354,7 @@ gs_status gs_pairtab_ensure_deep(gs_index *ix, uint32_t slot, uint32_t P, uint32
   size_t free_b = 0, total_b = 0;
   GS_HIP(hipMemGetInfo(&free_b, &total_b));
   double reserve = 56e9;
-  if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
+  if (const char *e = gs_opt(ix, "GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
   if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
   if (2.0 * 64.0 * (double)(1ull << (2 * kb)) + reserve > (double)free_b) return GS_OK;
   for (int s = 0; s < 2; s++) {

@@ -124,7 +124,49 @@ struct gs_search_args {
    * within m <= 3 substitutions one of the four chunks is intact, so an item reads the four buckets of its own
    * chunks instead of the whole list; nullptr: the list is scanned in order */
   const uint32_t *cand_off[2], *cand_ids[2];
+  /* ---- heavy items shared among waves (table-seeded variants, arena on, one PAM pass) ----------------------
+   * One wave owns one item, and on a repeat-rich genome a quarter of the items hold 10^4 .. 10^5 records each: the
+   * launch lasted as long as the wave slots that drew two or three of them.  A verification pass (k_search_body::
+   * verify) whose queued descriptors cover share_min groups of eight rows or more is not run by the item's wave: the
+   * descriptors go to a queue in memory as PACKAGES of at most share_max groups - 64 descriptors, self-contained
+   * next to the item number, the side (this strand's table / the other strand's) and the PAM-pair table - and the
+   * waves that find the work counter exhausted run them: same code, entered with the queue preloaded and no recipes.
+   * A helper's records go to arena chunks of its own (chunk_seq = 0x40000000 | its number among the item's helper
+   * chunks, chunk_fill = what it holds), its counts to sh_acc; k_share_scan/dir/fix (below) then close the gaps
+   * (records from the item's last chunks into the holes), so everything downstream sees the layout it always saw.
+   * Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility): packages are whole 128-byte lines written once per
+   * launch with write-through (sc1) stores, drained, then an sc1 flag per package; a consumer holds ticket t
+   * (one atomicAdd on the head), polls flag t, acquires at agent scope and reads with sc1 loads.  No wave waits for
+   * another except a helper for the package of its ticket, whose writer never waits: every wave reaches its exit. */
+  uint4 *shq;           /* nullptr: off.  SHQ_PKG uint4 per package: [0] = {item, shared item, side | table << 1 | descriptors << 8, 0} */
+  uint32_t *shq_ctl;    /* [0] packages reserved, [32] tickets handed out, [64] waves that left the item phase, [96] shared items */
+  uint32_t *shq_ready;  /* per package: written */
+  uint32_t *sh_list;    /* shared item -> slot */
+  uint32_t *sh_acc;     /* per shared item 16 words: [0] records of helpers, [1] their chunks, [8..15] per mismatch class */
+  uint32_t *chunk_fill; /* per chunk of a helper: records it holds */
+  uint32_t shq_cap, sh_max, share_min, share_max, n_waves;
 };
+#define SHQ_PKG 72u /* uint4 per package: header + 64 descriptors, padded to nine 128-byte lines */
+#define SH_NONE 0xFFFFFFFFu
+#define SH_HELPER_SEQ 0x40000000u
+typedef uint32_t __attribute__((address_space(1))) gs_gu32;
+typedef unsigned long long __attribute__((address_space(1))) gs_gu64;
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p) {
+  return __hip_atomic_load((const gs_gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v) {
+  __hip_atomic_store((gs_gu32 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* 16 bytes as two write-through / L1-bypassing 8-byte accesses */
+__device__ __forceinline__ void st16_agent(uint4 *p, const uint4 v) {
+  __hip_atomic_store((gs_gu64 *)p, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store((gs_gu64 *)p + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint4 ld16_agent(const uint4 *p) {
+  const unsigned long long lo = __hip_atomic_load((const gs_gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load((const gs_gu64 *)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
 #define DSC_LO 27u  /* descriptor.y bits 29:27: fewest substitutions allowed among the remaining guide symbols */
 #define DSC_EXC 30u /* descriptor.y bit 30: the interval holds exception rows (gs_strand_dev::exc_row) */
 
@@ -232,16 +274,63 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
    * microsecond chip-wide (MI355X_MICROARCH.md, dequeue), so a counter bumped once per item held a launch of
    * 2 M items at 22.9 ms whatever the items did (measured with the seeding switched off: 22.9 of 26.5 ms) */
   uint32_t item_next = 0, item_end = 0;
+  const bool sharing = !WALK && a.shq != nullptr;
+  bool items_done = false; /* the work counter is exhausted: this wave runs packages of shared items until none is left */
   for (;;) {
-    if (item_next == item_end) {
+    if (!items_done && item_next == item_end) {
       uint32_t base = 0;
       if (lane == 0) base = atomicAdd(a.work, a.take);
       base = __builtin_amdgcn_readfirstlane(base);
-      if (base >= a.n_items) break; /* exit condition every wave reaches */
-      item_next = base;
-      item_end = base + a.take < a.n_items ? base + a.take : a.n_items;
+      if (base >= a.n_items) {
+        if (!sharing) break; /* exit condition every wave reaches */
+        items_done = true;
+        if (lane == 0) atomicAdd(&a.shq_ctl[64], 1u); /* this wave reserves no package any more */
+      } else {
+        item_next = base;
+        item_end = base + a.take < a.n_items ? base + a.take : a.n_items;
+      }
     }
-    const uint32_t item = item_next++;
+    /* a helper episode: one package = one verification pass of somebody else's item */
+    bool helper = false, h_side_b = false;
+    uint32_t h_item = 0, h_sid = 0, h_tab = 3u, h_n = 0;
+    const uint4 *h_pkg = nullptr;
+    if (items_done) {
+      /* Ticket t: package t is this wave's, if it is ever reserved.  The wave waits for its flag; once every wave has
+       * left its items no reservation can follow, and a ticket at or beyond the reserved count leaves.  The writer of
+       * a reserved package never waits for anything, and the spin is bounded all the same (GS_ERR_DEVICE, no hang). */
+      uint32_t got = SH_NONE;
+      if (lane == 0) {
+        const uint32_t t = atomicAdd(&a.shq_ctl[32], 1u);
+        if (t < a.shq_cap) {
+          for (uint32_t spins = 0;; ++spins) {
+            if (ld_agent(a.shq_ready + t) != 0u) {
+              got = t;
+              break;
+            }
+            if ((spins & 3u) == 3u && ld_agent(&a.shq_ctl[64]) >= a.n_waves && t >= ld_agent(&a.shq_ctl[0])) break;
+            if (spins > (1u << 20)) { /* ~3 s of sleeping: something is broken; fail the call, drain the grid */
+              atomicOr(a.err, 2u);
+              break;
+            }
+            __builtin_amdgcn_s_sleep(100);
+          }
+        }
+      }
+      got = __builtin_amdgcn_readfirstlane(got);
+      if (got == SH_NONE) break; /* exit condition every wave reaches: all items taken, no package left for this ticket */
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      h_pkg = a.shq + (size_t)got * SHQ_PKG;
+      const uint4 hd = ld16_agent(h_pkg);
+      h_item = __builtin_amdgcn_readfirstlane(hd.x);
+      h_sid = __builtin_amdgcn_readfirstlane(hd.y);
+      const uint32_t hz = __builtin_amdgcn_readfirstlane(hd.z);
+      h_side_b = (hz & 1u) != 0u;
+      h_tab = (hz >> 1) & 3u;
+      h_n = hz >> 8;
+      if (h_n == 0u || h_n > WAVE || h_item >= a.n_items) continue; /* a filler for a reservation the queue had no room for */
+      helper = true;
+    }
+    const uint32_t item = helper ? h_item : item_next++;
     /* all forward-index items first, then all reverse-index items: at any moment the waves
      * touch one strand's Occ array, which halves the hot footprint (TLB reach) */
     const uint32_t n_guides = a.n_items >> 1;
@@ -260,17 +349,22 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     const uint32_t gr_npams = __builtin_amdgcn_readfirstlane(gp[6]);
     const uint32_t gr_valid = __builtin_amdgcn_readfirstlane(gp[7]);
     if (!gr_valid || bailed) {
-      if (lane == 0) a.counts[slot] = 0;
-      if (a.arena != nullptr && lane < 8u) a.cls[(size_t)slot * 8u + lane] = 0u;
+      if (!helper) {
+        if (lane == 0) a.counts[slot] = 0;
+        if (a.arena != nullptr && lane < 8u) a.cls[(size_t)slot * 8u + lane] = 0u;
+      }
       continue;
     }
+    uint32_t sid = SH_NONE; /* this item's number among the shared items, once a pass of it has been handed out */
+    uint32_t cur_tab = 3u;  /* the PAM-pair table this strand's seeds are going through (3: the strand's own table) */
     uint32_t guard_left = a.max_iter; /* rounds this item's loops may still take (every outer step runs a counted inner loop) */
     const gs_strand_dev &sd = a.sd[strand];
     const uint4 *__restrict__ blocks = sd.blocks;
     const uint32_t npams = P ? gr_npams : 1u;
     const bool fanning = P > 0 && npams > 1u; /* a finished 20-mer fans out per PAM pattern */
     uint4 *out = a.slots + (a.slot_off ? (size_t)a.slot_off[slot] : (size_t)slot * a.cap);
-    const uint32_t item_cap = a.slot_off ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : a.cap;
+    /* (a helper owns no slots: its records go to arena chunks of its own from the first one on) */
+    const uint32_t item_cap = helper ? 0u : a.slot_off ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : a.cap;
     uint32_t n_match = 0;
     if (a.append) n_match = __builtin_amdgcn_readfirstlane(a.counts[slot]);
     if (a.arena != nullptr) {
@@ -347,7 +441,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
             if (id >= a.arena_chunks) break; /* arena exhausted: the item goes on counting only */
             if (lane == 0) {
               a.chunk_item[id] = slot;
-              a.chunk_seq[id] = nch;
+              if (helper) { /* numbered among the item's helper chunks; what it holds is said when the episode ends */
+                a.chunk_seq[id] = SH_HELPER_SEQ | atomicAdd(&a.sh_acc[16u * h_sid + 1u], 1u);
+                a.chunk_fill[id] = ARENA_CHUNK;
+              } else {
+                a.chunk_seq[id] = nch;
+              }
               wmisc[2] = wmisc[1];
               wmisc[1] = id;
             }
@@ -424,6 +523,47 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
       if (!R) return;
       const uint32_t excl = incl - vgrp;
+      if constexpr (!WALK) {
+        /* ---- a heavy pass is handed to the waves that have run out of items (gs_search_args::shq) ---- */
+        if (sharing && !helper && R >= a.share_min) {
+          if (sid == SH_NONE) {
+            uint32_t s = 0;
+            if (lane == 0) s = atomicAdd(&a.shq_ctl[96], 1u);
+            sid = __builtin_amdgcn_readfirstlane(s);
+            if (sid < a.sh_max && lane == 0) a.sh_list[sid] = slot;
+          }
+          if (sid < a.sh_max) {
+            /* packages of at most share_max groups: consecutive descriptors (each <= 128 groups <= share_max) */
+            const uint32_t pid = lane < take ? excl / a.share_max : 0u;
+            const uint32_t np = __builtin_amdgcn_readlane(pid, (int)(take - 1u)) + 1u;
+            uint32_t qb = 0;
+            if (lane == 0) qb = atomicAdd(&a.shq_ctl[0], np);
+            qb = __builtin_amdgcn_readfirstlane(qb);
+            if (qb + np <= a.shq_cap) {
+              const uint32_t ppid = dpp_or_zero<0x138>(pid + 1u); /* the lane below's package + 1 (lane 0: 0) */
+              const bool first = lane < take && ppid != pid + 1u;
+              const uint64_t bm = __ballot(first);
+              const uint64_t upto = (2ull << lane) - 1ull; /* lanes 0 .. lane (lane 63: all) */
+              const uint32_t start = 63u - (uint32_t)__builtin_clzll((bm & upto) | 1ull);
+              const uint64_t above = bm & ~upto;
+              const uint32_t nxt = above ? (uint32_t)__builtin_ctzll(above) : take;
+              uint4 *pk = a.shq + (size_t)(qb + pid) * SHQ_PKG;
+              if (lane < take) st16_agent(pk + 1u + (lane - start), mine);
+              if (first) st16_agent(pk, make_uint4(item, sid, (modeB ? 1u : 0u) | (cur_tab << 1) | ((nxt - start) << 8), 0u));
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every store of the packages has left before their flags do */
+              if (first) st_agent(a.shq_ready + qb + pid, 1u);
+              return;
+            }
+            /* no room in the queue (a later batch gets a larger one): empty packages for what was reserved, and the
+             * pass runs here */
+            if (qb < a.shq_cap && lane < a.shq_cap - qb && lane < np) {
+              st16_agent(a.shq + (size_t)(qb + lane) * SHQ_PKG, make_uint4(0u, 0u, 0u, 0u));
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              st_agent(a.shq_ready + qb + lane, 1u);
+            }
+          }
+        }
+      }
       /* descriptor.y = first group (14 bits) | mismatches so far << 14 | rows << 17 | ... */
       if (lane < take) dsrc[lane].y = mine.y | excl;
       const uint32_t g = modeB ? a.x_len : L - k; /* guide symbols among the remaining ones */
@@ -730,10 +870,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         }
         if (!all) pslots = 0u;
       }
+      /* a helper goes through the one table its package names (or none: the other strand's side) */
+      if (helper) pslots = (!h_side_b && h_tab < 2u) ? 1u << h_tab : 0u;
       if (!fallback) {
         /* literal-N windows within reach whose (a, o) belongs to the other side - or all of them:
          * the PAM-pair tables hold no row with a symbol outside A,C,G,T next to it */
-        const uint32_t ncand = a.n_cand[strand];
+        const uint32_t ncand = helper ? 0u : a.n_cand[strand]; /* (the item's own wave reports the windows) */
         const uint64_t lmask = (1ull << (2u * L)) - 1ull;
         const uint64_t xmask = (1ull << (2u * sx)) - 1ull, komask = (1ull << (2u * k)) - 1ull;
 #ifdef GS_X_NO_BUCKETS
@@ -741,7 +883,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
 #else
         const uint32_t *cids = a.cand_ids[strand];
 #endif
-        const uint32_t nseg = cids != nullptr ? 4u : 1u;
+        const uint32_t nseg = helper ? 0u : cids != nullptr ? 4u : 1u;
         for (uint32_t sg = 0; sg < nseg; ++sg) {
         uint32_t s0 = 0, s1 = ncand;
         if (cids != nullptr) { /* the bucket of this item's chunk sg */
@@ -804,8 +946,14 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         }
         for (uint32_t j = 0; j < sx; ++j) qrem_b |= (3u - ((uint32_t)(gr_q >> (2u * (sx - 1u - j))) & 3u)) << (2u * j);
         /* lanes of one pass over the recipes: one per recipe, or - deep tables - four, one per base under the N */
-        const uint32_t nlanes = deep ? 4u * a.n_rec_b : a.n_rec_b;
-        fill_dtab(true);
+        /* (a helper has no recipes to go through: its queue comes filled and the loop below only drains it) */
+        const uint32_t nlanes = helper ? 0u : deep ? 4u * a.n_rec_b : a.n_rec_b;
+        if (!helper) fill_dtab(true);
+        if (helper && h_side_b) {
+          if (lane < h_n) vq[lane] = ld16_agent(h_pkg + 1u + lane);
+          qn = h_n;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        }
         /* the guide part of the other strand's k-mer: step P+y holds the complement of guide symbol L-1-y */
         const uint32_t nYb = deep ? L - sx : nY;
         uint32_t pidxg = 0;
@@ -942,17 +1090,21 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         }
       }
       if (fallback) {
-        n_fb++; /* every seed from this strand */
+        if (!helper) n_fb++; /* every seed from this strand */
       } else {
-        n_two++;
         rec = pslots ? a.rec_a8 : a.rec_a;
         nrec = pslots ? a.n_rec_a8 : a.n_rec_a;
-        if (pslots) n_pair++;
+        if (!helper) {
+          n_two++;
+          if (pslots) n_pair++;
+        }
       }
     }
+    if (helper) nrec = 0u;
     auto next_pairtab = [&]() __attribute__((always_inline)) {
       const uint32_t s = (pslots & 1u) ? 0u : 1u;
       pslots &= ~(1u << s);
+      cur_tab = s;
       const gs_pairtab_dev &p = a.pt[s][strand];
       atab8 = own_sgprs(p.tab);
       arot8 = own_sgprs(p.rot);
@@ -970,9 +1122,19 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     const uint32_t gmask13 = gA >= 13u ? 0x3FFFFFFu : gmaskA;
     uint32_t qhot = 0u;
     for (uint32_t j = 0; j < 6u && j < gA; ++j) qhot |= 1u << (4u * j + ((qremA >> (2u * j)) & 3u));
-    if (seeding) {
+    if (seeding && !helper) {
       fill_dtab(false);
       if (nrec == 0u) seeds_left = false;
+    }
+    if (helper) {
+      /* this strand's side of a package: ONE seeding step without recipes, whose queue loop finds the pass ended and
+       * the queue filled - the verification below is the one the item's own wave would have run */
+      seeds_left = !h_side_b;
+      if (!h_side_b) {
+        if (lane < h_n) vq[lane] = ld16_agent(h_pkg + 1u + lane);
+        qn = h_n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      }
     }
     /* as on the other side: the next step's recipe is requested a step ahead */
     uint2 rc_ahead = make_uint2(0u, 0u);
@@ -1263,12 +1425,25 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       } /* WALK */
     }
+    if (helper) {
+      /* the episode's records, chunks and class counts join the item's through sh_acc; its last chunk says what it holds
+       * (k_share_fix closes the gaps behind the launch) */
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
+      const bool short_of = n_match > (nch << ARENA_SHIFT); /* the arena ran out: counted, not kept (the host searches the batch's overflow again) */
+      if (lane == 0 && n_match != 0u) atomicAdd(&a.sh_acc[16u * h_sid], n_match);
+      if (lane == 1u && nch != 0u && !short_of) a.chunk_fill[last] = n_match - ((nch - 1u) << ARENA_SHIFT);
+      if (lane >= 8u && lane < 16u && wmisc[lane - 4u] != 0u) atomicAdd(&a.sh_acc[16u * h_sid + lane], wmisc[lane - 4u]);
+      if (short_of) n_fail++;
+      continue;
+    }
     if (lane == 0) a.counts[slot] = n_match;
     if (n_match > item_cap) n_ovf++;
     if (a.arena != nullptr) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
-      if (lane == 0) a.nchunk[slot] = make_uint2(nch, last);
+      /* (a shared item: its number instead of the last chunk - nobody appends to it - for k_share_dir/fix) */
+      if (lane == 0) a.nchunk[slot] = make_uint2(nch, sid < a.sh_max ? 0x80000000u | sid : last);
       if (lane < 8u) a.cls[(size_t)slot * 8u + lane] = wmisc[4u + lane];
       if (n_match > item_cap && n_match - item_cap > (nch << ARENA_SHIFT)) n_fail++;
     }
@@ -1786,6 +1961,7 @@ __global__ __launch_bounds__(256) void k_arena_gather(gs_agather_args a) {
   } else {
     const uint32_t c = b - 2u * a.n_o;
     if (c >= a.n_used) return;
+    if (a.chunk_seq[c] == 0xFFFFFFFFu) return; /* emptied when a shared item's gaps were closed (k_share_fix) */
     const uint32_t item = a.chunk_item[c];
     const uint32_t pos = a.redo_pos[item >> 1];
     if (pos == 0xFFFFFFFFu) return; /* cannot happen: an item with chunks overflowed its slots */
@@ -1798,6 +1974,192 @@ __global__ __launch_bounds__(256) void k_arena_gather(gs_agather_args a) {
   }
   uint4 *dst = a.dst + (a.dst_off ? (size_t)a.dst_off[j] : (size_t)j * a.cap2) + first;
   for (uint32_t i = threadIdx.x; i < nrec; i += blockDim.x) dst[i] = src[i];
+}
+
+/* ---- shared items (gs_search_args::shq): the gaps their helpers left are closed -----------------------------
+ * Behind k_search a shared item's records lie in its slots (the owner's first `cap`), the owner's chunks (full but
+ * the last) and the helpers' chunks (each episode's last one partly filled).  Everything downstream reads an item as
+ * "slots, then chunks 0, 1, .. in order, all full but the last": k_share_fix moves the records that lie beyond the
+ * item's total into the holes before it (their order inside an item means nothing: the ordering kernels sort by
+ * (sequence, row)), renumbers the chunks, drops the emptied ones (chunk_seq = 0xFFFFFFFF) and adds the helpers' counts. */
+struct gs_share_args {
+  const uint32_t *ctl;     /* gs_search_args::shq_ctl */
+  const uint32_t *sh_list;
+  const uint32_t *sh_acc;
+  uint32_t *counts;
+  uint2 *nchunk;
+  uint32_t *cls;
+  const uint32_t *chunk_item;
+  uint32_t *chunk_seq;
+  const uint32_t *chunk_fill;
+  const uint32_t *arena_next;
+  uint4 *slots, *arena;
+  uint32_t *dbase; /* [sh_max + 1] first directory entry of each shared item */
+  uint32_t *dir;   /* the item's chunks in order: the owner's, then the helpers' */
+  unsigned long long *stats;
+  uint32_t sh_max, cap, arena_chunks;
+};
+#define SH_MAXSEG 4096u /* slots + chunks of one shared item the fix holds in LDS (4 M records) */
+__global__ __launch_bounds__(1024) void k_share_scan(gs_share_args a) {
+  __shared__ uint32_t s_w[16], s_carry;
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), w = tid / WAVE;
+  const uint32_t n_sh = a.ctl[96] < a.sh_max ? a.ctl[96] : a.sh_max;
+  if (tid == 0) s_carry = 0u;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < n_sh + 1u; i0 += 1024u) {
+    const uint32_t sid = i0 + tid;
+    uint32_t v = 0;
+    if (sid < n_sh) v = a.nchunk[a.sh_list[sid]].x + a.sh_acc[16u * sid + 1u];
+    const uint32_t incl = wave_incl_sum(v);
+    if (lane == WAVE - 1u) s_w[w] = incl;
+    __syncthreads();
+    uint32_t b = s_carry;
+    for (uint32_t u = 0; u < w; ++u) b += s_w[u];
+    if (sid <= n_sh) a.dbase[sid] = b + incl - v;
+    __syncthreads();
+    if (tid == 1023u) s_carry = b + incl;
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_share_dir(gs_share_args a) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_used = *a.arena_next < a.arena_chunks ? *a.arena_next : a.arena_chunks;
+  if (c >= n_used) return;
+  const uint32_t slot = a.chunk_item[c];
+  const uint2 nc = a.nchunk[slot];
+  if (!(nc.y >> 31)) return;
+  const uint32_t sid = nc.y & 0x7FFFFFFFu;
+  const uint32_t n_sh = a.ctl[96] < a.sh_max ? a.ctl[96] : a.sh_max;
+  if (sid >= n_sh) return;
+  const uint32_t seq = a.chunk_seq[c];
+  const uint32_t j = (seq & SH_HELPER_SEQ) ? nc.x + (seq & (SH_HELPER_SEQ - 1u)) : seq;
+  const uint32_t d0 = a.dbase[sid];
+  if (j < a.dbase[sid + 1u] - d0) a.dir[d0 + j] = c;
+}
+__global__ __launch_bounds__(256) void k_share_fix(gs_share_args a) {
+  /* segment 0 = the slots, segment 1 + j = chunk j of the directory */
+  __shared__ uint32_t s_fill[SH_MAXSEG + 1u], s_hole[SH_MAXSEG + 2u], s_mov[SH_MAXSEG + 2u];
+  __shared__ uint32_t s_red[3][4], s_tot[3];
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), w = tid / WAVE;
+  const uint32_t n_sh = a.ctl[96] < a.sh_max ? a.ctl[96] : a.sh_max;
+  for (uint32_t sid = blockIdx.x; sid < n_sh; sid += gridDim.x) {
+    const uint32_t slot = a.sh_list[sid];
+    const uint32_t own = a.counts[slot], H = a.sh_acc[16u * sid], nho = a.nchunk[slot].x;
+    const uint32_t d0 = a.dbase[sid], ns = a.dbase[sid + 1u] - d0;
+    const uint32_t *dir = a.dir + d0;
+    const uint32_t T = own + H, cap = a.cap;
+    const bool own_short = own > cap && own - cap > (nho << ARENA_SHIFT);
+    const uint32_t nseg = ns + 1u;
+    __syncthreads(); /* (the previous item's tables are no longer read) */
+    if (ns > SH_MAXSEG || own_short) {
+      /* not in a state to be closed up (or the arena ran out under the owner): the total is exact, the host searches the
+       * batch's overflowing guides again - this item among them */
+      if (tid == 0) {
+        a.counts[slot] = T > cap ? T : cap + 1u;
+        atomicAdd(&a.stats[6], 1ull);
+        atomicAdd(&a.stats[1], 1ull);
+      }
+      continue;
+    }
+    /* what each segment holds */
+    uint32_t v_sum = 0;
+    for (uint32_t s = tid; s < nseg; s += 256u) {
+      uint32_t f;
+      if (s == 0u)
+        f = own < cap ? own : cap;
+      else if (s - 1u < nho)
+        f = s < nho ? ARENA_CHUNK : own - cap - ((nho - 1u) << ARENA_SHIFT);
+      else
+        f = a.chunk_fill[dir[s - 1u]];
+      if (f > ARENA_CHUNK && s != 0u) f = ARENA_CHUNK;
+      s_fill[s] = f;
+      v_sum += f;
+    }
+    for (int o = 32; o > 0; o >>= 1) v_sum += (uint32_t)__shfl_xor((int)v_sum, o);
+    if (lane == 0) s_red[0][w] = v_sum;
+    __syncthreads();
+    const uint32_t V = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    if (V != T) { /* a helper was short of chunks: as above */
+      if (tid == 0) {
+        a.counts[slot] = T > cap ? T : cap + 1u;
+        atomicAdd(&a.stats[6], 1ull);
+        atomicAdd(&a.stats[1], 1ull);
+      }
+      continue;
+    }
+    /* holes before place T and records at or beyond it, per segment; thread t takes a run of per segments */
+    const uint32_t per = (nseg + 255u) / 256u, s_lo = tid * per, s_hi = s_lo + per < nseg ? s_lo + per : nseg;
+    uint32_t h_sum = 0, m_sum = 0;
+    for (uint32_t s = s_lo; s < s_hi; ++s) {
+      const uint32_t start = s == 0u ? 0u : cap + ((s - 1u) << ARENA_SHIFT), room = s == 0u ? cap : ARENA_CHUNK, f = s_fill[s];
+      const uint32_t in = T > start ? (T - start < room ? T - start : room) : 0u; /* places of the segment before T */
+      const uint32_t hole = in > f ? in - f : 0u, mov = f > in ? f - in : 0u;
+      s_hole[s] = hole;
+      s_mov[s] = mov;
+      h_sum += hole;
+      m_sum += mov;
+    }
+    const uint32_t hi = wave_incl_sum(h_sum), mi = wave_incl_sum(m_sum);
+    if (lane == WAVE - 1u) {
+      s_red[1][w] = hi;
+      s_red[2][w] = mi;
+    }
+    __syncthreads();
+    uint32_t hb = hi - h_sum, mb = mi - m_sum;
+    for (uint32_t u = 0; u < w; ++u) {
+      hb += s_red[1][u];
+      mb += s_red[2][u];
+    }
+    if (tid == 255u) {
+      s_tot[1] = hb + h_sum;
+      s_tot[2] = mb + m_sum;
+    }
+    for (uint32_t s = s_lo; s < s_hi; ++s) { /* exclusive prefixes in place */
+      const uint32_t h = s_hole[s], m = s_mov[s];
+      s_hole[s] = hb;
+      s_mov[s] = mb;
+      hb += h;
+      mb += m;
+    }
+    __syncthreads();
+    const uint32_t M = s_tot[2];
+    if (tid == 0) {
+      s_hole[nseg] = s_tot[1];
+      s_mov[nseg] = M;
+    }
+    __syncthreads();
+    if (s_tot[1] == M) {
+      for (uint32_t r = tid; r < M; r += 256u) {
+        /* mover r: the last segment whose prefix is <= r (segments without movers share a prefix with their successor) */
+        uint32_t lo = 0, hi2 = nseg;
+        while (hi2 - lo > 1u) {
+          const uint32_t mid = (lo + hi2) >> 1;
+          if (s_mov[mid] <= r) lo = mid; else hi2 = mid;
+        }
+        const uint32_t sm = lo, fm = s_fill[sm];
+        const uint32_t startm = cap + ((sm - 1u) << ARENA_SHIFT); /* (segment 0 holds no mover unless T = 0: then M = 0) */
+        const uint32_t inm = T > startm ? (T - startm < fm ? T - startm : fm) : 0u;
+        const uint4 *src = a.arena + (((size_t)dir[sm - 1u] << ARENA_SHIFT) + inm + (r - s_mov[sm]));
+        lo = 0, hi2 = nseg;
+        while (hi2 - lo > 1u) {
+          const uint32_t mid = (lo + hi2) >> 1;
+          if (s_hole[mid] <= r) lo = mid; else hi2 = mid;
+        }
+        const uint32_t sh = lo, off = s_fill[sh] + (r - s_hole[sh]);
+        uint4 *dst = sh == 0u ? a.slots + ((size_t)slot * cap + off) : a.arena + (((size_t)dir[sh - 1u] << ARENA_SHIFT) + off);
+        *dst = *src;
+      }
+    }
+    const uint32_t nf = T > cap ? (T - cap + ARENA_CHUNK - 1u) >> ARENA_SHIFT : 0u;
+    for (uint32_t j = tid; j < ns; j += 256u) a.chunk_seq[dir[j]] = j < nf ? j : 0xFFFFFFFFu;
+    if (tid < 8u) a.cls[(size_t)slot * 8u + tid] += a.sh_acc[16u * sid + 8u + tid];
+    if (tid == 0) {
+      a.counts[slot] = T;
+      a.nchunk[slot] = make_uint2(nf, nf ? dir[nf - 1u] : 0u);
+      if (own <= cap && T > cap) atomicAdd(&a.stats[1], 1ull);
+      if (s_tot[1] != M) atomicAdd(&a.stats[6], 1ull); /* (cannot happen: V = T makes holes and movers equal) */
+    }
+  }
 }
 
 /* ---- guides with more matches than an LDS sort can hold: repeat-derived guides at any budget,
@@ -1983,7 +2345,7 @@ __global__ __launch_bounds__(256) void k_big2_compact(gs_big2_compact_args a) {
     g = sb >> 1;
   } else {
     const uint32_t c = blockIdx.x - a.n_items;
-    if (c >= a.n_used) return;
+    if (c >= a.n_used || a.chunk_seq[c] == 0xFFFFFFFFu) return; /* (emptied by k_share_fix) */
     const uint32_t item = a.chunk_item[c];
     uint32_t sb = item;
     if (a.list) {
@@ -2331,7 +2693,7 @@ static uint32_t choose_cap(const gs_index *ix, uint32_t m, uint32_t L, uint32_t 
    * top, and the largest count the last batch showed unless a repeat-derived guide made it huge */
   double want = 1.5 * mean + 8.0 * sqrt(mean > 1 ? mean : 1) + 64;
   if (seen_max > want) want = seen_max * 1.05 < 3.0 * mean + 64 ? seen_max * 1.05 : 3.0 * mean + 64;
-  if (const char *e = getenv("GS_SLOT_CAP")) want = atof(e);
+  if (const char *e = gs_opt(ix, "GS_SLOT_CAP")) want = atof(e);
   uint32_t cap = 64;
   while (cap < want && cap < 256) cap <<= 1;
   if (want > 256) cap = (uint32_t)((want + 255) / 256) * 256;
@@ -2582,7 +2944,7 @@ static gs_status gs_recipes_for(gs_index *ix, uint32_t L, uint32_t P, uint32_t m
   R.key[1] = key[1];
   R.valid = true;
   ix->rec_cur = slot;
-  if (getenv("GS_DEBUG"))
+  if (gs_opt(ix, "GS_DEBUG"))
     fprintf(stderr, "[gs] seed recipes: %zu one-sided, %zu + %zu two-sided (%.1f MB)\n", n_full, n_a, n_b, 8e-6 * all.size());
   return GS_OK;
 }
@@ -2608,7 +2970,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       (void)hipGetLastError();
       ix->rot_off = true;
       ix->pairtab_nofit = 0; /* 86 GB came back: a pair that did not fit may now */
-      if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: rotated table copies dropped, batch redone without them\n");
+      if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: rotated table copies dropped, batch redone without them\n");
       rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets,
                                  d_hits, stats);
     }
@@ -2617,7 +2979,7 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
       gs_pairtab_free(ix, 0);
       gs_pairtab_free(ix, 1);
       ix->pairtab_off = true;
-      if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: PAM-pair tables dropped, batch redone without them\n");
+      if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: PAM-pair tables dropped, batch redone without them\n");
       rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets,
                                  d_hits, stats);
     }
@@ -2759,7 +3121,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     return GS_ERR_UNSUPPORTED;
   }
   const bool two_ok = v_rem != 0 && mismatches >= 1 && v_rem + 1 <= ix->pt_k && P + 1 <= ix->pt_k && ix->pt_k - P <= 21 &&
-                      L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !getenv("GS_NO_BIDIR");
+                      L <= 31 && ix->strand[0].isa && ix->strand[1].isa && !gs_opt(ix, "GS_NO_BIDIR");
   /* the pairs of bases the batch's patterns end in (k_prepare's tally), most frequent first */
   uint32_t want[2] = {16, 16}, n_codes = 0;
   for (uint32_t c = 0; c < 16; c++) {
@@ -2773,13 +3135,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       want[1] = c;
     }
   }
-  const uint32_t max_pt = getenv("GS_PAIRTABS") ? std::min(2u, (uint32_t)atol(getenv("GS_PAIRTABS"))) : 2u;
-  const bool pairable = two_ok && P >= 2 && v_rem >= 2 && n_codes >= 1 && !ix->pairtab_off && !getenv("GS_NO_PAIRTAB");
+  const uint32_t max_pt = gs_opt(ix, "GS_PAIRTABS") ? std::min(2u, (uint32_t)atol(gs_opt(ix, "GS_PAIRTABS"))) : 2u;
+  const bool pairable = two_ok && P >= 2 && v_rem >= 2 && n_codes >= 1 && !ix->pairtab_off && !gs_opt(ix, "GS_NO_PAIRTAB");
   /* deep tables for the other strand's side: every pattern of the batch must have its PAM-pair table */
   uint32_t deep_kb = ix->pt_k - 2; /* guide symbols a deep table is indexed by */
-  if (const char *e = getenv("GS_DEEP_SYMBOLS")) deep_kb = (uint32_t)atoi(e);
+  if (const char *e = gs_opt(ix, "GS_DEEP_SYMBOLS")) deep_kb = (uint32_t)atoi(e);
   bool try_deep = pairable && P == 3 && h_pairs[16] == 0 && n_codes <= max_pt && deep_kb + P >= ix->pt_k && deep_kb <= 14 &&
-                  deep_kb + 2 <= L && L <= deep_kb + 16 && L - deep_kb + 2 <= ix->pt_k && !getenv("GS_NO_DEEP");
+                  deep_kb + 2 <= L && L <= deep_kb + 16 && L - deep_kb + 2 <= ix->pt_k && !gs_opt(ix, "GS_NO_DEEP");
   for (int attempt = 0; attempt < 2; attempt++) {
     deep = try_deep;
     bidir = false;
@@ -2803,7 +3165,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         }
       }
       gs_choose_astar(m, nX, nO, nR, epam, astar, pairable ? 0.4 : 1.5, deep ? 1.6 : 1.9);
-      if (const char *e = getenv("GS_ASTAR")) { /* experiments: "2,2,1,1" */
+      if (const char *e = gs_opt(ix, "GS_ASTAR")) { /* experiments: "2,2,1,1" */
         uint32_t o = 0;
         for (const char *p = e; *p && o < 8; o++) {
           astar[o] = (uint32_t)strtoul(p, (char **)&p, 10);
@@ -2895,10 +3257,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
           size_t free_b = 0, total_b = 0;
           GS_HIP(hipMemGetInfo(&free_b, &total_b));
           double reserve = 64e9;
-          if (const char *e = getenv("GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
+          if (const char *e = gs_opt(ix, "GS_PAIRTAB_RESERVE_GB")) reserve = atof(e) * 1e9;
           if (reserve > 0.25 * (double)total_b) reserve = 0.25 * (double)total_b;
           double room = (double)free_b + (double)ix->pairtab[0].bytes + (double)ix->pairtab[1].bytes - reserve;
-          if (const char *e = getenv("GS_INDEX_BUDGET_GB"))
+          if (const char *e = gs_opt(ix, "GS_INDEX_BUDGET_GB"))
             room = std::min(room, atof(e) * 1e9 - (double)(ix->strand[0].bytes + ix->strand[1].bytes));
           const double one = 2.0 * 8.0 * (double)(1ull << (2 * ix->pt_k)) + 10.0 * 1.5 * ((double)ix->strand[0].n + (double)ix->strand[1].n) / 16.0 +
                              8.0 * (double)(1ull << (2 * ix->pt_k)) + 64e6;
@@ -2990,8 +3352,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       std::vector<uint32_t> bidx[2];
       for (uint32_t s = 0; s < 2; s++) {
         uint32_t from = 256;
-        if (const char *e = getenv("GS_CAND_BUCKETS_FROM")) from = (uint32_t)atol(e);
-        if (n_cand[s] <= from || mismatches > 3 || L < 20 || getenv("GS_NO_CAND_BUCKETS")) continue;
+        if (const char *e = gs_opt(ix, "GS_CAND_BUCKETS_FROM")) from = (uint32_t)atol(e);
+        if (n_cand[s] <= from || mismatches > 3 || L < 20 || gs_opt(ix, "GS_NO_CAND_BUCKETS")) continue;
         const uint32_t nc = n_cand[s];
         bidx[s].assign(4u * 1025u + 4u * (size_t)nc, 0u);
         for (uint32_t c = 0; c < 4; c++) {
@@ -3019,7 +3381,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         di += bidx[s].size();
       }
     }
-    if (getenv("GS_DEBUG"))
+    if (gs_opt(ix, "GS_DEBUG"))
       fprintf(stderr, "[gs] two-sided seeding: astar %u,%u,%u,%u,%u,%u,%u,%u over |X|=%u |O|=%u |R|=%u, "
               "literal-N windows %u + %u%s, PAM-pair tables %u%s\n", astar[0], astar[1], astar[2], astar[3], astar[4], astar[5],
               astar[6], astar[7], x_len, ix->pt_k - x_len, L - ix->pt_k, n_cand[0], n_cand[1],
@@ -3034,13 +3396,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   uint32_t arena_chunks = 0;
   {
     uint64_t want = ix->arena_chunks;
-    if (const char *e = getenv("GS_ARENA_CHUNKS")) want = (uint64_t)atoll(e);
-    if (getenv("GS_NO_ARENA")) want = 0;
+    if (const char *e = gs_opt(ix, "GS_ARENA_CHUNKS")) want = (uint64_t)atoll(e);
+    if (gs_opt(ix, "GS_NO_ARENA")) want = 0;
     if (want > (1ull << 21)) want = 1ull << 21; /* 32 GB of records */
     if (want) {
       auto reserve_arena = [&]() {
         return gs_reserve(ix->w_arena, sizeof(uint4) * (want << ARENA_SHIFT)) == GS_OK &&
-               gs_reserve(ix->w_arena_meta, 8 * want + 64) == GS_OK && gs_reserve(ix->w_nchunk, sizeof(uint2) * (2 * n + 2)) == GS_OK &&
+               gs_reserve(ix->w_arena_meta, 16 * want + 64) == GS_OK && gs_reserve(ix->w_nchunk, sizeof(uint2) * (2 * n + 2)) == GS_OK &&
                gs_reserve(ix->w_cls, 32 * (2 * n + 2)) == GS_OK;
       };
       if (!reserve_arena()) {
@@ -3072,6 +3434,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (with_arena) GS_HIP(hipMemsetAsync(d_arena_next, 0, 4, st));
     gs_search_args sa;
     memset(&sa, 0, sizeof(sa));
+    ix->last_share[0] = ix->last_share[1] = ix->last_share[2] = ix->last_share[3] = 0;
     sa.sd[0] = ix->strand[0].d;
     sa.sd[1] = ix->strand[1].d;
     sa.slots = slots;
@@ -3092,6 +3455,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       sa.nchunk = (uint2 *)ix->w_nchunk.p;
       sa.cls = (uint32_t *)ix->w_cls.p;
       sa.arena_chunks = arena_chunks;
+      sa.chunk_fill = sa.chunk_item + 2 * (size_t)arena_chunks;
     }
     /* items per visit to the work counter: enough to keep the counter far from its ~88 visits per microsecond,
      * few enough that every resident wave still gets several visits (balance at the tail) */
@@ -3099,18 +3463,18 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       const uint64_t waves = (uint64_t)cus * 32u;
       uint64_t take = (2ull * ng) / (waves * 64u); /* 2 M items: 3 (23.8 ms against 26.4 one at a time; 8: 24.4, 64: 26.2) */
       take = take < 1 ? 1 : take > 4 ? 4 : take;
-      if (const char *e = getenv("GS_SEARCH_TAKE")) take = (uint64_t)std::max(1l, atol(e));
+      if (const char *e = gs_opt(ix, "GS_SEARCH_TAKE")) take = (uint64_t)std::max(1l, atol(e));
       sa.take = (uint32_t)take;
     }
-    sa.max_iter = getenv("GS_SEARCH_MAX_ITER") ? (uint32_t)atol(getenv("GS_SEARCH_MAX_ITER")) : (1u << 26);
+    sa.max_iter = gs_opt(ix, "GS_SEARCH_MAX_ITER") ? (uint32_t)atol(gs_opt(ix, "GS_SEARCH_MAX_ITER")) : (1u << 26);
     sa.err = d_work + 5;
     sa.v_max = VERIFY_MAX_DEFAULT;
-    if (const char *e = getenv("GS_VERIFY_MAX")) {
+    if (const char *e = gs_opt(ix, "GS_VERIFY_MAX")) {
       const long v = atol(e);
       sa.v_max = v < 1 ? 1u : v > 1023 ? 1023u : (uint32_t)v;
     }
-    sa.dbg_skip = getenv("GS_DBG_SKIP") ? (uint32_t)atol(getenv("GS_DBG_SKIP")) : 0u;
-    sa.cnt_shift = getenv("GS_COUNT_SHIFT") ? (uint32_t)std::min(12l, std::max(4l, atol(getenv("GS_COUNT_SHIFT")))) : 6u;
+    sa.dbg_skip = gs_opt(ix, "GS_DBG_SKIP") ? (uint32_t)atol(gs_opt(ix, "GS_DBG_SKIP")) : 0u;
+    sa.cnt_shift = gs_opt(ix, "GS_COUNT_SHIFT") ? (uint32_t)std::min(12l, std::max(4l, atol(gs_opt(ix, "GS_COUNT_SHIFT")))) : 6u;
     sa.astar = 0xFFFFFFFFu;
     if (ix->pt_k >= 4 && ix->pt_k + 1 <= L && !(flags & GS_FLAG_FAITHFUL_WALK)) {
       /* seeds = depth-pt_k nodes: variants of the first pt_k-2 query symbols with j <= m
@@ -3155,17 +3519,45 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     uint32_t per_cu = (uint32_t)(160u * 1024u / lds_wg);
     /* every item through PAM-pair + deep tables (no pattern ends in an N, each has its tables): the kernel
      * without the strand tables' side of the seeding */
-    const bool spec = !walk && sa.bidir && sa.bdeep && n_pt != 0 && n_pt == n_codes && h_pairs[16] == 0 && !getenv("GS_NO_SPEC");
+    const bool spec = !walk && sa.bidir && sa.bdeep && n_pt != 0 && n_pt == n_codes && h_pairs[16] == 0 && !gs_opt(ix, "GS_NO_SPEC");
     const uint32_t weu = walk ? GS_WAVES_EU : spec ? GS_WAVES_EU_PD : GS_WAVES_EU_FAST;
     if (per_cu > weu) per_cu = weu; /* 4 SIMDs x weu waves = weu four-wave workgroups per CU */
     uint32_t grid = (uint32_t)cus * per_cu;
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
-    if (getenv("GS_DEBUG")) {
+    if (gs_opt(ix, "GS_DEBUG")) {
       int occ = 0;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, walk ? k_search_walk : k_search_fast, WAVE * SEARCH_WAVES, dyn);
       fprintf(stderr, "[gs] k_search (%s): grid %u x %u threads, LDS %zu B per workgroup, %d workgroups per CU resident\n",
               walk ? "walk" : "table", grid, WAVE * SEARCH_WAVES, lds_wg, occ);
+    }
+    /* heavy items shared among waves (gs_search_args::shq): table-seeded kernels with the arena, one PAM pass */
+    uint32_t *d_shctl = nullptr;
+    uint32_t share_min = ix->opt_share_min, share_max = ix->opt_share_max;
+    if (const char *e = gs_opt(ix, "GS_SHARE_MIN")) share_min = (uint32_t)std::max(0l, atol(e));
+    if (const char *e = gs_opt(ix, "GS_SHARE_MAX")) share_max = (uint32_t)std::max(128l, atol(e));
+    if (with_arena && !walk && n_chunks == 1 && share_min != 0) {
+      uint64_t qcap = ix->shq_packages;
+      if (const char *e = gs_opt(ix, "GS_SHARE_QUEUE")) qcap = (uint64_t)std::max(1ll, atoll(e));
+      if (qcap > (1ull << 20)) qcap = 1ull << 20; /* 1.2 GB of packages */
+      const uint32_t sh_max = std::min<uint32_t>(2 * ng, 1u << 18);
+      const size_t meta = 512 + 4 * (size_t)qcap + 4 * (size_t)sh_max + 64 * (size_t)sh_max;
+      if (gs_reserve(ix->w_shq, 16 * (size_t)SHQ_PKG * qcap) == GS_OK && gs_reserve(ix->w_sh_meta, meta + 4 * ((size_t)sh_max + 2)) == GS_OK) {
+        d_shctl = (uint32_t *)ix->w_sh_meta.p;
+        sa.shq = (uint4 *)ix->w_shq.p;
+        sa.shq_ctl = d_shctl;
+        sa.shq_ready = d_shctl + 128;
+        sa.sh_list = sa.shq_ready + qcap;
+        sa.sh_acc = sa.sh_list + sh_max;
+        sa.shq_cap = (uint32_t)qcap;
+        sa.sh_max = sh_max;
+        sa.share_min = share_min;
+        sa.share_max = std::max(128u, share_max);
+        sa.n_waves = grid * SEARCH_WAVES;
+        GS_HIP(hipMemsetAsync(d_shctl, 0, meta, st));
+      } else {
+        (void)hipGetLastError(); /* no room for the queue: every item stays with its wave */
+      }
     }
     GS_HIP(hipEventRecord(ix->ev[1], st));
     for (uint32_t c = 0; c < n_chunks; c++) { /* four PAM patterns per pass, appending to the same slots */
@@ -3185,9 +3577,49 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     GS_HIP(hipEventRecord(ix->ev[2], st));
     unsigned long long h7[20] = {0}; /* the stats and, behind them, the work words */
+    uint32_t h_ctl[128] = {0};
     GS_HIP(hipMemcpyAsync(h7, d_stats, sizeof(h7), hipMemcpyDeviceToHost, st));
+    if (d_shctl) GS_HIP(hipMemcpyAsync(h_ctl, d_shctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
+    if (d_shctl) {
+      ix->last_share[0] = std::min(h_ctl[96], sa.sh_max); /* shared items */
+      ix->last_share[1] = h_ctl[0];                       /* packages reserved */
+      ix->last_share[2] = sa.shq_cap;
+      ix->last_share[3] = h_ctl[32];                      /* tickets handed out */
+      if (!gs_opt(ix, "GS_SHARE_QUEUE") && (uint64_t)h_ctl[0] + h_ctl[0] / 4 + 64 > ix->shq_packages) ix->shq_packages = (uint64_t)h_ctl[0] + h_ctl[0] / 4 + 64;
+      if (h_ctl[96] != 0u && ((const uint32_t *)(h7 + 16))[5] == 0u) {
+        /* close the gaps the helpers left (k_share_fix), then read the counters again: it may add overflowing items */
+        gs_share_args fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.ctl = d_shctl;
+        fa.sh_list = sa.sh_list;
+        fa.sh_acc = sa.sh_acc;
+        fa.counts = counts;
+        fa.nchunk = sa.nchunk;
+        fa.cls = sa.cls;
+        fa.chunk_item = sa.chunk_item;
+        fa.chunk_seq = sa.chunk_seq;
+        fa.chunk_fill = sa.chunk_fill;
+        fa.arena_next = d_arena_next;
+        fa.slots = slots;
+        fa.arena = sa.arena;
+        fa.dbase = sa.sh_acc + 16 * (size_t)sa.sh_max;
+        fa.dir = sa.chunk_item + 3 * (size_t)arena_chunks;
+        fa.stats = d_stats;
+        fa.sh_max = sa.sh_max;
+        fa.cap = cap_;
+        fa.arena_chunks = arena_chunks;
+        const uint32_t n_sh = (uint32_t)ix->last_share[0];
+        hipLaunchKernelGGL(k_share_scan, dim3(1), dim3(1024), 0, st, fa);
+        hipLaunchKernelGGL(k_share_dir, dim3((arena_chunks + 255) / 256), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL(k_share_fix, dim3(std::min<uint32_t>(n_sh, (uint32_t)cus * 8u)), dim3(256), 0, st, fa);
+        GS_HIP(hipEventRecord(ix->ev[2], st));
+        GS_HIP(hipMemcpyAsync(h7, d_stats, sizeof(h7), hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        GS_HIP(hipGetLastError());
+      }
+    }
     h_stats[0] = h7[0];
     h_stats[1] = h7[1];
     if (with_arena) arena_fail = h7[6];
@@ -3298,7 +3730,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   auto big_fits_v2 = [&](uint32_t n_set) -> bool {
     uint32_t gbits = 1;
     while ((1ull << gbits) < n_set) gbits++;
-    return gbits + 4 + big_rbits <= 64 && !getenv("GS_BIG_ORDER_V1");
+    return gbits + 4 + big_rbits <= 64 && !gs_opt(ix, "GS_BIG_ORDER_V1");
   };
   /* arena_list != nullptr or arena_all: the set's records are read from the main slots and the overflow
    * arena (the set = the guides of arena_list, or the whole batch), not from a contiguous copy */
@@ -3405,18 +3837,18 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
        * two rows of a run may then differ by a multiple of 2^b only through the high part.  0: not usable. */
       const uint32_t wbits = gbits + 4 + rbits;
       auto composite_bits = [&]() -> uint32_t {
-        if (getenv("GS_BIG2_NO_COMPOSITE") || wbits >= 64) return 0u;
+        if (gs_opt(ix, "GS_BIG2_NO_COMPOSITE") || wbits >= 64) return 0u;
         uint32_t rb = 64 - wbits > 32 ? 32u : 64u - wbits;
-        if (const char *e = getenv("GS_BIG2_ROWBITS")) return std::min<uint32_t>(rb, (uint32_t)std::max(1l, atol(e)));
+        if (const char *e = gs_opt(ix, "GS_BIG2_ROWBITS")) return std::min<uint32_t>(rb, (uint32_t)std::max(1l, atol(e)));
         /* the runs to put right afterwards multiply as the row bits shrink (hg38 size, 20 k repeat-rich guides:
          * 243-548 per batch at 25 bits, 4.3 x 10^5 at 17 and 121 ms against the two sorts' 77): below 22 bits -
          * sort words beyond 42 - the two sorts serve */
         return rb >= 22 ? rb : 0u;
       };
-      const bool two_from_start = ix->big_long_runs || getenv("GS_BIG2_TWO_SORTS");
+      const bool two_from_start = ix->big_long_runs || gs_opt(ix, "GS_BIG2_TWO_SORTS");
       uint32_t rowb = two_from_start ? composite_bits() : 0u;
       ca.row_bits = rowb;
-      ca.row_off = getenv("GS_BIG2_ROWOFF") ? (uint32_t)atol(getenv("GS_BIG2_ROWOFF")) : 0u;
+      ca.row_off = gs_opt(ix, "GS_BIG2_ROWOFF") ? (uint32_t)atol(gs_opt(ix, "GS_BIG2_ROWOFF")) : 0u;
       hipLaunchKernelGGL(k_big2_compact, dim3(n_it + (from_arena ? n_used : 0u)), dim3(256), 0, st, ca);
       size_t s1 = 0, s2 = 0, s3 = 0;
       GS_HIP(rocprim::radix_sort_pairs(nullptr, s1, rk, rkb, idx, idxb, (size_t)T, 0, 32, st));
@@ -3432,7 +3864,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
        * batch with long runs of one sequence (a repeat-rich genome): then, and for the batch that shows the
        * first such run, two stable sorts: by first row, then by W. */
       uint32_t short_max = 32;
-      if (const char *e = getenv("GS_BIG2_SHORT")) short_max = (uint32_t)std::max(1l, atol(e));
+      if (const char *e = gs_opt(ix, "GS_BIG2_SHORT")) short_max = (uint32_t)std::max(1l, atol(e));
       if (!two_from_start) {
         tbs = ix->w_h_tmp.cap;
         GS_HIP(rocprim::radix_sort_pairs(ix->w_h_tmp.p, tbs, W, Wb, idx, idxb, (size_t)T, 0, wbits, st));
@@ -3493,7 +3925,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
                              ca.row_off, (const uint32_t *)list, h_n, (uint32_t *)ix->w_b_keep.p);
         }
         big_fixed += h_n;
-        if (getenv("GS_DEBUG"))
+        if (gs_opt(ix, "GS_DEBUG"))
           fprintf(stderr, "[gs] composite ordering: %llu records, word bits %u, row bits %u, %u descents inside runs\n", T, wbits,
                   wshift, h_n);
       }
@@ -3634,7 +4066,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
    * m <= 5: 96.8 ms per 100 k guides against 105.5 - from 1,024 slots on, where the bitonic network over
    * 16-byte records in LDS costs more than nine radix passes (m <= 4, 512 slots: 32.9 against 35.1, LDS kept) */
   uint32_t wide_from = 1024;
-  if (const char *e = getenv("GS_ORDER_WIDE_FROM")) wide_from = (uint32_t)atol(e);
+  if (const char *e = gs_opt(ix, "GS_ORDER_WIDE_FROM")) wide_from = (uint32_t)atol(e);
   const bool big_batch = cap > LDS_CAP_MAX || (cap >= wide_from && (wide_key ? gs_tileorder_fits(L, P, mismatches) : big_fits_v2(n32)));
   if ((rc = gs_reserve(ix->w_slots, sizeof(uint4) * (size_t)cap * 2 * n)) != GS_OK) return rc;
   unsigned long long h_stats[2] = {0, 0};
@@ -3721,7 +4153,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
      * then these guides are searched once more with slots of the exact sizes, and the next batch gets
      * the arena this one would have needed */
     const bool arena_ok = arena_chunks != 0 && arena_fail == 0;
-    if (arena_chunks != 0 && !getenv("GS_ARENA_CHUNKS") && need_chunks + need_chunks / 4 + 64 > ix->arena_chunks)
+    if (arena_chunks != 0 && !gs_opt(ix, "GS_ARENA_CHUNKS") && need_chunks + need_chunks / 4 + 64 > ix->arena_chunks)
       ix->arena_chunks = need_chunks + need_chunks / 4 + 64;
     if (arena_ok) {
       GS_HIP(hipMemcpyAsync(&n_used, d_arena_next, 4, hipMemcpyDeviceToHost, st));
@@ -3777,7 +4209,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     for (uint32_t i = 0; i < n_alt * P; i++) mix((uint8_t)alt_pams[i]);
   }
   bool tile = set_exists && arena_chunks != 0 && (n_o == 0 || ovf_arena_ok) && v_rem != 0 && gs_tileorder_fits(L, P, mismatches) &&
-              !(ix->tile_order_off && ix->tile_order_off_key == tile_key) && !getenv("GS_NO_TILE_ORDER");
+              !(ix->tile_order_off && ix->tile_order_off_key == tile_key) && !gs_opt(ix, "GS_NO_TILE_ORDER");
   bool tile_used = false, tile_fell_back = false;
   uint64_t total = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
@@ -3908,7 +4340,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       GS_HIP(hipMemcpy(d_stats + 2, &cur, 8, hipMemcpyHostToDevice));
       break;
     }
-    if (getenv("GS_DEBUG")) fprintf(stderr, "[gs] per-guide tile ordering gave up (flags %u): device-wide ordering instead\n", viol);
+    if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] per-guide tile ordering gave up (flags %u): device-wide ordering instead\n", viol);
     tile = false;
     tile_fell_back = true;
     /* overlapping PAM patterns or interval records are a property of the batch's shape: later batches of this handle skip the attempt */
@@ -3921,7 +4353,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   unsigned long long h_stats3[16] = {0};
   GS_HIP(hipMemcpyAsync(h_stats3, d_stats, sizeof(h_stats3), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
-  if (bidir && getenv("GS_DEBUG"))
+  if (bidir && gs_opt(ix, "GS_DEBUG"))
     fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu; slots %u per item, "
             "%u guides redone%s%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (whole batch through the wide ordering)" : "",
             tile_used ? " (per guide in LDS tiles)" : "");

@@ -396,7 +396,7 @@ struct gs_to_chunk_args {
 };
 __global__ __launch_bounds__(256) void k_to_chunks(gs_to_chunk_args a) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= a.n_used) return;
+  if (c >= a.n_used || a.chunk_seq[c] == 0xFFFFFFFFu) return; /* (emptied when a shared item's gaps were closed: gs_search.hip, k_share_fix) */
   const uint32_t item = a.chunk_item[c];
   uint32_t sb = item;
   if (a.by_list) {
@@ -1194,8 +1194,8 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.L = in.L;
   ra.P = in.P;
   ra.v_rem = in.v_rem;
-  ra.sample_per = getenv("GS_TILE_SAMPLE_PER") ? (uint32_t)std::max(1l, atol(getenv("GS_TILE_SAMPLE_PER"))) : 0u;
-  ra.big_from = getenv("GS_TILE_BIG_FROM") ? (uint32_t)std::max(1024l, atol(getenv("GS_TILE_BIG_FROM"))) : TO_TILE;
+  ra.sample_per = gs_opt(ix, "GS_TILE_SAMPLE_PER") ? (uint32_t)std::max(1l, atol(gs_opt(ix, "GS_TILE_SAMPLE_PER"))) : 0u;
+  ra.big_from = gs_opt(ix, "GS_TILE_BIG_FROM") ? (uint32_t)std::max(1024l, atol(gs_opt(ix, "GS_TILE_BIG_FROM"))) : TO_TILE;
   if (S.n_big) {
     hipLaunchKernelGGL(k_to_splitters<128u>, dim3(S.n_big), dim3(128), 0, st, ra);
     hipLaunchKernelGGL(k_to_splitters<TO_SNT>, dim3(S.n_big), dim3(TO_SNT), 0, st, ra);
@@ -1213,14 +1213,14 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
     gs_to_tab tab;
     unsigned long long words = ~0ull;
     to_make_tab(in.L, in.P, in.m, tab, &words);
-    if (words < (1ull << TO_WPACK_BITS) && !getenv("GS_TILE_NO_PACK"))
+    if (words < (1ull << TO_WPACK_BITS) && !gs_opt(ix, "GS_TILE_NO_PACK"))
       hipLaunchKernelGGL(k_to_wsort<true>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
     else
       hipLaunchKernelGGL(k_to_wsort<false>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
     const hipError_t ee = hipEventSynchronize(ev);
     (void)hipEventDestroy(ev);
     GS_HIP(ee);
-    if (getenv("GS_DEBUG"))
+    if (gs_opt(ix, "GS_DEBUG"))
       fprintf(stderr, "[gs] tile ordering: tiles beyond one wave: %u of up to 1024 records, %u of up to 4096, %u beyond\n", n_slow[0], n_slow[1], n_slow[2]);
     if (n_slow[0]) hipLaunchKernelGGL(k_to_sort<128u>, dim3(n_slow[0]), dim3(128), to_sort_lds(128u), st, ra, (const uint32_t *)ra.slow[0]);
     if (n_slow[1]) hipLaunchKernelGGL(k_to_sort<TO_NT>, dim3(n_slow[1]), dim3(TO_NT), to_sort_lds(TO_NT), st, ra, (const uint32_t *)ra.slow[1]);
@@ -1239,7 +1239,7 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
             (double)d[0] / d[3], (double)d[1] / d[3], (double)d[2] / d[3], d[3], (double)d[4] / d[3]);
   }
 #endif
-  if (getenv("GS_DEBUG"))
+  if (gs_opt(ix, "GS_DEBUG"))
     fprintf(stderr, "[gs] tile ordering: %u items, %u of them dealt into %u bucket units of 128 records, %u tiles\n", S.n_it, S.n_big, S.n_btiles, S.n_tiles);
   *violations = h[0];
   S.n_records = ((uint64_t)h[3] << 32) | h[2];

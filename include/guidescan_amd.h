@@ -169,6 +169,19 @@ void gs_index_close(gs_index *ix);
  * [12] Occ block lines, [3] lines of the seed recipe lists.  (the bytes the
  * roofline is priced on.)  [7] >> 8: items whose seeds went through PAM-pair tables. */
 gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]);
+/* The last search launch's sharing of heavy items among waves: [0] items of which at least one
+ * verification pass was handed to other waves, [1] packages reserved in the queue, [2] packages the queue holds,
+ * [3] tickets the helping waves drew. */
+gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[4]);
+/* Switches of a handle.  The library's tuning and test switches ("GS_NO_BIDIR", "GS_SHARE_MIN", "GS_DEBUG", ... -
+ * DESIGN.md names each where it acts) are a per-handle table: filled from the process environment's GS_* variables
+ * ONCE, when the handle is made (gs_index_build / _with_sa / _open_sdsl / _open_sa), and changed only through
+ * gs_index_set_option (value NULL removes the entry).  No gs_enumerate* / gs_score* / gs_kmers* call reads the
+ * environment: a host that calls setenv from another thread cannot change a running batch.  The reference has no
+ * counterpart (its behaviour is fixed at compile time, src/guidescan.cxx:24-27).  gs_index_get_option copies the
+ * value into out[cap] (GS_ERR_ARG when the switch is not set or does not fit). */
+gs_status gs_index_set_option(gs_index *ix, const char *key, const char *value);
+gs_status gs_index_get_option(const gs_index *ix, const char *key, char *out, uint64_t cap);
 /* Hold / release the handle's lock (see gs_index above): between the two, calls on this handle
  * from other threads wait, and the device buffers a gs_enumerate_device call returned stay as
  * they are.  Stands where the reference needs nothing (its index is const and its per-call state

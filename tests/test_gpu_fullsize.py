@@ -108,12 +108,12 @@ def three_paths_same_bytes(torch, gidx, d_seqs, d_pams, n, m, n_walk, on_host=Fa
     if on_host:
         d_off, d_hits, st = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
         off, hits = device_result_to_host(hip, d_off, d_hits, n, st["n_hits"])
-        os.environ["GS_NO_BIDIR"] = "1"
+        gidx.set_option("GS_NO_BIDIR", "1")
         try:
             d_o, d_h, st2 = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
             o2, h2 = device_result_to_host(hip, d_o, d_h, n, st2["n_hits"])
         finally:
-            del os.environ["GS_NO_BIDIR"]
+            gidx.set_option("GS_NO_BIDIR", None)
         assert np.array_equal(o2, off) and h2.tobytes() == hits.tobytes(), "one-sided and two-sided seeding differ"
         del o2, h2
         d_o, d_h, st3 = gidx.enumerate_device(d_seqs.data_ptr(), n_walk, 20, d_pams.data_ptr(), 3, mismatches=m,
@@ -124,12 +124,12 @@ def three_paths_same_bytes(torch, gidx, d_seqs, d_pams, n, m, n_walk, on_host=Fa
         return off, hits, st, st3
     d_off, d_hits, st = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
     off, hits = device_result_to_torch(torch, hip, d_off, d_hits, n, st["n_hits"])
-    os.environ["GS_NO_BIDIR"] = "1"
+    gidx.set_option("GS_NO_BIDIR", "1")
     try:
         d_o, d_h, st2 = gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=m)
         o2, h2 = device_result_to_torch(torch, hip, d_o, d_h, n, st2["n_hits"])
     finally:
-        del os.environ["GS_NO_BIDIR"]
+        gidx.set_option("GS_NO_BIDIR", None)
     assert torch.equal(o2, off) and torch.equal(h2, hits), "one-sided and two-sided seeding differ"
     d_o, d_h, st3 = gidx.enumerate_device(d_seqs.data_ptr(), n_walk, 20, d_pams.data_ptr(), 3, mismatches=m,
                                           faithful=True)
@@ -220,9 +220,9 @@ def test_chr1_sized_assembly_with_5000_n_runs(monkeypatch, capfd):
         off, hits, st = gidx.enumerate(seqs, pams, mismatches=3)
         err = capfd.readouterr().err
         assert "bucketed by 5-symbol chunks" in err, err[-400:]
-        monkeypatch.setenv("GS_NO_CAND_BUCKETS", "1")
+        gidx.set_option("GS_NO_CAND_BUCKETS", "1")
         off2, hits2, st2 = gidx.enumerate(seqs, pams, mismatches=3)
-        monkeypatch.delenv("GS_NO_CAND_BUCKETS")
+        gidx.set_option("GS_NO_CAND_BUCKETS", None)
         assert "bucketed" not in capfd.readouterr().err
         assert np.array_equal(off, off2) and hits.tobytes() == hits2.tobytes()
         lit = 0
@@ -452,12 +452,12 @@ def test_config5_hg38_m6_2048_guides_properties_and_paths(hg38):
     hg38.gidx.score_device(hg38.gs, d_seqs.data_ptr(), n, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
     spec = d_spec.cpu().numpy()
     assert np.all(np.isfinite(spec)) and np.all(spec > 0) and np.all(spec <= 1.0)
-    os.environ["GS_NO_BIDIR"] = "1"
+    hg38.gidx.set_option("GS_NO_BIDIR", "1")
     try:
         d_o, d_h, st2 = hg38.gidx.enumerate_device(d_seqs.data_ptr(), n, 20, d_pams.data_ptr(), 3, mismatches=6)
         o2, h2 = device_result_to_host(hip, d_o, d_h, n, st2["n_hits"])
     finally:
-        del os.environ["GS_NO_BIDIR"]
+        hg38.gidx.set_option("GS_NO_BIDIR", None)
     assert np.array_equal(o2, off) and h2.tobytes() == hits.tobytes(), "one-sided and two-sided seeding differ"
     # the 64-guide batch of the reference leg (same seed: the same first guides)
     off64, hits64, _ = hg38.gidx.enumerate(seqs[:64], pams[:64], mismatches=6)

@@ -396,7 +396,7 @@ def test_two_sided_pieces_exceptions_and_windows(monkeypatch, capfd):
             opts = ol.make_opts(mismatches=m, alt_pams=alt)
             expected = [oracle_hits_as_records(oidx, g, "NGG", opts, 3)[0] for g in guides]
             for vmax in ("1", "3", "9", "14", "1023"):
-                monkeypatch.setenv("GS_VERIFY_MAX", vmax)
+                gidx.set_option("GS_VERIFY_MAX", vmax)
                 capfd.readouterr()
                 offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt)
                 err = capfd.readouterr().err
@@ -456,10 +456,10 @@ def test_many_literal_n_windows(monkeypatch, capfd, buckets):
         pams = np.tile(np.frombuffer(b"NGG", np.uint8), (len(guides), 1))
         for m, alt, no_tables in ((3, (), False), (4, ("NAG",), False), (3, (), True), (2, ("NGN",), False)):
             if no_tables:
-                monkeypatch.setenv("GS_NO_PAIRTAB", "1")
+                gidx.set_option("GS_NO_PAIRTAB", "1")
             capfd.readouterr()
             offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt)
-            monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
+            gidx.set_option("GS_NO_PAIRTAB", None)
             err = capfd.readouterr().err
             mt = re.search(r"literal-N windows (\d+) \+ (\d+)", err)
             assert mt and int(mt.group(1)) > 128 and int(mt.group(2)) > 128, mt   # more than two passes of 64 per strand
@@ -503,15 +503,15 @@ def test_two_sided_seeding_bit_exact(pk, L, monkeypatch, capfd):
             pams = np.tile(np.frombuffer(own.encode(), np.uint8), (len(guides), 1))
             opts = ol.make_opts(mismatches=m, alt_pams=alt, start=start)
             if cfg.get("one_table"):
-                monkeypatch.setenv("GS_PAIRTABS", "1")
+                gidx.set_option("GS_PAIRTABS", "1")
             if cfg.get("no_tables"):
-                monkeypatch.setenv("GS_NO_PAIRTAB", "1")
+                gidx.set_option("GS_NO_PAIRTAB", "1")
             capfd.readouterr()
             # frozen: GS_FLAG_NO_NEW_TABLES - a pair the handle has no table for (NCG) goes without, one it has (NGG) uses it
             offsets, hits, stats = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alt, start=start,
                                                   no_new_tables=cfg.get("frozen", False))
-            monkeypatch.delenv("GS_PAIRTABS", raising=False)
-            monkeypatch.delenv("GS_NO_PAIRTAB", raising=False)
+            gidx.set_option("GS_PAIRTABS", None)
+            gidx.set_option("GS_NO_PAIRTAB", None)
             err = capfd.readouterr().err
             # (12, 20): X = L + P - k = 11 symbols reaches step k - 2 of the table's two-symbol extension (round 4); a
             # four-symbol PAM there leaves 12 > k - 1 and the batch is seeded from one side
@@ -576,9 +576,16 @@ ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                # long runs from the start: one sort of (word, row bits) - all 32 row bits on these small genomes -,
                # and the two stable sorts it replaces
                ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1"),
-               ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1", "GS_BIG2_NO_COMPOSITE", "1")]
+               ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1", "GS_BIG2_NO_COMPOSITE", "1"),
+               # heavy items shared among waves (k_search's package queue): never; every verification pass, in the smallest
+               # packages; the same with an arena that runs out under the helpers; with a queue of four packages
+               ("GS_SHARE_MIN", "0"),
+               ("GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
+               ("GS_ARENA_CHUNKS", "5", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
+               ("GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_SHARE_QUEUE", "4"),
+               ("GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_NO_TILE_ORDER", "1")]
 ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "tiles-unpacked", "device-wide", "raw-key-order", "one-sort-and-runs", "composite-sort",
-             "two-sorts"]
+             "two-sorts", "never-shared", "every-pass-shared", "shared-arena-exhausted", "shared-queue-of-four", "shared-device-wide"]
 
 
 def set_mode(monkeypatch, arena):
@@ -622,6 +629,12 @@ def test_repeat_guide_with_thousands_of_matches(monkeypatch, arena):
             assert big > 2048
             ctr = gidx.last_counters()
             assert ctr["guides_redone"] >= 1 and ctr["overflow_from_arena"] == (arena is None or "ARENA" not in arena[0]), (ctr, m, faithful)
+            sh = gidx.last_sharing()
+            if arena and "GS_SHARE_MIN" in arena and arena[arena.index("GS_SHARE_MIN") + 1] != "0" and not faithful:
+                # every item with a pass to verify was handed out; each package was run by a wave that drew its ticket
+                assert sh["shared_items"] >= 2 and sh["packages"] >= 8 and sh["tickets"] >= min(sh["packages"], sh["queue_packages"]), (sh, m)
+            if faithful or (arena and ("GS_NO_ARENA" in arena or ("GS_SHARE_MIN", "0") == tuple(arena[:2]))):
+                assert sh["shared_items"] == 0, (sh, m, faithful)
             # the default: ordered per guide in LDS tiles (the walk's interval records are not its business)
             if arena is None:
                 assert ctr["ordered_in_tiles"] == (not faithful), (ctr, m, faithful)
@@ -699,13 +712,13 @@ def test_an_item_of_more_than_half_a_million_records(monkeypatch, capfd):
         seqs = np.concatenate([other[:1], np.array([list(site)], dtype=np.uint8), other[1:]])
         pams = np.tile(np.frombuffer(b"NGG", np.uint8), (3, 1))
         import re
-        monkeypatch.setenv("GS_DEBUG", "1")
+        gidx.set_option("GS_DEBUG", "1")
         opts = ol.make_opts(1)
         want = [oracle_hits_as_records(oidx, seqs[i].tobytes().decode(), "NGG", opts, 3)[0] for i in range(3)]
         assert len(want[1]) >= n_copies + 1000
         for per in (None, "1024"):
             if per:
-                monkeypatch.setenv("GS_TILE_BIG_FROM", per)
+                gidx.set_option("GS_TILE_BIG_FROM", per)
             capfd.readouterr()
             offsets, hits, _ = gidx.enumerate(seqs, pams, mismatches=1)
             err = capfd.readouterr().err
@@ -716,6 +729,61 @@ def test_an_item_of_more_than_half_a_million_records(monkeypatch, capfd):
             for i in range(3):
                 got = gpu_hits_as_records(offsets, hits, i, seqs[i].tobytes().decode(), 3)
                 assert len(got) == len(want[i]) and got == want[i], (i, per)
+    finally:
+        gidx.close()
+        oidx.close()
+
+
+def test_a_heavy_item_is_run_by_many_waves():
+    """One (guide, strand) item of 2 x 10^5 records - 190,000 near-copies of one site with 0..3 substitutions on the +
+    strand, 10,000 on the - strand - next to five ordinary guides: k_search hands its verification passes to the waves
+    that have run out of items (packages of at most 2,048 row groups in a queue in memory; gs_search.hip, `shq`), their
+    records land in arena chunks of their own and k_share_fix closes the gaps.  The hit bytes equal those of the run
+    in which the item stays with its wave (GS_SHARE_MIN=0), and the oracle's lists (process.hpp:100-115 order)."""
+    rng = np.random.default_rng(23)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    site = rng.choice(acgt, 20)
+    n_plus, n_minus, unit = 190_000, 10_000, 40
+    n_copies = n_plus + n_minus
+    text = rng.choice(acgt, n_copies * unit + 60_000).astype(np.uint8)
+    body = text[:n_copies * unit].reshape(n_copies, unit)
+    copies = np.tile(site, (n_copies, 1))
+    nsub = rng.integers(0, 4, n_copies)
+    for c in np.nonzero(nsub)[0]:
+        for q in rng.choice(20, size=int(nsub[c]), replace=False):
+            copies[c, q] = rng.choice([x for x in b"ACGT" if x != copies[c, q]])
+    body[:n_plus, 6:26] = copies[:n_plus]
+    body[:n_plus, 27:29] = ord("G")
+    rc = synth.reverse_complement_bytes(np.concatenate([copies[n_plus:], rng.choice(acgt, (n_minus, 1)),
+                                                        np.full((n_minus, 2), ord("G"), np.uint8)], axis=1).reshape(-1))
+    body[n_plus:, 6:29] = rc.reshape(n_minus, 23)[::-1]
+    oidx = ol.OracleIndex(text)
+    gidx = api.GenomeIndex.build(text, device=0)
+    try:
+        other, _, _, _ = synth.sample_guides(text[n_copies * unit:], 5, seed=9)
+        seqs = np.concatenate([other[:2], np.array([list(site)], dtype=np.uint8), other[2:]])
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
+        gidx.set_option("GS_SHARE_MIN", "0")
+        off0, hits0, _ = gidx.enumerate(seqs, pams, mismatches=3)
+        assert gidx.last_sharing()["shared_items"] == 0
+        gidx.set_option("GS_SHARE_MIN", None)
+        off1, hits1, _ = gidx.enumerate(seqs, pams, mismatches=3)
+        sh, ctr = gidx.last_sharing(), gidx.last_counters()
+        assert sh["shared_items"] >= 1 and sh["packages"] >= 8 and sh["tickets"] >= sh["packages"], sh
+        assert ctr["matches_max_per_item"] >= n_plus and ctr["ordered_in_tiles"] and not ctr["tile_ordering_gave_up"], ctr
+        assert np.array_equal(off0, off1) and hits0.tobytes() == hits1.tobytes()
+        # smaller packages, more of them: the same bytes again
+        gidx.set_options(GS_SHARE_MIN="64", GS_SHARE_MAX="256")
+        off2, hits2, _ = gidx.enumerate(seqs, pams, mismatches=3)
+        assert gidx.last_sharing()["packages"] > sh["packages"]
+        assert np.array_equal(off0, off2) and hits0.tobytes() == hits2.tobytes()
+        opts = ol.make_opts(3)
+        for i in range(seqs.shape[0]):
+            g = seqs[i].tobytes().decode()
+            exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
+            got = gpu_hits_as_records(off1, hits1, i, g, 3)
+            assert len(got) == len(exp) and got == exp, i
+            assert i != 2 or len(exp) >= n_copies
     finally:
         gidx.close()
         oidx.close()
@@ -759,9 +827,9 @@ def test_tile_ordering_gives_up_and_the_device_wide_form_takes_over(monkeypatch)
                 assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, (i, alt)
 
         check((), True, False)
-        monkeypatch.setenv("GS_TILE_SAMPLE_PER", "1")     # buckets outgrow their slots: gives up, same hits
+        gidx.set_option("GS_TILE_SAMPLE_PER", "1")     # buckets outgrow their slots: gives up, same hits
         check((), False, True)
-        monkeypatch.delenv("GS_TILE_SAMPLE_PER")
+        gidx.set_option("GS_TILE_SAMPLE_PER", None)
         check(("NGG",), False, True)                       # every site twice: gives up, the device-wide form drops the copies
         check(("NGG",), False, False)                      # ... and this shape is not tried again on this handle
         check(("NAG",), True, False)                       # another shape is
@@ -793,19 +861,19 @@ def test_composite_ordering_puts_runs_right(monkeypatch):
     try:
         seqs = np.array([list(site)], dtype=np.uint8)
         pams = np.frombuffer(b"NGG", np.uint8).reshape(1, 3)
-        monkeypatch.setenv("GS_NO_TILE_ORDER", "1")
-        monkeypatch.setenv("GS_BIG2_TWO_SORTS", "1")
-        monkeypatch.setenv("GS_BIG2_NO_COMPOSITE", "1")
+        gidx.set_option("GS_NO_TILE_ORDER", "1")
+        gidx.set_option("GS_BIG2_TWO_SORTS", "1")
+        gidx.set_option("GS_BIG2_NO_COMPOSITE", "1")
         ref_off, ref_hits, _ = gidx.enumerate(seqs, pams, mismatches=3)
         exp, _ = oracle_hits_as_records(oidx, site.tobytes().decode(), "NGG", ol.make_opts(3), 3)
         assert gpu_hits_as_records(ref_off, ref_hits, 0, site.tobytes().decode(), 3) == exp
         assert not gidx.last_counters()["ordered_by_one_composite_sort"]
-        monkeypatch.delenv("GS_BIG2_NO_COMPOSITE")
+        gidx.set_option("GS_BIG2_NO_COMPOSITE", None)
         for bits, step in ((13, 512), (9, 64), (5, 8)):
-            monkeypatch.setenv("GS_BIG2_ROWBITS", str(bits))
+            gidx.set_option("GS_BIG2_ROWBITS", str(bits))
             fixed = 0
             for off in range(0, 1 << bits, step):
-                monkeypatch.setenv("GS_BIG2_ROWOFF", str(off))
+                gidx.set_option("GS_BIG2_ROWOFF", str(off))
                 offsets, hits, _ = gidx.enumerate(seqs, pams, mismatches=3)
                 ctr = gidx.last_counters()
                 assert ctr["ordered_by_one_composite_sort"], (bits, off, ctr)
@@ -896,11 +964,11 @@ def test_search_iteration_bound_fails_cleanly(toy_gpu, monkeypatch):
     pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8)
     want = gidx.enumerate(seqs, pams, mismatches=3)
     for faithful in (False, True):
-        monkeypatch.setenv("GS_SEARCH_MAX_ITER", "2")
+        gidx.set_option("GS_SEARCH_MAX_ITER", "2")
         with pytest.raises(api.GsError) as e:
             gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
         assert e.value.status == 2
-        monkeypatch.delenv("GS_SEARCH_MAX_ITER")
+        gidx.set_option("GS_SEARCH_MAX_ITER", None)
         got = gidx.enumerate(seqs, pams, mismatches=3, faithful=faithful)
         assert np.array_equal(got[0], want[0]) and got[1].tobytes() == want[1].tobytes()
 

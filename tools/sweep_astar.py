@@ -25,10 +25,7 @@ def main():
     seqs, pams, _, _ = synth.sample_guides(text, batch, seed=1000)
     d_s, d_p = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
     for cand in [None] + sys.argv[4:]:
-        if cand is None:
-            os.environ.pop("GS_ASTAR", None)
-        else:
-            os.environ["GS_ASTAR"] = cand
+        gidx.set_option("GS_ASTAR", cand)
         best = None
         for _ in range(3):
             _, _, st = gidx.enumerate_device(d_s.data_ptr(), batch, 20, d_p.data_ptr(), 3, mismatches=m)
