@@ -186,6 +186,7 @@ struct gs_index {
   /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
   double seen_mean[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
   double seen_max[8] = {0};
+  uint64_t seen_hpass[8] = {0}, seen_items[8] = {0}; /* verification passes of share_min row groups or more in the last batch at this budget, and its items */
   bool last_raw_valid = false;   /* w_raw holds the raw hit counts of the last batch (GS_FLAG_RAW_COUNTS) */
   uint64_t last_unsupported = 0; /* guides of the last batch flagged GS_GUIDE_NEEDS_GENERAL (w_flags) */
   uint64_t seen_key[8] = {0};

@@ -31,7 +31,7 @@
 #ifndef VQ_DRAIN
 #define VQ_DRAIN 64 /* verify as soon as this many seeds wait (a seeding step adds at most 64) */
 #endif
-#define WAVE_LDS_FAST (VQ_CAP + 32 + DTAB + 3) /* 16-byte entries per wave of the table-only variant: 3.9 KiB */
+#define WAVE_LDS_FAST (VQ_CAP + 32 + DTAB + 5) /* 16-byte entries per wave of the table-only variant: 3.9 KiB */
 #define WAVE_LDS_ENTRIES (STACK_ENTRIES + WAVE_LDS_FAST) /* the walking variant adds the X/G stacks: 8 KiB */
 #define MAX_FANOUT 5      /* children one node can push (A,C,G,T + literal N / 4 PAM copies) */
 
@@ -145,6 +145,13 @@ struct gs_search_args {
   uint32_t *sh_acc;     /* per shared item 16 words: [0] records of helpers, [1] their chunks, [8..15] per mismatch class */
   uint32_t *chunk_fill; /* per chunk of a helper: records it holds */
   uint32_t shq_cap, sh_max, share_min, share_max, n_waves;
+  /* every table-seeded instantiation counts the verification passes of share_min row groups or more: what tells the
+   * host whether the next batch of this shape is better served by the heavy instantiation */
+  uint32_t *hpass;
+  /* GS_DEBUG: where the heavy launch's time goes, in ticks of the 100 MHz wall clock (8 x uint64 behind shq_ctl + 104):
+   * [0] first wave's start (min), [1] last wave leaving its items (max), [2] last wave's exit (max), [3] sum of the
+   * waves' item phases, [4] of their helper episodes, [5] of their waits for a package, [6] episodes */
+  uint32_t sh_prof;
 };
 #define SHQ_PKG 72u /* uint4 per package: header + 64 descriptors, padded to nine 128-byte lines */
 #define SH_NONE 0xFFFFFFFFu
@@ -174,6 +181,9 @@ __device__ __forceinline__ uint4 ld16_agent(const uint4 *p) {
 #define DTAB 88u /* per-item substitution table: 4 entries per step of this strand's k-mer (k <= 16) or per
                     guide symbol of the other strand's (k - P <= 21); the two sides seed one after the other */
 
+#ifndef GS_VU
+#define GS_VU 4u /* candidate rows per lane whose second-level loads are in flight together (k_search_body::verify) */
+#endif
 #define SEED_LOW_MAX 128 /* refill the stacks from the prefix table when they hold this few nodes */
 
 /* ---- search: one wavefront per (guide, strand) ----------------------------
@@ -224,7 +234,7 @@ __device__ __forceinline__ const T *own_sgprs(const T *p) {
   return (const T *)(const T __attribute__((address_space(1))) *)(((uint64_t)hi << 32) | lo);
 }
 
-template <bool CNT, bool WALK, bool SPEC = false>
+template <bool CNT, bool WALK, bool SPEC = false, bool HEAVY = false>
 __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk) {
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
   /* Where a path lives in the 64-bit word the search carries next to a seed or a hit.  The walking variant packs
@@ -243,6 +253,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   unsigned long long n_ext = 0, n_ovf = 0;
   uint32_t n_fail = 0; /* items that needed more overflow chunks than the arena had left */
   bool bailed = false; /* an item of this wave passed the iteration bound */
+  uint32_t n_hpass = 0; /* verification passes of at least share_min row groups */
   uint32_t n_two = 0, n_fb = 0, n_pair = 0; /* items seeded from both strands / one-sided although two-sided seeding is on */
   /* request counters (CNT): table lines, ctx16 lines, ctx words, SA/ISA gathers of the search, Occ lines */
   uint32_t c_tab = 0, c_c16 = 0, c_ctx = 0, c_isa = 0, c_occ = 0, c_rec = 0;
@@ -268,13 +279,37 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   uint2 *own2 = (uint2 *)(vq + VQ_CAP);        /* owner markers of a pass, two per lane */
   uint32_t *own = (uint32_t *)own2;
   uint4 *dtab = vq + VQ_CAP + 32;              /* substitution table of the item: {index xor, path lo, path hi, -} */
-  uint32_t *wmisc = (uint32_t *)(dtab + DTAB); /* overflow chunks of the item: {taken, the last one, the one before}; [4..11] matches per mismatch count */
+  /* overflow chunks of the item: {taken, the last one, the one before}; [3] its number among the shared items;
+   * [4..11] matches per mismatch count; [12..14] a helper episode's package: {side | table << 1 | descriptors << 8, the
+   * shared item, the package's place in the queue} - wave-uniform state that is read at a handful of places lives
+   * here and not in scalar registers, which the seeding loops are short of */
+  uint32_t *wmisc = (uint32_t *)(dtab + DTAB);
+  /* [16..18] the wave's reserve of arena chunks {next, end, chunks the next visit to the counter takes}: one atomic on
+   * one word serves ~88 waves per microsecond chip-wide, and a repeat-rich batch of 20,000 guides takes 480,000 chunks -
+   * 5.5 ms of a 9.6 ms launch if every chunk were a visit.  A wave takes 1, 2, 4 ... 16 chunks per visit; what it leaves
+   * unused stays marked empty (chunk_seq = 0xFFFFFFFF, written before the launch). */
+  if (lane == 0) {
+    wmisc[16] = 0u;
+    wmisc[17] = 0u;
+    wmisc[18] = 1u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
   /* Items are taken from the work counter `take` at a time: one atomic on one word serves about 88 waves per
    * microsecond chip-wide (MI355X_MICROARCH.md, dequeue), so a counter bumped once per item held a launch of
    * 2 M items at 22.9 ms whatever the items did (measured with the seeding switched off: 22.9 of 26.5 ms) */
   uint32_t item_next = 0, item_end = 0;
-  const bool sharing = !WALK && a.shq != nullptr;
+  const bool sharing = HEAVY && a.shq != nullptr;
+#ifdef GS_SH_PROFILE
+  unsigned long long *const prof = (HEAVY && a.sh_prof) ? (unsigned long long *)(a.shq_ctl + 104) : nullptr;
+#else
+  unsigned long long *const prof = nullptr; /* (a build with -DGS_SH_PROFILE times the phases: tools/ab_share_variants.sh) */
+#endif
+  unsigned long long t_prev = 0, t_help = 0, t_wait = 0, n_epi = 0;
+  if (prof != nullptr) {
+    t_prev = wall_clock64();
+    if (lane == 0) atomicMin(&prof[0], t_prev);
+  }
   bool items_done = false; /* the work counter is exhausted: this wave runs packages of shared items until none is left */
   for (;;) {
     if (!items_done && item_next == item_end) {
@@ -285,15 +320,22 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         if (!sharing) break; /* exit condition every wave reaches */
         items_done = true;
         if (lane == 0) atomicAdd(&a.shq_ctl[64], 1u); /* this wave reserves no package any more */
+        if (prof != nullptr) {
+          const unsigned long long t = wall_clock64();
+          if (lane == 0) {
+            atomicMax(&prof[1], t);
+            atomicAdd(&prof[3], t - t_prev);
+          }
+          t_prev = t;
+        }
       } else {
         item_next = base;
         item_end = base + a.take < a.n_items ? base + a.take : a.n_items;
       }
     }
     /* a helper episode: one package = one verification pass of somebody else's item */
-    bool helper = false, h_side_b = false;
-    uint32_t h_item = 0, h_sid = 0, h_tab = 3u, h_n = 0;
-    const uint4 *h_pkg = nullptr;
+    bool helper = false;
+    uint32_t h_item = 0;
     if (items_done) {
       /* Ticket t: package t is this wave's, if it is ever reserved.  The wave waits for its flag; once every wave has
        * left its items no reservation can follow, and a ticket at or beyond the reserved count leaves.  The writer of
@@ -317,17 +359,23 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         }
       }
       got = __builtin_amdgcn_readfirstlane(got);
+      if (prof != nullptr) { /* (t_prev: the end of the item phase or of the last episode) */
+        const unsigned long long t = wall_clock64();
+        t_wait += t - t_prev;
+        t_prev = t;
+      }
       if (got == SH_NONE) break; /* exit condition every wave reaches: all items taken, no package left for this ticket */
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      h_pkg = a.shq + (size_t)got * SHQ_PKG;
-      const uint4 hd = ld16_agent(h_pkg);
+      const uint4 hd = ld16_agent(a.shq + (size_t)got * SHQ_PKG);
       h_item = __builtin_amdgcn_readfirstlane(hd.x);
-      h_sid = __builtin_amdgcn_readfirstlane(hd.y);
       const uint32_t hz = __builtin_amdgcn_readfirstlane(hd.z);
-      h_side_b = (hz & 1u) != 0u;
-      h_tab = (hz >> 1) & 3u;
-      h_n = hz >> 8;
-      if (h_n == 0u || h_n > WAVE || h_item >= a.n_items) continue; /* a filler for a reservation the queue had no room for */
+      if ((hz >> 8) == 0u || (hz >> 8) > WAVE || h_item >= a.n_items) continue; /* a filler for a reservation the queue had no room for */
+      if (lane == 0) {
+        wmisc[12] = hz;
+        wmisc[13] = hd.y;
+        wmisc[14] = got;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       helper = true;
     }
     const uint32_t item = helper ? h_item : item_next++;
@@ -355,8 +403,6 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       }
       continue;
     }
-    uint32_t sid = SH_NONE; /* this item's number among the shared items, once a pass of it has been handed out */
-    uint32_t cur_tab = 3u;  /* the PAM-pair table this strand's seeds are going through (3: the strand's own table) */
     uint32_t guard_left = a.max_iter; /* rounds this item's loops may still take (every outer step runs a counted inner loop) */
     const gs_strand_dev &sd = a.sd[strand];
     const uint4 *__restrict__ blocks = sd.blocks;
@@ -370,7 +416,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     if (a.arena != nullptr) {
       uint2 nc = make_uint2(0u, 0u);
       if (a.append) nc = a.nchunk[slot];
-      if (lane < 3u) wmisc[lane] = lane == 0u ? nc.x : lane == 1u ? nc.y : 0u;
+      if (lane < 4u) wmisc[lane] = lane == 0u ? nc.x : lane == 1u ? nc.y : lane == 2u ? 0u : SH_NONE;
       if (lane >= 4u && lane < 12u) wmisc[lane] = a.append ? a.cls[(size_t)slot * 8u + (lane - 4u)] : 0u;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
@@ -436,13 +482,23 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint32_t need = (hi - item_cap + ARENA_CHUNK - 1u) >> ARENA_SHIFT;
           while (nch < need) {
             uint32_t id = 0;
-            if (lane == 0) id = atomicAdd(a.arena_next, 1u);
+            if (lane == 0) {
+              uint32_t rn = wmisc[16];
+              if (rn == wmisc[17]) { /* the reserve is used up: the next one, twice as large (up to 16 chunks) */
+                const uint32_t g = wmisc[18];
+                rn = atomicAdd(a.arena_next, g);
+                wmisc[17] = rn + g;
+                wmisc[18] = g < 16u ? 2u * g : 16u;
+              }
+              id = rn;
+              wmisc[16] = rn + 1u;
+            }
             id = __builtin_amdgcn_readfirstlane(id);
             if (id >= a.arena_chunks) break; /* arena exhausted: the item goes on counting only */
             if (lane == 0) {
               a.chunk_item[id] = slot;
               if (helper) { /* numbered among the item's helper chunks; what it holds is said when the episode ends */
-                a.chunk_seq[id] = SH_HELPER_SEQ | atomicAdd(&a.sh_acc[16u * h_sid + 1u], 1u);
+                a.chunk_seq[id] = SH_HELPER_SEQ | atomicAdd(&a.sh_acc[16u * wmisc[13] + 1u], 1u);
                 a.chunk_fill[id] = ARENA_CHUNK;
               } else {
                 a.chunk_seq[id] = nch;
@@ -523,14 +579,20 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
       if (!R) return;
       const uint32_t excl = incl - vgrp;
-      if constexpr (!WALK) {
+      if (!WALK && R >= a.share_min) n_hpass++;
+      if constexpr (HEAVY) {
         /* ---- a heavy pass is handed to the waves that have run out of items (gs_search_args::shq) ---- */
         if (sharing && !helper && R >= a.share_min) {
+          uint32_t sid = __builtin_amdgcn_readfirstlane(wmisc[3]);
           if (sid == SH_NONE) {
             uint32_t s = 0;
             if (lane == 0) s = atomicAdd(&a.shq_ctl[96], 1u);
             sid = __builtin_amdgcn_readfirstlane(s);
-            if (sid < a.sh_max && lane == 0) a.sh_list[sid] = slot;
+            if (lane == 0) {
+              wmisc[3] = sid;
+              if (sid < a.sh_max) a.sh_list[sid] = slot;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           }
           if (sid < a.sh_max) {
             /* packages of at most share_max groups: consecutive descriptors (each <= 128 groups <= share_max) */
@@ -549,6 +611,8 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
               const uint32_t nxt = above ? (uint32_t)__builtin_ctzll(above) : take;
               uint4 *pk = a.shq + (size_t)(qb + pid) * SHQ_PKG;
               if (lane < take) st16_agent(pk + 1u + (lane - start), mine);
+              /* the PAM-pair table this strand's seeds are going through (3: the strand's own table) */
+              const uint32_t cur_tab = (modeB || arow == nullptr) ? 3u : arow == a.pt[0][strand].rowid ? 0u : 1u;
               if (first) st16_agent(pk, make_uint4(item, sid, (modeB ? 1u : 0u) | (cur_tab << 1) | ((nxt - start) << 8), 0u));
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* every store of the packages has left before their flags do */
               if (first) st_agent(a.shq_ready + qb + pid, 1u);
@@ -639,92 +703,224 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           }
         }
         cm &= ((1u << nrow[0]) - 1u) | (((1u << nrow[1]) - 1u) << 8); /* rows that exist */
-        /* second level, one candidate row per lane per round (rare: a row passes the first
-         * level with probability ~0.5 % at budget 1): the full 16-symbol word decides */
-        while (__ballot(cm != 0u)) {
-          const bool has = cm != 0u;
-          const uint32_t pick = has ? (uint32_t)__builtin_ctz(cm) : 0u;
-          cm &= cm - 1u;
-          const bool hi = (pick >> 3) != 0u;
-          const uint4 dd = hi ? dsc[1] : dsc[0];
-          const uint32_t row = (hi ? row0[1] : row0[0]) + (pick & 7u);
-          const uint32_t kv = hi ? kkv[1] : kkv[0];
-          uint32_t w = 0u;
-          if (has) w = vctx[row];
-          if constexpr (CNT) c_ctx += (uint32_t)__popcll(__ballot(has));
-          /* exception rows: the true symbols decide.  Under a guide symbol nothing outside
-           * A,C,G,T can match or be substituted (index.hpp:31,230-247); under a PAM 'N' a literal
-           * 'N' of the text matches (index.hpp:139-149) */
-          uint32_t nmask = 0u; /* bit u: the text holds a literal N under PAM symbol u */
-          bool excbad = false;
-          const bool fl = has && ((dd.y >> DSC_EXC) & 1u) != 0u;
-          if (__ballot(fl)) {
-            if (fl) {
-              uint32_t el = 0, eh = sv.n_exc;
-              while (el < eh) {
-                const uint32_t mid = (el + eh) >> 1;
-                if (sv.exc_row[mid] < row)
-                  el = mid + 1;
-                else
-                  eh = mid;
-              }
-              if (el < sv.n_exc && sv.exc_row[el] == row) {
-                const uint64_t nb = sv.exc_sym[el];
-                const uint32_t upto = modeB ? g : g + P;
-                for (uint32_t j = 0; j < upto; ++j) {
-                  const uint32_t c = (uint32_t)(nb >> (4u * j)) & 15u;
-                  if (c > 3u) {
-                    if (j < g || c != 4u)
-                      excbad = true;
+        /* (the heavy instantiation takes the form with several rows in flight when some lane has two candidates or more,
+         * else the plain one: on a genome without repeat families a pass has a handful of candidates in all) */
+        if (HEAVY && __ballot((cm & (cm - 1u)) != 0u) != 0ull) {
+          /* second level: the full 16-symbol word decides (rare on a genome without repeat families: a row passes the
+           * first level with probability ~0.5 % at budget 1; inside a family nearly every row does).  GS_VU candidate rows
+           * per lane and round, their loads issued side by side - the context words, then the rows' numbers in the
+           * strand's suffix array (this side) or the site's position and this strand's row for it (the other side): a
+           * round of ONE row per lane waited for two or three dependent gathers, and that wait, not bytes or instructions,
+           * was the search's time on a repeat-rich genome (13 of 16 ms; 3.5 us per round of 64 rows). */
+          while (__ballot(cm != 0u)) {
+            uint32_t pkw = 0u;         /* per candidate 8 bits: 0x80 there is one, low bits = its place among the lane's 16 rows */
+            uint32_t cw[GS_VU];        /* its context word */
+            uint32_t co[GS_VU];        /* its row as the strand's suffix array numbers it (the other side: this strand's row of the site) */
+            uint32_t cmeta[GS_VU];     /* bit 0 the guide symbols fit, bits 3:1 substitutions among them, bits 11:4 literal N under PAM symbol u */
+  #pragma unroll
+            for (uint32_t u = 0; u < GS_VU; ++u) {
+              const bool has = cm != 0u;
+              const uint32_t pick = has ? (uint32_t)__builtin_ctz(cm) : 0u;
+              cm &= cm - 1u;
+              pkw |= ((has ? 0x80u : 0u) | pick) << (8u * u);
+              const uint32_t row = ((pick >> 3) ? row0[1] : row0[0]) + (pick & 7u);
+              cw[u] = 0u;
+              if (has) cw[u] = vctx[row];
+              if constexpr (CNT) c_ctx += (uint32_t)__popcll(__ballot(has));
+            }
+  #pragma unroll
+            for (uint32_t u = 0; u < GS_VU; ++u) {
+              const uint32_t pb = (pkw >> (8u * u)) & 0xFFu, pick = pb & 15u;
+              const bool has = (pb & 0x80u) != 0u, hi = (pick >> 3) != 0u;
+              const uint32_t dy = hi ? dsc[1].y : dsc[0].y;
+              const uint32_t row = (hi ? row0[1] : row0[0]) + (pick & 7u);
+              const uint32_t kv = hi ? kkv[1] : kkv[0];
+              const uint32_t w = cw[u];
+              /* exception rows: the true symbols decide.  Under a guide symbol nothing outside
+               * A,C,G,T can match or be substituted (index.hpp:31,230-247); under a PAM 'N' a literal
+               * 'N' of the text matches (index.hpp:139-149) */
+              uint32_t nmask = 0u; /* bit u: the text holds a literal N under PAM symbol u */
+              bool excbad = false;
+              const bool fl = has && ((dy >> DSC_EXC) & 1u) != 0u;
+              if (__ballot(fl)) {
+                if (fl) {
+                  uint32_t el = 0, eh = sv.n_exc;
+                  while (el < eh) {
+                    const uint32_t mid = (el + eh) >> 1;
+                    if (sv.exc_row[mid] < row)
+                      el = mid + 1;
                     else
-                      nmask |= 1u << (j - g);
+                      eh = mid;
+                  }
+                  if (el < sv.n_exc && sv.exc_row[el] == row) {
+                    const uint64_t nb = sv.exc_sym[el];
+                    const uint32_t upto = modeB ? g : g + P;
+                    for (uint32_t j = 0; j < upto; ++j) {
+                      const uint32_t c = (uint32_t)(nb >> (4u * j)) & 15u;
+                      if (c > 3u) {
+                        if (j < g || c != 4u)
+                          excbad = true;
+                        else
+                          nmask |= 1u << (j - g);
+                      }
+                    }
+                  }
+                }
+              }
+              const uint32_t xf = (w ^ qrem) & gmask;
+              const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
+              const bool gok = has && !excbad && kv + mmv <= m && mmv >= ((dy >> DSC_LO) & 7u);
+              cmeta[u] = (gok ? 1u : 0u) | (mmv << 1) | (nmask << 4);
+              co[u] = row;
+              if (modeB) {
+                if (gok) co[u] = sv.sa[row]; /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
+                if constexpr (CNT) c_isa += 2u * (uint32_t)__popcll(__ballot(gok));
+              } else if (arow != nullptr) {
+                if (gok) co[u] = arow[row];
+                if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(gok));
+              }
+            }
+            if (modeB) {
+  #pragma unroll
+              for (uint32_t u = 0; u < GS_VU; ++u)
+                if (cmeta[u] & 1u) co[u] = sd.isa[(sd.n - 1u) - (co[u] - g) - (L + P)];
+            }
+            /* the hits, one candidate per lane at a time (ONE copy of the emission code: the candidates move up a place) */
+  #pragma unroll 1
+            for (uint32_t u = 0; u < GS_VU; ++u) {
+              const uint32_t pick = pkw & 15u, cmt = cmeta[0], w = cw[0], orow = co[0];
+              const bool gok = (cmt & 1u) != 0u;
+              const bool more = __ballot((pkw >> 8) != 0u) != 0ull;
+              const bool hi = (pick >> 3) != 0u;
+              const uint4 dd = hi ? dsc[1] : dsc[0];
+              const uint32_t kv = hi ? kkv[1] : kkv[0], mmv = (cmt >> 1) & 7u, nmask = cmt >> 4;
+              pkw >>= 8;
+  #pragma unroll
+              for (uint32_t v = 0; v + 1u < GS_VU; ++v) {
+                cw[v] = cw[v + 1u];
+                co[v] = co[v + 1u];
+                cmeta[v] = cmeta[v + 1u];
+              }
+              cmeta[GS_VU - 1u] = 0u;
+              if (__ballot(gok)) {
+                const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PMASK;
+                if (modeB) {
+                  /* word symbol j is guide symbol g-1-j, complemented: the bases as this strand reads them against
+                   * the guide's own; code j belongs at path bit 50 - 2 (g-1-j) */
+                  const uint64_t gpath = (uint64_t)path_codes16(~w & gmask, ~qrem & gmask) << (52u + PB - 2u * g);
+                  const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath;
+                  route(gok, true, false, orow, orow, mmeta, 0u);
+                } else {
+                  for (uint32_t pj = 0; pj < npams; ++pj) {
+                    const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+                    bool ok = gok;
+                    uint64_t ppath = 0;
+                    for (uint32_t q = 0; q < P; ++q) {
+                      const uint32_t pc = (pw >> (3u * q)) & 7u;
+                      const uint32_t tb = (w >> (2u * (g + q))) & 3u;
+                      const bool isn = ((nmask >> q) & 1u) != 0u;
+                      ok = ok && (isn ? pc == 4u : (pc == 4u || pc == tb));
+                      ppath |= (uint64_t)(isn ? 3u : (tb < 3u ? tb : 4u)) << (PSP - 2u * L - 3u * q);
+                    }
+                    if (!__ballot(ok)) continue;
+                    /* word symbol v is guide symbol k+v: code v belongs at path bit 50 - 2 (k+v), the fields in reverse order */
+                    const uint64_t gpath = ((uint64_t)rev_fields16(path_codes16(w & gmask, qrem)) << 32) >> (12u - PB + 2u * k);
+                    const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath | ppath;
+                    route(ok, true, false, orow, orow, mmeta, 1u);
+                  }
+                }
+              }
+              if (!more) break;
+            }
+          }
+        } else {
+          /* second level, one candidate row per lane per round (rare: a row passes the first
+           * level with probability ~0.5 % at budget 1): the full 16-symbol word decides */
+          while (__ballot(cm != 0u)) {
+            const bool has = cm != 0u;
+            const uint32_t pick = has ? (uint32_t)__builtin_ctz(cm) : 0u;
+            cm &= cm - 1u;
+            const bool hi = (pick >> 3) != 0u;
+            const uint4 dd = hi ? dsc[1] : dsc[0];
+            const uint32_t row = (hi ? row0[1] : row0[0]) + (pick & 7u);
+            const uint32_t kv = hi ? kkv[1] : kkv[0];
+            uint32_t w = 0u;
+            if (has) w = vctx[row];
+            if constexpr (CNT) c_ctx += (uint32_t)__popcll(__ballot(has));
+            /* exception rows: the true symbols decide.  Under a guide symbol nothing outside
+             * A,C,G,T can match or be substituted (index.hpp:31,230-247); under a PAM 'N' a literal
+             * 'N' of the text matches (index.hpp:139-149) */
+            uint32_t nmask = 0u; /* bit u: the text holds a literal N under PAM symbol u */
+            bool excbad = false;
+            const bool fl = has && ((dd.y >> DSC_EXC) & 1u) != 0u;
+            if (__ballot(fl)) {
+              if (fl) {
+                uint32_t el = 0, eh = sv.n_exc;
+                while (el < eh) {
+                  const uint32_t mid = (el + eh) >> 1;
+                  if (sv.exc_row[mid] < row)
+                    el = mid + 1;
+                  else
+                    eh = mid;
+                }
+                if (el < sv.n_exc && sv.exc_row[el] == row) {
+                  const uint64_t nb = sv.exc_sym[el];
+                  const uint32_t upto = modeB ? g : g + P;
+                  for (uint32_t j = 0; j < upto; ++j) {
+                    const uint32_t c = (uint32_t)(nb >> (4u * j)) & 15u;
+                    if (c > 3u) {
+                      if (j < g || c != 4u)
+                        excbad = true;
+                      else
+                        nmask |= 1u << (j - g);
+                    }
                   }
                 }
               }
             }
-          }
-          const uint32_t xf = (w ^ qrem) & gmask;
-          const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
-          const bool gok = has && !excbad && kv + mmv <= m && mmv >= ((dd.y >> DSC_LO) & 7u);
-          if (!__ballot(gok)) continue;
-          const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PMASK;
-          if (modeB) {
-            /* word symbol j is guide symbol g-1-j, complemented: the bases as this strand reads them against
-             * the guide's own; code j belongs at path bit 50 - 2 (g-1-j) */
-            const uint64_t gpath = (uint64_t)path_codes16(~w & gmask, ~qrem & gmask) << (52u + PB - 2u * g);
-            uint32_t rowA = 0;
-            if (gok) {
-              /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
-              const uint32_t pB = sv.sa[row];
-              const uint32_t sA = (sd.n - 1u) - (pB - g) - (L + P);
-              rowA = sd.isa[sA];
+            const uint32_t xf = (w ^ qrem) & gmask;
+            const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
+            const bool gok = has && !excbad && kv + mmv <= m && mmv >= ((dd.y >> DSC_LO) & 7u);
+            if (!__ballot(gok)) continue;
+            const uint64_t spath = (((uint64_t)dd.w << 32) | dd.z) & PMASK;
+            if (modeB) {
+              /* word symbol j is guide symbol g-1-j, complemented: the bases as this strand reads them against
+               * the guide's own; code j belongs at path bit 50 - 2 (g-1-j) */
+              const uint64_t gpath = (uint64_t)path_codes16(~w & gmask, ~qrem & gmask) << (52u + PB - 2u * g);
+              uint32_t rowA = 0;
+              if (gok) {
+                /* site = [pB - v_rem, pB - v_rem + L + P) on the other strand */
+                const uint32_t pB = sv.sa[row];
+                const uint32_t sA = (sd.n - 1u) - (pB - g) - (L + P);
+                rowA = sd.isa[sA];
+              }
+              if constexpr (CNT) c_isa += 2u * (uint32_t)__popcll(__ballot(gok));
+              const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath;
+              route(gok, true, false, rowA, rowA, mmeta, 0u);
+              continue;
             }
-            if constexpr (CNT) c_isa += 2u * (uint32_t)__popcll(__ballot(gok));
-            const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath;
-            route(gok, true, false, rowA, rowA, mmeta, 0u);
-            continue;
-          }
-          uint32_t orow = row; /* the row as the strand's suffix array numbers it */
-          if (arow != nullptr) {
-            if (gok) orow = arow[row];
-            if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(gok));
-          }
-          for (uint32_t pj = 0; pj < npams; ++pj) {
-            const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-            bool ok = gok;
-            uint64_t ppath = 0;
-            for (uint32_t u = 0; u < P; ++u) {
-              const uint32_t pc = (pw >> (3u * u)) & 7u;
-              const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-              const bool isn = ((nmask >> u) & 1u) != 0u;
-              ok = ok && (isn ? pc == 4u : (pc == 4u || pc == tb));
-              ppath |= (uint64_t)(isn ? 3u : (tb < 3u ? tb : 4u)) << (PSP - 2u * L - 3u * u);
+            uint32_t orow = row; /* the row as the strand's suffix array numbers it */
+            if (arow != nullptr) {
+              if (gok) orow = arow[row];
+              if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(gok));
             }
-            if (!__ballot(ok)) continue;
-            /* word symbol v is guide symbol k+v: code v belongs at path bit 50 - 2 (k+v), the fields in reverse order */
-            const uint64_t gpath = ((uint64_t)rev_fields16(path_codes16(w & gmask, qrem)) << 32) >> (12u - PB + 2u * k);
-            const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath | ppath;
-            route(ok, true, false, orow, orow, mmeta, 1u);
+            for (uint32_t pj = 0; pj < npams; ++pj) {
+              const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+              bool ok = gok;
+              uint64_t ppath = 0;
+              for (uint32_t u = 0; u < P; ++u) {
+                const uint32_t pc = (pw >> (3u * u)) & 7u;
+                const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+                const bool isn = ((nmask >> u) & 1u) != 0u;
+                ok = ok && (isn ? pc == 4u : (pc == 4u || pc == tb));
+                ppath |= (uint64_t)(isn ? 3u : (tb < 3u ? tb : 4u)) << (PSP - 2u * L - 3u * u);
+              }
+              if (!__ballot(ok)) continue;
+              /* word symbol v is guide symbol k+v: code v belongs at path bit 50 - 2 (k+v), the fields in reverse order */
+              const uint64_t gpath = ((uint64_t)rev_fields16(path_codes16(w & gmask, qrem)) << 32) >> (12u - PB + 2u * k);
+              const uint64_t mmeta = ((uint64_t)(kv + mmv) << KSH) | spath | gpath | ppath;
+              route(ok, true, false, orow, orow, mmeta, 1u);
+            }
           }
         }
       }
@@ -871,7 +1067,10 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         if (!all) pslots = 0u;
       }
       /* a helper goes through the one table its package names (or none: the other strand's side) */
-      if (helper) pslots = (!h_side_b && h_tab < 2u) ? 1u << h_tab : 0u;
+      if (helper) {
+        const uint32_t hz = __builtin_amdgcn_readfirstlane(wmisc[12]);
+        pslots = (!(hz & 1u) && ((hz >> 1) & 3u) < 2u) ? 1u << ((hz >> 1) & 3u) : 0u;
+      }
       if (!fallback) {
         /* literal-N windows within reach whose (a, o) belongs to the other side - or all of them:
          * the PAM-pair tables hold no row with a symbol outside A,C,G,T next to it */
@@ -949,10 +1148,14 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         /* (a helper has no recipes to go through: its queue comes filled and the loop below only drains it) */
         const uint32_t nlanes = helper ? 0u : deep ? 4u * a.n_rec_b : a.n_rec_b;
         if (!helper) fill_dtab(true);
-        if (helper && h_side_b) {
-          if (lane < h_n) vq[lane] = ld16_agent(h_pkg + 1u + lane);
-          qn = h_n;
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (helper) {
+          const uint32_t hz = __builtin_amdgcn_readfirstlane(wmisc[12]);
+          if (hz & 1u) {
+            const uint4 *pkg = a.shq + (size_t)__builtin_amdgcn_readfirstlane(wmisc[14]) * SHQ_PKG;
+            if (lane < (hz >> 8)) vq[lane] = ld16_agent(pkg + 1u + lane);
+            qn = hz >> 8;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          }
         }
         /* the guide part of the other strand's k-mer: step P+y holds the complement of guide symbol L-1-y */
         const uint32_t nYb = deep ? L - sx : nY;
@@ -1104,7 +1307,6 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     auto next_pairtab = [&]() __attribute__((always_inline)) {
       const uint32_t s = (pslots & 1u) ? 0u : 1u;
       pslots &= ~(1u << s);
-      cur_tab = s;
       const gs_pairtab_dev &p = a.pt[s][strand];
       atab8 = own_sgprs(p.tab);
       arot8 = own_sgprs(p.rot);
@@ -1129,10 +1331,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     if (helper) {
       /* this strand's side of a package: ONE seeding step without recipes, whose queue loop finds the pass ended and
        * the queue filled - the verification below is the one the item's own wave would have run */
-      seeds_left = !h_side_b;
-      if (!h_side_b) {
-        if (lane < h_n) vq[lane] = ld16_agent(h_pkg + 1u + lane);
-        qn = h_n;
+      const uint32_t hz = __builtin_amdgcn_readfirstlane(wmisc[12]);
+      seeds_left = !(hz & 1u);
+      if (!(hz & 1u)) {
+        const uint4 *pkg = a.shq + (size_t)__builtin_amdgcn_readfirstlane(wmisc[14]) * SHQ_PKG;
+        if (lane < (hz >> 8)) vq[lane] = ld16_agent(pkg + 1u + lane);
+        qn = hz >> 8;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       }
     }
@@ -1431,10 +1635,17 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
       const bool short_of = n_match > (nch << ARENA_SHIFT); /* the arena ran out: counted, not kept (the host searches the batch's overflow again) */
+      const uint32_t h_sid = __builtin_amdgcn_readfirstlane(wmisc[13]);
       if (lane == 0 && n_match != 0u) atomicAdd(&a.sh_acc[16u * h_sid], n_match);
       if (lane == 1u && nch != 0u && !short_of) a.chunk_fill[last] = n_match - ((nch - 1u) << ARENA_SHIFT);
       if (lane >= 8u && lane < 16u && wmisc[lane - 4u] != 0u) atomicAdd(&a.sh_acc[16u * h_sid + lane], wmisc[lane - 4u]);
       if (short_of) n_fail++;
+      if (prof != nullptr) {
+        const unsigned long long t = wall_clock64();
+        t_help += t - t_prev;
+        t_prev = t;
+        n_epi++;
+      }
       continue;
     }
     if (lane == 0) a.counts[slot] = n_match;
@@ -1443,15 +1654,23 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
       /* (a shared item: its number instead of the last chunk - nobody appends to it - for k_share_dir/fix) */
-      if (lane == 0) a.nchunk[slot] = make_uint2(nch, sid < a.sh_max ? 0x80000000u | sid : last);
+      const uint32_t sid = __builtin_amdgcn_readfirstlane(wmisc[3]);
+      if (lane == 0) a.nchunk[slot] = make_uint2(nch, (HEAVY && sid < a.sh_max) ? 0x80000000u | sid : last);
       if (lane < 8u) a.cls[(size_t)slot * 8u + lane] = wmisc[4u + lane];
       if (n_match > item_cap && n_match - item_cap > (nch << ARENA_SHIFT)) n_fail++;
     }
+  }
+  if (prof != nullptr && lane == 0) {
+    atomicMax(&prof[2], wall_clock64());
+    atomicAdd(&prof[4], t_help);
+    atomicAdd(&prof[5], t_wait);
+    atomicAdd(&prof[6], n_epi);
   }
   if (lane == 0) {
     if (n_ext) atomicAdd(&a.stats[0], n_ext);
     if (n_ovf) atomicAdd(&a.stats[1], n_ovf);
     if (n_fail) atomicAdd(&a.stats[6], (unsigned long long)n_fail);
+    if (!WALK && n_hpass) atomicAdd(a.hpass, n_hpass);
     if (bailed) atomicOr(a.err, 1u);
     if (n_two) atomicAdd(&a.stats[4], (unsigned long long)n_two);
     if (n_fb) atomicAdd(&a.stats[5], (unsigned long long)n_fb);
@@ -1467,11 +1686,11 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   }
 }
 
-#define GS_DEF_SEARCH(NAME, CNT, WALK, SPEC, WEU)                                                                    \
+#define GS_DEF_SEARCH(NAME, CNT, WALK, SPEC, WEU, ...)                                                               \
   __global__ __launch_bounds__(WAVE *SEARCH_WAVES) __attribute__((amdgpu_waves_per_eu(WEU, WEU))) void NAME(          \
       gs_search_args a) {                                                                                             \
     __shared__ uint4 s_stack[SEARCH_WAVES][(WALK) ? WAVE_LDS_ENTRIES : WAVE_LDS_FAST];                                 \
-    k_search_body<CNT, WALK, SPEC>(a, s_stack[threadIdx.x / WAVE]);                                                    \
+    k_search_body<CNT, WALK, SPEC, ##__VA_ARGS__>(a, s_stack[threadIdx.x / WAVE]);                                     \
   }
 GS_DEF_SEARCH(k_search_walk, false, true, false, GS_WAVES_EU)       /* reference-order walk; remainders beyond ctx[] */
 GS_DEF_SEARCH(k_search_fast, false, false, false, GS_WAVES_EU_FAST) /* table seeding, any mix of tables */
@@ -1482,6 +1701,15 @@ GS_DEF_SEARCH(k_search_count, true, false, false, GS_WAVES_EU_FAST) /* the same 
 #endif
 GS_DEF_SEARCH(k_search_fast_pd, false, false, true, GS_WAVES_EU_PD)
 GS_DEF_SEARCH(k_search_count_pd, true, false, true, GS_WAVES_EU_PD)
+/* HEAVY: the instantiations for a handle whose earlier batches showed items of thousands of records (a repeat-rich genome; m >= 5):
+ * heavy verification passes are handed to the waves that ran out of items (gs_search_args::shq) and the second level of the
+ * verification keeps GS_VU rows per lane in flight.  The same results; on a genome without such items the plain forms are faster
+ * (1 M guides at m <= 3: 21 ms against 28-32 - the second level is rare there and its unrolled form costs instructions and registers). */
+#ifndef GS_WAVES_EU_HEAVY
+#define GS_WAVES_EU_HEAVY 8
+#endif
+GS_DEF_SEARCH(k_search_heavy, false, false, false, GS_WAVES_EU_HEAVY, true)
+GS_DEF_SEARCH(k_search_heavy_pd, false, false, true, GS_WAVES_EU_HEAVY, true)
 
 /* ---- prepare: ASCII -> packed records (process.hpp:51-63) ------------------ */
 __device__ __forceinline__ int base_code(uint8_t c) {
@@ -2024,7 +2252,7 @@ __global__ __launch_bounds__(1024) void k_share_scan(gs_share_args a) {
 __global__ __launch_bounds__(256) void k_share_dir(gs_share_args a) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n_used = *a.arena_next < a.arena_chunks ? *a.arena_next : a.arena_chunks;
-  if (c >= n_used) return;
+  if (c >= n_used || a.chunk_seq[c] == 0xFFFFFFFFu) return; /* (reserved by a wave and never used) */
   const uint32_t slot = a.chunk_item[c];
   const uint2 nc = a.nchunk[slot];
   if (!(nc.y >> 31)) return;
@@ -3424,6 +3652,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   }
   uint32_t *d_arena_next = d_work + 4;
   uint64_t arena_fail = 0; /* items of the main pass the arena had no chunk left for */
+  uint64_t arena_raw = 0;  /* chunks its waves reserved (theirs, their helpers' partly filled ones, reserves not used up) */
   auto run_search = [&](const gs_guide_rec *guides, uint32_t ng, uint4 *slots, uint32_t *counts,
                         uint32_t cap_, unsigned long long h_stats[2],
                         const uint64_t *slot_off = nullptr, bool with_arena = false) -> gs_status {
@@ -3431,10 +3660,16 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     GS_HIP(hipMemsetAsync(d_stats + 6, 0, 8, st));   /* items the arena failed */
     GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
     GS_HIP(hipMemsetAsync(d_work + 5, 0, 4, st));
-    if (with_arena) GS_HIP(hipMemsetAsync(d_arena_next, 0, 4, st));
+    GS_HIP(hipMemsetAsync(d_work + 8, 0, 4, st));
+    if (with_arena) {
+      GS_HIP(hipMemsetAsync(d_arena_next, 0, 4, st));
+      /* every chunk empty until a wave says whose it is: waves reserve several per visit to the counter (k_search) */
+      GS_HIP(hipMemsetAsync((uint32_t *)ix->w_arena_meta.p + arena_chunks, 0xFF, 4 * (size_t)arena_chunks, st));
+      GS_HIP(hipMemsetAsync(ix->w_arena_meta.p, 0, 4 * (size_t)arena_chunks, st));
+    }
     gs_search_args sa;
     memset(&sa, 0, sizeof(sa));
-    ix->last_share[0] = ix->last_share[1] = ix->last_share[2] = ix->last_share[3] = 0;
+    if (with_arena) ix->last_share[0] = ix->last_share[1] = ix->last_share[2] = ix->last_share[3] = 0; /* (of the main pass: a redo shares nothing) */
     sa.sd[0] = ix->strand[0].d;
     sa.sd[1] = ix->strand[1].d;
     sa.slots = slots;
@@ -3468,6 +3703,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     sa.max_iter = gs_opt(ix, "GS_SEARCH_MAX_ITER") ? (uint32_t)atol(gs_opt(ix, "GS_SEARCH_MAX_ITER")) : (1u << 26);
     sa.err = d_work + 5;
+    sa.hpass = d_work + 8;
     sa.v_max = VERIFY_MAX_DEFAULT;
     if (const char *e = gs_opt(ix, "GS_VERIFY_MAX")) {
       const long v = atol(e);
@@ -3520,7 +3756,23 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     /* every item through PAM-pair + deep tables (no pattern ends in an N, each has its tables): the kernel
      * without the strand tables' side of the seeding */
     const bool spec = !walk && sa.bidir && sa.bdeep && n_pt != 0 && n_pt == n_codes && h_pairs[16] == 0 && !gs_opt(ix, "GS_NO_SPEC");
-    const uint32_t weu = walk ? GS_WAVES_EU : spec ? GS_WAVES_EU_PD : GS_WAVES_EU_FAST;
+    /* heavy items shared among waves (gs_search_args::shq): table-seeded kernels with the arena, one PAM pass */
+    uint32_t *d_shctl = nullptr;
+    uint32_t share_min = ix->opt_share_min, share_max = ix->opt_share_max;
+    if (const char *e = gs_opt(ix, "GS_SHARE_MIN")) share_min = (uint32_t)std::max(0l, atol(e));
+    if (const char *e = gs_opt(ix, "GS_SHARE_MAX")) share_max = (uint32_t)std::max(128l, atol(e));
+    sa.share_min = share_min ? share_min : 0xFFFFFFFFu; /* (every instantiation counts the passes that large: gs_search_args::hpass) */
+    /* the heavy instantiation: asked for (GS_HEAVY=1 / 0), or the last batch of this shape on this handle showed heavy
+     * verification passes - one per sixteen items, or any at all in a batch of at most 64 items per wave slot of the chip
+     * (beyond that the heavy items spread over the waves by themselves, and the plain instantiation is the faster one
+     * where such passes are rare: 1 M guides at m <= 3 on a genome without repeat families, 22 ms against 32 - the
+     * heavy form's second level spills registers; m <= 6, which has none: 61 against 73-80) */
+    bool heavy = with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0 && mismatches < 8 &&
+                 ix->seen_key[mismatches] == (((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START)) &&
+                 ix->seen_hpass[mismatches] != 0 &&
+                 (16.0 * (double)ix->seen_hpass[mismatches] >= (double)ix->seen_items[mismatches] || 2 * (uint64_t)ng <= 64ull * (uint64_t)cus * 32u);
+    if (const char *e = gs_opt(ix, "GS_HEAVY")) heavy = atol(e) != 0 && with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0;
+    const uint32_t weu = walk ? GS_WAVES_EU : heavy ? GS_WAVES_EU_HEAVY : spec ? GS_WAVES_EU_PD : GS_WAVES_EU_FAST;
     if (per_cu > weu) per_cu = weu; /* 4 SIMDs x weu waves = weu four-wave workgroups per CU */
     uint32_t grid = (uint32_t)cus * per_cu;
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
@@ -3531,12 +3783,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       fprintf(stderr, "[gs] k_search (%s): grid %u x %u threads, LDS %zu B per workgroup, %d workgroups per CU resident\n",
               walk ? "walk" : "table", grid, WAVE * SEARCH_WAVES, lds_wg, occ);
     }
-    /* heavy items shared among waves (gs_search_args::shq): table-seeded kernels with the arena, one PAM pass */
-    uint32_t *d_shctl = nullptr;
-    uint32_t share_min = ix->opt_share_min, share_max = ix->opt_share_max;
-    if (const char *e = gs_opt(ix, "GS_SHARE_MIN")) share_min = (uint32_t)std::max(0l, atol(e));
-    if (const char *e = gs_opt(ix, "GS_SHARE_MAX")) share_max = (uint32_t)std::max(128l, atol(e));
-    if (with_arena && !walk && n_chunks == 1 && share_min != 0) {
+    if (heavy) {
       uint64_t qcap = ix->shq_packages;
       if (const char *e = gs_opt(ix, "GS_SHARE_QUEUE")) qcap = (uint64_t)std::max(1ll, atoll(e));
       if (qcap > (1ull << 20)) qcap = 1ull << 20; /* 1.2 GB of packages */
@@ -3554,7 +3801,9 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         sa.share_min = share_min;
         sa.share_max = std::max(128u, share_max);
         sa.n_waves = grid * SEARCH_WAVES;
+        sa.sh_prof = gs_opt(ix, "GS_DEBUG") ? 1u : 0u;
         GS_HIP(hipMemsetAsync(d_shctl, 0, meta, st));
+        if (sa.sh_prof) GS_HIP(hipMemsetAsync(d_shctl + 104, 0xFF, 8, st)); /* the minimum's start value */
       } else {
         (void)hipGetLastError(); /* no room for the queue: every item stays with its wave */
       }
@@ -3568,6 +3817,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         hipLaunchKernelGGL(k_search_walk, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (spec && count_req)
         hipLaunchKernelGGL(k_search_count_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+      else if (spec && sa.shq != nullptr)
+        hipLaunchKernelGGL(k_search_heavy_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+      else if (sa.shq != nullptr)
+        hipLaunchKernelGGL(k_search_heavy, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (spec)
         hipLaunchKernelGGL(k_search_fast_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (count_req)
@@ -3576,12 +3829,20 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         hipLaunchKernelGGL(k_search_fast, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
     }
     GS_HIP(hipEventRecord(ix->ev[2], st));
-    unsigned long long h7[20] = {0}; /* the stats and, behind them, the work words */
+    unsigned long long h7[22] = {0}; /* the stats and, behind them, the work words */
     uint32_t h_ctl[128] = {0};
     GS_HIP(hipMemcpyAsync(h7, d_stats, sizeof(h7), hipMemcpyDeviceToHost, st));
     if (d_shctl) GS_HIP(hipMemcpyAsync(h_ctl, d_shctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
+    if (d_shctl && sa.sh_prof) {
+      const unsigned long long *pr = (const unsigned long long *)(h_ctl + 104);
+      const double us = 0.01, nw = (double)sa.n_waves;
+      fprintf(stderr, "[gs] heavy launch: %u waves; the last wave left its items after %.0f us, the last exit after %.0f us; per wave: items %.0f us, "
+              "helper episodes %.0f us (%.1f episodes), waiting for a package %.0f us; shared items %u, packages %u (queue %u)\n",
+              sa.n_waves, us * (double)(pr[1] - pr[0]), us * (double)(pr[2] - pr[0]), us * (double)pr[3] / nw, us * (double)pr[4] / nw,
+              (double)pr[6] / nw, us * (double)pr[5] / nw, h_ctl[96], h_ctl[0], sa.shq_cap);
+    }
     if (d_shctl) {
       ix->last_share[0] = std::min(h_ctl[96], sa.sh_max); /* shared items */
       ix->last_share[1] = h_ctl[0];                       /* packages reserved */
@@ -3623,6 +3884,11 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     h_stats[0] = h7[0];
     h_stats[1] = h7[1];
     if (with_arena) arena_fail = h7[6];
+    if (with_arena) arena_raw = ((const uint32_t *)(h7 + 16))[4];
+    if (with_arena && mismatches < 8) { /* the main pass: heavy verification passes per item, for the next batch's choice */
+      ix->seen_hpass[mismatches] = ((const uint32_t *)(h7 + 16))[8];
+      ix->seen_items[mismatches] = 2 * (uint64_t)ng;
+    }
     if (((const uint32_t *)(h7 + 16))[5] != 0u) {
       gs_set_error("internal: an item of the search passed its iteration bound (GS_SEARCH_MAX_ITER)");
       return GS_ERR_DEVICE;
@@ -4153,6 +4419,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
      * then these guides are searched once more with slots of the exact sizes, and the next batch gets
      * the arena this one would have needed */
     const bool arena_ok = arena_chunks != 0 && arena_fail == 0;
+    if (arena_raw > need_chunks) need_chunks = arena_raw; /* (what the waves reserved: a later batch should find as much) */
     if (arena_chunks != 0 && !gs_opt(ix, "GS_ARENA_CHUNKS") && need_chunks + need_chunks / 4 + 64 > ix->arena_chunks)
       ix->arena_chunks = need_chunks + need_chunks / 4 + 64;
     if (arena_ok) {

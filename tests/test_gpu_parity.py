@@ -577,13 +577,14 @@ ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                # and the two stable sorts it replaces
                ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1"),
                ("GS_NO_TILE_ORDER", "1", "GS_BIG2_TWO_SORTS", "1", "GS_BIG2_NO_COMPOSITE", "1"),
-               # heavy items shared among waves (k_search's package queue): never; every verification pass, in the smallest
+               # heavy items shared among waves (k_search's package queue; GS_HEAVY=1: the instantiation a handle otherwise
+               # picks after a batch that showed an item of 4,096 records): never; every verification pass, in the smallest
                # packages; the same with an arena that runs out under the helpers; with a queue of four packages
                ("GS_SHARE_MIN", "0"),
-               ("GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
-               ("GS_ARENA_CHUNKS", "5", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
-               ("GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_SHARE_QUEUE", "4"),
-               ("GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_NO_TILE_ORDER", "1")]
+               ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
+               ("GS_ARENA_CHUNKS", "2", "GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
+               ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_SHARE_QUEUE", "4"),
+               ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_NO_TILE_ORDER", "1")]
 ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "tiles-unpacked", "device-wide", "raw-key-order", "one-sort-and-runs", "composite-sort",
              "two-sorts", "never-shared", "every-pass-shared", "shared-arena-exhausted", "shared-queue-of-four", "shared-device-wide"]
 
@@ -739,7 +740,7 @@ def test_a_heavy_item_is_run_by_many_waves():
     strand, 10,000 on the - strand - next to five ordinary guides: k_search hands its verification passes to the waves
     that have run out of items (packages of at most 2,048 row groups in a queue in memory; gs_search.hip, `shq`), their
     records land in arena chunks of their own and k_share_fix closes the gaps.  The hit bytes equal those of the run
-    in which the item stays with its wave (GS_SHARE_MIN=0), and the oracle's lists (process.hpp:100-115 order)."""
+    in which the item stays with its wave (the plain instantiation), and the oracle's lists (process.hpp:100-115 order)."""
     rng = np.random.default_rng(23)
     acgt = np.frombuffer(b"ACGT", np.uint8)
     site = rng.choice(acgt, 20)
@@ -763,20 +764,24 @@ def test_a_heavy_item_is_run_by_many_waves():
         other, _, _, _ = synth.sample_guides(text[n_copies * unit:], 5, seed=9)
         seqs = np.concatenate([other[:2], np.array([list(site)], dtype=np.uint8), other[2:]])
         pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
-        gidx.set_option("GS_SHARE_MIN", "0")
+        # a handle's first batch of a shape runs the plain instantiation, which counts the verification passes of 512 row
+        # groups and more; the second batch finds them in the count and takes the heavy instantiation by itself
         off0, hits0, _ = gidx.enumerate(seqs, pams, mismatches=3)
         assert gidx.last_sharing()["shared_items"] == 0
-        gidx.set_option("GS_SHARE_MIN", None)
         off1, hits1, _ = gidx.enumerate(seqs, pams, mismatches=3)
         sh, ctr = gidx.last_sharing(), gidx.last_counters()
         assert sh["shared_items"] >= 1 and sh["packages"] >= 8 and sh["tickets"] >= sh["packages"], sh
         assert ctr["matches_max_per_item"] >= n_plus and ctr["ordered_in_tiles"] and not ctr["tile_ordering_gave_up"], ctr
         assert np.array_equal(off0, off1) and hits0.tobytes() == hits1.tobytes()
-        # smaller packages, more of them: the same bytes again
+        # smaller packages, more of them: the same bytes again; and with the plain instantiation asked for
         gidx.set_options(GS_SHARE_MIN="64", GS_SHARE_MAX="256")
         off2, hits2, _ = gidx.enumerate(seqs, pams, mismatches=3)
         assert gidx.last_sharing()["packages"] > sh["packages"]
         assert np.array_equal(off0, off2) and hits0.tobytes() == hits2.tobytes()
+        gidx.set_option("GS_HEAVY", "0")
+        off3, hits3, _ = gidx.enumerate(seqs, pams, mismatches=3)
+        assert gidx.last_sharing()["shared_items"] == 0
+        assert np.array_equal(off0, off3) and hits0.tobytes() == hits3.tobytes()
         opts = ol.make_opts(3)
         for i in range(seqs.shape[0]):
             g = seqs[i].tobytes().decode()
