@@ -191,6 +191,10 @@ struct gs_index {
   uint64_t last_unsupported = 0; /* guides of the last batch flagged GS_GUIDE_NEEDS_GENERAL (w_flags) */
   uint64_t seen_key[8] = {0};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_tile = nullptr;  /* gs_tileorder_run: behind the copy of the slow-tile counts */
+  uint32_t *h_pin = nullptr;     /* 256 bytes of page-locked host memory: small results of asynchronous copies that are read behind an event */
+  std::atomic<uint64_t> lock_owner{0}; /* gs_index_lock: the thread that holds the handle (0: none), and how many times */
+  uint32_t lock_depth = 0;
   uint32_t pt_k = 0; /* depth of the prefix interval tables (0: none) */
   unsigned long long last_counters[16] = {0}; /* k_search's stats array of the last gs_enumerate_device call */
   std::vector<gs_nrun> nruns_text; /* 'N' runs of the forward text */

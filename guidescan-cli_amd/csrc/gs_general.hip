@@ -481,12 +481,27 @@ static gs_status enumerate_general(gs_index *ix, const char *guides, uint64_t n,
    * room for all (the first version always searched twice: a counting pass, then a filling pass at exact offsets) */
   uint64_t T = 0, cap = std::max<uint64_t>((uint64_t)n * 256u, 1u << 16);
   if (const char *e = gs_opt(ix, "GS_GENERAL_POOL")) cap = (uint64_t)std::max(1ll, atoll(e));
+  {
+    /* the guess may take a quarter of what is free next to a resident index (12 KB per guide is 12 GB for 10^6 guides);
+     * a smaller pool only means that a batch with many hits is searched a second time with room for exactly its records */
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+      const uint64_t fit = (uint64_t)(free_b / 4) / sizeof(gs_grec);
+      if (cap > fit) cap = std::max<uint64_t>(fit, 1u << 12);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   for (int attempt = 0; attempt < 2; attempt++) {
     if (d_a.p) {
       hipFree(d_a.p);
       d_a.p = nullptr;
     }
-    GS_TRY(d_a.get(sizeof(gs_grec) * cap));
+    if (attempt == 0 && d_a.get(sizeof(gs_grec) * cap) != GS_OK) {
+      (void)hipGetLastError(); /* no room for the guess: count with a small pool, then allocate what the batch needs */
+      cap = 1u << 12;
+    }
+    if (!d_a.p) GS_TRY(d_a.get(sizeof(gs_grec) * cap));
     GS_HIP(hipMemset(d_misc.p, 0, 64));
     sa.recs = (gs_grec *)d_a.p;
     sa.slot_off = nullptr;

@@ -12,6 +12,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <functional>
 #include <system_error>
 #include <thread>
 #include <cstdlib>
@@ -966,19 +967,28 @@ extern "C" void gs_index_close(gs_index *ix) {
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)
     if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
+  if (ix->ev_tile) hipEventDestroy(ix->ev_tile);
+  if (ix->h_pin) hipHostFree(ix->h_pin);
   gs_pairtab_free(ix, 0);
   gs_pairtab_free(ix, 1);
   delete ix;
 }
 /* hold the handle across several device-pointer calls (enumerate, score, copies of the results they leave in HBM):
  * other threads' calls on the handle wait */
+static uint64_t this_thread_tag() { return (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1ull; }
 extern "C" gs_status gs_index_lock(gs_index *ix) {
   if (!ix) return GS_ERR_ARG;
   ix->mtx.lock();
+  ix->lock_owner.store(this_thread_tag());
+  ix->lock_depth++;
   return GS_OK;
 }
+/* (unlocking a std::recursive_mutex the thread does not own is undefined behaviour: a thread that does not hold the
+ * handle through gs_index_lock gets GS_ERR_ARG instead) */
 extern "C" gs_status gs_index_unlock(gs_index *ix) {
   if (!ix) return GS_ERR_ARG;
+  if (ix->lock_owner.load() != this_thread_tag() || ix->lock_depth == 0) return GS_ERR_ARG;
+  if (--ix->lock_depth == 0) ix->lock_owner.store(0);
   ix->mtx.unlock();
   return GS_OK;
 }

@@ -14,6 +14,8 @@
 #include "gs_common.h"
 #include "cfd_table.h"
 
+#include <algorithm>
+
 #define WAVE 64
 #define SCORE_WAVES 4
 
@@ -81,26 +83,62 @@ __device__ __forceinline__ bool sc_sentinel(const uint64_t *cum, uint32_t n_chr,
   return s < 0 || e > len; /* :46-48 */
 }
 
-/* Two kernels.  k_score_hits: one thread per hit - its CFD (printer.hpp:98-113) and the three facts the
- * aggregation needs (distance, dropped at a chromosome boundary, perfect xGG hit); every hit is
- * independent, so guides with 10^5 hits spread over the whole chip.  k_score_sum: one wavefront per guide
- * walks its hits in order - only the float additions are sequential (they are not associative and the
- * reference adds hit by hit) and --max-off-targets' per-distance counters. */
-__global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, uint64_t n_hits, float *cf, uint8_t *info) {
+/* Three steps.  k_score_hits: one thread per hit - its CFD (printer.hpp:98-113) and the three facts the aggregation
+ * needs (distance, dropped at a chromosome boundary, perfect xGG hit); every hit is independent, so guides with 10^5
+ * hits spread over the whole chip.  k_score_classes / k_score_place: the guides in order of falling hit count (by the
+ * count's binary logarithm).  k_score_sum: ONE LANE per guide walks its hits in order - the float additions are
+ * sequential (they are not associative and the reference adds hit by hit, printer.hpp:251-297 / :115-170), and so are
+ * --max-off-targets' per-distance counters; 64 guides of about the same length share a wave. */
+#define SC_CHUNK 4096u  /* hits a wave of k_score_hits takes at a time: one search for its first guide, then a walk */
+#define SC_MAXCHR 2048u /* chromosomes whose prefix sums the block keeps in LDS (more: read from memory) */
+#define SC_BINS 4096u
+struct gs_score_geo {
+  const uint16_t *bin_chr; /* [SC_BINS] chromosome that holds position bin << bin_shift | 0x8000 when the bin reaches into the next one */
+  uint32_t bin_shift;
+};
+/* src/genomics/structures.cxx:7-52 with the chromosome found through a table of 4,096 bins (one LDS read; a bin with a
+ * chromosome boundary inside walks on from there) instead of a binary search per hit */
+__device__ __forceinline__ bool sc_sentinel_lds(const uint64_t *s_cum, const uint16_t *s_bin, const uint32_t bin_shift, const uint32_t n_chr,
+                                                const long long pos, const uint32_t L, const uint32_t P) {
+  const bool minus = pos < 0;
+  const unsigned long long ab = (unsigned long long)(minus ? -pos : pos);
+  if (n_chr == 0u || ab >= s_cum[n_chr]) return true;
+  const uint32_t e = s_bin[ab >> bin_shift];
+  uint32_t c = e & 0x7FFFu;
+  if (e & 0x8000u)
+    while (s_cum[c + 1u] <= ab) c++;
+  const long long off = (long long)(ab - s_cum[c]);
+  const long long len = (long long)(s_cum[c + 1u] - s_cum[c]);
+  long long s1, e1;
+  if (!minus) {
+    e1 = off + 1;
+    s1 = e1 - (long long)L - (long long)P + 1;
+  } else {
+    s1 = off + 1;
+    e1 = s1 + (long long)L + (long long)P - 1;
+  }
+  return s1 < 0 || e1 > len; /* :46-48 */
+}
+__global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, gs_score_geo geo, uint64_t n_hits, float *cf, uint8_t *info) {
   __shared__ double s_tab[336];
+  __shared__ uint64_t s_cum[SC_MAXCHR + 1u];
+  __shared__ uint16_t s_bin[SC_BINS];
+  const bool geo_lds = a.n_chr <= SC_MAXCHR;
   for (uint32_t i = threadIdx.x; i < 336u; i += blockDim.x) s_tab[i] = a.tab[i];
+  if (geo_lds) {
+    for (uint32_t i = threadIdx.x; i <= a.n_chr; i += blockDim.x) s_cum[i] = a.chr_cum[i];
+    for (uint32_t i = threadIdx.x; i < SC_BINS; i += blockDim.x) s_bin[i] = geo.bin_chr[i];
+  }
   __syncthreads();
-  const uint32_t L = a.L, P = a.P, slen = L + P;
+  const uint32_t L = a.L, P = a.P, slen = L + P, lane = threadIdx.x & (WAVE - 1u);
   /* pam = match_sequence.substr(20, 3) when the sequence has at least 20 symbols */
   const uint32_t pam_len = slen < 20u ? 0u : (slen - 20u < 3u ? slen - 20u : 3u);
   const bool scored = L == 20u && pam_len == 3u; /* printer.hpp:99 */
-  for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < n_hits; h += (uint64_t)gridDim.x * blockDim.x) {
-    /* the guide of hit h: last g with offsets[g] <= h.  One binary search per wavefront (for its first hit,
-     * on scalar loads), then a short walk: 64 consecutive hits belong to one guide on a repeat-rich
-     * batch and to five on a batch with 13 hits per guide */
-    const uint64_t h_lane0 = h - (threadIdx.x & (WAVE - 1u));
-    const uint64_t h_first = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(h_lane0 >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)h_lane0); /* wave-uniform: scalar loads below */
+  const uint64_t n_chunks = (n_hits + SC_CHUNK - 1u) / SC_CHUNK;
+  const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) / WAVE, n_waves = (uint64_t)gridDim.x * blockDim.x / WAVE;
+  for (uint64_t ch = wave0; ch < n_chunks; ch += n_waves) {
+    /* the guide of the chunk's first hit: last g with offsets[g] <= h (wave-uniform: scalar loads), then the lanes walk */
+    const uint64_t h_first = ch * SC_CHUNK;
     uint32_t lo = 0, hi = a.n;
     while (hi - lo > 1u) {
       const uint32_t mid = (lo + hi) >> 1;
@@ -109,130 +147,146 @@ __global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, uint64_t n_
       else
         hi = mid;
     }
-    while (lo + 1u < a.n && a.offsets[lo + 1u] <= h) lo++;
-    const uint8_t *gd = a.guides + (size_t)lo * L;
-    const gs_hit hit = a.hits[h];
-    const uint64_t path = (hit.key >> 1) & ((1ull << 59) - 1ull); /* key bits 59:1: position 0 at the top */
-    const uint32_t d = (uint32_t)(hit.key >> 61);
-    float c = 1.0f;
-    uint32_t pgg = 0u;
-    bool lw;
-    if (scored) {
-      /* positions in order (each product is rounded to float before the next, printer.hpp:104-109).  A
-       * position enters when match_sequence[i] differs from the guide's symbol, case-sensitively: always
-       * where the hit has a substitution (lower case); elsewhere never when the guide was searched as
-       * given, while with --start the two strings are compared as the reference compares them */
-      uint64_t todo = a.start ? 0xFFFFFull : 0ull;
-      if (!a.start)
-        for (uint32_t i = 0; i < 20u; ++i) todo |= (uint64_t)(((path >> (57u - 2u * i)) & 3ull) != 0ull) << i;
-      while (todo) {
-        const uint32_t i = (uint32_t)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t su = sc_seq_at(gd, L, a.start, path, i, lw);
-        const uint32_t mu = sc_comp_upper(su); /* match_sequence[i] = complement(sequence[i]), case kept */
-        const uint32_t gc = gd[i];
-        if (lw || gc != mu) {
-          const int r = sc_bidx(gc);  /* 'T' is looked up as 'U': same slot */
-          const int dd = sc_bidx(su); /* toupper(complement(match_sequence[i])) == sequence[i] */
-          const double sc = (r >= 0 && dd >= 0) ? s_tab[(r * 4 + dd) * 20 + (int)i] : 0.0;
-          c = (float)((double)c * sc);
+    uint32_t g = lo;
+    const uint64_t h_end = h_first + SC_CHUNK < n_hits ? h_first + SC_CHUNK : n_hits;
+    for (uint64_t h = h_first + lane; h < h_end; h += WAVE) {
+      while (g + 1u < a.n && a.offsets[g + 1u] <= h) g++;
+      const uint8_t *gd = a.guides + (size_t)g * L;
+      const gs_hit hit = a.hits[h];
+      const uint64_t path = (hit.key >> 1) & ((1ull << 59) - 1ull); /* key bits 59:1: position 0 at the top */
+      const uint32_t d = (uint32_t)(hit.key >> 61);
+      float c = 1.0f;
+      uint32_t pgg = 0u;
+      bool lw;
+      if (scored) {
+        /* positions in order (each product is rounded to float before the next, printer.hpp:104-109).  A
+         * position enters when match_sequence[i] differs from the guide's symbol, case-sensitively: always
+         * where the hit has a substitution (lower case); elsewhere never when the guide was searched as
+         * given, while with --start the two strings are compared as the reference compares them */
+        uint64_t todo = a.start ? 0xFFFFFull : 0ull;
+        if (!a.start) {
+          /* bit i: the 2-bit field of position i (path bits 58 - 2 i : 57 - 2 i) is not zero */
+          const uint64_t f = path >> 19; /* position i at bits 39 - 2 i : 38 - 2 i */
+          const uint64_t nz = (f | (f >> 1)) & 0x5555555555ull;
+          for (uint32_t i = 0; i < 20u; ++i) todo |= ((nz >> (38u - 2u * i)) & 1ull) << i;
         }
+        while (todo) {
+          const uint32_t i = (uint32_t)__builtin_ctzll(todo);
+          todo &= todo - 1ull;
+          const uint32_t su = sc_seq_at(gd, L, a.start, path, i, lw);
+          const uint32_t mu = sc_comp_upper(su); /* match_sequence[i] = complement(sequence[i]), case kept */
+          const uint32_t gc = gd[i];
+          if (lw || gc != mu) {
+            const int r = sc_bidx(gc);  /* 'T' is looked up as 'U': same slot */
+            const int dd = sc_bidx(su); /* toupper(complement(match_sequence[i])) == sequence[i] */
+            const double sc = (r >= 0 && dd >= 0) ? s_tab[(r * 4 + dd) * 20 + (int)i] : 0.0;
+            c = (float)((double)c * sc);
+          }
+        }
+        const int b1 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, lw)));
+        const int b2 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, lw)));
+        const double ps = (b1 >= 0 && b2 >= 0) ? s_tab[320 + b1 * 4 + b2] : 0.0;
+        c = (float)((double)c * ps);
       }
-      const int b1 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, lw)));
-      const int b2 = sc_bidx(sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, lw)));
-      const double ps = (b1 >= 0 && b2 >= 0) ? s_tab[320 + b1 * 4 + b2] : 0.0;
-      c = (float)((double)c * ps);
+      if (d == 0u && pam_len == 3u) { /* perfect NGG-style hit, printer.hpp:145-146 / :262 */
+        bool l1, l2;
+        const uint32_t p1 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, l1));
+        const uint32_t p2 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, l2));
+        pgg = (!l1 && !l2 && p1 == 'G' && p2 == 'G') ? 1u : 0u;
+      }
+      const bool sent = geo_lds ? sc_sentinel_lds(s_cum, s_bin, geo.bin_shift, a.n_chr, (long long)hit.pos, L, P)
+                                : sc_sentinel(a.chr_cum, a.n_chr, (long long)hit.pos, L, P);
+      cf[h] = c;
+      info[h] = (uint8_t)(d | ((sent ? 1u : 0u) << 3) | (pgg << 4));
     }
-    if (d == 0u && pam_len == 3u) { /* perfect NGG-style hit, printer.hpp:145-146 / :262 */
-      bool l1, l2;
-      const uint32_t p1 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 21u, l1));
-      const uint32_t p2 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, l2));
-      pgg = (!l1 && !l2 && p1 == 'G' && p2 == 'G') ? 1u : 0u;
-    }
-    const uint32_t sent = sc_sentinel(a.chr_cum, a.n_chr, (long long)hit.pos, L, P) ? 1u : 0u;
-    cf[h] = c;
-    info[h] = (uint8_t)(d | (sent << 3) | (pgg << 4));
   }
 }
 
-__global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a, const float *cf, const uint8_t *info) {
-  const uint32_t lane = threadIdx.x & (WAVE - 1u);
-  const uint32_t wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
-  for (uint32_t g = blockIdx.x * nw + wave; g < a.n; g += gridDim.x * nw) {
-    const uint64_t hb = a.offsets[g], he = a.offsets[g + 1u];
-    float sum = 0.0f;
-    uint32_t perfect = 0u, cur_d = 0xFFFFFFFFu;
-    unsigned long long raw = 0, kept = 0; /* hits / hits that counted so far at distance cur_d */
-    const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
-    /* the next block's loads are in flight while this block's additions run (a guide with 4 x 10^5 hits is
-     * 6,900 blocks on one wavefront: their load latency, not the additions, set its time) */
-    float c_next = 0.0f;
-    uint32_t inf_next = 8u;
-    if (hb + lane < he) {
-      c_next = cf[hb + lane];
-      inf_next = info[hb + lane];
-    }
-    for (uint64_t h0 = hb; h0 < he; h0 += WAVE) {
-      const uint64_t h = h0 + lane;
-      const bool valid = h < he;
-      const float c = c_next;
-      const uint32_t inf = inf_next;
-      c_next = 0.0f;
-      inf_next = 8u;
-      if (h + WAVE < he) {
-        c_next = cf[h + WAVE];
-        inf_next = info[h + WAVE];
-      }
-      uint32_t d = 8u, sent = 0u, pgg = 0u;
-      if (valid) {
-        d = inf & 7u;
-        sent = (inf >> 3) & 1u;
-        pgg = (inf >> 4) & 1u;
-      }
-      /* --max-off-targets: a hit is passed over when `max_off` hits of its distance came before it - CSV:
-       * counted on the raw index (printer.hpp:259); SAM: on the hits that counted (:129), i.e. the ones not
-       * dropped at a chromosome boundary (while below the bound every such hit counts).  Hits are ordered by
-       * distance, so both counts are prefix counts inside the distance class: per lane from ballots, across
-       * the 64-hit blocks through (cur_d, raw, kept). */
-      bool skip = false;
-      if (a.max_off != -1) {
-        uint64_t same = 0, same_ok = 0;
-        for (uint32_t dv = 0; dv < 8u; ++dv) {
-          const uint64_t b1 = __ballot(valid && d == dv), b2 = __ballot(valid && d == dv && !sent);
-          if (d == dv) {
-            same = b1;
-            same_ok = b2;
-          }
-        }
-        const unsigned long long before = (a.sam ? (unsigned long long)__popcll(same_ok & below) : (unsigned long long)__popcll(same & below)) +
-                                          (d == cur_d ? (a.sam ? kept : raw) : 0ull);
-        skip = valid && before >= (unsigned long long)a.max_off;
-        /* carry: the class of the block's last hit */
-        const uint32_t nv = (uint32_t)__popcll(__ballot(valid));
-        const uint32_t d_last = (uint32_t)__shfl((int)d, (int)(nv - 1u));
-        const unsigned long long n_last = __popcll(__ballot(valid && d == d_last)),
-                                 ok_last = __popcll(__ballot(valid && d == d_last && !sent));
-        if (d_last == cur_d) {
-          raw += n_last;
-          kept += ok_last;
-        } else {
-          cur_d = d_last;
-          raw = n_last;
-          kept = ok_last;
-        }
-      }
-      if (__ballot(valid && !skip && pgg != 0u)) perfect = 1u;
-      /* the sum itself runs hit by hit (float addition is not associative and the reference adds in
-       * order): hits that do not count add +0, which leaves every partial sum as it is */
-      const uint32_t abits = __float_as_uint((valid && !skip && !sent) ? c : 0.0f);
-#pragma unroll
-      for (int i = 0; i < WAVE; ++i) sum += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)abits, i));
-    }
-    if (!perfect) sum += 1.0f;
-    float sp = 0.0f;
-    if (sum > 0.0f) sp = __fdiv_rn(1.0f, sum);
-    a.spec[g] = sp; /* all lanes, same address (no lane-conditional tail in the guide loop) */
+/* guides by the binary logarithm of their hit count: cls[c] = guides of class c (hits in [2^c, 2^(c+1)), class 0 also
+ * the guides without hits), then each guide's place in the order of falling classes */
+__global__ __launch_bounds__(256) void k_score_classes(const uint64_t *offsets, uint32_t n, uint32_t *cls) {
+  __shared__ uint32_t s_c[40];
+  if (threadIdx.x < 40u) s_c[threadIdx.x] = 0u;
+  __syncthreads();
+  for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+    const uint64_t c = offsets[g + 1u] - offsets[g];
+    atomicAdd(&s_c[63u - (uint32_t)__builtin_clzll(c | 1ull)], 1u);
   }
+  __syncthreads();
+  if (threadIdx.x < 40u && s_c[threadIdx.x]) atomicAdd(&cls[threadIdx.x], s_c[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void k_score_place(const uint64_t *offsets, uint32_t n, const uint32_t *cls, uint32_t *cursor, uint32_t *order) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const uint64_t c = offsets[g + 1u] - offsets[g];
+  const uint32_t k = 63u - (uint32_t)__builtin_clzll(c | 1ull);
+  uint32_t base = 0;
+  for (uint32_t j = 39u; j > k; --j) base += cls[j]; /* the classes of more hits go first */
+  order[base + atomicAdd(&cursor[k], 1u)] = g;
+}
+__global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a, const float *cf, const uint8_t *info, const uint32_t *order) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = t < a.n;
+  const uint32_t g = on ? order[t] : 0u;
+  const uint64_t hb = on ? a.offsets[g] : 0ull, he = on ? a.offsets[g + 1u] : 0ull;
+  float sum = 0.0f;
+  uint32_t perfect = 0u, cur_d = 0xFFFFFFFFu;
+  unsigned long long raw = 0, kept = 0; /* hits / hits that counted so far at distance cur_d */
+  const float *pc = cf + hb;
+  const uint8_t *pi = info + hb;
+  const uint64_t len = he - hb;
+  /* four hits per round, the next round's loads on their way while this round's four additions run: the additions of one
+   * guide wait for one another (4.4 x 10^5 of them for the heaviest guide of the repeat-rich batch: its lane alone is the
+   * kernel's length), the 63 other lanes of the wave run theirs beside it */
+  float c4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  uint32_t i4[4] = {8u, 8u, 8u, 8u};
+#pragma unroll
+  for (uint32_t u = 0; u < 4u; ++u)
+    if (u < len) {
+      c4[u] = pc[u];
+      i4[u] = pi[u];
+    }
+  for (uint64_t i = 0; __ballot(i < len) != 0ull; i += 4u) {
+    float cc[4];
+    uint32_t ii[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      cc[u] = c4[u];
+      ii[u] = i4[u];
+      c4[u] = 0.0f;
+      i4[u] = 8u;
+      if (i + 4u + u < len) {
+        c4[u] = pc[i + 4u + u];
+        i4[u] = pi[i + 4u + u];
+      }
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const bool valid = i + u < len;
+      const uint32_t d = ii[u] & 7u, sent = (ii[u] >> 3) & 1u, pgg = (ii[u] >> 4) & 1u;
+      /* --max-off-targets: a hit is passed over when `max_off` hits of its distance came before it - CSV: counted on
+       * the raw index (printer.hpp:259); SAM: on the hits that counted (:129), i.e. the ones not dropped at a
+       * chromosome boundary.  Hits are ordered by distance: both counts start again when the distance changes. */
+      bool skip = false;
+      if (a.max_off != -1 && valid) {
+        if (d != cur_d) {
+          cur_d = d;
+          raw = 0;
+          kept = 0;
+        }
+        skip = (a.sam ? kept : raw) >= (unsigned long long)a.max_off;
+        raw++;
+        if (!sent) kept++;
+      }
+      if (valid && !skip && pgg != 0u) perfect = 1u;
+      /* hit by hit, in order; a hit that does not count adds +0, which leaves the partial sum as it is */
+      sum += (valid && !skip && !sent) ? cc[u] : 0.0f;
+    }
+  }
+  if (!perfect) sum += 1.0f;
+  float sp = 0.0f;
+  if (sum > 0.0f) sp = __fdiv_rn(1.0f, sum);
+  if (on) a.spec[g] = sp;
 }
 
 extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L, uint32_t P,
@@ -252,8 +306,9 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   GS_HIP(hipSetDevice(ix->device));
   gs_status rc;
   const size_t cum_bytes = 8 * ((size_t)gs->n_chr + 1);
-  if ((rc = gs_reserve(ix->w_score, 336 * sizeof(double) + cum_bytes)) != GS_OK) return rc;
-  std::vector<uint64_t> host(336 + (size_t)gs->n_chr + 1);
+  const size_t bins_at = 336 * sizeof(double) + cum_bytes; /* behind the prefix sums: the bin table (uint16 x SC_BINS, as 1,024 uint64), 40 + 40 class words, the order */
+  if ((rc = gs_reserve(ix->w_score, bins_at + 2 * SC_BINS + 4 * 80 + 4 * ((size_t)n + 1))) != GS_OK) return rc;
+  std::vector<uint64_t> host(336 + (size_t)gs->n_chr + 1 + SC_BINS / 4);
   memcpy(host.data(), gs_cfd_mm, 320 * sizeof(double));
   memcpy(host.data() + 320, gs_cfd_pam, 16 * sizeof(double));
   uint64_t acc = 0;
@@ -261,6 +316,20 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   for (uint32_t i = 0; i < gs->n_chr; i++) {
     acc += gs->chr_lengths[i];
     host[337 + i] = acc;
+  }
+  /* the chromosome of every 4,096th-of-the-genome bin's first position; 0x8000: the bin reaches into the next chromosome */
+  uint32_t bin_shift = 0;
+  while ((acc >> bin_shift) >= SC_BINS) bin_shift++;
+  {
+    uint16_t *bins = (uint16_t *)(host.data() + 337 + gs->n_chr);
+    uint32_t c = 0;
+    for (uint32_t b = 0; b < SC_BINS; b++) {
+      const uint64_t lo = (uint64_t)b << bin_shift, hi = (((uint64_t)b + 1) << bin_shift) - 1;
+      while (c + 1 < gs->n_chr && host[337 + c] <= lo) c++;
+      uint16_t e = (uint16_t)(c < 0x7FFFu ? c : 0x7FFFu);
+      if (gs->n_chr && hi >= host[337 + c]) e |= 0x8000u;
+      bins[b] = e;
+    }
   }
   GS_HIP(hipMemcpyAsync(ix->w_score.p, host.data(), 8 * host.size(), hipMemcpyHostToDevice, st));
   GS_HIP(hipStreamSynchronize(st)); /* `host` is a local */
@@ -290,14 +359,23 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   if ((rc = gs_reserve(ix->w_score_tmp, (d_cfd ? 0 : 4 * n_hits) + n_hits + 64)) != GS_OK) return rc;
   float *cf = d_cfd ? (float *)d_cfd : (float *)ix->w_score_tmp.p;
   uint8_t *info = (uint8_t *)ix->w_score_tmp.p + (d_cfd ? 0 : 4 * n_hits);
+  gs_score_geo geo;
+  geo.bin_chr = (const uint16_t *)((const char *)ix->w_score.p + bins_at);
+  geo.bin_shift = bin_shift;
+  uint32_t *d_cls = (uint32_t *)((char *)ix->w_score.p + bins_at + 2 * SC_BINS), *d_cursor = d_cls + 40, *d_order = d_cls + 80;
+  GS_HIP(hipMemsetAsync(d_cls, 0, 4 * 80, st));
   if (n_hits) {
-    uint64_t gh = (n_hits + 255) / 256;
-    if (gh > (uint64_t)cus * 32u) gh = (uint64_t)cus * 32u;
-    hipLaunchKernelGGL(k_score_hits, dim3((uint32_t)gh), dim3(256), 0, st, a, n_hits, cf, info);
+    uint64_t gh = ((n_hits + SC_CHUNK - 1) / SC_CHUNK + 3) / 4; /* four waves per workgroup, a chunk per wave and visit */
+    if (gh > (uint64_t)cus * 8u) gh = (uint64_t)cus * 8u;
+    hipLaunchKernelGGL(k_score_hits, dim3((uint32_t)gh), dim3(256), 0, st, a, geo, n_hits, cf, info);
   }
-  uint32_t grid = (uint32_t)((n + SCORE_WAVES - 1) / SCORE_WAVES);
-  if (grid > (uint32_t)cus * 16u) grid = (uint32_t)cus * 16u;
-  hipLaunchKernelGGL(k_score_sum, dim3(grid), dim3(WAVE * SCORE_WAVES), 0, st, a, (const float *)cf, (const uint8_t *)info);
+  const uint32_t n32 = (uint32_t)n;
+  hipLaunchKernelGGL(k_score_classes, dim3(std::min<uint32_t>((n32 + 255) / 256, (uint32_t)cus * 4u)), dim3(256), 0, st,
+                     (const uint64_t *)d_offsets, n32, d_cls);
+  hipLaunchKernelGGL(k_score_place, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint64_t *)d_offsets, n32, (const uint32_t *)d_cls,
+                     d_cursor, d_order);
+  hipLaunchKernelGGL(k_score_sum, dim3((n32 + WAVE * SCORE_WAVES - 1) / (WAVE * SCORE_WAVES)), dim3(WAVE * SCORE_WAVES), 0, st, a,
+                     (const float *)cf, (const uint8_t *)info, (const uint32_t *)d_order);
   GS_HIP(hipStreamSynchronize(st));
   GS_HIP(hipGetLastError());
   return GS_OK;

@@ -2731,6 +2731,7 @@ __global__ __launch_bounds__(256) void k_big2_fixruns(uint4 *S2, uint4 *tmp, con
     atomicMax(&s_hi, hi);
     __syncthreads();
     const uint32_t hmin = s_lo, hmax = s_hi;
+    __syncthreads(); /* every thread has read them: thread 0 writes s_lo again as the loop's first statement */
     uint64_t base = 0;
     /* one pass per value the high part TAKES (the next one is found during the pass), not per integer between
      * the least and the greatest: with few row bits a run's rows can span thousands of multiples of 2^row_bits */

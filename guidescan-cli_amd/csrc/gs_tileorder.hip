@@ -1205,11 +1205,13 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   if (S.n_tiles) {
     /* the tiles one wave cannot take: how many is known once the buckets are counted - the host waits for that number
      * alone (an event behind its copy) while k_to_wsort runs */
-    uint32_t n_slow[3] = {0u, 0u, 0u};
-    hipEvent_t ev;
-    GS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    /* (the event and the page-locked words the copy lands in belong to the handle) */
+    if (!ix->ev_tile) GS_HIP(hipEventCreateWithFlags(&ix->ev_tile, hipEventDisableTiming));
+    if (!ix->h_pin) GS_HIP(hipHostMalloc((void **)&ix->h_pin, 256, hipHostMallocDefault));
+    uint32_t *n_slow = ix->h_pin;
+    n_slow[0] = n_slow[1] = n_slow[2] = 0u;
     GS_HIP(hipMemcpyAsync(n_slow, ra.slow_n, 12, hipMemcpyDeviceToHost, st));
-    GS_HIP(hipEventRecord(ev, st));
+    GS_HIP(hipEventRecord(ix->ev_tile, st));
     gs_to_tab tab;
     unsigned long long words = ~0ull;
     to_make_tab(in.L, in.P, in.m, tab, &words);
@@ -1217,9 +1219,7 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
       hipLaunchKernelGGL(k_to_wsort<true>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
     else
       hipLaunchKernelGGL(k_to_wsort<false>, dim3((S.n_tiles + TO_WNW - 1u) / TO_WNW), dim3(TO_WNW * WAVE), 0, st, ra, S.n_tiles);
-    const hipError_t ee = hipEventSynchronize(ev);
-    (void)hipEventDestroy(ev);
-    GS_HIP(ee);
+    GS_HIP(hipEventSynchronize(ix->ev_tile));
     if (gs_opt(ix, "GS_DEBUG"))
       fprintf(stderr, "[gs] tile ordering: tiles beyond one wave: %u of up to 1024 records, %u of up to 4096, %u beyond\n", n_slow[0], n_slow[1], n_slow[2]);
     if (n_slow[0]) hipLaunchKernelGGL(k_to_sort<128u>, dim3(n_slow[0]), dim3(128), to_sort_lds(128u), st, ra, (const uint32_t *)ra.slow[0]);

@@ -22,6 +22,7 @@
 #include <fstream>
 #include <iostream>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -746,12 +747,16 @@ int do_enumerate(int argc, char **argv) {
   std::cout << "Stages (overlapping): device " << job.s_device << " s, text formatting " << job.s_format
             << " s, file writes " << job.s_write << " s\n";
   for (gs_index *p : ix) gs_index_close(p);
+  /* only a regular file is ever removed: -o /dev/stdout, a FIFO or a device node stays (written through pwrite they
+   * fail with ESPIPE, and unlinking them would delete the node itself) */
+  struct stat fst;
+  const bool regular = fstat(fd, &fst) == 0 && S_ISREG(fst.st_mode);
   if (close(fd) != 0) write_ok = false;
   if (!write_ok) std::cerr << "error: short write to " << output << "\n";
   if (rcode || !write_ok) {
     /* a run that failed leaves no file that looks like a database (CSV/SAM rows up to the failed batch, a BAM
      * without its end-of-file block) */
-    if (unlink(output.c_str()) == 0) std::cerr << "error: " << output << " removed (incomplete)\n";
+    if (regular && unlink(output.c_str()) == 0) std::cerr << "error: " << output << " removed (incomplete)\n";
   }
   return (write_ok && !rcode) ? 0 : 1;
 }

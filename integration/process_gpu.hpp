@@ -25,6 +25,7 @@
 
 #include <ostream>
 #include <stdexcept>
+#include <memory>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -62,6 +63,7 @@ namespace genomics {
       gs_result_ex* res = nullptr;
       check(gs_enumerate_general_pams(gpu, seqs.data(), idx.size(), L, pams.data(), P, alts.data(), alt_lens.data(),
                                       alt_lens.size(), mismatches, rna, dna, flags, &res), "general path");
+      std::unique_ptr<gs_result_ex, void (*)(gs_result_ex*)> hold(res, gs_result_ex_free); /* (freed on a throw below, too) */
       uint64_t n = 0;
       const uint64_t* off = nullptr;
       const gs_hit_ex* hits = nullptr;
@@ -83,11 +85,12 @@ namespace genomics {
           }
         }
       }
-      gs_result_ex_free(res);
     }
 
-    /* the fast path for the whole batch; the guides it flags are listed in `flagged` and keep empty lists */
-    inline void enumerate_fast(gs_index* gpu, const std::vector<kmer>& kmers, uint32_t L, uint32_t P,
+    /* the fast path for the whole batch; the guides it flags are listed in `flagged` and keep empty lists.  false: the
+     * fast path does not take this batch shape (GS_ERR_UNSUPPORTED: e.g. a match sequence beyond 52 key bits on an index
+     * whose table is too shallow for it) - the general path does */
+    inline bool enumerate_fast(gs_index* gpu, const std::vector<kmer>& kmers, uint32_t L, uint32_t P,
                                const enumerate_cmd_options& opts, uint32_t mismatches, uint32_t flags,
                                std::vector<off_target_lists>* lists, std::vector<uint32_t>* raw,
                                std::vector<size_t>& flagged) {
@@ -96,8 +99,11 @@ namespace genomics {
       for (const auto& a : opts.alt_pams) alts += a;
       const uint32_t n_alt = P ? opts.alt_pams.size() : 0;   // process.hpp:51-56: no PAM, no alt PAMs
       gs_result* res = nullptr;
-      check(gs_enumerate(gpu, seqs.data(), kmers.size(), L, pams.data(), P, alts.data(), n_alt, mismatches,
-                         flags | (raw ? GS_FLAG_RAW_COUNTS : 0), &res), "fast path");
+      const gs_status rc = gs_enumerate(gpu, seqs.data(), kmers.size(), L, pams.data(), P, alts.data(), n_alt, mismatches,
+                                        flags | (raw ? GS_FLAG_RAW_COUNTS : 0), &res);
+      if (rc == GS_ERR_UNSUPPORTED) return false;
+      check(rc, "fast path");
+      std::unique_ptr<gs_result, void (*)(gs_result*)> hold(res, gs_result_free);
       gs_result_view v;
       gs_result_get(res, &v);
       std::vector<char> buf(L + P + 1);
@@ -117,22 +123,25 @@ namespace genomics {
           l[m.mismatches].push_back(std::make_tuple(hit.pos, m));
         }
       }
-      gs_result_free(res);
+      return true;
     }
 
     /* one search of the batch: fast path + the general path for what it flags, or the general path for all */
     inline void enumerate(gs_index* gpu, const std::vector<kmer>& kmers, uint32_t L, uint32_t P,
                           const enumerate_cmd_options& opts, uint32_t mismatches, uint32_t rna, uint32_t dna,
                           uint32_t flags, std::vector<off_target_lists>* lists, std::vector<uint32_t>* raw) {
-      bool general = rna != 0 || dna != 0 || 2 * L + 3 * P > 52; /* (beyond the fast path's 52 key bits) */
+      /* the fast path carries match sequences of up to 59 key bits (23-mers with a four-symbol PAM: 58); where a batch
+       * needs what only 52 bits allow (a shallow table, the device-wide ordering) it says GS_ERR_UNSUPPORTED and the
+       * general path - 100 x slower - takes the batch, as in host/guidescan_main.cpp */
+      bool general = rna != 0 || dna != 0 || 2 * L + 3 * P > 59;
       if (P)
         for (const auto& a : opts.alt_pams) general = general || a.size() != P;
+      std::vector<size_t> flagged;
+      if (!general && !enumerate_fast(gpu, kmers, L, P, opts, mismatches, flags, lists, raw, flagged)) general = true;
       if (general) {
         enumerate_general(gpu, kmers, {}, L, P, opts, mismatches, rna, dna, flags, lists, raw);
         return;
       }
-      std::vector<size_t> flagged;
-      enumerate_fast(gpu, kmers, L, P, opts, mismatches, flags, lists, raw, flagged);
       if (!flagged.empty()) enumerate_general(gpu, kmers, flagged, L, P, opts, mismatches, 0, 0, flags, lists, raw);
     }
   }
