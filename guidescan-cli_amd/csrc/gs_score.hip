@@ -86,9 +86,9 @@ __device__ __forceinline__ bool sc_sentinel(const uint64_t *cum, uint32_t n_chr,
 /* Three steps.  k_score_hits: one thread per hit - its CFD (printer.hpp:98-113) and the three facts the aggregation
  * needs (distance, dropped at a chromosome boundary, perfect xGG hit); every hit is independent, so guides with 10^5
  * hits spread over the whole chip.  k_score_classes / k_score_place: the guides in order of falling hit count (by the
- * count's binary logarithm).  k_score_sum: ONE LANE per guide walks its hits in order - the float additions are
- * sequential (they are not associative and the reference adds hit by hit, printer.hpp:251-297 / :115-170), and so are
- * --max-off-targets' per-distance counters; 64 guides of about the same length share a wave. */
+ * count's binary logarithm), so that the longest chains start first.  k_score_sum: one wavefront per guide adds its
+ * scores in order.  (One LANE per guide - 64 chains per wave, each lane streaming its own hits - was built and is
+ * 14 x slower: a lane's next loads wait a memory latency per four hits, 220 ms for the heaviest guide alone.) */
 #define SC_CHUNK 4096u  /* hits a wave of k_score_hits takes at a time: one search for its first guide, then a walk */
 #define SC_MAXCHR 2048u /* chromosomes whose prefix sums the block keeps in LDS (more: read from memory) */
 #define SC_BINS 4096u
@@ -119,7 +119,11 @@ __device__ __forceinline__ bool sc_sentinel_lds(const uint64_t *s_cum, const uin
   }
   return s1 < 0 || e1 > len; /* :46-48 */
 }
-__global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, gs_score_geo geo, uint64_t n_hits, float *cf, uint8_t *info) {
+/* cf: every hit's CFD (the caller's array; or nullptr); info: the fact bytes (--max-off-targets: k_score_sum_maxoff reads
+ * them) or nullptr; cfm: the score as it enters the guide's sum (+0 for a hit dropped at a chromosome boundary) and perfect[g]:
+ * the guide has a perfect xGG hit - what k_score_sum reads */
+__global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, gs_score_geo geo, uint64_t n_hits, float *cf, uint8_t *info, float *cfm,
+                                                    uint32_t *perfect) {
   __shared__ double s_tab[336];
   __shared__ uint64_t s_cum[SC_MAXCHR + 1u];
   __shared__ uint16_t s_bin[SC_BINS];
@@ -158,18 +162,35 @@ __global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, gs_score_ge
       float c = 1.0f;
       uint32_t pgg = 0u;
       bool lw;
-      if (scored) {
-        /* positions in order (each product is rounded to float before the next, printer.hpp:104-109).  A
-         * position enters when match_sequence[i] differs from the guide's symbol, case-sensitively: always
-         * where the hit has a substitution (lower case); elsewhere never when the guide was searched as
-         * given, while with --start the two strings are compared as the reference compares them */
-        uint64_t todo = a.start ? 0xFFFFFull : 0ull;
-        if (!a.start) {
-          /* bit i: the 2-bit field of position i (path bits 58 - 2 i : 57 - 2 i) is not zero */
-          const uint64_t f = path >> 19; /* position i at bits 39 - 2 i : 38 - 2 i */
-          const uint64_t nz = (f | (f >> 1)) & 0x5555555555ull;
-          for (uint32_t i = 0; i < 20u; ++i) todo |= ((nz >> (38u - 2u * i)) & 1ull) << i;
+      if (scored && !a.start) {
+        /* The guide searched as given: a position enters the product exactly where the hit has a substitution (its
+         * two-bit field of the path is not zero: lower case in match.sequence, index.hpp:243), in position order, each
+         * product rounded to float before the next (printer.hpp:104-109).  On base indices (A,C,G,T = 0..3) instead of
+         * characters: the guide's base r = sequence[i]; the text's base under it is the (code - 1)-th of the three others
+         * of its complement, and toupper(complement(match_sequence[i])) is that base itself: d. */
+        const uint64_t f = path >> 19; /* position i at bits 39 - 2 i : 38 - 2 i */
+        uint64_t nz = (f | (f >> 1)) & 0x5555555555ull;
+        while (nz) {
+          const uint32_t hb = 63u - (uint32_t)__builtin_clzll(nz);
+          nz &= ~(1ull << hb);
+          const uint32_t i = (38u - hb) >> 1;
+          const int r = sc_bidx(gd[i]);
+          const int q = 3 - r; /* the query base: the guide's complement (process.hpp:63) */
+          int dd = (int)((f >> hb) & 3ull) - 1;
+          if (dd >= q) dd++;
+          const double sc = r >= 0 ? s_tab[(r * 4 + dd) * 20 + (int)i] : 0.0;
+          c = (float)((double)c * sc);
         }
+        /* PAM symbols 1 and 2 of match.sequence (codes A,C,G,N,T = 0..4), complemented: the score's d-side bases */
+        const uint32_t c1 = (uint32_t)(path >> (56u - 2u * L - 3u)) & 7u, c2 = (uint32_t)(path >> (56u - 2u * L - 6u)) & 7u;
+        const int b1 = c1 == 3u ? -1 : c1 >= 4u ? 0 : 3 - (int)c1, b2 = c2 == 3u ? -1 : c2 >= 4u ? 0 : 3 - (int)c2;
+        const double ps = (b1 >= 0 && b2 >= 0) ? s_tab[320 + b1 * 4 + b2] : 0.0;
+        c = (float)((double)c * ps);
+        pgg = (d == 0u && c1 == 1u && c2 == 1u) ? 1u : 0u; /* perfect xGG hit (printer.hpp:145-146 / :262): match_sequence ends in GG */
+      } else {
+      if (scored) {
+        /* --start: the two strings are compared position by position as the reference compares them, case-sensitively */
+        uint64_t todo = 0xFFFFFull;
         while (todo) {
           const uint32_t i = (uint32_t)__builtin_ctzll(todo);
           todo &= todo - 1ull;
@@ -194,10 +215,15 @@ __global__ __launch_bounds__(256) void k_score_hits(gs_score_args a, gs_score_ge
         const uint32_t p2 = sc_comp_upper(sc_seq_at(gd, L, a.start, path, 22u, l2));
         pgg = (!l1 && !l2 && p1 == 'G' && p2 == 'G') ? 1u : 0u;
       }
+      }
       const bool sent = geo_lds ? sc_sentinel_lds(s_cum, s_bin, geo.bin_shift, a.n_chr, (long long)hit.pos, L, P)
                                 : sc_sentinel(a.chr_cum, a.n_chr, (long long)hit.pos, L, P);
-      cf[h] = c;
-      info[h] = (uint8_t)(d | ((sent ? 1u : 0u) << 3) | (pgg << 4));
+      if (cf != nullptr) cf[h] = c;
+      if (info != nullptr) info[h] = (uint8_t)(d | ((sent ? 1u : 0u) << 3) | (pgg << 4));
+      if (cfm != nullptr) {
+        cfm[h] = sent ? 0.0f : c;
+        if (pgg) perfect[g] = 1u; /* (every writer stores the same word: a repeat family's guide has thousands of perfect hits - an atomic per hit made this kernel 12 ms instead of 5) */
+      }
     }
   }
 }
@@ -224,69 +250,174 @@ __global__ __launch_bounds__(256) void k_score_place(const uint64_t *offsets, ui
   for (uint32_t j = 39u; j > k; --j) base += cls[j]; /* the classes of more hits go first */
   order[base + atomicAdd(&cursor[k], 1u)] = g;
 }
-__global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a, const float *cf, const uint8_t *info, const uint32_t *order) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool on = t < a.n;
-  const uint32_t g = on ? order[t] : 0u;
-  const uint64_t hb = on ? a.offsets[g] : 0ull, he = on ? a.offsets[g + 1u] : 0ull;
-  float sum = 0.0f;
-  uint32_t perfect = 0u, cur_d = 0xFFFFFFFFu;
-  unsigned long long raw = 0, kept = 0; /* hits / hits that counted so far at distance cur_d */
-  const float *pc = cf + hb;
-  const uint8_t *pi = info + hb;
-  const uint64_t len = he - hb;
-  /* four hits per round, the next round's loads on their way while this round's four additions run: the additions of one
-   * guide wait for one another (4.4 x 10^5 of them for the heaviest guide of the repeat-rich batch: its lane alone is the
-   * kernel's length), the 63 other lanes of the wave run theirs beside it */
-  float c4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  uint32_t i4[4] = {8u, 8u, 8u, 8u};
-#pragma unroll
-  for (uint32_t u = 0; u < 4u; ++u)
-    if (u < len) {
-      c4[u] = pc[u];
-      i4[u] = pi[u];
+/* --max-off-targets given: one wavefront per guide, 64 hits per round, the per-distance counters from ballots and the
+ * additions as a chain of v_readlane / v_add pairs (the form every batch took until round 5) */
+__global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum_maxoff(gs_score_args a, const float *cf, const uint8_t *info) {
+  const uint32_t lane = threadIdx.x & (WAVE - 1u);
+  const uint32_t wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
+  for (uint32_t g = blockIdx.x * nw + wave; g < a.n; g += gridDim.x * nw) {
+    const uint64_t hb = a.offsets[g], he = a.offsets[g + 1u];
+    float sum = 0.0f;
+    uint32_t perfect = 0u, cur_d = 0xFFFFFFFFu;
+    unsigned long long raw = 0, kept = 0; /* hits / hits that counted so far at distance cur_d */
+    const uint64_t below = lane ? (~0ull >> (64u - lane)) : 0ull;
+    /* the next block's loads are in flight while this block's additions run (a guide with 4 x 10^5 hits is
+     * 6,900 blocks on one wavefront: their load latency, not the additions, set its time) */
+    float c_next = 0.0f;
+    uint32_t inf_next = 8u;
+    if (hb + lane < he) {
+      c_next = cf[hb + lane];
+      inf_next = info[hb + lane];
     }
-  for (uint64_t i = 0; __ballot(i < len) != 0ull; i += 4u) {
-    float cc[4];
-    uint32_t ii[4];
-#pragma unroll
-    for (uint32_t u = 0; u < 4u; ++u) {
-      cc[u] = c4[u];
-      ii[u] = i4[u];
-      c4[u] = 0.0f;
-      i4[u] = 8u;
-      if (i + 4u + u < len) {
-        c4[u] = pc[i + 4u + u];
-        i4[u] = pi[i + 4u + u];
+    for (uint64_t h0 = hb; h0 < he; h0 += WAVE) {
+      const uint64_t h = h0 + lane;
+      const bool valid = h < he;
+      const float c = c_next;
+      const uint32_t inf = inf_next;
+      c_next = 0.0f;
+      inf_next = 8u;
+      if (h + WAVE < he) {
+        c_next = cf[h + WAVE];
+        inf_next = info[h + WAVE];
       }
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < 4u; ++u) {
-      const bool valid = i + u < len;
-      const uint32_t d = ii[u] & 7u, sent = (ii[u] >> 3) & 1u, pgg = (ii[u] >> 4) & 1u;
-      /* --max-off-targets: a hit is passed over when `max_off` hits of its distance came before it - CSV: counted on
-       * the raw index (printer.hpp:259); SAM: on the hits that counted (:129), i.e. the ones not dropped at a
-       * chromosome boundary.  Hits are ordered by distance: both counts start again when the distance changes. */
+      uint32_t d = 8u, sent = 0u, pgg = 0u;
+      if (valid) {
+        d = inf & 7u;
+        sent = (inf >> 3) & 1u;
+        pgg = (inf >> 4) & 1u;
+      }
+      /* --max-off-targets: a hit is passed over when `max_off` hits of its distance came before it - CSV:
+       * counted on the raw index (printer.hpp:259); SAM: on the hits that counted (:129), i.e. the ones not
+       * dropped at a chromosome boundary (while below the bound every such hit counts).  Hits are ordered by
+       * distance, so both counts are prefix counts inside the distance class: per lane from ballots, across
+       * the 64-hit blocks through (cur_d, raw, kept). */
       bool skip = false;
-      if (a.max_off != -1 && valid) {
-        if (d != cur_d) {
-          cur_d = d;
-          raw = 0;
-          kept = 0;
+      if (a.max_off != -1) {
+        uint64_t same = 0, same_ok = 0;
+        for (uint32_t dv = 0; dv < 8u; ++dv) {
+          const uint64_t b1 = __ballot(valid && d == dv), b2 = __ballot(valid && d == dv && !sent);
+          if (d == dv) {
+            same = b1;
+            same_ok = b2;
+          }
         }
-        skip = (a.sam ? kept : raw) >= (unsigned long long)a.max_off;
-        raw++;
-        if (!sent) kept++;
+        const unsigned long long before = (a.sam ? (unsigned long long)__popcll(same_ok & below) : (unsigned long long)__popcll(same & below)) +
+                                          (d == cur_d ? (a.sam ? kept : raw) : 0ull);
+        skip = valid && before >= (unsigned long long)a.max_off;
+        /* carry: the class of the block's last hit */
+        const uint32_t nv = (uint32_t)__popcll(__ballot(valid));
+        const uint32_t d_last = (uint32_t)__shfl((int)d, (int)(nv - 1u));
+        const unsigned long long n_last = __popcll(__ballot(valid && d == d_last)),
+                                 ok_last = __popcll(__ballot(valid && d == d_last && !sent));
+        if (d_last == cur_d) {
+          raw += n_last;
+          kept += ok_last;
+        } else {
+          cur_d = d_last;
+          raw = n_last;
+          kept = ok_last;
+        }
       }
-      if (valid && !skip && pgg != 0u) perfect = 1u;
-      /* hit by hit, in order; a hit that does not count adds +0, which leaves the partial sum as it is */
-      sum += (valid && !skip && !sent) ? cc[u] : 0.0f;
+      if (__ballot(valid && !skip && pgg != 0u)) perfect = 1u;
+      /* the sum itself runs hit by hit (float addition is not associative and the reference adds in
+       * order): hits that do not count add +0, which leaves every partial sum as it is */
+      const uint32_t abits = __float_as_uint((valid && !skip && !sent) ? c : 0.0f);
+#pragma unroll
+      for (int i = 0; i < WAVE; ++i) sum += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)abits, i));
     }
+    if (!perfect) sum += 1.0f;
+    float sp = 0.0f;
+    if (sum > 0.0f) sp = __fdiv_rn(1.0f, sum);
+    a.spec[g] = sp; /* all lanes, same address (no lane-conditional tail in the guide loop) */
   }
-  if (!perfect) sum += 1.0f;
-  float sp = 0.0f;
-  if (sum > 0.0f) sp = __fdiv_rn(1.0f, sum);
-  if (on) a.spec[g] = sp;
+}
+
+/* The sum of a guide's CFDs, hit by hit in order (float addition is not associative and the reference adds sequentially:
+ * printer.hpp:251-297 / :115-170).  One wavefront per guide at a time, guides in order of falling hit count from a
+ * counter.  The scores arrive as they enter the sum (k_score_hits wrote +0 for what does not count: it leaves every
+ * partial sum as it is): 512 per round, eight neighbouring ones per lane, written to LDS; then the chain runs from LDS,
+ * four scores per broadcast read, on the first 16 lanes only (a broadcast to all 64 moves 256 bytes of LDS traffic per
+ * hit): 5 instructions per four hits where the v_readlane / v_add pairs of the first form took 8, and the loads of the next
+ * TWO rounds are in flight meanwhile.  What bounds the kernel is the heaviest guide's own chain (4.4 x 10^5 dependent
+ * additions on the repeat-rich batch).  Tried and dropped: one LANE per guide, each lane streaming its own hits (a lane's
+ * next loads wait a memory latency per four hits: 220 ms for the heaviest guide alone); the scores through the scalar
+ * cache, eight per s_load_dwordx8, one v_add_f32 with a scalar operand per hit (a wave keeps 256 bytes in flight where a
+ * memory latency needs 4 KB: 6.6 ms against 3.9). */
+#define SC_ROUND 512u
+#define SC_PER 8u /* hits per lane and round */
+typedef float sc_f4u __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a, const float *cfm, const uint32_t *perfect, const uint32_t *order,
+                                                                 uint32_t *next) {
+  __shared__ float s_buf[SCORE_WAVES][SC_ROUND];
+  const uint32_t lane = threadIdx.x & (WAVE - 1u);
+  float *buf = s_buf[threadIdx.x / WAVE];
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(next, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= a.n) break;
+    const uint32_t g = order[t];
+    const uint64_t hb = a.offsets[g], len = a.offsets[g + 1u] - hb;
+    const float *pc = cfm + hb + SC_PER * lane;
+    float sum = 0.0f;
+    /* (no load is guarded - a test per load made the compiler wait for each before the next, eight memory latencies per
+     * round: what lies beyond the guide's last hit, the next guide's scores or the 8 KB behind the array, is replaced by
+     * +0 when the round is written to LDS) */
+    sc_f4u cA0 = *(const sc_f4u *)pc, cA1 = *(const sc_f4u *)(pc + 4), cB0 = *(const sc_f4u *)(pc + SC_ROUND), cB1 = *(const sc_f4u *)(pc + SC_ROUND + 4);
+    for (uint64_t base = 0; base < len; base += SC_ROUND) {
+      float c[SC_PER];
+      const sc_f4u n0 = *(const sc_f4u *)(pc + base + 2u * SC_ROUND), n1 = *(const sc_f4u *)(pc + base + 2u * SC_ROUND + 4);
+      const uint64_t q0 = base + SC_PER * lane;
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        c[u] = q0 + u < len ? cA0[u] : 0.0f;
+        c[4u + u] = q0 + 4u + u < len ? cA1[u] : 0.0f;
+      }
+      cA0 = cB0;
+      cA1 = cB1;
+      cB0 = n0;
+      cB1 = n1;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* (the chain of the round before has read the buffer) */
+      *(float4 *)(buf + SC_PER * lane) = make_float4(c[0], c[1], c[2], c[3]);
+      *(float4 *)(buf + SC_PER * lane + 4u) = make_float4(c[4], c[5], c[6], c[7]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      /* the chain: eight broadcast reads (32 scores) are on their way while the 32 before them are added - a read that
+       * waited for the additions before it cost 35 cycles per hit.  Places beyond the guide's last hit hold +0 (every
+       * lane wrote its eight): rounds of 32 need no test. */
+      const uint32_t left = len - base < SC_ROUND ? (uint32_t)(len - base) : SC_ROUND;
+      if (lane < 16u) {
+        float4 va[8], vb[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8u; ++q) va[q] = *(const float4 *)(buf + 4u * q);
+        for (uint32_t j = 0; j < left; j += 64u) {
+#pragma unroll
+          for (uint32_t q = 0; q < 8u; ++q) vb[q] = *(const float4 *)(buf + ((j + 32u + 4u * q) & (SC_ROUND - 1u)));
+#pragma unroll
+          for (uint32_t q = 0; q < 8u; ++q) {
+            sum += va[q].x;
+            sum += va[q].y;
+            sum += va[q].z;
+            sum += va[q].w;
+          }
+          if (j + 32u >= left) break;
+#pragma unroll
+          for (uint32_t q = 0; q < 8u; ++q) va[q] = *(const float4 *)(buf + ((j + 64u + 4u * q) & (SC_ROUND - 1u)));
+#pragma unroll
+          for (uint32_t q = 0; q < 8u; ++q) {
+            sum += vb[q].x;
+            sum += vb[q].y;
+            sum += vb[q].z;
+            sum += vb[q].w;
+          }
+        }
+      }
+    }
+    sum = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum)));
+    if (!perfect[g]) sum += 1.0f;
+    float sp = 0.0f;
+    if (sum > 0.0f) sp = __fdiv_rn(1.0f, sum);
+    a.spec[g] = sp; /* all lanes, same address */
+  }
 }
 
 extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L, uint32_t P,
@@ -306,8 +437,8 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   GS_HIP(hipSetDevice(ix->device));
   gs_status rc;
   const size_t cum_bytes = 8 * ((size_t)gs->n_chr + 1);
-  const size_t bins_at = 336 * sizeof(double) + cum_bytes; /* behind the prefix sums: the bin table (uint16 x SC_BINS, as 1,024 uint64), 40 + 40 class words, the order */
-  if ((rc = gs_reserve(ix->w_score, bins_at + 2 * SC_BINS + 4 * 80 + 4 * ((size_t)n + 1))) != GS_OK) return rc;
+  const size_t bins_at = 336 * sizeof(double) + cum_bytes; /* behind the prefix sums: the bin table (uint16 x SC_BINS, as 1,024 uint64), 40 + 40 class words, the guide counter, the order */
+  if ((rc = gs_reserve(ix->w_score, bins_at + 2 * SC_BINS + 4 * 96 + 4 * ((size_t)n + 1))) != GS_OK) return rc;
   std::vector<uint64_t> host(336 + (size_t)gs->n_chr + 1 + SC_BINS / 4);
   memcpy(host.data(), gs_cfd_mm, 320 * sizeof(double));
   memcpy(host.data() + 320, gs_cfd_pam, 16 * sizeof(double));
@@ -356,26 +487,40 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   uint64_t n_hits = 0;
   GS_HIP(hipMemcpyAsync(&n_hits, (const uint64_t *)d_offsets + n, 8, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
-  if ((rc = gs_reserve(ix->w_score_tmp, (d_cfd ? 0 : 4 * n_hits) + n_hits + 64)) != GS_OK) return rc;
-  float *cf = d_cfd ? (float *)d_cfd : (float *)ix->w_score_tmp.p;
-  uint8_t *info = (uint8_t *)ix->w_score_tmp.p + (d_cfd ? 0 : 4 * n_hits);
+  /* --max-off-targets: every CFD (the caller's array or one of the handle's) and the fact bytes; else the scores as they
+   * enter the sums (+ 8 KB: the last guide's unguarded loads reach up to three rounds beyond them) and a word per guide */
+  const bool with_max = max_off_targets != -1;
+  if ((rc = gs_reserve(ix->w_score_tmp, with_max ? (d_cfd ? 0 : 4 * n_hits) + n_hits + 64 : 4 * n_hits + 8192 + 128 + 4 * (n + 1))) != GS_OK) return rc;
+  float *cf = d_cfd ? (float *)d_cfd : with_max ? (float *)ix->w_score_tmp.p : nullptr;
+  uint8_t *info = with_max ? (uint8_t *)ix->w_score_tmp.p + (d_cfd ? 0 : 4 * n_hits) : nullptr;
+  float *cfm = with_max ? nullptr : (float *)ix->w_score_tmp.p;
+  uint32_t *d_perfect = with_max ? nullptr : (uint32_t *)((char *)ix->w_score_tmp.p + ((4 * n_hits + 8192 + 63) & ~(size_t)63));
+  if (!with_max) GS_HIP(hipMemsetAsync(d_perfect, 0, 4 * n, st));
   gs_score_geo geo;
   geo.bin_chr = (const uint16_t *)((const char *)ix->w_score.p + bins_at);
   geo.bin_shift = bin_shift;
-  uint32_t *d_cls = (uint32_t *)((char *)ix->w_score.p + bins_at + 2 * SC_BINS), *d_cursor = d_cls + 40, *d_order = d_cls + 80;
-  GS_HIP(hipMemsetAsync(d_cls, 0, 4 * 80, st));
+  uint32_t *d_cls = (uint32_t *)((char *)ix->w_score.p + bins_at + 2 * SC_BINS), *d_cursor = d_cls + 40, *d_next = d_cls + 80, *d_order = d_cls + 96;
+  GS_HIP(hipMemsetAsync(d_cls, 0, 4 * 96, st));
   if (n_hits) {
     uint64_t gh = ((n_hits + SC_CHUNK - 1) / SC_CHUNK + 3) / 4; /* four waves per workgroup, a chunk per wave and visit */
     if (gh > (uint64_t)cus * 8u) gh = (uint64_t)cus * 8u;
-    hipLaunchKernelGGL(k_score_hits, dim3((uint32_t)gh), dim3(256), 0, st, a, geo, n_hits, cf, info);
+    hipLaunchKernelGGL(k_score_hits, dim3((uint32_t)gh), dim3(256), 0, st, a, geo, n_hits, cf, info, cfm, d_perfect);
   }
   const uint32_t n32 = (uint32_t)n;
   hipLaunchKernelGGL(k_score_classes, dim3(std::min<uint32_t>((n32 + 255) / 256, (uint32_t)cus * 4u)), dim3(256), 0, st,
                      (const uint64_t *)d_offsets, n32, d_cls);
   hipLaunchKernelGGL(k_score_place, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint64_t *)d_offsets, n32, (const uint32_t *)d_cls,
                      d_cursor, d_order);
-  hipLaunchKernelGGL(k_score_sum, dim3((n32 + WAVE * SCORE_WAVES - 1) / (WAVE * SCORE_WAVES)), dim3(WAVE * SCORE_WAVES), 0, st, a,
-                     (const float *)cf, (const uint8_t *)info, (const uint32_t *)d_order);
+  if (a.max_off != -1) {
+    uint32_t grid = (uint32_t)((n + SCORE_WAVES - 1) / SCORE_WAVES);
+    if (grid > (uint32_t)cus * 16u) grid = (uint32_t)cus * 16u;
+    hipLaunchKernelGGL(k_score_sum_maxoff, dim3(grid), dim3(WAVE * SCORE_WAVES), 0, st, a, (const float *)cf, (const uint8_t *)info);
+  } else {
+    uint32_t grid = (uint32_t)((n + SCORE_WAVES - 1) / SCORE_WAVES);
+    if (grid > (uint32_t)cus * 8u) grid = (uint32_t)cus * 8u;
+    hipLaunchKernelGGL(k_score_sum, dim3(grid), dim3(WAVE * SCORE_WAVES), 0, st, a, (const float *)cfm, (const uint32_t *)d_perfect,
+                       (const uint32_t *)d_order, d_next);
+  }
   GS_HIP(hipStreamSynchronize(st));
   GS_HIP(hipGetLastError());
   return GS_OK;

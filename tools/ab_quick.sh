@@ -1,5 +1,10 @@
-# quick check on one GPU box: the sharing / ordering parity tests, then the repeat-rich batch under the plain and the heavy
-# instantiation (GS_LIB_PATH may name a variant build; with a -DGS_SH_PROFILE build GS_DEBUG=1 prints the heavy launch's phases)
+# quick check on one GPU box: scoring tests, then the scoring kernels timed (rocprofv3 kernel stats) on the repeat-rich batch and the m <= 6 batch
 cd /root/repo
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "repeat_guide or heavy_item or tile_sizes or gives_up" 2>&1 | tail -3
-timeout -k 10 400 python tools/rep_share_sweep.py hg38rep 20000 3 3 0:2048 512:2048 256:1024 2>&1 | grep -h "^{\|heavy launch" | tail -8
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests/test_gpu_score_kmers.py -x -q -m gpu 2>&1 | tail -3
+for w in "hg38rep 20000 3" "hg38 20000 6"; do
+  rm -rf /tmp/sc_prof
+  rocprofv3 --kernel-trace --stats -f csv -d /tmp/sc_prof -- python3 tools/score_bench.py $w 4 2>/dev/null | grep -h "^{"
+  f=$(find /tmp/sc_prof -name '*kernel_stats.csv' | head -1)
+  grep -h "k_score" $f | cut -c1-160
+done
