@@ -41,10 +41,15 @@ WORKLOADS = {
     # lie inside repeats and have 10^3..10^5 hits: small batches
     "chr1rep": ("CHR1", 20_000, (0.29, 0.21, 0.21, 0.29)),
     "hg38rep": ("GRCH38_LENGTHS", 20_000, (0.29, 0.21, 0.21, 0.29)),
+    # ... with an Alu-like SINE family: 1.2e6 copies at 2-15 % from the unit (the young ones nearly identical): a guide
+    # drawn from it has several 10^5 sites within three mismatches
+    "hg38alu": ("GRCH38_LENGTHS", 20_000, (0.29, 0.21, 0.21, 0.29)),
 }
 
 
 def make_workload_genome(synth, workload, lengths, probs, out=None):
+    if workload.endswith("alu"):
+        return synth.make_repeat_genome(lengths, seed=1, probs=probs, out=out, sine_div=(0.02, 0.15), sine_copies=1_200_000)
     if workload.endswith("rep"):
         return synth.make_repeat_genome(lengths, seed=1, probs=probs, out=out)
     return synth.make_genome(lengths, seed=1, probs=probs, out=out)

@@ -604,9 +604,10 @@ class GenomeIndex:
 
     def last_sharing(self):
         """heavy items shared among waves in the last search launch (gs_index_last_sharing)"""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         _check(lib().gs_index_last_sharing(self._h, out))
-        return dict(shared_items=int(out[0]), packages=int(out[1]), queue_packages=int(out[2]), tickets=int(out[3]))
+        return dict(shared_items=int(out[0]), packages=int(out[1]), queue_packages=int(out[2]), tickets=int(out[3]),
+                    guides_ordered_device_wide_alone=int(out[4]))
 
     def last_counters(self):
         """k_search's counters of the last enumerate_device call (see gs_index_last_counters)"""

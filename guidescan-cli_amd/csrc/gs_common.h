@@ -178,9 +178,9 @@ struct gs_index {
       w_shq, w_sh_meta,
       /* per-guide ordering in LDS tiles (gs_tileorder.hip): k_search's per-class counts, the plan's scans, tile
        * descriptors, bucket space, chunk index, partitioned items, class starts, rank tables + flags */
-      w_cls, w_t_plan, w_t_tiles, w_t_buckets, w_t_chunkof, w_t_big, w_t_rel, w_t_tab;
+      w_cls, w_t_plan, w_t_tiles, w_t_buckets, w_t_chunkof, w_t_big, w_t_rel, w_t_tab, w_t_excl, w_t_spill, w_b_redo_pos2;
   uint32_t opt_share_min = 512, opt_share_max = 2048; /* groups of eight rows: a verification pass of share_min or more is handed out, in packages of at most share_max (0: items are never shared) */
-  unsigned long long last_share[4] = {0, 0, 0, 0}; /* the last search launch: shared items, packages reserved, queue capacity, tickets handed out */
+  unsigned long long last_share[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* the last batch: shared items, packages reserved, queue capacity, tickets handed out; [4] guides beyond the tiles' reach, ordered device-wide alone */
   uint64_t shq_packages = 16384; /* packages the next batch's queue holds (1,152 bytes each): grown when a batch reserved more */
   uint64_t arena_chunks = 4096; /* chunks of 1,024 records the next batch's arena holds: grown when a batch needed more */
   /* matches per item the last batch showed, per mismatch budget (slot sizing), and what it was measured on */
@@ -246,6 +246,8 @@ struct gs_tileorder_in {
 };
 struct gs_tileorder_state {
   uint32_t n_it = 0, n_tiles = 0, n_btiles = 0, n_chunks = 0, n_big = 0, n_deal = 0;
+  uint32_t spill_units = 0, spill_cap = 0; /* bucket units kept for the buckets that outgrow their slots; records the spill list holds */
+  uint32_t n_excl = 0; /* guides with an item beyond the tiles' reach (ix->w_t_excl lists them): ordered device-wide by the caller */
   uint64_t n_records = 0; /* records of the set (set by gs_tileorder_run) */
 };
 /* does the sort word (class base + rank of the sequence, then the row) fit 64 bits? */

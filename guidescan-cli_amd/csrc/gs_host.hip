@@ -57,10 +57,10 @@ extern "C" gs_status gs_index_get_option(const gs_index *ix, const char *key, ch
   memcpy(out, v, n + 1);
   return GS_OK;
 }
-extern "C" gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[4]) {
+extern "C" gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[8]) {
   GS_HANDLE_LOCK(ix);
   if (!ix || !out) return GS_ERR_ARG;
-  for (int i = 0; i < 4; i++) out[i] = ix->last_share[i];
+  for (int i = 0; i < 8; i++) out[i] = ix->last_share[i];
   return GS_OK;
 }
 

@@ -2894,6 +2894,16 @@ __global__ void k_count_stats(const uint32_t *counts, uint32_t n_items, unsigned
     atomicMax(&out[1], mx);
   }
 }
+/* arena chunks the items' records beyond their slots take (the exact counts are known even when the arena ran out) */
+__global__ void k_need_chunks(const uint32_t *counts, uint32_t n_items, uint32_t cap, uint32_t *out) {
+  uint32_t v = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = counts[i];
+    if (c > cap) v += (c - cap + ARENA_CHUNK - 1u) >> ARENA_SHIFT;
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (lane_id() == 0 && v) atomicAdd(out, v);
+}
 
 /* ---- host side of the pipeline ---------------------------------------------- */
 /* slots per (guide, strand) of the first pass.  Up to three mismatches: 64 and the overflow redo
@@ -3193,8 +3203,30 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   try { /* the plans and lists built per batch live in std containers: nothing may throw across the C boundary */
     gs_status rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream,
                                          d_offsets, d_hits, stats);
-    /* the batch's workspace did not fit next to the derived tables: they go, one kind at a time - first the
-     * strand tables' rotated copies, then the PAM-pair tables - and the batch is redone */
+    /* the batch's workspace did not fit.  First what earlier batches left on the handle and this one may not need goes -
+     * a batch ordered device-wide leaves tens of bytes per record in a dozen arrays that a batch ordered in tiles never
+     * touches, and the other way round (10^9 records: 70 GB either way) - and the batch is redone: every workspace
+     * buffer grows again on demand.  Then the derived tables, one kind at a time: the strand tables' rotated copies,
+     * then the PAM-pair tables. */
+    if (rc == GS_ERR_NOMEM && ix) {
+      (void)hipGetLastError();
+      size_t freed = 0;
+      for (gs_buffer *b : {&ix->w_b_src, &ix->w_b_cnt, &ix->w_b_prefix, &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_w1, &ix->w_b_idx,
+                           &ix->w_b_idxb, &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_s, &ix->w_slots2, &ix->w_h_tmp,
+                           &ix->w_t_buckets, &ix->w_t_tiles, &ix->w_t_chunkof, &ix->w_t_big, &ix->w_hits, &ix->w_score_tmp, &ix->w_score_io,
+                           &ix->w_arena, &ix->w_shq, &ix->w_slots}) {
+        if (b->p) {
+          freed += b->cap;
+          (void)hipFree(b->p);
+        }
+        b->p = nullptr;
+        b->cap = 0;
+      }
+      if (freed > ((size_t)1 << 30)) {
+        if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] out of device memory: %.1f GB of workspace released, batch redone\n", 1e-9 * (double)freed);
+        rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets, d_hits, stats);
+      }
+    }
     if (rc == GS_ERR_NOMEM && ix && gs_strand_rot_release(ix)) {
       (void)hipGetLastError();
       ix->rot_off = true;
@@ -3670,7 +3702,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     gs_search_args sa;
     memset(&sa, 0, sizeof(sa));
-    if (with_arena) ix->last_share[0] = ix->last_share[1] = ix->last_share[2] = ix->last_share[3] = 0; /* (of the main pass: a redo shares nothing) */
+    if (with_arena) ix->last_share[0] = ix->last_share[1] = ix->last_share[2] = ix->last_share[3] = ix->last_share[4] = 0; /* (of the main pass: a redo shares nothing) */
     sa.sd[0] = ix->strand[0].d;
     sa.sd[1] = ix->strand[1].d;
     sa.slots = slots;
@@ -4004,7 +4036,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   auto big_order = [&](uint32_t n_set, const uint32_t *counts_main, uint32_t cap_, const uint32_t *redo_pos,
                        const uint64_t *slot_off2, const uint32_t *counts2, uint32_t *nmatch_out,
                        uint32_t *nhits_out, bool from_arena = false, const uint32_t *arena_list = nullptr,
-                       uint32_t n_used = 0) -> gs_status {
+                       uint32_t n_used = 0, const uint32_t *arena_redo_pos = nullptr) -> gs_status {
     gs_status r2;
     const uint32_t n_it = 2 * n_set;
     if ((r2 = gs_reserve(ix->w_b_src, sizeof(gs_big_src) * ((size_t)n_it + 1))) != GS_OK) return r2;
@@ -4082,7 +4114,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         ca.chunk_seq = ca.chunk_item + arena_chunks;
         ca.counts = (const uint32_t *)ix->w_counts.p;
         ca.list = arena_list;
-        ca.redo_pos = (const uint32_t *)ix->w_b_redo_pos.p;
+        ca.redo_pos = arena_redo_pos ? arena_redo_pos : (const uint32_t *)ix->w_b_redo_pos.p;
         ca.cap = cap;
         ca.n_used = n_used;
       }
@@ -4340,6 +4372,34 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   if ((rc = run_search((const gs_guide_rec *)ix->w_grec.p, n32, (uint4 *)ix->w_slots.p,
                        (uint32_t *)ix->w_counts.p, cap, h_stats, nullptr, arena_chunks != 0)) != GS_OK)
     return rc;
+  if (arena_chunks != 0 && arena_fail != 0 && !gs_opt(ix, "GS_ARENA_CHUNKS") && n_chunks == 1) {
+    /* The arena ran out: a handle's first batch on a repeat-rich genome (the arena starts at 64 MB and is sized from
+     * what earlier batches needed).  The counts are exact all the same, so the arena this batch needs is known: it is
+     * made that large and the main pass runs once more - a second k_search (tens of ms) instead of the exact-size second
+     * pass of the overflowing guides and, for them, the device-wide ordering (half a second at 5 x 10^8 records); the
+     * per-guide tile ordering then serves this batch like every later one, and allocates its workspace now. */
+    uint32_t *d_need = d_work + 10, h_need = 0;
+    GS_HIP(hipMemsetAsync(d_need, 0, 4, st));
+    hipLaunchKernelGGL(k_need_chunks, dim3(std::min<uint32_t>((2 * n32 + 255) / 256, 1024u)), dim3(256), 0, st,
+                       (const uint32_t *)ix->w_counts.p, 2 * n32, cap, d_need);
+    GS_HIP(hipMemcpyAsync(&h_need, d_need, 4, hipMemcpyDeviceToHost, st));
+    GS_HIP(hipStreamSynchronize(st));
+    uint64_t want = (uint64_t)h_need + h_need / 4 + (uint64_t)cus * 32u * 16u + 64; /* (+ the waves' reserves) */
+    if (want > (1ull << 21)) want = 1ull << 21;
+    if (want > arena_chunks && gs_reserve(ix->w_arena, sizeof(uint4) * (want << ARENA_SHIFT)) == GS_OK &&
+        gs_reserve(ix->w_arena_meta, 16 * want + 64) == GS_OK) {
+      if (gs_opt(ix, "GS_DEBUG"))
+        fprintf(stderr, "[gs] the arena ran out (%u chunks, %u needed): main pass run again with %llu\n", arena_chunks, h_need, (unsigned long long)want);
+      arena_chunks = (uint32_t)want;
+      ix->arena_chunks = want;
+      arena_fail = 0;
+      if ((rc = run_search((const gs_guide_rec *)ix->w_grec.p, n32, (uint4 *)ix->w_slots.p, (uint32_t *)ix->w_counts.p, cap, h_stats, nullptr,
+                           true)) != GS_OK)
+        return rc;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   if (stats) stats->n_ext = h_stats[0];
   GS_HIP(hipMemsetAsync(d_stats + 2, 0, 8, st)); /* match counter */
   unsigned long long h_cstat[2] = {0, 0}; /* sum and maximum of this batch's exact per-item counts */
@@ -4479,6 +4539,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   bool tile = set_exists && arena_chunks != 0 && (n_o == 0 || ovf_arena_ok) && v_rem != 0 && gs_tileorder_fits(L, P, mismatches) &&
               !(ix->tile_order_off && ix->tile_order_off_key == tile_key) && !gs_opt(ix, "GS_NO_TILE_ORDER");
   bool tile_used = false, tile_fell_back = false;
+  uint32_t guides_left_out = 0; /* guides with an item beyond the tiles' reach, ordered device-wide by themselves */
+  const uint32_t TO_F_DUP_HOST = 2u; /* (gs_tileorder.hip's TO_F_DUP: one sequence at one row twice) */
   uint64_t total = 0;
   for (int attempt = 0; attempt < 2; attempt++) {
     gs_tileorder_in ti;
@@ -4599,6 +4661,47 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     ti.hits = (gs_hit *)ix->w_hits.p;
     uint32_t viol = 0;
     if ((rc = gs_tileorder_run(ix, ti, ts, st, &viol)) != GS_OK) return rc;
+    if (!viol && ts.n_excl != 0) {
+      /* guides with an item beyond the tiles' reach (10^6 records: a guide inside the largest repeat family of a genome):
+       * these alone through the device-wide ordering, their records read where k_search left them; the hit list has
+       * their places already (as many hits as records: checked - a difference means one sequence at one row twice, and
+       * the batch is then ordered device-wide as a whole, like any batch whose tiles meet that) */
+      if (wide_key || !big_fits_v2(ts.n_excl)) {
+        gs_set_error("a guide with more than 10^6 match records per index and a match sequence beyond 52 key bits: the device-wide "
+                     "ordering does not carry such keys (gs_enumerate_general does)");
+        return GS_ERR_UNSUPPORTED;
+      }
+      const uint32_t n_x = ts.n_excl;
+      const uint32_t *xlist = (const uint32_t *)ix->w_t_excl.p;
+      if ((rc = gs_reserve(ix->w_b_redo_pos2, 4 * ((size_t)n + 1))) != GS_OK) return rc;
+      if ((rc = gs_reserve(ix->w_nmatch2, sizeof(uint32_t) * (size_t)std::max(n_x, n_o))) != GS_OK) return rc;
+      if ((rc = gs_reserve(ix->w_nhits2, sizeof(uint32_t) * (size_t)std::max(n_x, n_o))) != GS_OK) return rc;
+      hipLaunchKernelGGL(k_fill_u32, dim3((n32 + 255) / 256), dim3(256), 0, st, (uint32_t *)ix->w_b_redo_pos2.p, 0xFFFFFFFFu, n32);
+      hipLaunchKernelGGL(k_mark_redo, dim3((n_x + 255) / 256), dim3(256), 0, st, xlist, n_x, (uint32_t *)ix->w_b_redo_pos2.p);
+      if (n_used == 0) { /* (the chunks in use, when no earlier step asked for them) */
+        GS_HIP(hipMemcpyAsync(&n_used, d_arena_next, 4, hipMemcpyDeviceToHost, st));
+        GS_HIP(hipStreamSynchronize(st));
+        if (n_used > arena_chunks) n_used = arena_chunks;
+      }
+      if ((rc = big_order(n_x, nullptr, 0, nullptr, nullptr, nullptr, (uint32_t *)ix->w_nmatch2.p, (uint32_t *)ix->w_nhits2.p, true, xlist,
+                          n_used, (const uint32_t *)ix->w_b_redo_pos2.p)) != GS_OK)
+        return rc;
+      std::vector<uint32_t> hx(n_x), lx(n_x), cx(2 * (size_t)n_x);
+      GS_HIP(hipMemcpy(hx.data(), ix->w_nhits2.p, 4 * (size_t)n_x, hipMemcpyDeviceToHost));
+      GS_HIP(hipMemcpy(lx.data(), xlist, 4 * (size_t)n_x, hipMemcpyDeviceToHost));
+      bool same = true;
+      for (uint32_t j = 0; j < n_x && same; j++) {
+        GS_HIP(hipMemcpy(&cx[2 * j], (const uint32_t *)ix->w_counts.p + 2 * (size_t)lx[j], 8, hipMemcpyDeviceToHost));
+        same = (uint64_t)hx[j] == (uint64_t)cx[2 * j] + cx[2 * j + 1];
+      }
+      if (same) {
+        big_locate(xlist);
+        guides_left_out = n_x;
+        ix->last_share[4] = n_x;
+      } else {
+        viol = TO_F_DUP_HOST;
+      }
+    }
     if (!viol) {
       tile_used = true;
       /* matches counter: these guides were skipped by (or never went through) k_order */
@@ -4625,6 +4728,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     fprintf(stderr, "[gs] items: seeded from both strands %llu, one-sided (PAM with more than two N) %llu; slots %u per item, "
             "%u guides redone%s%s\n", h_stats3[4], h_stats3[5], cap, n_o, big_batch ? " (whole batch through the wide ordering)" : "",
             tile_used ? " (per guide in LDS tiles)" : "");
+  if (guides_left_out && gs_opt(ix, "GS_DEBUG"))
+    fprintf(stderr, "[gs] %u guide(s) with an item beyond the tiles' reach ordered device-wide by themselves\n", guides_left_out);
   h_stats3[6] = n_o;
   h_stats3[7] = (h_stats3[7] << 8) | (big_batch ? 1u : 0u) | (redo_big ? 2u : 0u) |
                 (n_o && arena_chunks != 0 && arena_fail == 0 ? 4u : 0u) | /* bit 2: the overflowing guides came out of the arena, no second pass */

@@ -255,16 +255,27 @@ struct gs_to_plan_args {
 __device__ __host__ __forceinline__ uint32_t to_buckets(const uint32_t c, uint32_t &su) {
   su = 0u;
   if (c <= TO_TILE) return 0u;
+  /* A bucket's slot is 1.5-1.8 x its aim (until round 5: 2.9-6.2 x, so that no bucket ever outgrew it - 3.7 x the
+   * records in bucket space, 29 GB on the repeat-rich batch and 60 GB at 10^9 records).  What a bucket receives beyond
+   * its slot goes to a spill list; a bucket that did is moved, whole, to a slot of its real size behind the planned
+   * ones (k_to_bucketsum, k_to_respill): one bucket in a thousand at 32 samples per splitter, a few in a hundred at 8. */
   uint32_t target;
   if (c <= 256u * 400u)
-    target = 400u, su = 9u; /* 32 samples per splitter: one bucket in fifteen grows past 512 */
+    target = 400u, su = 4u; /* 32 samples per splitter: one bucket in fifteen grows past its 512 */
   else if (c <= 512u * 320u)
-    target = 320u, su = 10u; /* 16 */
+    target = 320u, su = 4u; /* 16 */
   else if (c <= 1024u * 288u)
-    target = 288u, su = 14u; /* 8 */
+    target = 288u, su = 4u; /* 8 */
   else
-    target = 1024u, su = 50u; /* 8 (to a million records: 1,024 buckets, ordered by the workgroup kernels - the 1,024-thread form takes 8,192) */
+    target = 1024u, su = 12u; /* 8 (to a million records: 1,024 buckets, ordered by the workgroup kernels - the 1,024-thread form takes 8,192) */
   return (c + target - 1u) / target;
+}
+/* An item beyond TO_NBMAX buckets of 1,024 records (a guide inside the largest repeat family of a genome: 10^6 records
+ * and more) is not dealt: its GUIDE - both items - is left out of the tiles and goes, alone, through the device-wide
+ * ordering (gs_search.hip, big_order on the list k_to_fill writes); the rest of the batch stays here. */
+#define TO_ITEM_MAX (TO_NBMAX * 1024u)
+__device__ __forceinline__ bool to_left_out(const uint32_t *counts, const uint32_t item) {
+  return counts[item] > TO_ITEM_MAX || counts[item ^ 1u] > TO_ITEM_MAX;
 }
 __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
   __shared__ uint32_t s_w[5][16], s_carry[5];
@@ -276,13 +287,9 @@ __global__ __launch_bounds__(1024) void k_to_plan(gs_to_plan_args a) {
     uint32_t v[5] = {0u, 0u, 0u, 0u, 0u};
     if (sb < a.n_it) {
       const uint32_t item = a.list ? 2u * a.list[sb >> 1] + (sb & 1u) : sb;
-      const uint32_t c = a.counts[item];
+      const uint32_t c = to_left_out(a.counts, item) ? 0u : a.counts[item]; /* (a guide that is left out has no tiles, buckets or chunks here) */
       uint32_t su;
-      uint32_t nb = to_buckets(c, su);
-      if (nb > TO_NBMAX) { /* an item beyond a million records: the device-wide form orders this batch */
-        atomicOr(a.flags, TO_F_BIG);
-        nb = 0u;
-      }
+      const uint32_t nb = to_buckets(c, su);
       v[0] = c == 0u ? 0u : nb ? nb : 1u;
       v[1] = nb * su;
       v[2] = c > a.cap ? (c - a.cap + ARENA_CHUNK - 1u) / ARENA_CHUNK : 0u;
@@ -334,13 +341,15 @@ struct gs_to_fill_args {
                        records of item s in classes before d: a record's place = rel[2d + s] + its rank in the item */
   uint32_t *nhits;  /* of the batch: hits per guide */
   uint32_t *flags;
+  uint32_t *excl;   /* guides (of the batch) that are left out: flags[40] of them */
 };
 __global__ __launch_bounds__(256) void k_to_fill(gs_to_fill_args a) {
   const uint32_t sb = blockIdx.x * blockDim.x + threadIdx.x;
   const bool in = sb < a.n_it;
   const uint32_t g = in ? (a.list ? a.list[sb >> 1] : (sb >> 1)) : 0u;
   const uint32_t item = 2u * g + (sb & 1u);
-  const uint32_t c = in ? a.counts[item] : 0u;
+  const bool left_out = in && to_left_out(a.counts, item);
+  const uint32_t c_all = in ? a.counts[item] : 0u, c = left_out ? 0u : c_all;
   uint32_t su;
   const uint32_t nb = to_buckets(c, su), tb = in ? a.tbase[sb] : 0u;
   if (c != 0u && nb == 0u) a.tiles[tb] = make_uint4(sb | TO_DIRECT, 0u, c, 0u);
@@ -377,15 +386,18 @@ __global__ __launch_bounds__(256) void k_to_fill(gs_to_fill_args a) {
       p1 += c1[d];
     }
     const uint32_t cb = a.counts[item + 1u];
-    if (p0 != c || p1 != cb) atomicOr(a.flags, TO_F_CLS); /* (cannot happen: k_search counts both) */
-    a.nhits[g] = c + cb;
+    if (p0 != c_all || p1 != cb) atomicOr(a.flags, TO_F_CLS); /* (cannot happen: k_search counts both) */
+    a.nhits[g] = c_all + cb;
+    if (left_out) a.excl[atomicAdd(a.flags + 40, 1u)] = g; /* the device-wide ordering takes this guide (its hits: as many as its records - the host checks) */
   }
 }
 /* records of the set (flags[2..3] as one 64-bit count) */
 __global__ __launch_bounds__(256) void k_to_total(const uint32_t *counts, const uint32_t *list, uint32_t n_it, unsigned long long *out) {
   unsigned long long v = 0;
-  for (uint64_t sb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sb < n_it; sb += (uint64_t)gridDim.x * blockDim.x)
-    v += counts[list ? 2u * list[sb >> 1] + ((uint32_t)sb & 1u) : (uint32_t)sb];
+  for (uint64_t sb = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sb < n_it; sb += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t item = list ? 2u * list[sb >> 1] + ((uint32_t)sb & 1u) : (uint32_t)sb;
+    if (!to_left_out(counts, item)) v += counts[item];
+  }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   if (lane_id() == 0 && v) atomicAdd(out, v);
 }
@@ -405,6 +417,7 @@ __global__ __launch_bounds__(256) void k_to_chunks(gs_to_chunk_args a) {
     sb = 2u * pos + (item & 1u);
   }
   const uint32_t seq = a.chunk_seq[c];
+  if (to_left_out(a.counts, item)) return;
   if (a.counts[item] > a.cap + (seq << ARENA_SHIFT)) a.chunk_of[a.cbase[sb] + seq] = c;
 }
 
@@ -438,6 +451,13 @@ struct gs_to_run_args {
   uint64_t genome_length;
   uint32_t *flags;
   uint32_t L, P, v_rem;
+  /* what a bucket received beyond its slot: the records and their tiles (flags[41] of them, spill_cap at most); a
+   * bucket that overflowed moves to spill_unit0 + ... units behind the planned slots (flags[42] units handed out, of
+   * spill_units), fill2[tile] = how much of the new slot is written; jobs (flags[43]): {tile, old slot unit, records to copy} */
+  uint4 *spill_rec;
+  uint32_t *spill_tile, *fill2;
+  uint4 *jobs;
+  uint32_t spill_cap, spill_unit0, spill_units;
   uint32_t sample_per; /* 0, or GS_TILE_SAMPLE_PER (tests) */
   uint32_t big_from;   /* tiles of more records go to the 1,024-thread kernel: TO_TILE (tests: GS_TILE_BIG_FROM) */
 };
@@ -598,7 +618,18 @@ __global__ __launch_bounds__(TO_NT) void k_to_deal(gs_to_run_args a) {
   for (uint32_t u = 0; u < 4u; ++u) {
     const uint32_t pos = s_cnt[blo[u]] + lp[u];
     /* a bucket record carries its sequence word where the (equal) last row was: the tile does not rank it again */
-    if (on[u] && pos < slots) out[(size_t)blo[u] * slots0 + pos] = make_uint4(rec[u].x, rec[u].y, rec[u].z, (uint32_t)(K[u] >> 32));
+    const uint4 br = make_uint4(rec[u].x, rec[u].y, rec[u].z, (uint32_t)(K[u] >> 32));
+    if (on[u] && pos < slots) {
+      out[(size_t)blo[u] * slots0 + pos] = br;
+    } else if (on[u]) { /* beyond the bucket's slot: to the spill list (k_to_respill gives the bucket a slot of its real size) */
+      const uint32_t e = atomicAdd(a.flags + 41, 1u);
+      if (e < a.spill_cap) {
+        a.spill_rec[e] = br;
+        a.spill_tile[e] = tb + blo[u];
+      } else {
+        atomicOr(a.flags, TO_F_BUCKET);
+      }
+    }
   }
 }
 
@@ -616,20 +647,28 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
   bool over = false;
   for (uint32_t q = 0; q < each; ++q) {
     const uint32_t b = lane * each + q;
-    if (b < nb) {
-      const uint32_t n = a.tiles[tb + b].z;
-      s += n;
-      over = over || n > slots;
-    }
+    if (b < nb) s += a.tiles[tb + b].z;
   }
   uint32_t run = wave_incl_sum(s) - s;
   for (uint32_t q = 0; q < each; ++q) {
     const uint32_t b = lane * each + q;
     if (b < nb) {
       const uint32_t n = a.tiles[tb + b].z;
-      a.tiles[tb + b].z = n < slots ? n : slots;
       a.tiles[tb + b].w = run;
       run += n;
+      if (n > slots) {
+        /* the bucket outgrew its slot: a slot of its real size behind the planned ones; what the old slot holds is
+         * copied there and the spilled records follow (k_to_respill) */
+        const uint32_t units = (n + TO_BU - 1u) / TO_BU, u0 = atomicAdd(a.flags + 42, units);
+        if (u0 + units <= a.spill_units && n <= 1024u * TO_KPT) {
+          a.jobs[atomicAdd(a.flags + 43, 1u)] = make_uint4(tb + b, a.tiles[tb + b].y, slots, 0u);
+          a.tiles[tb + b].y = a.spill_unit0 + u0;
+          a.fill2[tb + b] = slots;
+        } else {
+          over = true; /* (no room left, or beyond what one workgroup orders: the caller orders the batch the other way) */
+          a.tiles[tb + b].z = slots;
+        }
+      }
     }
     /* (one bucket in fifteen: a place on its list, one atomic per wave and list) */
     const uint32_t n = b < nb ? a.tiles[tb + b].z : 0u;
@@ -644,6 +683,28 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
     }
   }
   if (over) atomicOr(a.flags, TO_F_BUCKET);
+}
+
+/* buckets that outgrew their slots: (0) what the old slot holds goes to the new one, a workgroup per bucket and visit;
+ * (1) the spilled records follow, each to the next free place of its bucket's new slot */
+__global__ __launch_bounds__(256) void k_to_respill(gs_to_run_args a, const uint32_t phase) {
+  if (phase == 0u) {
+    const uint32_t nj = a.flags[43];
+    for (uint32_t j = blockIdx.x; j < nj; j += gridDim.x) {
+      const uint4 job = a.jobs[j];
+      const uint4 *src = a.buckets + (size_t)job.y * TO_BU;
+      uint4 *dst = a.buckets + (size_t)a.tiles[job.x].y * TO_BU;
+      for (uint32_t i = threadIdx.x; i < job.z; i += 256u) dst[i] = src[i];
+    }
+    return;
+  }
+  const uint32_t ne = a.flags[41] < a.spill_cap ? a.flags[41] : a.spill_cap;
+  for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < ne; e += gridDim.x * 256u) {
+    const uint32_t t = a.spill_tile[e];
+    const uint4 tile = a.tiles[t];
+    const uint32_t pos = atomicAdd(&a.fill2[t], 1u);
+    if (pos < tile.z) a.buckets[(size_t)tile.y * TO_BU + pos] = a.spill_rec[e];
+  }
 }
 
 /* ---- one tile: order its records in LDS and write its hits -------------------------------------------------------- */
@@ -1114,7 +1175,13 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   S.n_big = tot[3];
   S.n_deal = tot[4];
   if ((rc = gs_reserve(ix->w_t_tiles, (16 + 8) * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* descriptors, then the splitters */
-  if ((rc = gs_reserve(ix->w_t_buckets, 16 * (size_t)TO_BU * S.n_btiles + 16)) != GS_OK) return rc;
+  /* bucket space: the planned slots, an eighth more for the buckets that outgrow theirs (k_to_respill), the spill list
+   * (an eighth of the dealt records: 20 bytes each), a word per tile and a job per moved bucket */
+  S.spill_units = S.n_btiles / 8u + 2048u;
+  S.spill_cap = S.n_deal * (TO_DEAL / 8u) + 65536u;
+  if (gs_opt(ix, "GS_TILE_NO_SPILL")) S.spill_units = S.spill_cap = 0u; /* (tests: a bucket beyond its slot then sends the batch to the device-wide ordering) */
+  if ((rc = gs_reserve(ix->w_t_buckets, 16 * (size_t)TO_BU * ((size_t)S.n_btiles + S.spill_units) + 16)) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_t_spill, 20 * (size_t)S.spill_cap + (4 + 16) * ((size_t)S.n_tiles + 1) + 64)) != GS_OK) return rc;
   if ((rc = gs_reserve(ix->w_t_chunkof, 4 * ((size_t)S.n_chunks + 1) + 12 * ((size_t)S.n_tiles + 1))) != GS_OK) return rc; /* the chunk index, then the three lists */
   const size_t deal_at = (4 * ((size_t)S.n_big + 1) + 31) & ~(size_t)31; /* the list, then the deal map */
   if ((rc = gs_reserve(ix->w_t_big, deal_at + 32 * ((size_t)S.n_deal + 1))) != GS_OK) return rc;
@@ -1139,6 +1206,8 @@ gs_status gs_tileorder_plan(gs_index *ix, const gs_tileorder_in &in, hipStream_t
   fa.rel = (uint32_t *)ix->w_t_rel.p;
   fa.nhits = in.nhits;
   fa.flags = d_flags;
+  if ((rc = gs_reserve(ix->w_t_excl, 4 * ((size_t)in.n_set + 1))) != GS_OK) return rc;
+  fa.excl = (uint32_t *)ix->w_t_excl.p;
   hipLaunchKernelGGL(k_to_fill, dim3((n_it + 255) / 256), dim3(256), 0, st, fa);
   hipLaunchKernelGGL(k_to_total, dim3(std::min<uint32_t>((n_it + 255) / 256, 512u)), dim3(256), 0, st, in.counts, in.list, n_it,
                      (unsigned long long *)(d_flags + 2));
@@ -1183,6 +1252,13 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   ra.slow_n = d_flags + 32;
   ra.tiles = (uint4 *)ix->w_t_tiles.p;
   ra.buckets = (uint4 *)ix->w_t_buckets.p;
+  ra.spill_rec = (uint4 *)ix->w_t_spill.p;
+  ra.jobs = ra.spill_rec + S.spill_cap;
+  ra.spill_tile = (uint32_t *)(ra.jobs + (S.n_tiles + 1));
+  ra.fill2 = ra.spill_tile + S.spill_cap;
+  ra.spill_cap = S.spill_cap;
+  ra.spill_unit0 = S.n_btiles;
+  ra.spill_units = S.spill_units;
   ra.tab = (const gs_to_tab *)ix->w_t_tab.p;
   ra.rel = (const uint32_t *)ix->w_t_rel.p;
   ra.offsets = in.offsets;
@@ -1201,6 +1277,10 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
     hipLaunchKernelGGL(k_to_splitters<TO_SNT>, dim3(S.n_big), dim3(TO_SNT), 0, st, ra);
     hipLaunchKernelGGL(k_to_deal, dim3(S.n_deal), dim3(TO_NT), 0, st, ra);
     hipLaunchKernelGGL(k_to_bucketsum, dim3((S.n_big + 3u) / 4u), dim3(256), 0, st, ra, S.n_big);
+    if (S.spill_cap != 0u && S.n_tiles != 0u) {
+      hipLaunchKernelGGL(k_to_respill, dim3(std::min<uint32_t>(S.n_tiles, 2048u)), dim3(256), 0, st, ra, 0u);
+      hipLaunchKernelGGL(k_to_respill, dim3(std::min<uint32_t>((S.spill_cap + 255u) / 256u, 2048u)), dim3(256), 0, st, ra, 1u);
+    }
   }
   if (S.n_tiles) {
     /* the tiles one wave cannot take: how many is known once the buckets are counted - the host waits for that number
@@ -1229,7 +1309,7 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
       hipLaunchKernelGGL(k_to_sort<1024u>, dim3(n_slow[2]), dim3(1024), to_sort_lds(1024u), st, ra, (const uint32_t *)ra.slow[2]);
     }
   }
-  uint32_t h[32] = {0};
+  uint32_t h[48] = {0};
   GS_HIP(hipMemcpyAsync(h, d_flags, sizeof(h), hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
 #ifdef TO_PROFILE
@@ -1240,9 +1320,11 @@ gs_status gs_tileorder_run(gs_index *ix, const gs_tileorder_in &in, gs_tileorder
   }
 #endif
   if (gs_opt(ix, "GS_DEBUG"))
-    fprintf(stderr, "[gs] tile ordering: %u items, %u of them dealt into %u bucket units of 128 records, %u tiles\n", S.n_it, S.n_big, S.n_btiles, S.n_tiles);
+    fprintf(stderr, "[gs] tile ordering: %u items, %u of them dealt into %u bucket units of 128 records, %u tiles; %u records beyond their bucket's slot, "
+            "%u buckets moved to %u units of the %u kept for that\n", S.n_it, S.n_big, S.n_btiles, S.n_tiles, h[41], h[43], h[42], S.spill_units);
   *violations = h[0];
   S.n_records = ((uint64_t)h[3] << 32) | h[2];
+  S.n_excl = h[40]; /* guides left to the device-wide ordering (ix->w_t_excl) */
   GS_HIP(hipGetLastError());
   return GS_OK;
 }

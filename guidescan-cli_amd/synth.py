@@ -88,7 +88,7 @@ def _mutate(rng, block, div):
     return block
 
 
-def plant_repeats(text, lengths, seed=1, fraction=0.45, chunk_bytes=1 << 28):
+def plant_repeats(text, lengths, seed=1, fraction=0.45, chunk_bytes=1 << 28, sine_div=(0.10, 0.15), sine_copies=None):
     """Overwrite ~`fraction` of an i.i.d. genome with repeat families, both strands (a real assembly is
     about half interspersed repeats; guides drawn from them have 10^4..10^5 near-copies):
       SINE-like   : 300 bp unit, divergence 10-15 % from the unit per copy      (22 % of the repeat bases)
@@ -96,7 +96,10 @@ def plant_repeats(text, lengths, seed=1, fraction=0.45, chunk_bytes=1 << 28):
       tandem      : arrays of a 2-170 bp motif, 1-4 kb long, divergence 2 %       (8 %)
       segmental   : duplications of 100 kb stretches of the genome itself at 1 %  (25 %)
     At 3.09 Gbp and fraction 0.45 that is ~1.0e6 SINE-like and ~1.6e5 LINE-like copies.  Seeded;
-    copies may overlap (later ones win); N blocks are not written over."""
+    copies may overlap (later ones win); N blocks are not written over.
+    sine_div / sine_copies: the SINE-like family's divergence range and copy number - (0.02, 0.15) and 1.2e6 copies
+    make it Alu-like (young copies 2 % from the unit: a guide drawn from it has several 10^5 sites within three
+    mismatches, bench.py's hg38alu workload)."""
     rng = np.random.Generator(np.random.PCG64(seed + 77))
     total = int(text.shape[0])
     rep = fraction * total
@@ -124,7 +127,7 @@ def plant_repeats(text, lengths, seed=1, fraction=0.45, chunk_bytes=1 << 28):
                 text[idx] = block[m]
 
     sine = _ACGT[rng.integers(0, 4, size=300)]
-    place(sine, int(0.22 * rep / 300), 0.10, 0.15)
+    place(sine, int(0.22 * rep / 300) if sine_copies is None else int(sine_copies), sine_div[0], sine_div[1])
     line = _ACGT[rng.integers(0, 4, size=6000)]
     place(line, int(0.45 * rep / 3250), 0.05, 0.05, min_len=500)
     n_tandem = int(0.08 * rep / 2500)
@@ -150,12 +153,12 @@ def plant_repeats(text, lengths, seed=1, fraction=0.45, chunk_bytes=1 << 28):
     return text
 
 
-def make_repeat_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), fraction=0.45, out=None):
-    """make_genome + plant_repeats, N blocks as make_genome lays them"""
+def make_repeat_genome(lengths, seed=1, probs=(0.29, 0.21, 0.21, 0.29), fraction=0.45, out=None, **family):
+    """make_genome + plant_repeats (family: its sine_div / sine_copies), N blocks as make_genome lays them"""
     text, names, lengths = make_genome(lengths, seed=seed, probs=probs, n_blocks=False, out=out)
     if not text.flags.writeable:
         text = text.copy()
-    plant_repeats(text, lengths, seed=seed, fraction=fraction)
+    plant_repeats(text, lengths, seed=seed, fraction=fraction, **family)
     off = 0
     for ln in lengths:
         if ln > 100_000:

@@ -169,10 +169,11 @@ void gs_index_close(gs_index *ix);
  * [12] Occ block lines, [3] lines of the seed recipe lists.  (the bytes the
  * roofline is priced on.)  [7] >> 8: items whose seeds went through PAM-pair tables. */
 gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]);
-/* The last search launch's sharing of heavy items among waves: [0] items of which at least one
- * verification pass was handed to other waves, [1] packages reserved in the queue, [2] packages the queue holds,
- * [3] tickets the helping waves drew. */
-gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[4]);
+/* The last batch's heavy items (DESIGN.md sections 5.1, 5.3): [0] items of which at least one verification pass was
+ * handed to other waves, [1] packages reserved in the queue, [2] packages the queue holds, [3] tickets the helping waves
+ * drew; [4] guides with an item of more than 2^20 match records, which the per-guide tile ordering leaves to the
+ * device-wide ordering - alone, the rest of the batch stays in tiles; [5..7] zero. */
+gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[8]);
 /* Switches of a handle.  The library's tuning and test switches ("GS_NO_BIDIR", "GS_SHARE_MIN", "GS_DEBUG", ... -
  * DESIGN.md names each where it acts) are a per-handle table: filled from the process environment's GS_* variables
  * ONCE, when the handle is made (gs_index_build / _with_sa / _open_sdsl / _open_sa), and changed only through

@@ -220,7 +220,7 @@ def test_options_are_validated_without_a_device():
     assert L.gs_index_set_option(None, b"GS_DEBUG", b"1") == 1
     buf = C.create_string_buffer(8)
     assert L.gs_index_get_option(None, b"GS_DEBUG", buf, 8) == 1
-    out = (C.c_uint64 * 4)()
+    out = (C.c_uint64 * 8)()
     assert L.gs_index_last_sharing(None, out) == 1
 
 

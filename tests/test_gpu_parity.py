@@ -735,6 +735,51 @@ def test_an_item_of_more_than_half_a_million_records(monkeypatch, capfd):
         oidx.close()
 
 
+def test_a_guide_beyond_the_tiles_reach_goes_alone_to_the_device_wide_ordering():
+    """1,600,000 copies of one site on the + strand (a guide inside the largest repeat family of a real genome): its
+    item holds more than 2^20 match records, beyond what the per-guide tile ordering deals into buckets.  That GUIDE
+    alone is ordered device-wide (gs_search.hip, big_order on the list gs_tileorder.hip's k_to_fill leaves); the rest
+    of the batch - a guide of 300,000 copies that is dealt into buckets, guides of a few hits - stays in tiles.  Until
+    round 5 one such item sent the whole batch through the device-wide ordering.  Every guide's hit list equals the
+    oracle's (process.hpp:100-115 order; the std::set's dedupe, structures.hpp:33-43, has nothing to drop here)."""
+    rng = np.random.default_rng(31)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    site, site2 = rng.choice(acgt, 20), rng.choice(acgt, 20)
+    n1, n2, unit = 1_600_000, 300_000, 32
+    text = rng.choice(acgt, (n1 + n2) * unit + 40_000).astype(np.uint8)
+    body = text[:(n1 + n2) * unit].reshape(n1 + n2, unit)
+    which = rng.permutation(n1 + n2) < n1
+    body[which, 4:24] = site
+    body[~which, 4:24] = site2
+    body[:, 24] = rng.choice(acgt, n1 + n2)
+    body[:, 25:27] = ord("G")
+    gidx = api.GenomeIndex.build(text, device=0)
+    oidx = ol.OracleIndex(text, sa_provider=lambda s: gidx.suffix_array(s), nthreads=8)
+    try:
+        other, _, _, _ = synth.sample_guides(text[(n1 + n2) * unit:], 3, seed=9)
+        seqs = np.concatenate([other[:1], np.array([list(site)], dtype=np.uint8), other[1:2], np.array([list(site2)], dtype=np.uint8),
+                               other[2:]])
+        pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
+        offsets, hits, _ = gidx.enumerate(seqs, pams, mismatches=1)
+        ctr, sh = gidx.last_counters(), gidx.last_sharing()
+        assert ctr["ordered_in_tiles"] and not ctr["tile_ordering_gave_up"] and ctr["matches_max_per_item"] >= n1, ctr
+        assert sh["guides_ordered_device_wide_alone"] == 1, sh
+        opts = ol.make_opts(1)
+        for i in range(seqs.shape[0]):
+            g = seqs[i].tobytes().decode()
+            exp, _ = oracle_hits_as_records(oidx, g, "NGG", opts, 3)
+            got = gpu_hits_as_records(offsets, hits, i, g, 3)
+            assert len(got) == len(exp) and got == exp, i
+            assert (i != 1 or len(exp) >= n1) and (i != 3 or len(exp) >= n2)
+        # a second batch on the handle (the heavy instantiation of the search by now): the same lists
+        off2, hits2, _ = gidx.enumerate(seqs, pams, mismatches=1)
+        assert np.array_equal(offsets, off2) and hits.tobytes() == hits2.tobytes()
+        assert gidx.last_sharing()["guides_ordered_device_wide_alone"] == 1
+    finally:
+        gidx.close()
+        oidx.close()
+
+
 def test_a_heavy_item_is_run_by_many_waves():
     """One (guide, strand) item of 2 x 10^5 records - 190,000 near-copies of one site with 0..3 substitutions on the +
     strand, 10,000 on the - strand - next to five ordinary guides: k_search hands its verification passes to the waves
@@ -832,8 +877,13 @@ def test_tile_ordering_gives_up_and_the_device_wide_form_takes_over(monkeypatch)
                 assert gpu_hits_as_records(offsets, hits, i, g, 3) == exp, (i, alt)
 
         check((), True, False)
-        gidx.set_option("GS_TILE_SAMPLE_PER", "1")     # buckets outgrow their slots: gives up, same hits
+        # a sample of one word per splitter and a quarter of the slots: most buckets outgrow theirs - what they receive
+        # beyond goes to the spill list and the buckets move to slots of their real size (k_to_respill): same hits, in tiles
+        gidx.set_option("GS_TILE_SAMPLE_PER", "1")
+        check((), True, False)
+        gidx.set_option("GS_TILE_NO_SPILL", "1")       # ... without the spill list: gives up, same hits
         check((), False, True)
+        gidx.set_option("GS_TILE_NO_SPILL", None)
         gidx.set_option("GS_TILE_SAMPLE_PER", None)
         check(("NGG",), False, True)                       # every site twice: gives up, the device-wide form drops the copies
         check(("NGG",), False, False)                      # ... and this shape is not tried again on this handle

@@ -1,10 +1,5 @@
-# quick check on one GPU box: scoring tests, then the scoring kernels timed (rocprofv3 kernel stats) on the repeat-rich batch and the m <= 6 batch
+# quick check on one GPU box
 cd /root/repo
-export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests/test_gpu_score_kmers.py -x -q -m gpu 2>&1 | tail -3
-for w in "hg38rep 20000 3" "hg38 20000 6"; do
-  rm -rf /tmp/sc_prof
-  rocprofv3 --kernel-trace --stats -f csv -d /tmp/sc_prof -- python3 tools/score_bench.py $w 4 2>/dev/null | grep -h "^{"
-  f=$(find /tmp/sc_prof -name '*kernel_stats.csv' | head -1)
-  grep -h "k_score" $f | cut -c1-160
-done
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "beyond_the_tiles or half_a_million or heavy_item or repeat_guide or tile_sizes or gives_up" 2>&1 | tail -3
+GS_DEBUG=1 timeout -k 10 400 python tools/rep_steps.py 5 2>&1 | grep -h "^step\|arena ran out\|released\|dropped" | tail -12
+GS_DEBUG=1 timeout -k 10 900 python tools/rep_share_sweep.py hg38alu 20000 3 3 512:2048 > gpurun_out/r05_alu3.log 2>&1; grep -h "^{\|arena ran out\|released\|dropped\|Error" gpurun_out/r05_alu3.log | tail -8; grep -h "tile ordering: [0-9]* items\|guide(s) with an item" gpurun_out/r05_alu3.log | tail -3
