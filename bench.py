@@ -72,6 +72,11 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch guides per GPU per step (the default); strong: --batch guides per step in all, "
                          "split over the ranks in contiguous shards (configs 4/5: a fixed guide set over 8 GPUs)")
+    ap.add_argument("--deal", type=int, default=0,
+                    help="with --scaling strong: the step's guides are handed out in chunks of this many from one shared counter "
+                         "(the rendezvous store's atomic add; guidescan-cli_amd/parallel.py) instead of one contiguous shard per "
+                         "rank - a rank that draws repeat-dense chunks draws fewer (src/guidescan.cxx:226-231 deals round-robin for "
+                         "that reason); 0 = contiguous shards")
     ap.add_argument("--stream", type=int, default=0,
                     help="a step goes through its guides in sub-batches of this many (config 5: 1 M guides at <= 6 "
                          "mismatches as 50 batches of 20 k); 0 = one call per step")
@@ -144,12 +149,15 @@ def main():
         # one seeded guide set per step for the whole job, rank r takes the contiguous shard r of every step
         # (src/guidescan.cxx:226-251 deals guides to threads; here to GPUs, each with the whole index)
         batch_all = batch
-        b = parallel.shard_bounds(batch_all, world)
-        lo, hi = b[rank], b[rank + 1]
-        batch = hi - lo
         all_seqs, all_pams, _, _ = synth.sample_guides(text, batch_all * nb, seed=1000)
-        pick = np.concatenate([np.arange(i * batch_all + lo, i * batch_all + hi) for i in range(nb)])
-        seqs, pams = np.ascontiguousarray(all_seqs[pick]), np.ascontiguousarray(all_pams[pick])
+        if args.deal:
+            seqs, pams = all_seqs, all_pams   # every rank holds the step's guides and enumerates the chunks it draws
+        else:
+            b = parallel.shard_bounds(batch_all, world)
+            lo, hi = b[rank], b[rank + 1]
+            batch = hi - lo
+            pick = np.concatenate([np.arange(i * batch_all + lo, i * batch_all + hi) for i in range(nb)])
+            seqs, pams = np.ascontiguousarray(all_seqs[pick]), np.ascontiguousarray(all_pams[pick])
         del all_seqs, all_pams
     else:
         # every step and every rank gets its own guides (seeded): shard r of the global batch
@@ -172,9 +180,24 @@ def main():
                               score_buf["spec"].data_ptr())
         return d_off, d_hits, st
 
+    busy = {"s": 0.0, "chunks": 0}
+
     def step(i):
         s = d_seqs[i * batch:(i + 1) * batch]
         p = d_pams[i * batch:(i + 1) * batch]
+        if args.scaling == "strong" and args.deal:
+            # chunks of the step's guides from the shared counter; what the step returns is the sum over this rank's chunks
+            acc = {"st": None, "last": (None, None)}
+
+            def one(c, lo, hi):
+                d_off, d_hits, st = one_call(s[lo:hi], p[lo:hi], hi - lo)
+                acc["st"] = st if acc["st"] is None else {k: acc["st"][k] + st[k] for k in st}
+                acc["last"] = (d_off, d_hits)
+            mine, sec = parallel.deal_chunks(one, batch, args.deal, f"step{i}", dist)
+            busy["s"] += sec
+            busy["chunks"] += len(mine)
+            zero = {"n_ext": 0, "n_matches": 0, "n_hits": 0, "ms_search": 0.0, "ms_total": 0.0}
+            return acc["last"][0], acc["last"][1], acc["st"] or zero
         if not args.stream or args.stream >= batch:
             return one_call(s, p, batch)
         tot = None
@@ -227,6 +250,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    busy["s"] = 0.0
+    busy["chunks"] = 0
     t0 = time.perf_counter()
     n_ext = n_hits = 0
     ms_search = ms_total = 0.0
@@ -238,8 +263,19 @@ def main():
         n_hits += st["n_hits"]
         ms_search += st["ms_search"]
         ms_total += st["ms_total"]
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0   # this rank's own steps, before it waits for the others
     fence()
     elapsed = time.perf_counter() - t0
+    # every rank's own time per step and what the slowest adds to the job ((max - mean) / max): the MAX below is `value`'s clock
+    rank_s = parallel.gather_floats(own_elapsed, dist)
+    rank_chunks = parallel.gather_floats(float(busy["chunks"]), dist)
+    if dist is not None and args.scaling == "strong":   # hits are per rank in a split job: the job's total
+        th = torch.tensor([float(n_hits)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(th, op=dist.ReduceOp.SUM)
+        n_hits_job = float(th.item())
+    else:
+        n_hits_job = float(n_hits) * world
     last_ctr = gidx.last_counters()   # of the last timed call (the flags of the counting pass are in `req`)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -288,7 +324,11 @@ def main():
         "value": value,
         "unit": "guides/s",
         # the same timed region in hits: what a repeat-rich genome is priced in (guides/s falls with the hits per guide)
-        "hits_per_s": n_hits * world / elapsed,
+        "hits_per_s": n_hits_job / elapsed,
+        "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in rank_s],
+        "rank_imbalance": parallel.imbalance(rank_s),
+        "dealt_in_chunks_of": args.deal if (args.scaling == "strong" and args.deal) else None,
+        "chunks_per_rank": [int(x) for x in rank_chunks] if (args.scaling == "strong" and args.deal) else None,
         "n_gpus": world,
         "steps": K,
         "warmup": args.warmup,
@@ -319,6 +359,10 @@ def main():
                      # kernel sources (hash checked), or null
                      "traffic_measured_in_this_run": False,
                      "traffic_source": traffic_src, "instruction_issue": issue,
+                     # `traffic` is FETCH_SIZE + WRITE_SIZE, and FETCH_SIZE tallies every read request as 64 bytes: the
+                     # requests themselves, and the bytes they brought (a PAM-pair block is one request of 128)
+                     **memory_side_fields(recorded_memory_side(args.workload, n_cnt, m), ms_search / (K * launches_per_step)),
+                     "request_ceiling": REQUEST_CEILING,
                      "alg_bytes_per_launch": alg_bytes_per_launch,
                      "avg_launch_ms": ms_search / (K * launches_per_step),
                      "guides_per_launch": n_cnt,
@@ -495,12 +539,19 @@ def stub_main(args):
     batch = args.batch or batch
     text, names, lengths = shared_genome(synth, args.workload, lengths, probs, dist, int(os.environ.get("LOCAL_RANK", "0")))
     batch_all = batch * world
-    if args.scaling == "strong":   # the same contiguous shards the GPU path takes
+    dealt = []
+    if args.scaling == "strong":   # the same contiguous shards - or chunks from the shared counter - the GPU path takes
         batch_all = batch
         b = parallel.shard_bounds(batch_all, world)
         all_seqs, all_pams, _, _ = synth.sample_guides(text, batch_all, seed=1000)
-        seqs, pams = all_seqs[b[rank]:b[rank + 1]], all_pams[b[rank]:b[rank + 1]]
-        batch = b[rank + 1] - b[rank]
+        if args.deal:
+            mine, _ = parallel.deal_chunks(lambda c, lo, hi: dealt.append((lo, hi)), batch_all, args.deal, "stub", dist)
+            pick = np.concatenate([np.arange(lo, hi) for lo, hi in dealt]) if dealt else np.zeros(0, np.int64)
+            seqs, pams = all_seqs[pick], all_pams[pick]
+            batch = int(pick.shape[0])
+        else:
+            seqs, pams = all_seqs[b[rank]:b[rank + 1]], all_pams[b[rank]:b[rank + 1]]
+            batch = b[rank + 1] - b[rank]
     else:
         seqs, pams, _, _ = synth.sample_guides(text, batch, seed=1000 + rank)
     acc = []
@@ -553,6 +604,57 @@ def recorded_traffic(workload, batch, m):
                 and rec.get("kernel_sha") == stamp):
             return rec["fetch_bytes"] + rec["write_bytes"], rec["source"], rec.get("issue")
     return None, None, None
+
+
+# What the random-request ceiling IS (tools/gather_calib.hip, profiles/r05_gather_calib*): every pattern that misses the L2
+# - 16-byte words, 64-byte blocks, 128-byte blocks of one load instruction - costs ONE L2 request and ONE read request to
+# the fabric (TCC_REQ = TCC_EA0_RDREQ = 1 per block) and runs at 4.8e10 requests per second from a 40 GB table, 5.7e10
+# from a table inside the 256 MB Infinity Cache, 1.8e11 and more from one inside the L2; confining a wave-instruction's 64
+# addresses to one 4 KB / 64 KB / 2 MB page changes nothing (not translation).  It is the rate at which the chip turns
+# L2 misses into DRAM row activations (8 stacks x 32 pseudo-channels, four activates per tFAW window) - a request for 128
+# bytes of one row costs what a request for 16 does.
+REQUEST_CEILING = {"per_s_hbm": 4.8e10, "per_s_infinity_cache": 5.7e10, "per_s_l2_resident_at_least": 1.76e11,
+                   "what": "L2-miss read requests (one per aligned block of up to 128 bytes per load instruction): DRAM row "
+                           "activations behind the fabric, not translation (tools/gather_calib.hip, profiles/r05_gather_calib.txt)"}
+
+
+def recorded_memory_side(workload, batch, m):
+    """the whole record of recorded_traffic's pass: fabric read requests and the bytes they brought (FETCH_SIZE tallies every
+    read request as 64 bytes, a 128-byte block's too: tools/gather_calib), VALU issue, share of wave cycles spent waiting"""
+    f = ROOT / "profiles" / "traffic.json"
+    if not f.exists():
+        return None
+    stamp = kernel_stamp()
+    for rec in json.loads(f.read_text()):
+        if rec["workload"] == workload and rec["batch"] == batch and rec["mismatches"] == m and rec.get("kernel_sha") == stamp:
+            return rec
+    return None
+
+
+def memory_side_fields(rec, launch_ms):
+    """roofline fields from a recorded PMC pass, priced on the launch time measured in THIS run"""
+    if not rec:
+        return {"traffic_requests": None, "traffic_bytes_corrected": None, "frac_hbm": None}
+    out = {"traffic_requests": rec.get("read_requests"), "traffic_bytes_corrected": None, "frac_hbm": None}
+    rd = rec.get("read_bytes_corrected")
+    if rd is None and rec.get("read_bytes_corrected_bounds"):
+        rd = rec["read_bytes_corrected_bounds"][1]
+        out["traffic_bytes_corrected_is_upper_bound"] = True
+        out["traffic_bytes_corrected_bounds"] = [b + rec["write_bytes"] for b in rec["read_bytes_corrected_bounds"]]
+    if rd is not None:
+        out["traffic_bytes_corrected"] = rd + rec["write_bytes"]
+        out["traffic_bytes_corrected_from"] = rec.get("read_bytes_corrected_from", "read requests x the block each brings") + " + WRITE_SIZE"
+        if launch_ms:
+            out["frac_hbm"] = out["traffic_bytes_corrected"] / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if rec.get("read_requests") and launch_ms:
+        out["requests_per_s"] = rec["read_requests"] / (launch_ms * 1e-3)
+        out["frac_of_request_ceiling"] = out["requests_per_s"] / REQUEST_CEILING["per_s_hbm"]
+    if rec.get("issue"):
+        i = rec["issue"]
+        out["valu_frac_of_issue_cycles"] = i["valu_wave_instructions"] * 4.0 / (1024 * 2.4e9 * i["duration_ms"] * 1e-3)
+        out["wait_any_share_of_wave_cycles"] = i.get("wait_any_share")
+    out["pmc_source"] = rec["source"]
+    return out
 
 
 def side_steps(torch, api, gidx, d_seqs, d_pams, batch, i, L, P, m, text, names, lengths):
@@ -653,6 +755,7 @@ def timed_row(torch, api, gidx, text, names, lengths, L, P, m, n_guides, steps, 
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     ctr = gidx.last_counters()
+    sh = gidx.last_sharing()
     el_enum = el - t_score
     return {"guides_per_step": n_guides, "mismatches": m, "steps": steps, "guides_per_s": n_guides * steps / el,
             "hits_per_s": hits / el, "hits_per_guide": hits / (n_guides * steps), "ms_per_step": el / steps * 1e3,
@@ -661,7 +764,10 @@ def timed_row(torch, api, gidx, text, names, lengths, L, P, m, n_guides, steps, 
             # what of the enumerate step (prepare .. locate, wall clock) is not the search kernel
             "non_search_share_of_enumerate": 1.0 - (ms_search / 1e3) / el_enum if el_enum > 0 else None,
             "ordered_per_guide_in_lds_tiles": ctr["ordered_in_tiles"], "tile_ordering_gave_up": ctr["tile_ordering_gave_up"],
-            "guides_redone": ctr["guides_redone"], "matches_max_per_item": ctr["matches_max_per_item"], "warmup_steps_ms": warm}
+            "guides_redone": ctr["guides_redone"], "matches_max_per_item": ctr["matches_max_per_item"], "warmup_steps_ms": warm,
+            # heavy items handed to idle waves (k_search's heavy instantiation, picked by the handle after a batch with heavy passes)
+            "heavy_instantiation": sh["queue_packages"] != 0, "shared_items": sh["shared_items"], "packages": sh["packages"],
+            "guides_ordered_device_wide_alone": sh["guides_ordered_device_wide_alone"]}
 
 
 def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P):
@@ -670,20 +776,46 @@ def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P):
     indexed, 20,000 guides at <= 3 mismatches (bench.py --workload hg38rep)."""
     rows = {}
     rows["hg38_20k_m6_cfd"] = timed_row(torch, api, gidx, text, names, lengths, L, P, 6, 20000, 3, True, 4242)
+    rows["hg38_20k_m6_cfd"]["roofline"] = row_roofline("hg38", 20000, 6, rows["hg38_20k_m6_cfd"])
     gidx.close()
-    t0 = time.time()
-    text2, names2, lengths2 = make_workload_genome(synth, "hg38rep", lengths, probs)
-    t_gen = time.time() - t0
-    t0 = time.time()
-    g2 = api.GenomeIndex.build(text2, device=torch.cuda.current_device())
-    torch.cuda.synchronize()
-    t_idx = time.time() - t0
-    try:
-        rows["hg38rep_20k_m3"] = dict(timed_row(torch, api, g2, text2, names2, lengths2, L, P, 3, 20000, 3, False, 1000),
-                                      genome_gen_s=round(t_gen, 1), index_build_s=round(t_idx, 1))
-    finally:
-        g2.close()
+    # the repeat-rich genome, and the one whose SINE-like family is Alu-like (1.2e6 copies at 2-15 %)
+    for wl, key, steps in (("hg38rep", "hg38rep_20k_m3", 3), ("hg38alu", "hg38alu_20k_m3", 2)):
+        t0 = time.time()
+        text2, names2, lengths2 = make_workload_genome(synth, wl, lengths, probs)
+        t_gen = time.time() - t0
+        t0 = time.time()
+        g2 = api.GenomeIndex.build(text2, device=torch.cuda.current_device())
+        torch.cuda.synchronize()
+        t_idx = time.time() - t0
+        try:
+            rows[key] = dict(timed_row(torch, api, g2, text2, names2, lengths2, L, P, 3, 20000, steps, False, 1000),
+                             genome_gen_s=round(t_gen, 1), index_build_s=round(t_idx, 1))
+            rows[key]["roofline"] = row_roofline(wl, 20000, 3, rows[key])
+        finally:
+            g2.close()
+        del text2
     return rows, None
+
+
+def row_roofline(workload, batch, m, row):
+    """the roofline of an extra row's dominant kernel (k_search): the memory side from the recorded PMC passes of
+    `bench.py --workload W --batch B --mismatches M` (tools/profile_round.sh, stamped with the kernel sources' hash),
+    priced on the launch time measured in this run; hits moved per second as the algorithmic side (16 bytes written per
+    match record, one context word and one row number gathered per record)"""
+    launch_ms = row["k_search_ms_per_step"]
+    rec = recorded_memory_side(workload, batch, m)
+    mem = memory_side_fields(rec, launch_ms)
+    hits = row["hits_per_guide"] * row["guides_per_step"]
+    alg = 16.0 * hits + 64.0 * (rec["read_requests"] if rec and rec.get("read_requests") else 0.0)
+    out = {"bound": "hbm", "kernel": "k_search" + (" (heavy instantiation)" if row.get("heavy_instantiation") else ""),
+           "avg_launch_ms": launch_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "achieved": (mem["traffic_bytes_corrected"] / (launch_ms * 1e-3) / 1e9) if mem.get("traffic_bytes_corrected") else None,
+           "frac": mem.get("frac_hbm"), "traffic": (rec["fetch_bytes"] + rec["write_bytes"]) if rec else None,
+           "alg_bytes_per_launch": alg if rec else None,
+           "alg_bytes_are": "16 B per match record written + 64 B per read request of the recorded pass (the requests ARE the "
+                            "algorithm's: every one is a table block, a context piece or a row gather it asks for)"}
+    out.update(mem)
+    return out
 
 
 def verify_last_batch(torch, gidx, d_seqs, d_pams, batch, i, L, P, m, text, seqs):

@@ -38,20 +38,24 @@ def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     text, _, _ = synth.make_genome([150_000], seed=6)
-    seqs, pams, _, _ = synth.sample_guides(text, 23, seed=2)   # odd count: uneven shards
+    seqs, pams, _, _ = synth.sample_guides(text, 23, seed=2)   # odd count: uneven chunks
     fn = oracle_enumerate_fn(text)
-    off, hits, stats = parallel.enumerate_sharded(fn, seqs, pams, dist=dist)
-    b = parallel.shard_bounds(23, world)
-    assert stats["n"] == b[rank + 1] - b[rank]
+    out_dir = os.path.dirname(out)
+    # chunks of 4 guides drawn from the shared counter: every rank writes the hit lists of what it drew to its own file
+    path, mine, busy = parallel.enumerate_dealt(fn, seqs, pams, out_dir, 4, "t1", dist=dist)
     el = parallel.timed_steps(lambda i: None, 2, 1, lambda: None, dist=dist)
     assert el >= 0
+    took = [None] * world
+    dist.all_gather_object(took, mine)
+    assert sorted(c for t in took for c in t) == list(range(6))      # every chunk exactly once
+    dist.barrier()
     if rank == 0:
         full_off, full_hits, _ = fn(seqs, pams)
+        off, hits = parallel.merge_chunk_files([os.path.join(out_dir, f"hits.rank{r}.gschunks") for r in range(world)], 23,
+                                               api.HIT_DTYPE)
         assert np.array_equal(off, full_off)
         assert np.array_equal(hits, full_hits)
         open(out, "w").write("ok %d" % len(full_hits))
-    else:
-        assert off is None
     dist.destroy_process_group()
 
 
@@ -59,13 +63,50 @@ def test_shard_bounds():
     assert parallel.shard_bounds(10, 4) == [0, 3, 6, 8, 10]
     assert parallel.shard_bounds(2, 4) == [0, 1, 2, 2, 2]
     assert parallel.shard_bounds(0, 2) == [0, 0, 0]
+    assert parallel.chunk_bounds(10, 4) == [(0, 4), (4, 8), (8, 10)]
+    assert parallel.chunk_bounds(0, 4) == []
+    assert abs(parallel.imbalance([1.0, 1.0, 2.0]) - (2.0 - 4.0 / 3.0) / 2.0) < 1e-12
 
 
-def test_world2_gloo_sharded_equals_unsharded(tmp_path):
+def test_world2_gloo_dealt_chunks_equal_the_whole_batch(tmp_path):
     out = tmp_path / "r0.txt"
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(out)), nprocs=2, join=True)
     assert out.read_text().startswith("ok")
+
+
+def _skew_worker(rank, world, port, out_dir):
+    """a job whose first stretch of guides is repeat-dense (ten times the cost per guide): contiguous shards leave one rank
+    with nearly all of the work; chunks drawn from the shared counter spread it"""
+    import json
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, chunk = 6400, 100
+    cost = np.where(np.arange(n) < n // 8, 10.0, 1.0) * 4e-5          # seconds per guide
+
+    def work(c, lo, hi):
+        time.sleep(float(cost[lo:hi].sum()))
+    dist.barrier()
+    mine, busy = parallel.deal_chunks(work, n, chunk, "skew", dist=dist)
+    dealt = parallel.gather_floats(busy, dist)
+    b = parallel.shard_bounds(n, world)
+    static = parallel.gather_floats(float(cost[b[rank]:b[rank + 1]].sum()), dist)
+    if rank == 0:
+        json.dump({"dealt": dealt, "static": static, "chunks": len(mine)}, open(os.path.join(out_dir, "skew.json"), "w"))
+    dist.destroy_process_group()
+
+
+def test_dealt_chunks_balance_a_skewed_job(tmp_path):
+    """world 2 and 4 on gloo: the imbalance (what the slowest rank adds to the job) stays within 10 % with chunks drawn from
+    the counter, where contiguous shards of the same job are 35-60 % out of balance"""
+    import json
+    for world in (2, 4):
+        port = 31500 + (os.getpid() + world) % 2000
+        mp.spawn(_skew_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+        r = json.load(open(tmp_path / "skew.json"))
+        assert parallel.imbalance(r["dealt"]) <= 0.10, r
+        assert parallel.imbalance(r["static"]) >= 0.30, r
 
 
 def _run_bench_stub(cmd, env_extra):
@@ -118,6 +159,11 @@ def test_bench_strong_scaling_splits_one_guide_set():
                           "--steps", "2", "--warmup", "1", "--workload", "saccer3", "--batch", "65", "--scaling", "strong"], {})
     assert j1["guides_per_rank"] == [65]
     assert sum(j2["guide_checksums"]) == j1["guide_checksums"][0]     # the same guides, split
+    # chunks of 10 guides from the shared counter instead of two shards: every guide on exactly one rank
+    jd = _run_bench_stub([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--workload", "saccer3", "--batch", "65", "--scaling", "strong", "--deal", "10"], {})
+    assert sum(jd["guides_per_rank"]) == 65 and all(g % 10 in (0, 5) for g in jd["guides_per_rank"])
+    assert sum(jd["guide_checksums"]) == j1["guide_checksums"][0]
     # weak scaling keeps --batch per rank
     jw = _run_bench_stub([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0",
                           "--workload", "saccer3", "--batch", "65"], {})
