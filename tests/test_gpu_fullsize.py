@@ -555,3 +555,104 @@ def test_hg38_out_of_memory_drops_derived_tables_and_redoes_the_batch(hg38):
     assert hg38.gidx.last_counters()["items_pair_tables"] == 0
     o3, h3 = device_result_to_host(hip, d_o, d_h, n4, st3["n_hits"])
     assert np.array_equal(o3, off) and h3.tobytes() == hits.tobytes()
+
+
+# ---- configs 4 and 5 beyond the reference leg's reach: committed checksums -------------------------------------
+# The sums below were written by this test's own first run on an MI355X box (round 5) - the same batches whose sampled
+# guides the tests above compare with the compiled reference line by line - and pin every offset, every hit record and
+# every specificity bit of the runs: a change in any kernel that moves one hit shows here.
+CONFIG4_TWO_CHROMOSOMES = {"candidates": 8_493_342, "hits": 110_009_853, "checksum": "9de46e73bf38e5e5"}
+CONFIG5_STREAM_100K = {"hits": 1_079_231_985, "checksum": "1d26cdb4bdf31a49"}
+
+
+def fold_batch(torch, hip, csum, d_off, d_hits, n, n_hits, d_spec=None):
+    """tools/config5_stream.py's checksum: hit records folded with their place, then the offsets and specificity bits"""
+    off = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    assert hip.hipMemcpy(off.data_ptr(), d_off, 8 * (n + 1), 3) == 0
+    step = 1 << 26
+    for h0 in range(0, n_hits, step):
+        m = min(step, n_hits - h0)
+        piece = torch.empty((m, 2), dtype=torch.int64, device="cuda")
+        assert hip.hipMemcpy(piece.data_ptr(), d_hits + 16 * h0, 16 * m, 3) == 0
+        w = torch.arange(h0, h0 + m, dtype=torch.int64, device="cuda") * 0x9E3779B1 + 12345
+        csum = (csum + int(((piece[:, 0] ^ piece[:, 1]) * w).sum().item())) & 0xFFFFFFFFFFFFFFFF
+        del piece, w
+    tail = int(d_spec.view(torch.int32).long().sum().item()) if d_spec is not None else 0
+    csum = (csum * 1099511628211 + int((off * torch.arange(1, n + 2, device="cuda")).sum().item()) + tail) & 0xFFFFFFFFFFFFFFFF
+    del off
+    return csum
+
+
+def test_config4_two_chromosomes_and_config5_stream_checksums(hg38):
+    """BASELINE config 4 on two chromosomes (every NGG candidate of chr21 and chr22 scanned on the device, 8.5 x 10^6
+    guides, enumerated from HBM at <= 3 mismatches in batches of 2^20) and config 5 as a stream (100,000 sampled guides at
+    <= 6 mismatches + CFD in batches of 20,000): hit totals and checksums equal the committed ones, every candidate finds
+    itself, and 128 candidates of chr22 give the compiled reference's CSV lines (chr21's and the sampled guides' lines are
+    compared above)."""
+    import torch
+    hip = _hip()
+    text = hg38.text
+    csum, total_hits, n_cand = 0, 0, 0
+    sub_seqs, sub_ids = None, None
+    for c in (20, 21):
+        c_off = int(sum(hg38.lengths[:c]))
+        d_chr = torch.from_numpy(np.ascontiguousarray(text[c_off:c_off + hg38.lengths[c]])).cuda()
+        km = api.generate_kmers(None, "NGG", 20, device=0, chrm_device_ptr=d_chr.data_ptr(), chrm_len=hg38.lengths[c])
+        try:
+            n_cand += km.n
+            for b0 in range(0, km.n, 1 << 20):
+                nb = min(1 << 20, km.n - b0)
+                d_off, d_hits, st = hg38.gidx.enumerate_device(km.seqs_ptr + b0 * 20, nb, 20, km.pams_ptr + b0 * 3, 3, mismatches=3)
+                assert st["n_hits"] >= nb
+                csum = fold_batch(torch, hip, csum, d_off, d_hits, nb, st["n_hits"])
+                total_hits += st["n_hits"]
+            if c == 21:
+                kseqs, kpams, kpos, ksense = km.to_host()
+                pick = np.sort(np.random.default_rng(8).choice(kseqs.shape[0], 128, replace=False))
+                sub_seqs = kseqs[pick]
+                sub_ids = [f"chr22:{int(kpos[j])}:{chr(ksense[j])}" for j in pick]
+        finally:
+            km.close()
+        del d_chr
+    got4 = {"candidates": n_cand, "hits": total_hits, "checksum": f"{csum:016x}"}
+    # config 5's stream
+    n, batch = 100_000, 20_000
+    seqs, pams, _, _ = synth.sample_guides(text, n, seed=1000)
+    d_s, d_p = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+    csum5, hits5 = 0, 0
+    for lo in range(0, n, batch):
+        d_off, d_hits, st = hg38.gidx.enumerate_device(d_s.data_ptr() + lo * 20, batch, 20, d_p.data_ptr() + lo * 3, 3, mismatches=6)
+        d_spec = torch.empty(batch, dtype=torch.float32, device="cuda")
+        hg38.gidx.score_device(hg38.gs, d_s.data_ptr() + lo * 20, batch, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
+        csum5 = fold_batch(torch, hip, csum5, d_off, d_hits, batch, st["n_hits"], d_spec)
+        hits5 += st["n_hits"]
+        del d_spec
+    got5 = {"hits": hits5, "checksum": f"{csum5:016x}"}
+    print("config 4 (chr21 + chr22):", got4, " config 5 stream (100 k):", got5)
+    assert got4 == CONFIG4_TWO_CHROMOSOMES, (got4, got5)
+    assert got5 == CONFIG5_STREAM_100K, (got4, got5)
+    got, _ = hg38.product_lines(sub_ids, sub_seqs, 3)
+    header, want = hg38.run_reference("c22", sub_ids, sub_seqs, 3, os.cpu_count() or 8)
+    assert len(got) == len(want) and got == want
+
+
+def test_hg38_reference_index_files_open_through_the_importer(hg38):
+    """SURVEY 8a row a12 at the size users download it: the <prefix>.forward / .reverse files the reference leg reads
+    (csa_wt<wt_huff<>,64,8192>::serialize, sdsl/include/sdsl/csa_wt.hpp:372-391; 1.48 GB per strand, n > 2^31, 32-bit-wide
+    samples) opened through gs_index_open_sdsl - wavelet tree expanded to the BWT, inverted to the text on the host's
+    threads, device layout rebuilt - give the SAME hit bytes as the index built from the text, for 4,096 guides.
+    LAST in this module: the built index is closed first (two hg38-sized indexes do not share the HBM with their
+    tables and workspace); the fixture's teardown closes the imported one."""
+    prefix = hg38.reference_prefix()
+    seqs, pams, _, _ = synth.sample_guides(hg38.text, 4096, seed=1001)
+    off, hits, _ = hg38.gidx.enumerate(seqs, pams, mismatches=3)
+    n_bytes = hg38.gidx.device_bytes
+    hg38.gidx.close()
+    t0 = time.time()
+    hg38.gidx = api.GenomeIndex.open_sdsl(prefix, device=0)
+    t_import = time.time() - t0
+    print(f"gs_index_open_sdsl at hg38 size: {t_import:.1f} s ({os.path.getsize(prefix + '.forward') / 1e9:.2f} GB per strand)")
+    assert hg38.gidx.genome_length == hg38.text.shape[0]
+    off2, hits2, _ = hg38.gidx.enumerate(seqs, pams, mismatches=3)
+    assert np.array_equal(off, off2) and hits.tobytes() == hits2.tobytes()
+    assert t_import < 600 and n_bytes > 0
