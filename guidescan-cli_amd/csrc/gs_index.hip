@@ -736,7 +736,7 @@ static void scan_n_runs(const uint8_t *text, uint64_t len, std::vector<gs_nrun> 
 
 /* ---------------- C-ABI: index lifecycle -------------------------------------- */
 static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t *sa_fwd,
-                              const uint32_t *sa_rev, int device, gs_index **out, gs_status bad_sa = GS_ERR_ARG) {
+                              const uint32_t *sa_rev, int device, gs_index **out, gs_status bad_sa = GS_ERR_ARG, bool sa_on_device = false) {
   if (!text || !out || len < 1) return GS_ERR_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
@@ -781,7 +781,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
     const uint32_t *given = s == 0 ? sa_fwd : sa_rev;
     const uint8_t *d_t = s == 0 ? d_fwd : d_rev;
     if (given) {
-      GS_HIP(hipMemcpy(d_sa, given, 4 * n, hipMemcpyHostToDevice));
+      GS_HIP(hipMemcpy(d_sa, given, 4 * n, sa_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
       /* a suffix array from outside (a file, the caller): every value in range and none twice, or no
        * table is derived from it - the builders read text[sa[r] - j] without looking */
       uint64_t bad = 0;
@@ -809,6 +809,15 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
 extern "C" gs_status gs_index_build(const uint8_t *text, uint64_t len, int device, gs_index **out) {
   try {
     return build_common(text, len, nullptr, nullptr, device, out);
+  } catch (const std::bad_alloc &) {
+    return GS_ERR_NOMEM;
+  }
+}
+/* suffix arrays that are in device memory already (the importer of the reference's index files, gs_sdsl_import.hip) */
+gs_status gs_build_from_device_sa(const uint8_t *text, uint64_t len, const uint32_t *d_sa_fwd, const uint32_t *d_sa_rev, int device, gs_index **out) {
+  if (!d_sa_fwd || !d_sa_rev) return GS_ERR_ARG;
+  try {
+    return build_common(text, len, d_sa_fwd, d_sa_rev, device, out, GS_ERR_FORMAT, true);
   } catch (const std::bad_alloc &) {
     return GS_ERR_NOMEM;
   }

@@ -81,9 +81,9 @@ typedef struct {
  * n_ext counts only the extensions actually executed below the table depth. */
 #define GS_FLAG_FAITHFUL_WALK 2u
 /* Measurement only: run the counting instantiation of the search kernel, which tallies the distinct
- * 64-byte lines each of its load instructions asks for (gs_index_last_counters; with GS_COUNT_SHIFT=7 in the
- * environment: 128-byte blocks, what the memory system serves as one random request).  Same results,
- * slower; never set in a timed call. */
+ * 64-byte lines each of its load instructions asks for (gs_index_last_counters; with the handle's switch
+ * GS_COUNT_SHIFT=7 - gs_index_set_option - 128-byte blocks, what the memory system serves as one random request).
+ * Same results, slower; never set in a timed call. */
 #define GS_FLAG_COUNT_REQUESTS 4u
 /* Also return, per guide, the number of hits BEFORE duplicate sequences are dropped
  * (gs_result_view.raw_hits): the quantity the reference's --threshold filter compares with 1
@@ -139,10 +139,14 @@ gs_status gs_index_build_with_sa(const uint8_t *text, uint64_t len, const uint32
 
 /* Import the reference's on-disk index: <prefix>.forward, <prefix>.reverse
  * (sdsl::csa_wt<wt_huff<>,64,8192>::serialize, sdsl/include/sdsl/csa_wt.hpp:372-382).
- * Replaces sdsl::load_from_file (src/guidescan.cxx:198-208). */
+ * Replaces sdsl::load_from_file (src/guidescan.cxx:198-208).  Both files are turned into text AND suffix array on the
+ * device - BWT by wavelet-tree access, LF walks from the SA samples, every step writing text[q - 1] and SA[row] - so no
+ * suffix sort runs; .reverse must be the index of reverse_complement(.forward's text) (src/guidescan.cxx:146-157),
+ * else GS_ERR_FORMAT.  Without a .reverse file (or with more than 16 distinct symbols) .forward's text is recovered on
+ * the host and both strands are built from it. */
 gs_status gs_index_open_sdsl(const char *prefix, int device, gs_index **out);
-/* The genome text stored in one reference index file (BWT inverted on the host); what
- * gs_index_open_sdsl feeds to the GPU builder.  *text is malloc'ed: release with gs_free. */
+/* The genome text stored in one reference index file (BWT inverted on the host: the importer's host path).
+ * *text is malloc'ed: release with gs_free. */
 gs_status gs_sdsl_extract_text(const char *index_file, uint8_t **text, uint64_t *len);
 
 /* Native index file: both suffix arrays of a built index (4 bytes per row and strand, with the text's

@@ -204,6 +204,51 @@ def test_literal_symbols_match_literally():
         oidx.close()
 
 
+def test_reference_index_files_on_the_device_and_damaged_ones(toy_gpu, tmp_path):
+    """gs_index_open_sdsl builds text and suffix arrays of both strands from the reference's files on the device, without
+    a suffix sort (gs_sdsl_import.hip: wavelet-tree access, LF walks from the file's own samples): the index answers as the
+    one built from the text.  A damaged file - eight bytes flipped anywhere in either file - is GS_ERR_FORMAT / _IO /
+    _UNSUPPORTED or, where the flip hit bytes the path does not use (the inverse samples), an index with the same answers:
+    never a fault, never other hits (the walks trust the file's samples: the arrays are checked as a permutation and,
+    at sampled places, as ordering the text)."""
+    toy, oidx, gidx = toy_gpu
+    golden = ol.ROOT / "tests" / "golden" / "toy"
+    group = [k for k in toy["kmers"] if len(k.pam) == 3][:16]
+    seqs = np.array([list(k.sequence.encode()) for k in group], dtype=np.uint8)
+    pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8)
+    off0, hits0, _ = gidx.enumerate(seqs, pams, mismatches=3)
+    imp = api.GenomeIndex.open_sdsl(golden / "toy.idx", device=0)
+    try:
+        off1, hits1, _ = imp.enumerate(seqs, pams, mismatches=3)
+    finally:
+        imp.close()
+    assert off1.tobytes() == off0.tobytes() and hits1.tobytes() == hits0.tobytes()
+    good = {e: (golden / f"toy.idx.{e}").read_bytes() for e in ("forward", "reverse")}
+    rng = np.random.default_rng(11)
+    opened = refused = 0
+    for trial in range(48):
+        which = ("forward", "reverse")[trial & 1]
+        b = bytearray(good[which])
+        at = int(rng.integers(0, len(b) - 8))
+        for j in range(8):
+            b[at + j] ^= 0xFF
+        for e in ("forward", "reverse"):
+            (tmp_path / f"d.idx.{e}").write_bytes(bytes(b) if e == which else good[e])
+        try:
+            ix = api.GenomeIndex.open_sdsl(tmp_path / "d.idx", device=0)
+        except api.GsError as e:
+            assert e.status in (4, 5, 6), (trial, which, at, e.status)
+            refused += 1
+            continue
+        try:
+            off2, hits2, _ = ix.enumerate(seqs, pams, mismatches=3)
+        finally:
+            ix.close()
+        assert off2.tobytes() == off0.tobytes() and hits2.tobytes() == hits0.tobytes(), (trial, which, at)
+        opened += 1
+    assert refused >= 8, (opened, refused)
+
+
 def test_empty_batch(toy_gpu):
     toy, oidx, gidx = toy_gpu
     offsets, hits, stats = gidx.enumerate(np.empty((0, 20), np.uint8), np.empty((0, 3), np.uint8))
