@@ -572,13 +572,14 @@ def stub_main(args):
 
 
 def kernel_stamp():
-    """sha256 of the sources that decide k_search's memory traffic: the kernel itself (gs_search.hip from
-    its argument struct to the end of its wrappers), the device helpers, the device layout of the index
-    (struct gs_pairtab_dev, gs_strand_dev) and its builders"""
+    """sha256 of the sources that decide k_search's memory traffic: the kernel itself (gs_search.hip up to the end of
+    its wrappers, gs_kernels.h: its argument struct and launch geometry), the device helpers, the device layout of the
+    index (struct gs_pairtab_dev, gs_strand_dev) and its builders"""
     import hashlib
     h = hashlib.sha256()
     src = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_search.hip").read_text()
-    h.update(src[src.index("struct gs_search_args {"):src.index("/* ---- prepare: ASCII")].encode())
+    h.update(src[:src.index("/* ---- prepare: ASCII")].encode())
+    h.update((ROOT / "guidescan-cli_amd" / "csrc" / "gs_kernels.h").read_bytes())
     com = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_common.h").read_text()
     h.update(com[com.index("struct gs_pairtab_dev {"):com.index("struct gs_strand {")].encode())  # the device layout
     h.update((ROOT / "guidescan-cli_amd" / "csrc" / "gs_device.h").read_bytes())

@@ -169,7 +169,7 @@ struct gs_index {
   gs_buffer w_guides, w_slots, w_counts, w_nmatch, w_nhits, w_offsets, w_hits, w_misc, w_blocksums,
       w_grec, w_flags, w_raw, w_ovf_list, w_grec2, w_slots2, w_counts2, w_nmatch2, w_nhits2, w_h_off, w_h_tmp,
       /* device-wide ordering of guides with more matches than an LDS sort holds (gs_search.hip) */
-      w_b_src, w_b_cnt, w_b_prefix, w_b_recs, w_b_w0, w_b_w0b, w_b_w1, w_b_idx, w_b_idxb, w_b_keep, w_b_keeps,
+      w_b_src, w_b_cnt, w_b_prefix, w_b_recs, w_b_w0, w_b_w0b, w_b_idx, w_b_idxb, w_b_keep, w_b_keeps,
       w_b_rows, w_b_rowss, w_b_redo_pos, w_b_s, w_b_tab,
       w_score, w_score_io, w_score_tmp, /* gs_score.hip: score tables + chromosome prefix sums; host-pointer staging */
       /* overflow arena of k_search (gs_search.hip): records, chunk owners + sequence numbers, chunks per item */

@@ -613,8 +613,6 @@ ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                ("GS_TILE_NO_PACK", "1"),
                # the device-wide ordering (what serves batches the per-guide tile ordering does not take):
                ("GS_NO_TILE_ORDER", "1"),
-               # ... in the form that serves sort words beyond 64 bits (raw keys)
-               ("GS_NO_TILE_ORDER", "1", "GS_BIG_ORDER_V1", "1"),
                # the one-word form as one sort + rows ordered inside the runs of equal words, whatever their length
                # (the default gives up on runs beyond 32 records and sorts by row first), and the two sorts from the start
                ("GS_NO_TILE_ORDER", "1", "GS_BIG2_SHORT", "1000000"),
@@ -630,7 +628,7 @@ ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                ("GS_ARENA_CHUNKS", "2", "GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
                ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_SHARE_QUEUE", "4"),
                ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_NO_TILE_ORDER", "1")]
-ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "tiles-unpacked", "device-wide", "raw-key-order", "one-sort-and-runs", "composite-sort",
+ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "tiles-unpacked", "device-wide", "one-sort-and-runs", "composite-sort",
              "two-sorts", "never-shared", "every-pass-shared", "shared-arena-exhausted", "shared-queue-of-four", "shared-device-wide"]
 
 
