@@ -607,7 +607,7 @@ class GenomeIndex:
         out = (C.c_uint64 * 8)()
         _check(lib().gs_index_last_sharing(self._h, out))
         return dict(shared_items=int(out[0]), packages=int(out[1]), queue_packages=int(out[2]), tickets=int(out[3]),
-                    guides_ordered_device_wide_alone=int(out[4]))
+                    guides_ordered_device_wide_alone=int(out[4]), launches_behind=int(out[5]), form=int(out[6]))
 
     def last_counters(self):
         """k_search's counters of the last enumerate_device call (see gs_index_last_counters)"""

@@ -192,6 +192,8 @@ struct gs_index {
   uint64_t seen_key[8] = {0};
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_tile = nullptr;  /* gs_tileorder_run: behind the copy of the slow-tile counts */
+  hipStream_t st_help = nullptr; /* lowest priority: the launch that runs published packages next to the search launch (run_search) */
+  hipEvent_t ev_help[2] = {nullptr, nullptr};
   uint32_t *h_pin = nullptr;     /* 256 bytes of page-locked host memory: small results of asynchronous copies that are read behind an event */
   std::atomic<uint64_t> lock_owner{0}; /* gs_index_lock: the thread that holds the handle (0: none), and how many times */
   uint32_t lock_depth = 0;

@@ -555,6 +555,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
     GS_HIP(hipMemsetAsync(d_work + 5, 0, 4, st));
     GS_HIP(hipMemsetAsync(d_work + 8, 0, 4, st));
+    GS_HIP(hipMemsetAsync(d_work + 9, 0x80, 4, st)); /* (0x80808080: what a launch without items finds in its work counter) */
     if (with_arena) {
       GS_HIP(hipMemsetAsync(d_arena_next, 0, 4, st));
       /* every chunk empty until a wave says whose it is: waves reserve several per visit to the counter (k_search) */
@@ -563,7 +564,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     gs_search_args sa;
     memset(&sa, 0, sizeof(sa));
-    if (with_arena) ix->last_share[0] = ix->last_share[1] = ix->last_share[2] = ix->last_share[3] = ix->last_share[4] = 0; /* (of the main pass: a redo shares nothing) */
+    if (with_arena) ix->last_share[0] = ix->last_share[1] = ix->last_share[2] = ix->last_share[3] = ix->last_share[4] = ix->last_share[5] = ix->last_share[6] = 0; /* (of the main pass: a redo shares nothing) */
     sa.sd[0] = ix->strand[0].d;
     sa.sd[1] = ix->strand[1].d;
     sa.slots = slots;
@@ -656,16 +657,30 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (const char *e = gs_opt(ix, "GS_SHARE_MIN")) share_min = (uint32_t)std::max(0l, atol(e));
     if (const char *e = gs_opt(ix, "GS_SHARE_MAX")) share_max = (uint32_t)std::max(128l, atol(e));
     sa.share_min = share_min ? share_min : 0xFFFFFFFFu; /* (every instantiation counts the passes that large: gs_search_args::hpass) */
-    /* the heavy instantiation: asked for (GS_HEAVY=1 / 0), or the last batch of this shape on this handle showed heavy
-     * verification passes - one per sixteen items, or any at all in a batch of at most 64 items per wave slot of the chip
-     * (beyond that the heavy items spread over the waves by themselves, and the plain instantiation is the faster one
-     * where such passes are rare: 1 M guides at m <= 3 on a genome without repeat families, 22 ms against 32 - the
-     * heavy form's second level spills registers; m <= 6, which has none: 61 against 73-80) */
-    bool heavy = with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0 && mismatches < 8 &&
-                 ix->seen_key[mismatches] == (((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START)) &&
-                 ix->seen_hpass[mismatches] != 0 &&
-                 (16.0 * (double)ix->seen_hpass[mismatches] >= (double)ix->seen_items[mismatches] || 2 * (uint64_t)ng <= 64ull * (uint64_t)cus * 32u);
-    if (const char *e = gs_opt(ix, "GS_HEAVY")) heavy = atol(e) != 0 && with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0;
+    /* Three forms.  Plain: every item with its wave.  Heavy, one launch (GS_HEAVY=1): heavy verification passes are
+     * published and the waves that ran out of items run them - the second level of the verification four rows per lane; twice the
+     * code, registers in scratch: 32 ms against 22 on 1 M guides of a genome without repeat families.  Split (GS_SPLIT_SHARE=2): the
+     * plain form publishes and leaves (+4 % on that batch), the heavy form - no items of its own - runs the packages in a launch
+     * of the lowest priority beside it, taking the slots the first launch's waves leave.  By itself a handle picks from what the
+     * last batch of the same shape showed (gs_search_args::hpass): no heavy pass - plain; one per sixteen items, or any in a
+     * batch of at most 64 items per wave slot - heavy (a repeat-rich batch: 9.3 ms per 20,000 guides against 9.7 split, 16.2
+     * plain); fewer - split (1 M light guides + 8 of an Alu-like family, 650,000 hits each: 26.7 ms against 33.6 plain, 32.7 heavy). */
+    const bool share_ok = with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0;
+    const bool seen = mismatches < 8 &&
+                      ix->seen_key[mismatches] == (((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START)) &&
+                      ix->seen_hpass[mismatches] != 0;
+    const bool dense = seen && (16.0 * (double)ix->seen_hpass[mismatches] >= (double)ix->seen_items[mismatches] ||
+                                2 * (uint64_t)ng <= 64ull * (uint64_t)cus * 32u);
+    bool heavy = share_ok && dense;
+    uint32_t split = share_ok && seen && !dense ? 2u : 0u; /* 1: the second launch behind the first; 3: before it (tests) */
+    if (const char *e = gs_opt(ix, "GS_HEAVY")) {
+      heavy = atol(e) != 0 && share_ok;
+      split = 0u;
+    }
+    if (const char *e = gs_opt(ix, "GS_SPLIT_SHARE")) {
+      split = share_ok ? (uint32_t)std::min(3l, std::max(0l, atol(e))) : 0u;
+      if (split) heavy = false;
+    }
     const uint32_t weu = walk ? GS_WAVES_EU : heavy ? GS_WAVES_EU_HEAVY : spec ? GS_WAVES_EU_PD : GS_WAVES_EU_FAST;
     if (per_cu > weu) per_cu = weu; /* 4 SIMDs x weu waves = weu four-wave workgroups per CU */
     uint32_t grid = (uint32_t)cus * per_cu;
@@ -677,7 +692,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       fprintf(stderr, "[gs] k_search (%s): grid %u x %u threads, LDS %zu B per workgroup, %d workgroups per CU resident\n",
               walk ? "walk" : "table", grid, WAVE * SEARCH_WAVES, lds_wg, occ);
     }
-    if (heavy) {
+    if (heavy || split) {
       uint64_t qcap = ix->shq_packages;
       if (const char *e = gs_opt(ix, "GS_SHARE_QUEUE")) qcap = (uint64_t)std::max(1ll, atoll(e));
       if (qcap > (1ull << 20)) qcap = 1ull << 20; /* 1.2 GB of packages */
@@ -702,6 +717,15 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         (void)hipGetLastError(); /* no room for the queue: every item stays with its wave */
       }
     }
+    gs_search_args sh_args;
+    uint32_t sh_grid = 0;
+    auto launch_helpers = [&](hipStream_t hs) {
+      if (spec)
+        hipLaunchKernelGGL(k_search_heavy_pd, dim3(sh_grid), dim3(WAVE * SEARCH_WAVES), dyn, hs, sh_args);
+      else
+        hipLaunchKernelGGL(k_search_heavy, dim3(sh_grid), dim3(WAVE * SEARCH_WAVES), dyn, hs, sh_args);
+    };
+    if (with_arena) ix->last_share[6] = sa.shq == nullptr ? 0u : heavy ? 1u : 2u;
     GS_HIP(hipEventRecord(ix->ev[1], st));
     for (uint32_t c = 0; c < n_chunks; c++) { /* four PAM patterns per pass, appending to the same slots */
       sa.guides = guides + (size_t)c * ng;
@@ -711,7 +735,35 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         hipLaunchKernelGGL(k_search_walk, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (spec && count_req)
         hipLaunchKernelGGL(k_search_count_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
-      else if (spec && sa.shq != nullptr)
+      else if (split && sa.shq != nullptr) {
+        /* the launch without items: on a stream of the lowest priority beside the search launch (its workgroups get the
+         * slots the search launch's waves leave), or behind it on the same stream */
+        sh_args = sa;
+        sh_args.helper_only = 1u;
+        sh_args.work = d_work + 9; /* a counter that is past the items from the start */
+        sh_grid = (uint32_t)cus * std::min<uint32_t>((uint32_t)(160u * 1024u / lds_wg), GS_WAVES_EU_HEAVY);
+        const bool side = split == 2u;
+        if (side && !ix->st_help) {
+          int lo = 0, hi = 0;
+          GS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+          GS_HIP(hipStreamCreateWithPriority(&ix->st_help, hipStreamNonBlocking, lo));
+          for (hipEvent_t &e : ix->ev_help) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        if (side) { /* the queue's control words are zeroed: the other stream may start */
+          GS_HIP(hipEventRecord(ix->ev_help[0], st));
+          GS_HIP(hipStreamWaitEvent(ix->st_help, ix->ev_help[0], 0));
+        }
+        if (split == 3u) launch_helpers(st); /* (tests: a launch that comes too early leaves at once, everything is left for the one behind) */
+        if (spec)
+          hipLaunchKernelGGL(k_search_pub_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+        else
+          hipLaunchKernelGGL(k_search_pub, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
+        if (split != 3u) launch_helpers(side ? ix->st_help : st);
+        if (side) {
+          GS_HIP(hipEventRecord(ix->ev_help[1], ix->st_help));
+          GS_HIP(hipStreamWaitEvent(st, ix->ev_help[1], 0));
+        }
+      } else if (spec && sa.shq != nullptr)
         hipLaunchKernelGGL(k_search_heavy_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (sa.shq != nullptr)
         hipLaunchKernelGGL(k_search_heavy, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
@@ -729,6 +781,17 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (d_shctl) GS_HIP(hipMemcpyAsync(h_ctl, d_shctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
+    if (d_shctl && split && sh_grid != 0u && h_ctl[32] < h_ctl[0] && ((const uint32_t *)(h7 + 16))[5] == 0u) {
+      /* packages nobody ran: the launch without items was on the chip before the one it serves and left (k_search_body's
+       * first lines) - again, behind it */
+      launch_helpers(st);
+      GS_HIP(hipEventRecord(ix->ev[2], st));
+      GS_HIP(hipMemcpyAsync(h7, d_stats, sizeof(h7), hipMemcpyDeviceToHost, st));
+      GS_HIP(hipMemcpyAsync(h_ctl, d_shctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
+      GS_HIP(hipStreamSynchronize(st));
+      GS_HIP(hipGetLastError());
+      ix->last_share[5]++;
+    }
     if (d_shctl && sa.sh_prof) {
       const unsigned long long *pr = (const unsigned long long *)(h_ctl + 104);
       const double us = 0.01, nw = (double)sa.n_waves;

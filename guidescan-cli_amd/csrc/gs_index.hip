@@ -977,6 +977,9 @@ extern "C" void gs_index_close(gs_index *ix) {
   for (int i = 0; i < 4; i++)
     if (ix->ev[i]) hipEventDestroy(ix->ev[i]);
   if (ix->ev_tile) hipEventDestroy(ix->ev_tile);
+  for (hipEvent_t e : ix->ev_help)
+    if (e) hipEventDestroy(e);
+  if (ix->st_help) hipStreamDestroy(ix->st_help);
   if (ix->h_pin) hipHostFree(ix->h_pin);
   gs_pairtab_free(ix, 0);
   gs_pairtab_free(ix, 1);

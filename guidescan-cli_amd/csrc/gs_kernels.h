@@ -140,6 +140,7 @@ struct gs_search_args {
    * [0] first wave's start (min), [1] last wave leaving its items (max), [2] last wave's exit (max), [3] sum of the
    * waves' item phases, [4] of their helper episodes, [5] of their waits for a package, [6] episodes */
   uint32_t sh_prof;
+  uint32_t helper_only; /* a launch that has no items of its own: its waves run packages until the OTHER launch's n_waves have left their items */
 };
 #define SHQ_PKG 72u /* uint4 per package: header + 64 descriptors, padded to nine 128-byte lines */
 #define SH_NONE 0xFFFFFFFFu
@@ -347,6 +348,8 @@ __global__ void k_search_fast_pd(gs_search_args a);
 __global__ void k_search_count_pd(gs_search_args a);
 __global__ void k_search_heavy(gs_search_args a);
 __global__ void k_search_heavy_pd(gs_search_args a);
+__global__ void k_search_pub(gs_search_args a);
+__global__ void k_search_pub_pd(gs_search_args a);
 __global__ void k_prepare(gs_prep_args a);
 
 /* ---- gs_recipes.hip (host) ---- */

@@ -58,8 +58,13 @@ __device__ __forceinline__ const T *own_sgprs(const T *p) {
   return (const T *)(const T __attribute__((address_space(1))) *)(((uint64_t)hi << 32) | lo);
 }
 
-template <bool CNT, bool WALK, bool SPEC = false, bool HEAVY = false>
+/* SHARE: 0 - every item stays with its wave; 1 (HEAVY) - heavy verification passes are published as packages AND the waves
+ * that ran out of items run them (one launch: a repeat-rich batch); 2 - published only: the waves leave when the items are
+ * taken, and the packages are run by a launch of the HEAVY form that has no items of its own (gs_search_args::helper_only)
+ * on a second, low-priority stream: it fills the slots the first launch's waves leave behind */
+template <bool CNT, bool WALK, bool SPEC = false, int SHARE = 0>
 __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk) {
+  constexpr bool HEAVY = SHARE == 1, PUB = SHARE != 0;
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
   /* Where a path lives in the 64-bit word the search carries next to a seed or a hit.  The walking variant packs
    * the node's step, PAM pattern and fan-out flag above it (node meta, top of the file): 52 path bits, key = path << 8.
@@ -123,7 +128,15 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
    * microsecond chip-wide (MI355X_MICROARCH.md, dequeue), so a counter bumped once per item held a launch of
    * 2 M items at 22.9 ms whatever the items did (measured with the seeding switched off: 22.9 of 26.5 ms) */
   uint32_t item_next = 0, item_end = 0;
-  const bool sharing = HEAVY && a.shq != nullptr;
+  const bool sharing = PUB && a.shq != nullptr;
+  if constexpr (SHARE == 2) { /* the launch with the items is resident: the launch without may wait for it */
+    if (sharing && lane == 0) st_agent(&a.shq_ctl[65], 1u);
+  }
+  if constexpr (HEAVY) {
+    /* a launch without items that got onto the chip BEFORE the one it serves must not hold its slots (its waves would wait
+     * for waves that cannot start): it leaves, and the host runs what it left undone behind the other launch */
+    if (sharing && a.helper_only && __builtin_amdgcn_readfirstlane(ld_agent(&a.shq_ctl[65])) == 0u) return;
+  }
 #ifdef GS_SH_PROFILE
   unsigned long long *const prof = (HEAVY && a.sh_prof) ? (unsigned long long *)(a.shq_ctl + 104) : nullptr;
 #else
@@ -142,8 +155,9 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       base = __builtin_amdgcn_readfirstlane(base);
       if (base >= a.n_items) {
         if (!sharing) break; /* exit condition every wave reaches */
+        if (lane == 0 && !a.helper_only) atomicAdd(&a.shq_ctl[64], 1u); /* this wave reserves no package any more */
+        if constexpr (!HEAVY) break; /* (published only: the packages belong to the other launch) */
         items_done = true;
-        if (lane == 0) atomicAdd(&a.shq_ctl[64], 1u); /* this wave reserves no package any more */
         if (prof != nullptr) {
           const unsigned long long t = wall_clock64();
           if (lane == 0) {
@@ -404,7 +418,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       if (!R) return;
       const uint32_t excl = incl - vgrp;
       if (!WALK && R >= a.share_min) n_hpass++;
-      if constexpr (HEAVY) {
+      if constexpr (PUB) {
         /* ---- a heavy pass is handed to the waves that have run out of items (gs_search_args::shq) ---- */
         if (sharing && !helper && R >= a.share_min) {
           uint32_t sid = __builtin_amdgcn_readfirstlane(wmisc[3]);
@@ -1479,7 +1493,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
       /* (a shared item: its number instead of the last chunk - nobody appends to it - for k_share_dir/fix) */
       const uint32_t sid = __builtin_amdgcn_readfirstlane(wmisc[3]);
-      if (lane == 0) a.nchunk[slot] = make_uint2(nch, (HEAVY && sid < a.sh_max) ? 0x80000000u | sid : last);
+      if (lane == 0) a.nchunk[slot] = make_uint2(nch, (PUB && sid < a.sh_max) ? 0x80000000u | sid : last);
       if (lane < 8u) a.cls[(size_t)slot * 8u + lane] = wmisc[4u + lane];
       if (n_match > item_cap && n_match - item_cap > (nch << ARENA_SHIFT)) n_fail++;
     }
@@ -1526,8 +1540,11 @@ GS_DEF_SEARCH(k_search_count_pd, true, false, true, GS_WAVES_EU_PD)
  * heavy verification passes are handed to the waves that ran out of items (gs_search_args::shq) and the second level of the
  * verification keeps GS_VU rows per lane in flight.  The same results; on a genome without such items the plain forms are faster
  * (1 M guides at m <= 3: 21 ms against 28-32 - the second level is rare there and its unrolled form costs instructions and registers). */
-GS_DEF_SEARCH(k_search_heavy, false, false, false, GS_WAVES_EU_HEAVY, true)
-GS_DEF_SEARCH(k_search_heavy_pd, false, false, true, GS_WAVES_EU_HEAVY, true)
+GS_DEF_SEARCH(k_search_heavy, false, false, false, GS_WAVES_EU_HEAVY, 1)
+GS_DEF_SEARCH(k_search_heavy_pd, false, false, true, GS_WAVES_EU_HEAVY, 1)
+/* the plain forms that publish their heavy passes and leave (SHARE = 2) */
+GS_DEF_SEARCH(k_search_pub, false, false, false, GS_WAVES_EU_FAST, 2)
+GS_DEF_SEARCH(k_search_pub_pd, false, false, true, GS_WAVES_EU_PD, 2)
 
 /* ---- prepare: ASCII -> packed records (process.hpp:51-63) ------------------ */
 __device__ __forceinline__ int base_code(uint8_t c) {

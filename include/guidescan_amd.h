@@ -176,7 +176,10 @@ gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]);
 /* The last batch's heavy items (DESIGN.md sections 5.1, 5.3): [0] items of which at least one verification pass was
  * handed to other waves, [1] packages reserved in the queue, [2] packages the queue holds, [3] tickets the helping waves
  * drew; [4] guides with an item of more than 2^20 match records, which the per-guide tile ordering leaves to the
- * device-wide ordering - alone, the rest of the batch stays in tiles; [5..7] zero. */
+ * device-wide ordering - alone, the rest of the batch stays in tiles; [5] launches of the package-running form BEHIND the
+ * search launch (the one beside it came too early and left); [6] the form the search ran in: 0 every item with its wave,
+ * 1 one launch that publishes and helps, 2 two launches (the plain form publishes, the heavy form beside it runs the
+ * packages); [7] zero. */
 gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[8]);
 /* Switches of a handle.  The library's tuning and test switches ("GS_NO_BIDIR", "GS_SHARE_MIN", "GS_DEBUG", ... -
  * DESIGN.md names each where it acts) are a per-handle table: filled from the process environment's GS_* variables

@@ -627,9 +627,16 @@ ARENA_MODES = [None, ("GS_NO_ARENA", "1"), ("GS_ARENA_CHUNKS", "2"),
                ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
                ("GS_ARENA_CHUNKS", "2", "GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
                ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_SHARE_QUEUE", "4"),
-               ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_NO_TILE_ORDER", "1")]
+               ("GS_HEAVY", "1", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128", "GS_NO_TILE_ORDER", "1"),
+               # two launches: the plain form publishes every pass and leaves, the heavy form - no items of its own - runs the
+               # packages beside it on a stream of the lowest priority; the same with an arena that runs out; and with the
+               # second launch BEFORE the first (its waves leave at once: everything is left for a launch behind)
+               ("GS_SPLIT_SHARE", "2", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
+               ("GS_ARENA_CHUNKS", "2", "GS_SPLIT_SHARE", "2", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128"),
+               ("GS_SPLIT_SHARE", "3", "GS_SHARE_MIN", "1", "GS_SHARE_MAX", "128")]
 ARENA_IDS = ["arena-tiles", "second-pass", "arena-exhausted", "tiles-unpacked", "device-wide", "one-sort-and-runs", "composite-sort",
-             "two-sorts", "never-shared", "every-pass-shared", "shared-arena-exhausted", "shared-queue-of-four", "shared-device-wide"]
+             "two-sorts", "never-shared", "every-pass-shared", "shared-arena-exhausted", "shared-queue-of-four", "shared-device-wide",
+             "published-run-beside", "published-arena-exhausted", "published-run-behind"]
 
 
 def set_mode(monkeypatch, arena):
@@ -859,6 +866,7 @@ def test_a_heavy_item_is_run_by_many_waves():
         off1, hits1, _ = gidx.enumerate(seqs, pams, mismatches=3)
         sh, ctr = gidx.last_sharing(), gidx.last_counters()
         assert sh["shared_items"] >= 1 and sh["packages"] >= 8 and sh["tickets"] >= sh["packages"], sh
+        assert sh["form"] == 1, sh     # six guides: a batch this small publishes AND helps in one launch
         assert ctr["matches_max_per_item"] >= n_plus and ctr["ordered_in_tiles"] and not ctr["tile_ordering_gave_up"], ctr
         assert np.array_equal(off0, off1) and hits0.tobytes() == hits1.tobytes()
         # smaller packages, more of them: the same bytes again; and with the plain instantiation asked for
@@ -870,6 +878,17 @@ def test_a_heavy_item_is_run_by_many_waves():
         off3, hits3, _ = gidx.enumerate(seqs, pams, mismatches=3)
         assert gidx.last_sharing()["shared_items"] == 0
         assert np.array_equal(off0, off3) and hits0.tobytes() == hits3.tobytes()
+        # two launches (what a handle picks for a large batch with FEW heavy items): the plain form publishes and leaves,
+        # the heavy form runs the packages beside it (2), behind it (1), or - launched first, its waves leave at once -
+        # in a launch the host adds behind both (3)
+        gidx.set_option("GS_HEAVY", None)
+        for mode, behind in (("2", None), ("1", 0), ("3", 1)):
+            gidx.set_option("GS_SPLIT_SHARE", mode)
+            off4, hits4, _ = gidx.enumerate(seqs, pams, mismatches=3)
+            sh4 = gidx.last_sharing()
+            assert sh4["form"] == 2 and sh4["shared_items"] >= 1 and sh4["tickets"] >= sh4["packages"] > sh["packages"], (mode, sh4)
+            assert behind is None or sh4["launches_behind"] == behind, (mode, sh4)
+            assert np.array_equal(off0, off4) and hits0.tobytes() == hits4.tobytes(), mode
         opts = ol.make_opts(3)
         for i in range(seqs.shape[0]):
             g = seqs[i].tobytes().decode()
@@ -877,6 +896,22 @@ def test_a_heavy_item_is_run_by_many_waves():
             got = gpu_hits_as_records(off1, hits1, i, g, 3)
             assert len(got) == len(exp) and got == exp, i
             assert i != 2 or len(exp) >= n_copies
+        # the same item in a LARGE batch of light guides (more than 64 items per wave slot of the chip, heavy passes in far
+        # fewer than one item of sixteen): the first batch runs plain and counts the passes, the second takes the two
+        # launches by itself - the same bytes, and the heavy guide's list is the one checked against the oracle above
+        gidx.set_option("GS_SPLIT_SHARE", None)
+        gidx.set_options(GS_SHARE_MIN=None, GS_SHARE_MAX=None)
+        big_s = np.concatenate([np.tile(other, (60_000, 1)), np.array([list(site)], dtype=np.uint8)])
+        big_p = np.tile(np.frombuffer(b"NGG", np.uint8), (big_s.shape[0], 1))
+        boff0, bhits0, _ = gidx.enumerate(big_s, big_p, mismatches=2)     # (another budget: a shape this handle has not seen)
+        assert gidx.last_sharing()["form"] == 0
+        boff1, bhits1, _ = gidx.enumerate(big_s, big_p, mismatches=2)
+        shb = gidx.last_sharing()
+        assert shb["form"] == 2 and shb["shared_items"] >= 1, shb
+        assert np.array_equal(boff0, boff1) and bhits0.tobytes() == bhits1.tobytes()
+        g = bytes(site).decode()
+        exp, _ = oracle_hits_as_records(oidx, g, "NGG", ol.make_opts(2), 3)
+        assert gpu_hits_as_records(boff1, bhits1, big_s.shape[0] - 1, g, 3) == exp
     finally:
         gidx.close()
         oidx.close()

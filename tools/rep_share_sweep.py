@@ -34,11 +34,21 @@ def main():
     try:
         seqs, pams, _, _ = synth.sample_guides(text, n * (steps + 2), seed=1000)
         d_s, d_p = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+        used = []
         for si, s in enumerate(settings):
-            smin, smax = s.split(":")
-            # share_min 0: the plain instantiation; else the heavy one (what a handle picks by itself after a batch with an
-            # item of 4,096 records), with sharing from share_min row groups on
-            g.set_options(GS_SHARE_MIN=smin, GS_SHARE_MAX=smax, GS_HEAVY="0" if int(smin) == 0 else "1")
+            for k in used:
+                g.set_option(k, None)
+            used.clear()
+            if "=" in s or s == "default":   # KEY=V,KEY=V: any per-handle switches ("default": none - what a caller gets)
+                kv = dict(x.split("=") for x in s.split(",")) if s != "default" else {}
+                smin, smax = kv.get("GS_SHARE_MIN", "512"), kv.get("GS_SHARE_MAX", "2048")
+            else:
+                smin, smax = s.split(":")
+                # share_min 0: the plain instantiation; else the heavy one (what a handle picks by itself after a batch with
+                # heavy passes), with sharing from share_min row groups on
+                kv = dict(GS_SHARE_MIN=smin, GS_SHARE_MAX=smax, GS_HEAVY="0" if int(smin) == 0 else "1")
+            g.set_options(**kv)
+            used.extend(kv)
             rows, crc = [], 0
             for i in range(steps + 2):
                 torch.cuda.synchronize()
@@ -61,7 +71,7 @@ def main():
                         pos += c
                         left -= c
             a = np.array(rows, dtype=np.float64)
-            print(json.dumps({"workload": workload, "guides": n, "m": m, "share_min": int(smin), "share_max": int(smax),
+            print(json.dumps({"workload": workload, "guides": n, "m": m, "setting": s, "share_min": int(smin), "share_max": int(smax),
                               "step_ms": round(a[:, 0].mean(), 2), "k_search_ms": round(a[:, 1].mean(), 2),
                               "k_search_ms_min_max": [round(a[:, 1].min(), 2), round(a[:, 1].max(), 2)],
                               "hits_per_step": int(a[:, 2].mean()), "shared_items": int(a[:, 3].mean()),
