@@ -58,6 +58,57 @@ __device__ __forceinline__ const T *own_sgprs(const T *p) {
   return (const T *)(const T __attribute__((address_space(1))) *)(((uint64_t)hi << 32) | lo);
 }
 
+/* The publishing of a heavy pass, out of line (SHARE = 2: the plain form's loops keep their registers; the pass is rare there).
+ * Everything it needs comes by value - a reference to the kernel's argument struct would put the struct on the stack.
+ * Returns true when the pass went into the queue (the caller's pass is done), false when the queue had no room. */
+struct gs_pub_args {
+  uint4 *shq;
+  uint32_t *shq_ctl, *shq_ready, *sh_list;
+  uint32_t shq_cap, sh_max, share_max;
+};
+__device__ __noinline__ bool gs_publish_pass(const gs_pub_args q, uint32_t *wmisc, const uint32_t take, const uint4 mine, const uint32_t excl,
+                                             const uint32_t slot, const uint32_t item, const uint32_t side_tab) {
+  const uint32_t lane = lane_id();
+  uint32_t sid = __builtin_amdgcn_readfirstlane(wmisc[3]);
+  if (sid == SH_NONE) {
+    uint32_t s = 0;
+    if (lane == 0) s = atomicAdd(&q.shq_ctl[96], 1u);
+    sid = __builtin_amdgcn_readfirstlane(s);
+    if (lane == 0) {
+      wmisc[3] = sid;
+      if (sid < q.sh_max) q.sh_list[sid] = slot;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  }
+  if (sid >= q.sh_max) return false;
+  const uint32_t pid = lane < take ? excl / q.share_max : 0u;
+  const uint32_t np = __builtin_amdgcn_readlane(pid, (int)(take - 1u)) + 1u;
+  uint32_t qb = 0;
+  if (lane == 0) qb = atomicAdd(&q.shq_ctl[0], np);
+  qb = __builtin_amdgcn_readfirstlane(qb);
+  if (qb + np <= q.shq_cap) {
+    const uint32_t ppid = dpp_or_zero<0x138>(pid + 1u);
+    const bool first = lane < take && ppid != pid + 1u;
+    const uint64_t bm = __ballot(first);
+    const uint64_t upto = (2ull << lane) - 1ull;
+    const uint32_t start = 63u - (uint32_t)__builtin_clzll((bm & upto) | 1ull);
+    const uint64_t above = bm & ~upto;
+    const uint32_t nxt = above ? (uint32_t)__builtin_ctzll(above) : take;
+    uint4 *pk = q.shq + (size_t)(qb + pid) * SHQ_PKG;
+    if (lane < take) st16_agent(pk + 1u + (lane - start), mine);
+    if (first) st16_agent(pk, make_uint4(item, sid, side_tab | ((nxt - start) << 8), 0u));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (first) st_agent(q.shq_ready + qb + pid, 1u);
+    return true;
+  }
+  if (qb < q.shq_cap && lane < q.shq_cap - qb && lane < np) {
+    st16_agent(q.shq + (size_t)(qb + lane) * SHQ_PKG, make_uint4(0u, 0u, 0u, 0u));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_agent(q.shq_ready + qb + lane, 1u);
+  }
+  return false;
+}
+
 /* SHARE: 0 - every item stays with its wave; 1 (HEAVY) - heavy verification passes are published as packages AND the waves
  * that ran out of items run them (one launch: a repeat-rich batch); 2 - published only: the waves leave when the items are
  * taken, and the packages are run by a launch of the HEAVY form that has no items of its own (gs_search_args::helper_only)
@@ -151,8 +202,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
   for (;;) {
     if (!items_done && item_next == item_end) {
       uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(a.work, a.take);
-      base = __builtin_amdgcn_readfirstlane(base);
+      if (HEAVY && a.helper_only) { /* (a launch without items: no visit to the counter - 8,192 of them are 0.1 ms on one word) */
+        base = a.n_items;
+      } else {
+        if (lane == 0) base = atomicAdd(a.work, a.take);
+        base = __builtin_amdgcn_readfirstlane(base);
+      }
       if (base >= a.n_items) {
         if (!sharing) break; /* exit condition every wave reaches */
         if (lane == 0 && !a.helper_only) atomicAdd(&a.shq_ctl[64], 1u); /* this wave reserves no package any more */
@@ -179,7 +234,9 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
        * left its items no reservation can follow, and a ticket at or beyond the reserved count leaves.  The writer of
        * a reserved package never waits for anything, and the spin is bounded all the same (GS_ERR_DEVICE, no hang). */
       uint32_t got = SH_NONE;
-      if (lane == 0) {
+      /* (no ticket is drawn when none can be served any more - every wave has left its items, every package reserved has its
+       * ticket: the last visit of each of 8,192 waves to that one word was 0.1 ms at the end of every launch) */
+      if (lane == 0 && !(ld_agent(&a.shq_ctl[64]) >= a.n_waves && ld_agent(&a.shq_ctl[32]) >= ld_agent(&a.shq_ctl[0]))) {
         const uint32_t t = atomicAdd(&a.shq_ctl[32], 1u);
         if (t < a.shq_cap) {
           for (uint32_t spins = 0;; ++spins) {
@@ -418,7 +475,21 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       if (!R) return;
       const uint32_t excl = incl - vgrp;
       if (!WALK && R >= a.share_min) n_hpass++;
-      if constexpr (PUB) {
+      if constexpr (SHARE == 2) {
+        if (sharing && R >= a.share_min) {
+          gs_pub_args q;
+          q.shq = a.shq;
+          q.shq_ctl = a.shq_ctl;
+          q.shq_ready = a.shq_ready;
+          q.sh_list = a.sh_list;
+          q.shq_cap = a.shq_cap;
+          q.sh_max = a.sh_max;
+          q.share_max = a.share_max;
+          const uint32_t cur_tab = (modeB || arow == nullptr) ? 3u : arow == a.pt[0][strand].rowid ? 0u : 1u;
+          if (gs_publish_pass(q, wmisc, take, mine, excl, slot, item, (modeB ? 1u : 0u) | (cur_tab << 1))) return;
+        }
+      }
+      if constexpr (HEAVY) {
         /* ---- a heavy pass is handed to the waves that have run out of items (gs_search_args::shq) ---- */
         if (sharing && !helper && R >= a.share_min) {
           uint32_t sid = __builtin_amdgcn_readfirstlane(wmisc[3]);
