@@ -641,6 +641,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         }
       }
     }
+    if (sa.dbg_skip & 4u) sa.n_rec_full = sa.n_rec_a = sa.n_rec_b = sa.n_rec_a8 = 0u; /* (experiments: no recipe at all - what an item costs before its first seed) */
     /* persistent waves pulling (guide, strand) items: as many 4-wave workgroups per CU as their
      * LDS (verification queue 2.5 KiB + substitution table 1.4 KiB per wave, + 3.5 KiB of stacks in
      * the walking variant) and the registers (8 waves per SIMD = 8 workgroups per CU) allow */

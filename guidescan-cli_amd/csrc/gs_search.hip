@@ -476,7 +476,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t excl = incl - vgrp;
       if (!WALK && R >= a.share_min) n_hpass++;
       if constexpr (SHARE == 2) {
-        if (sharing && R >= a.share_min) {
+        if (sharing && __builtin_expect(R >= a.share_min, 0)) {
           gs_pub_args q;
           q.shq = a.shq;
           q.shq_ctl = a.shq_ctl;

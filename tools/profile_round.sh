@@ -31,7 +31,8 @@ for row in csv.reader(open(sys.argv[1])):
 PY
 fi
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY" \
-            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"; do
+            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
   name=$(echo $pass | cut -d' ' -f1 | tr 'A-Z' 'a-z')
   rocprofv3 --pmc $pass -f csv --kernel-include-regex 'k_search|k_order|k_locate|k_big2|k_score|k_to_|k_share' -d $OUT/pmc_$name -- python3 bench.py $ARGS --steps $STEPS --warmup $WARM > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
   echo "pmc $name rc=$?"
