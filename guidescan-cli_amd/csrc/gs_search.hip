@@ -116,6 +116,14 @@ __device__ __noinline__ bool gs_publish_pass(const gs_pub_args q, uint32_t *wmis
 template <bool CNT, bool WALK, bool SPEC = false, int SHARE = 0>
 __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *stk) {
   constexpr bool HEAVY = SHARE == 1, PUB = SHARE != 0;
+  /* launch-wide facts every item tests, named once: as expressions on the argument struct at each use they cost the headline
+   * launch 2.4 ms of 24.4 (335 -> 325 scalar values in spill lanes; profiles/r05_ab_compile_variants.txt, one box: the library
+   * before this line 24.38 ms, with it 22.02).  The same facts as template constants (a form of the kernel for a batch's main
+   * pass: nothing to append to, slots of one size, the arena on) allocate worse again: 23.01. */
+  const bool k_append = a.append != 0u;
+  const uint64_t *const k_slot_off = a.slot_off;
+  const bool k_arena = a.arena != nullptr;
+  const uint32_t k_cap = a.cap, k_n_items = a.n_items; /* (these two: 23.0 -> 22.7 ms on one box) */
   constexpr uint32_t STK = WALK ? STACK_ENTRIES : 0u;
   /* Where a path lives in the 64-bit word the search carries next to a seed or a hit.  The walking variant packs
    * the node's step, PAM pattern and fan-out flag above it (node meta, top of the file): 52 path bits, key = path << 8.
@@ -203,12 +211,12 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     if (!items_done && item_next == item_end) {
       uint32_t base = 0;
       if (HEAVY && a.helper_only) { /* (a launch without items: no visit to the counter - 8,192 of them are 0.1 ms on one word) */
-        base = a.n_items;
+        base = k_n_items;
       } else {
         if (lane == 0) base = atomicAdd(a.work, a.take);
         base = __builtin_amdgcn_readfirstlane(base);
       }
-      if (base >= a.n_items) {
+      if (base >= k_n_items) {
         if (!sharing) break; /* exit condition every wave reaches */
         if (lane == 0 && !a.helper_only) atomicAdd(&a.shq_ctl[64], 1u); /* this wave reserves no package any more */
         if constexpr (!HEAVY) break; /* (published only: the packages belong to the other launch) */
@@ -223,7 +231,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
         }
       } else {
         item_next = base;
-        item_end = base + a.take < a.n_items ? base + a.take : a.n_items;
+        item_end = base + a.take < k_n_items ? base + a.take : k_n_items;
       }
     }
     /* a helper episode: one package = one verification pass of somebody else's item */
@@ -264,7 +272,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint4 hd = ld16_agent(a.shq + (size_t)got * SHQ_PKG);
       h_item = __builtin_amdgcn_readfirstlane(hd.x);
       const uint32_t hz = __builtin_amdgcn_readfirstlane(hd.z);
-      if ((hz >> 8) == 0u || (hz >> 8) > WAVE || h_item >= a.n_items) continue; /* a filler for a reservation the queue had no room for */
+      if ((hz >> 8) == 0u || (hz >> 8) > WAVE || h_item >= k_n_items) continue; /* a filler for a reservation the queue had no room for */
       if (lane == 0) {
         wmisc[12] = hz;
         wmisc[13] = hd.y;
@@ -276,7 +284,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     const uint32_t item = helper ? h_item : item_next++;
     /* all forward-index items first, then all reverse-index items: at any moment the waves
      * touch one strand's Occ array, which halves the hot footprint (TLB reach) */
-    const uint32_t n_guides = a.n_items >> 1;
+    const uint32_t n_guides = k_n_items >> 1;
     const uint32_t strand = item >= n_guides ? 1u : 0u;
     const uint32_t guide = item - strand * n_guides;
     const uint32_t slot = 2u * guide + strand;
@@ -294,7 +302,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     if (!gr_valid || bailed) {
       if (!helper) {
         if (lane == 0) a.counts[slot] = 0;
-        if (a.arena != nullptr && lane < 8u) a.cls[(size_t)slot * 8u + lane] = 0u;
+        if (k_arena && lane < 8u) a.cls[(size_t)slot * 8u + lane] = 0u;
       }
       continue;
     }
@@ -303,16 +311,16 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     const uint4 *__restrict__ blocks = sd.blocks;
     const uint32_t npams = P ? gr_npams : 1u;
     const bool fanning = P > 0 && npams > 1u; /* a finished 20-mer fans out per PAM pattern */
-    uint4 *out = a.slots + (a.slot_off ? (size_t)a.slot_off[slot] : (size_t)slot * a.cap);
+    uint4 *out = a.slots + (k_slot_off ? (size_t)k_slot_off[slot] : (size_t)slot * k_cap);
     /* (a helper owns no slots: its records go to arena chunks of its own from the first one on) */
-    const uint32_t item_cap = helper ? 0u : a.slot_off ? (uint32_t)(a.slot_off[slot + 1] - a.slot_off[slot]) : a.cap;
+    const uint32_t item_cap = helper ? 0u : k_slot_off ? (uint32_t)(k_slot_off[slot + 1] - k_slot_off[slot]) : k_cap;
     uint32_t n_match = 0;
-    if (a.append) n_match = __builtin_amdgcn_readfirstlane(a.counts[slot]);
-    if (a.arena != nullptr) {
+    if (k_append) n_match = __builtin_amdgcn_readfirstlane(a.counts[slot]);
+    if (k_arena) {
       uint2 nc = make_uint2(0u, 0u);
-      if (a.append) nc = a.nchunk[slot];
+      if (k_append) nc = a.nchunk[slot];
       if (lane < 4u) wmisc[lane] = lane == 0u ? nc.x : lane == 1u ? nc.y : lane == 2u ? 0u : SH_NONE;
-      if (lane >= 4u && lane < 12u) wmisc[lane] = a.append ? a.cls[(size_t)slot * 8u + (lane - 4u)] : 0u;
+      if (lane >= 4u && lane < 12u) wmisc[lane] = k_append ? a.cls[(size_t)slot * 8u + (lane - 4u)] : 0u;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
     uint32_t xs = 0, gs = 0; /* sizes of the X and G stacks */
@@ -358,7 +366,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       if (be) {
         const uint32_t hi = n_match + (uint32_t)__popcll(be); /* one past the last record of this emission */
 #ifndef GS_X_NO_CLS
-        if (a.arena != nullptr) {
+        if (k_arena) {
           /* matches per mismatch count: lane d adds this emission's share of class d (one LDS add, distinct words) */
           const uint32_t kk = (uint32_t)((cmeta >> KSH) & 7ull);
           uint32_t add = 0;
@@ -369,7 +377,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           if (add) atomicAdd(&wmisc[4u + lane], add);
         }
 #endif
-        if (hi > item_cap && a.arena != nullptr) {
+        if (hi > item_cap && k_arena) {
           /* the emission reaches beyond the item's slots: take overflow chunks up to its last record
            * (wave-uniform; at most two per emission, almost always none) */
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -415,7 +423,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
           const uint4 rec = make_uint4((uint32_t)key, (uint32_t)(key >> 32), csp, cep);
           if (idx < item_cap) {
             out[idx] = rec;
-          } else if (a.arena != nullptr) {
+          } else if (k_arena) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t e = idx - item_cap, sq = e >> ARENA_SHIFT;
             const uint32_t nch = wmisc[0];
@@ -1559,7 +1567,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
     }
     if (lane == 0) a.counts[slot] = n_match;
     if (n_match > item_cap) n_ovf++;
-    if (a.arena != nullptr) {
+    if (k_arena) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const uint32_t nch = __builtin_amdgcn_readfirstlane(wmisc[0]), last = __builtin_amdgcn_readfirstlane(wmisc[1]);
       /* (a shared item: its number instead of the last chunk - nobody appends to it - for k_share_dir/fix) */
