@@ -788,7 +788,7 @@ def test_an_item_of_more_than_half_a_million_records(monkeypatch, capfd):
 def test_a_guide_beyond_the_tiles_reach_goes_alone_to_the_device_wide_ordering():
     """1,600,000 copies of one site on the + strand (a guide inside the largest repeat family of a real genome): its
     item holds more than 2^20 match records, beyond what the per-guide tile ordering deals into buckets.  That GUIDE
-    alone is ordered device-wide (gs_search.hip, big_order on the list gs_tileorder.hip's k_to_fill leaves); the rest
+    alone is ordered device-wide (gs_enumerate.hip, big_order on the list gs_tileorder.hip's k_to_fill leaves); the rest
     of the batch - a guide of 300,000 copies that is dealt into buckets, guides of a few hits - stays in tiles.  Until
     round 5 one such item sent the whole batch through the device-wide ordering.  Every guide's hit list equals the
     oracle's (process.hpp:100-115 order; the std::set's dedupe, structures.hpp:33-43, has nothing to drop here)."""

@@ -50,7 +50,7 @@ def test_bucket_plan_invariants(c):
 
 def test_items_beyond_the_plan_are_left_to_the_device_wide_ordering():
     p = api.tile_plan(1_048_577)
-    assert p["buckets"] > p["max_buckets"]     # k_to_plan / k_to_fill leave the GUIDE out of the tiles (gs_search.hip orders it alone)
+    assert p["buckets"] > p["max_buckets"]     # k_to_plan / k_to_fill leave the GUIDE out of the tiles (gs_enumerate.hip orders it alone)
 
 
 def test_bucket_space_stays_within_a_small_multiple_of_the_records():
