@@ -832,7 +832,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         const uint32_t n_sh = (uint32_t)ix->last_share[0];
         hipLaunchKernelGGL(k_share_scan, dim3(1), dim3(1024), 0, st, fa);
         hipLaunchKernelGGL(k_share_dir, dim3((arena_chunks + 255) / 256), dim3(256), 0, st, fa);
-        hipLaunchKernelGGL(k_share_fix, dim3(std::min<uint32_t>(n_sh, (uint32_t)cus * 8u)), dim3(256), 0, st, fa);
+        hipLaunchKernelGGL((k_share_fix<SH_SMALLSEG>), dim3(n_sh), dim3(256), 0, st, fa); /* a workgroup per item */
+        hipLaunchKernelGGL((k_share_fix<SH_MAXSEG>), dim3(std::min<uint32_t>(n_sh, (uint32_t)cus * 3u)), dim3(256), 0, st, fa);
         GS_HIP(hipEventRecord(ix->ev[2], st));
         GS_HIP(hipMemcpyAsync(h7, d_stats, sizeof(h7), hipMemcpyDeviceToHost, st));
         GS_HIP(hipStreamSynchronize(st));

@@ -241,6 +241,7 @@ struct gs_share_args {
   uint32_t sh_max, cap, arena_chunks;
 };
 #define SH_MAXSEG 4096u /* slots + chunks of one shared item the fix holds in LDS (4 M records) */
+#define SH_SMALLSEG 254u /* ... in its small form (260,000 records) */
 __global__ void k_order(gs_order_args a);
 __global__ void k_order_wg(gs_order_args a, uint32_t nmax);
 __global__ void k_scan_partial(const uint32_t *in, uint64_t *blocksum,
@@ -261,6 +262,7 @@ __global__ void k_patch_overflow(const uint32_t *list, uint32_t n_o, const uint3
 __global__ void k_arena_gather(gs_agather_args a);
 __global__ void k_share_scan(gs_share_args a);
 __global__ void k_share_dir(gs_share_args a);
+template <uint32_t MAXSEG>
 __global__ void k_share_fix(gs_share_args a);
 __global__ void k_raw_counts(const uint4 *slots, const uint32_t *counts, uint32_t n, uint32_t cap,
                                                     uint32_t *raw);

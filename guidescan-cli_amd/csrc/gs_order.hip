@@ -421,9 +421,12 @@ __global__ __launch_bounds__(256) void k_share_dir(gs_share_args a) {
   const uint32_t d0 = a.dbase[sid];
   if (j < a.dbase[sid + 1u] - d0) a.dir[d0 + j] = c;
 }
+/* MAXSEG: the segments the workgroup's tables hold.  Two launches: items of at most SH_SMALLSEG chunks - nearly all - with 3 KB of LDS
+ * (eight workgroups per CU), the others with SH_MAXSEG (49 KB: three per CU, which kept the whole kernel at 0.64 ms per 10,800 items). */
+template <uint32_t MAXSEG>
 __global__ __launch_bounds__(256) void k_share_fix(gs_share_args a) {
   /* segment 0 = the slots, segment 1 + j = chunk j of the directory */
-  __shared__ uint32_t s_fill[SH_MAXSEG + 1u], s_hole[SH_MAXSEG + 2u], s_mov[SH_MAXSEG + 2u];
+  __shared__ uint32_t s_fill[MAXSEG + 1u], s_hole[MAXSEG + 2u], s_mov[MAXSEG + 2u];
   __shared__ uint32_t s_red[3][4], s_tot[3];
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), w = tid / WAVE;
   const uint32_t n_sh = a.ctl[96] < a.sh_max ? a.ctl[96] : a.sh_max;
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(256) void k_share_fix(gs_share_args a) {
     const bool own_short = own > cap && own - cap > (nho << ARENA_SHIFT);
     const uint32_t nseg = ns + 1u;
     __syncthreads(); /* (the previous item's tables are no longer read) */
+    if ((ns > SH_SMALLSEG) != (MAXSEG > SH_SMALLSEG)) continue; /* (the other launch's item; workgroup-uniform) */
     if (ns > SH_MAXSEG || own_short) {
       /* not in a state to be closed up (or the arena ran out under the owner): the total is exact, the host searches the
        * batch's overflowing guides again - this item among them */
@@ -546,6 +550,8 @@ __global__ __launch_bounds__(256) void k_share_fix(gs_share_args a) {
     }
   }
 }
+template __global__ void k_share_fix<SH_SMALLSEG>(gs_share_args a);
+template __global__ void k_share_fix<SH_MAXSEG>(gs_share_args a);
 
 /* hits of a guide BEFORE the per-distance sets drop duplicate sequences: what the reference's
  * threshold filter counts (off_target_counter, process.hpp:25-27: ep - sp + 1 per callback, one

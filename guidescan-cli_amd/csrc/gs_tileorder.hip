@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
   const uint32_t nb = to_buckets(a.counts[2u * g + (sb & 1u)], su);
   const uint32_t tb = a.tbase[sb], slots = to_slots(a, su);
   const uint32_t each = (nb + WAVE - 1u) / WAVE;
-  uint32_t s = 0;
+  uint32_t s = 0, cl[3] = {0u, 0u, 0u};
   bool over = false;
   for (uint32_t q = 0; q < each; ++q) {
     const uint32_t b = lane * each + q;
@@ -670,16 +670,32 @@ __global__ __launch_bounds__(256) void k_to_bucketsum(gs_to_run_args a, const ui
         }
       }
     }
-    /* (one bucket in fifteen: a place on its list, one atomic per wave and list) */
-    const uint32_t n = b < nb ? a.tiles[tb + b].z : 0u;
-    for (uint32_t k = 0; k < 3u; ++k) {
-      const bool mine = n > TO_WTILE && (n > 128u * TO_KPT ? (n > a.big_from ? 2u : 1u) : 0u) == k;
-      const unsigned long long m = __ballot(mine);
-      if (m == 0ull) continue;
-      uint32_t base = 0;
-      if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(&a.slow_n[k], (uint32_t)__popcll(m));
-      base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(m));
-      if (mine) a.slow[k][base + lanes_below(m)] = tb + b;
+    /* (one bucket in fifteen goes on a list of the workgroup kernels: counted here, placed below) */
+    const uint32_t n2 = b < nb ? a.tiles[tb + b].z : 0u;
+    if (n2 > TO_WTILE) cl[n2 > 128u * TO_KPT ? (n2 > a.big_from ? 2u : 1u) : 0u]++;
+  }
+  /* a place on its list for every such bucket: ONE atomic per wave and list (three words serve every item of the batch: one
+   * atomic per bucket round and list - 50,000 on the repeat-rich batch - was 0.2 ms of waiting for them) */
+  uint32_t at[3];
+#pragma unroll
+  for (uint32_t k = 0; k < 3u; ++k) {
+    const uint32_t incl = wave_incl_sum(cl[k]);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    uint32_t base = 0;
+    if (tot != 0u) {
+      if (lane == 0u) base = atomicAdd(&a.slow_n[k], tot);
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    }
+    at[k] = base + incl - cl[k];
+  }
+  for (uint32_t q = 0; q < each; ++q) {
+    const uint32_t b = lane * each + q;
+    const uint32_t n2 = b < nb ? a.tiles[tb + b].z : 0u;
+    if (n2 > TO_WTILE) {
+      const uint32_t k = n2 > 128u * TO_KPT ? (n2 > a.big_from ? 2u : 1u) : 0u;
+      const uint32_t pos = k == 0u ? at[0]++ : k == 1u ? at[1]++ : at[2]++;
+      uint32_t *const dst = k == 0u ? a.slow[0] : k == 1u ? a.slow[1] : a.slow[2];
+      dst[pos] = tb + b;
     }
   }
   if (over) atomicOr(a.flags, TO_F_BUCKET);

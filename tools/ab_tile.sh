@@ -17,7 +17,7 @@ j = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
 rows = {r[0][:40]: r for r in csv.reader(open(sys.argv[2]))}
 out = {}
 for k, r in rows.items():
-    if k.startswith(("k_to_", "k_search", "void k_to_", "k_share", "k_order", "k_locate")):
+    if k.startswith(("k_to_", "k_search", "void k_to_", "k_share", "void k_share", "k_order", "k_locate")):
         out[k.replace("void ", "")[:28]] = round(float(r[3]) / 1e6, 3)   # AverageNs -> ms
 print(sys.argv[1], "step", round(j["ms_per_step"], 2), "ms", json.dumps(out))
 PY
