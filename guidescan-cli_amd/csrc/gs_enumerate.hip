@@ -743,12 +743,24 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         sh_args.helper_only = 1u;
         sh_args.work = d_work + 9; /* a counter that is past the items from the start */
         sh_grid = (uint32_t)cus * std::min<uint32_t>((uint32_t)(160u * 1024u / lds_wg), GS_WAVES_EU_HEAVY);
-        const bool side = split == 2u;
+        bool side = split == 2u;
         if (side && !ix->st_help) {
           int lo = 0, hi = 0;
-          GS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-          GS_HIP(hipStreamCreateWithPriority(&ix->st_help, hipStreamNonBlocking, lo));
-          for (hipEvent_t &e : ix->ev_help) GS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+          hipStream_t hs = nullptr;
+          bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+                    hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, lo) == hipSuccess;
+          for (hipEvent_t &e : ix->ev_help) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+          if (ok) {
+            ix->st_help = hs;
+          } else { /* no second stream to be had: the second launch goes behind the first on the caller's */
+            (void)hipGetLastError();
+            if (hs) (void)hipStreamDestroy(hs);
+            for (hipEvent_t &e : ix->ev_help) {
+              if (e) (void)hipEventDestroy(e);
+              e = nullptr;
+            }
+            side = false;
+          }
         }
         if (side) { /* the queue's control words are zeroed: the other stream may start */
           GS_HIP(hipEventRecord(ix->ev_help[0], st));

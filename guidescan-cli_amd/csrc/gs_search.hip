@@ -482,7 +482,7 @@ __device__ __forceinline__ void k_search_body(const gs_search_args &a, uint4 *st
       const uint32_t R = __builtin_amdgcn_readlane(incl, WAVE - 1); /* groups of this step */
       if (!R) return;
       const uint32_t excl = incl - vgrp;
-      if (!WALK && R >= a.share_min) n_hpass++;
+      if (!WALK && !helper && R >= a.share_min) n_hpass++; /* (an item's own passes: what the next batch's choice of form counts - a helper's packages are those passes again) */
       if constexpr (SHARE == 2) {
         if (sharing && __builtin_expect(R >= a.share_min, 0)) {
           gs_pub_args q;
