@@ -124,6 +124,8 @@ def lib():
     L.gs_index_last_counters.argtypes = [vp, vp]
     L.gs_index_last_sharing.restype = i32
     L.gs_index_last_sharing.argtypes = [vp, vp]
+    L.gs_index_prepare.restype = i32
+    L.gs_index_prepare.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.gs_index_set_option.restype = i32
     L.gs_index_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.gs_index_get_option.restype = i32
@@ -198,7 +200,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
            "gs_index_last_guide_flags", "gs_enumerate_general_pams", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
            "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_debug_tile_plan", "gs_index_lock", "gs_index_unlock",
-           "gs_index_last_sharing", "gs_index_set_option", "gs_index_get_option"]
+           "gs_index_last_sharing", "gs_index_set_option", "gs_index_get_option", "gs_index_prepare"]
 
 
 def _check(rc):
@@ -587,6 +589,13 @@ class GenomeIndex:
             finally:
                 _check(lib().gs_index_unlock(self._h))
         return hold()
+
+    def prepare(self, n, L=20, pam="NGG", alt_pams=(), mismatches=3, start=False):
+        """the first batch's one-off work (seed recipes, PAM-pair and deep tables, workspace for n guides) ahead of the first job
+        (gs_index_prepare)"""
+        alts = "".join(alt_pams).encode()
+        _check(lib().gs_index_prepare(self._h, int(n), L, pam.encode(), len(pam), alts if alt_pams else None, len(alt_pams), mismatches,
+                                      GS_FLAG_PAM_AT_START if start else 0))
 
     def set_option(self, key, value):
         """a switch of this handle (gs_index_set_option): value None removes it.  The environment's GS_* variables are

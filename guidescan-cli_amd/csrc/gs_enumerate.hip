@@ -1685,3 +1685,40 @@ extern "C" gs_status gs_resolve(gs_index *ix, int strand, const uint64_t *rows, 
   hipFree(d_out);
   return GS_OK;
 }
+
+/* ---- gs_index_prepare: the first batch's one-off work ahead of the first job ------------------------------------ */
+__global__ void k_prepare_fill(uint8_t *guides, uint8_t *pams, uint64_t n, uint32_t L, uint32_t P, uint4 pat /* <= 8 symbols in x, y */) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t h = (i + 1u) * 0x9E3779B97F4A7C15ull;
+  for (uint32_t t = 0; t < L; ++t) {
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    guides[i * L + t] = "ACGT"[(h >> 61) & 3u];
+  }
+  for (uint32_t u = 0; u < P; ++u) pams[i * P + u] = (uint8_t)((u < 4u ? pat.x >> (8u * u) : pat.y >> (8u * (u - 4u))) & 0xFFu);
+}
+extern "C" gs_status gs_index_prepare(gs_index *ix, uint64_t n, uint32_t L, const char *pam, uint32_t P, const char *alt_pams,
+                                      uint32_t n_alt, uint32_t mismatches, uint32_t flags) {
+  GS_HANDLE_LOCK(ix);
+  if (!ix || (P && !pam) || (n_alt && !alt_pams) || L < 1 || L > 31 || P > 8 || n >= (1ull << 31)) return GS_ERR_ARG;
+  if (n == 0) return GS_OK;
+  GS_HIP(hipSetDevice(ix->device));
+  uint8_t *d_g = nullptr, *d_p = nullptr;
+  GS_HIP(hipMalloc(&d_g, n * L));
+  if (hipMalloc(&d_p, n * (P ? P : 1u)) != hipSuccess) {
+    (void)hipFree(d_g);
+    (void)hipGetLastError();
+    return GS_ERR_NOMEM;
+  }
+  uint4 pat = make_uint4(0u, 0u, 0u, 0u);
+  for (uint32_t u = 0; u < P; ++u) (u < 4u ? pat.x : pat.y) |= (uint32_t)(uint8_t)pam[u] << (8u * (u & 3u));
+  hipLaunchKernelGGL(k_prepare_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_g, d_p, n, L, P, pat);
+  const void *off = nullptr, *hits = nullptr;
+  gs_result_view v;
+  const gs_status rc = gs_enumerate_device(ix, d_g, n, L, d_p, P, alt_pams, n_alt, mismatches, flags & ~GS_FLAG_COUNT_REQUESTS, nullptr, &off, &hits, &v);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(d_g);
+  (void)hipFree(d_p);
+  return rc;
+}

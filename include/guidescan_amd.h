@@ -222,6 +222,14 @@ gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uint64_t n, ui
                               const void *d_guide_pams, uint32_t P, const char *alt_pams,
                               uint32_t n_alt, uint32_t mismatches, uint32_t flags, void *stream,
                               const void **d_offsets, const void **d_hits, gs_result_view *stats);
+/* What the FIRST batch of a shape pays once per handle - the seed recipes, the PAM-pair and deep tables of the PAM patterns
+ * (0.3 s and 24-33 GB per strand at hg38 size), the workspace of a batch of n guides - done ahead of the first job: n guides
+ * of length L drawn from a generator (not from the genome: few hits), each with the pattern `pam` (P symbols), are enumerated
+ * with these alt PAMs, budget and flags and the result is dropped.  Nothing in the reference corresponds (its index is ready
+ * when loaded, src/guidescan.cxx:198-211); a service calls this after opening a handle so that a 2,500-guide job
+ * (manual/manual.tex:472-475) is not all warm-up.  The batch's own workspace for hits still grows with the first real batch. */
+gs_status gs_index_prepare(gs_index *ix, uint64_t n, uint32_t L, const char *pam, uint32_t P, const char *alt_pams,
+                           uint32_t n_alt, uint32_t mismatches, uint32_t flags);
 
 /* flags of the last gs_enumerate_device call on this handle (device memory, n bytes, valid until the
  * next call) and how many guides carry GS_GUIDE_NEEDS_GENERAL */

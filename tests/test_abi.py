@@ -222,6 +222,7 @@ def test_options_are_validated_without_a_device():
     assert L.gs_index_get_option(None, b"GS_DEBUG", buf, 8) == 1
     out = (C.c_uint64 * 8)()
     assert L.gs_index_last_sharing(None, out) == 1
+    assert L.gs_index_prepare(None, 10, 20, b"NGG", 3, None, 0, 3, 0) == 1      # no handle: GS_ERR_ARG, nothing touched
 
 
 def test_product_does_not_import_oracle():

@@ -249,6 +249,28 @@ def test_reference_index_files_on_the_device_and_damaged_ones(toy_gpu, tmp_path)
     assert refused >= 8, (opened, refused)
 
 
+def test_a_prepared_handle_answers_as_a_fresh_one(toy_gpu):
+    """gs_index_prepare runs the first batch's one-off work (seed recipes, PAM-pair / deep tables, workspace) on generated
+    guides and drops the result: the handle then answers a real batch with the bytes a fresh handle gives - for the shape it
+    was prepared for and for another one"""
+    toy, oidx, gidx = toy_gpu
+    group = [k for k in toy["kmers"] if len(k.pam) == 3]
+    seqs = np.array([list(k.sequence.encode()) for k in group], dtype=np.uint8)
+    pams = np.array([list(k.pam.encode()) for k in group], dtype=np.uint8)
+    other = api.GenomeIndex.build(toy["text"], device=0)
+    try:
+        other.prepare(5000, L=seqs.shape[1], pam="NGG", alt_pams=("NAG",), mismatches=3)
+        other.prepare(0, L=seqs.shape[1], pam="NGG", mismatches=2)      # nothing to do
+        for kw in (dict(mismatches=3, alt_pams=("NAG",)), dict(mismatches=4), dict(mismatches=2, start=True)):
+            a_off, a_hits, _ = gidx.enumerate(seqs, pams, **kw)
+            b_off, b_hits, _ = other.enumerate(seqs, pams, **kw)
+            assert a_off.tobytes() == b_off.tobytes() and a_hits.tobytes() == b_hits.tobytes(), kw
+        with pytest.raises(api.GsError):
+            other.prepare(10, L=40, pam="NGG")                           # a guide length the path does not take
+    finally:
+        other.close()
+
+
 def test_empty_batch(toy_gpu):
     toy, oidx, gidx = toy_gpu
     offsets, hits, stats = gidx.enumerate(np.empty((0, 20), np.uint8), np.empty((0, 3), np.uint8))
