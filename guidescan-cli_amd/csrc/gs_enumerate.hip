@@ -64,6 +64,12 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
   try { /* the plans and lists built per batch live in std containers: nothing may throw across the C boundary */
     gs_status rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream,
                                          d_offsets, d_hits, stats);
+    if (rc == GS_ERR_DEVICE && ix && ix->share_timed_out) { /* (run_search: the sharing's bounded wait ran out) */
+      ix->share_timed_out = false;
+      ix->opt_share_min = 0; /* this handle shares no more: whatever kept the launch off the chip may still be there */
+      if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] sharing timed out: batch redone with every item on its own wave\n");
+      rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets, d_hits, stats);
+    }
     /* the batch's workspace did not fit.  First what earlier batches left on the handle and this one may not need goes -
      * a batch ordered device-wide leaves tens of bytes per record in a dozen arrays that a batch ordered in tiles never
      * touches, and the other way round (10^9 records: 70 GB either way) - and the batch is redone: every workspace
@@ -860,7 +866,16 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       ix->seen_hpass[mismatches] = ((const uint32_t *)(h7 + 16))[8];
       ix->seen_items[mismatches] = 2 * (uint64_t)ng;
     }
+    if (sa.shq != nullptr && gs_opt(ix, "GS_DBG_SHARE_TIMEOUT")) ((uint32_t *)(h7 + 16))[5] |= 2u; /* (tests: as if a helping wave had given up) */
     if (((const uint32_t *)(h7 + 16))[5] != 0u) {
+      if ((((const uint32_t *)(h7 + 16))[5] & 2u) != 0u && sa.shq != nullptr) {
+        /* a wave waited ~3 s for a package that was reserved and never written: the launch's waves were not all on the
+         * chip together (another process on the device, a profiler holding CUs).  Not a wrong result - none is returned -
+         * and not the end of the handle: the caller redoes the batch with every item on its own wave. */
+        ix->share_timed_out = true;
+        gs_set_error("internal: a wave gave up waiting for a shared verification pass (the launch was not resident as a whole)");
+        return GS_ERR_DEVICE;
+      }
       gs_set_error("internal: an item of the search passed its iteration bound (GS_SEARCH_MAX_ITER)");
       return GS_ERR_DEVICE;
     }

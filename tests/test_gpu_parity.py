@@ -900,6 +900,16 @@ def test_a_heavy_item_is_run_by_many_waves():
         off3, hits3, _ = gidx.enumerate(seqs, pams, mismatches=3)
         assert gidx.last_sharing()["shared_items"] == 0
         assert np.array_equal(off0, off3) and hits0.tobytes() == hits3.tobytes()
+        # a helping wave that gives up waiting (the launch was not on the chip as a whole) fails the launch, not the call: the
+        # batch is redone with every item on its own wave, and the handle shares no more
+        gidx.set_options(GS_SHARE_MIN=None, GS_SHARE_MAX=None, GS_HEAVY="1", GS_DBG_SHARE_TIMEOUT="1")
+        off5, hits5, _ = gidx.enumerate(seqs, pams, mismatches=3)
+        assert gidx.last_sharing()["shared_items"] == 0 and gidx.last_sharing()["form"] == 0
+        assert np.array_equal(off0, off5) and hits0.tobytes() == hits5.tobytes()
+        gidx.set_options(GS_HEAVY=None, GS_DBG_SHARE_TIMEOUT=None)
+        gidx.close()
+        gidx = api.GenomeIndex.build(text, device=0)      # (a fresh handle: this one has given sharing up)
+        gidx.set_options(GS_SHARE_MIN="64", GS_SHARE_MAX="256")
         # two launches (what a handle picks for a large batch with FEW heavy items): the plain form publishes and leaves,
         # the heavy form runs the packages beside it (2), behind it (1), or - launched first, its waves leave at once -
         # in a launch the host adds behind both (3)
