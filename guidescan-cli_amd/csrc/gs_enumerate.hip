@@ -724,6 +724,17 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         (void)hipGetLastError(); /* no room for the queue: every item stays with its wave */
       }
     }
+    /* the form of a batch whose every pattern has its tables and that shares no item: 0 - k_search_fast_pd (one launch, every item
+     * sets itself up), 1 - two launches from descriptors (gs_seed.hip), 2 - ... with the guides scheduled by their symbols */
+    uint32_t seed_form = (spec && sa.shq == nullptr && !heavy && !split) ? 2u : 0u;
+    if (const char *e = gs_opt(ix, "GS_SEED_FORM")) seed_form = seed_form ? (uint32_t)std::min(2l, std::max(0l, atol(e))) : 0u;
+    const uint32_t seed_sort_from = gs_opt(ix, "GS_SEED_SORT_FROM") ? (uint32_t)atol(gs_opt(ix, "GS_SEED_SORT_FROM")) : 4096u;
+    uint32_t seed_grid = 0;
+    if (seed_form) {
+      const size_t lds_seed = sizeof(uint4) * (VQ_CAP + 32 + 24 + 6) * SEARCH_WAVES;
+      seed_grid = (uint32_t)cus * std::min<uint32_t>((uint32_t)(160u * 1024u / lds_seed), GS_WAVES_EU_SEED);
+      if (seed_grid > need) seed_grid = need;
+    }
     gs_search_args sh_args;
     uint32_t sh_grid = 0;
     auto launch_helpers = [&](hipStream_t hs) {
@@ -740,7 +751,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
       if (c) GS_HIP(hipMemsetAsync(d_work, 0, 4, st));
       if (walk)
         hipLaunchKernelGGL(k_search_walk, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
-      else if (spec && count_req)
+      else if (spec && count_req && !seed_form)
         hipLaunchKernelGGL(k_search_count_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (split && sa.shq != nullptr) {
         /* the launch without items: on a stream of the lowest priority beside the search launch (its workgroups get the
@@ -786,7 +797,14 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         hipLaunchKernelGGL(k_search_heavy_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (sa.shq != nullptr)
         hipLaunchKernelGGL(k_search_heavy, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
-      else if (spec)
+      else if (seed_form) {
+        /* the two-launch form (gs_seed.hip): descriptors per guide, the guides scheduled by their last / first symbols,
+         * the other strand's seeds + the window list, then this strand's seeds appending */
+        gs_search_args sb;
+        gs_status r2 = gs_seed_describe(ix, sa, ng, seed_form >= 2u && ng >= seed_sort_from, st, &sb);
+        if (r2 == GS_OK) r2 = gs_seed_launch(sb, seed_grid, count_req, st);
+        if (r2 != GS_OK) return r2;
+      } else if (spec)
         hipLaunchKernelGGL(k_search_fast_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (count_req)
         hipLaunchKernelGGL(k_search_count, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);

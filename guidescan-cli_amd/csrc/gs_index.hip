@@ -971,7 +971,7 @@ extern "C" void gs_index_close(gs_index *ix) {
                        &ix->w_b_recs, &ix->w_b_w0, &ix->w_b_w0b, &ix->w_b_idx, &ix->w_b_idxb,
                        &ix->w_b_keep, &ix->w_b_keeps, &ix->w_b_rows, &ix->w_b_rowss, &ix->w_b_redo_pos, &ix->w_b_s, &ix->w_b_tab,
                        &ix->w_cand, &ix->rec[0].buf, &ix->rec[1].buf, &ix->w_score, &ix->w_score_io, &ix->w_score_tmp, &ix->w_arena, &ix->w_arena_meta, &ix->w_nchunk, &ix->w_shq, &ix->w_sh_meta,
-                       &ix->w_cls, &ix->w_t_plan, &ix->w_t_tiles, &ix->w_t_buckets, &ix->w_t_chunkof, &ix->w_t_big, &ix->w_t_rel, &ix->w_t_tab, &ix->w_t_excl, &ix->w_t_spill, &ix->w_b_redo_pos2};
+                       &ix->w_cls, &ix->w_desc, &ix->w_sched, &ix->w_t_plan, &ix->w_t_tiles, &ix->w_t_buckets, &ix->w_t_chunkof, &ix->w_t_big, &ix->w_t_rel, &ix->w_t_tab, &ix->w_t_excl, &ix->w_t_spill, &ix->w_b_redo_pos2};
   for (gs_buffer *b : bufs)
     if (b->p) hipFree(b->p);
   for (int i = 0; i < 4; i++)

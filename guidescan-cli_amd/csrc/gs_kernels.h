@@ -141,6 +141,33 @@ struct gs_search_args {
    * waves' item phases, [4] of their helper episodes, [5] of their waits for a package, [6] episodes */
   uint32_t sh_prof;
   uint32_t helper_only; /* a launch that has no items of its own: its waves run packages until the OTHER launch's n_waves have left their items */
+  /* ---- the two-launch form of a batch whose every pattern has its PAM-pair + deep tables (gs_seed.hip) ----
+   * desc: one descriptor per guide (k_describe); sched_a / sched_b: the guides in the order each launch takes them (by
+   * their first / last symbols; nullptr: as given); xwork: eight work counters per launch, one per XCD, 128 bytes apart */
+  const struct gs_guide_desc *desc;
+  const uint32_t *sched_a, *sched_b;
+  uint32_t *xwork;
+};
+/* what an item of the table-seeded search derives from its guide alone (strand independent): 64 bytes, one scalar load */
+struct gs_guide_desc {
+  uint32_t q_lo, q_hi; /* gs_guide_rec::q */
+  uint32_t pam[4];
+  uint32_t meta;       /* [2:0] patterns (0: the guide is not valid), [4:3] PAM-pair table slots its patterns go through, [7:5] pairs the
+                          deep tables' masks test, [8 + j] the slot of pattern j's tables, [12 + 4 j +: 4] the bases pattern j's first symbol takes */
+  uint32_t pidx0;      /* this strand's side: table index of the guide's exact k-mer */
+  uint32_t pidxg;      /* the other strand's side: index of the complemented last L - x_len guide symbols */
+  uint32_t qrem_b;     /* the complemented first x_len guide symbols, last first */
+  uint32_t bsel_z, bsel_w; /* the bit of the guide's pair in each of a deep-table entry's four 16-bit masks */
+  uint32_t qhot;       /* the nearest six remaining guide symbols as one-hot nibbles (PAM-pair table filters) */
+  uint32_t key_a, key_b; /* scheduling keys: the first min(x_len, 8) symbols as the pair table indexes them; the last min(L - k, 8) as the deep table does */
+  uint32_t spare;
+};
+struct gs_describe_args {
+  const gs_guide_rec *guides;
+  gs_guide_desc *desc;
+  uint32_t *hist; /* [2][65536] or nullptr */
+  uint32_t n, L, P, k, x_len, n_pt;
+  uint32_t code[2];
 };
 #define SHQ_PKG 72u /* uint4 per package: header + 64 descriptors, padded to nine 128-byte lines */
 #define SH_NONE 0xFFFFFFFFu
@@ -188,6 +215,9 @@ __device__ __forceinline__ uint4 ld16_agent(const uint4 *p) {
 #endif
 #ifndef GS_WAVES_EU_HEAVY
 #define GS_WAVES_EU_HEAVY 8
+#endif
+#ifndef GS_WAVES_EU_SEED
+#define GS_WAVES_EU_SEED 8 /* gs_seed.hip */
 #endif
 
 /* ---- gs_order.hip ---- */
@@ -353,6 +383,15 @@ __global__ void k_search_heavy_pd(gs_search_args a);
 __global__ void k_search_pub(gs_search_args a);
 __global__ void k_search_pub_pd(gs_search_args a);
 __global__ void k_prepare(gs_prep_args a);
+
+/* ---- gs_seed.hip ---- */
+__global__ void k_seed_b(gs_search_args a);
+__global__ void k_seed_a(gs_search_args a);
+__global__ void k_seed_count_b(gs_search_args a);
+__global__ void k_seed_count_a(gs_search_args a);
+/* descriptors (+ schedules when `sorted`) of the guides sa.guides[0 .. ng); *out = sa with desc / sched_* / xwork set */
+gs_status gs_seed_describe(gs_index *ix, const gs_search_args &sa, uint32_t ng, bool sorted, hipStream_t st, gs_search_args *out);
+gs_status gs_seed_launch(const gs_search_args &sa, uint32_t grid, bool count_req, hipStream_t st);
 
 /* ---- gs_recipes.hip (host) ---- */
 void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, double epam, uint32_t astar[8], double verify_a = 1.5,
