@@ -802,6 +802,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
          * the other strand's seeds + the window list, then this strand's seeds appending */
         gs_search_args sb;
         gs_status r2 = gs_seed_describe(ix, sa, ng, seed_form >= 2u && ng >= seed_sort_from, st, &sb);
+        /* one item per visit: each XCD has its own counter (a sixteenth of the visits one word took), and the items that share
+         * a piece of a table are then in flight together */
+        sb.seed_opt = gs_opt(ix, "GS_SEED_OPT") ? (uint32_t)atol(gs_opt(ix, "GS_SEED_OPT")) : 0u;
+        sb.take = gs_opt(ix, "GS_SEED_TAKE") ? (uint32_t)std::max(1l, atol(gs_opt(ix, "GS_SEED_TAKE"))) : 1u;
         if (r2 == GS_OK) r2 = gs_seed_launch(sb, seed_grid, count_req, st);
         if (r2 != GS_OK) return r2;
       } else if (spec)

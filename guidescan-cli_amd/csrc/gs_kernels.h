@@ -147,6 +147,7 @@ struct gs_search_args {
   const struct gs_guide_desc *desc;
   const uint32_t *sched_a, *sched_b;
   uint32_t *xwork;
+  uint32_t seed_opt; /* bit 0: single-use reads non-temporal; bit 1: seeds without a substitution in X read the plain table */
 };
 /* what an item of the table-seeded search derives from its guide alone (strand independent): 64 bytes, one scalar load */
 struct gs_guide_desc {

@@ -513,6 +513,7 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
     /* the seeds of a step wait in the queue until a pass can be filled (a pass costs the same instructions for 10
      * seeds as for 64); intervals larger than a descriptor holds are queued piece by piece */
     uint32_t qn = 0;
+    const uint32_t v_max = a.v_max;
     auto queue_step = [&](uint32_t rem, uint32_t first, const uint32_t ymeta, const uint32_t sid, const bool drain_all) __attribute__((always_inline)) {
       for (;;) {
         if (guard_left == 0u) {
@@ -522,8 +523,12 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
         guard_left--;
         const uint64_t bq = __ballot(rem != 0u);
         if (bq && qn + WAVE <= SEED_VQ) {
-          const uint32_t rows = rem < a.v_max ? rem : a.v_max;
-          if (rem != 0u) vq[qn + lanes_below(bq)] = make_uint4(first, ymeta | (rows << 17), sid, 0u);
+          const uint32_t rows = rem < v_max ? rem : v_max;
+          if (rem != 0u) {
+            uint32_t *e = (uint32_t *)(vq + qn + lanes_below(bq));
+            *(uint2 *)e = make_uint2(first, ymeta | (rows << 17));
+            e[2] = sid;
+          }
           qn += __popcll(bq);
           first += rows;
           rem -= rows;
@@ -552,17 +557,19 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    /* the recipe's substitutions applied to the exact index: three table entries per round, read side by side */
+    /* the recipe's substitutions applied to the exact index.  A recipe's unused fields hold 3 = "step 0, digit 3" = nothing
+     * (gs_recipes.hip: recipe_word), so the first three fields are read whatever the recipe's count, side by side; the other
+     * four only by a batch whose budget allows more than three substitutions, in a round some lane needs */
     auto apply_recipe = [&](const uint2 rc, uint32_t pidx) __attribute__((always_inline)) -> uint32_t {
-      const uint32_t n = rc.x & 7u;
-      uint64_t f = (((uint64_t)rc.y << 32) | rc.x) >> 12;
-      for (uint32_t i = 0; __ballot(i < n) != 0ull; i += 3u) {
-        const uint32_t f0 = (uint32_t)f & 127u, f1 = (uint32_t)(f >> 7) & 127u, f2 = (uint32_t)(f >> 14) & 127u;
-        pidx ^= dtab[i < n ? f0 : 3u] ^ dtab[i + 1u < n ? f1 : 3u] ^ dtab[i + 2u < n ? f2 : 3u];
-        f >>= 21;
+      const uint32_t w0 = __builtin_amdgcn_alignbit(rc.y, rc.x, 12); /* fields 0..2: bits 12..32 of the word */
+      pidx ^= dtab[w0 & 127u] ^ dtab[(w0 >> 7) & 127u] ^ dtab[(w0 >> 14) & 127u];
+      if (m > 3u && __ballot((rc.x & 7u) > 3u) != 0ull) {
+        const uint32_t w1 = rc.y >> 1; /* fields 3..6: bits 33..60 */
+        pidx ^= dtab[w1 & 127u] ^ dtab[(w1 >> 7) & 127u] ^ dtab[(w1 >> 14) & 127u] ^ dtab[(w1 >> 21) & 127u];
       }
       return pidx;
     };
+    const uint32_t keep = (a.dbg_skip & 3u) ? 0u : 0xFFFFFFFFu; /* (timing experiments: GS_DBG_SKIP = 1, 2 keep no seed) */
 
     if constexpr (modeB) {
       /* ---- literal-N windows within reach (index.hpp:139-149): the tables hold no row with a symbol outside A,C,G,T
@@ -571,7 +578,7 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
         const uint32_t ncand = a.n_cand[strand];
         const uint64_t lmask = (1ull << (2u * L)) - 1ull;
         const uint32_t *cids = a.cand_ids[strand];
-        const uint32_t nseg = cids != nullptr ? 4u : 1u;
+        const uint32_t nseg = (a.dbg_skip & 8u) ? 0u : cids != nullptr ? 4u : 1u; /* (8: timing experiments - no window scan) */
         for (uint32_t sg = 0; sg < nseg; ++sg) {
           uint32_t s0 = 0, s1 = ncand;
           if (cids != nullptr) {
@@ -613,42 +620,63 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
           }
         }
       }
-      /* ---- the other strand's seeds: per pattern one pass over (recipe, base under the N), four lanes per recipe reading the
-       * four entries of one deep-table line ---- */
+      /* ---- the other strand's seeds: per pattern one pass over the recipes, a lane per recipe reading the deep-table line of
+       * its (k-2)-mer - four entries, one per base under the N, their loads in flight together - and queueing, entry by entry,
+       * what survives the entry's pair masks (four lanes per recipe, one entry each, decoded every recipe four times: 11 steps
+       * per item where this form takes 3) ---- */
       const uint32_t pidxg = dp[8], bsel_z = dp[10], bsel_w = dp[11], n_bpairs = (meta >> 5) & 7u;
-      const uint32_t nlanes = 4u * nrec;
       fill_dtab();
       uint2 rc_next = make_uint2(0u, 0u);
-      if (lane < nlanes) rc_next = recs[lane >> 2];
+      if (lane < nrec) rc_next = recs[lane];
       for (uint32_t bpj = 0; bpj < npams && !bailed; ++bpj) {
         const uint32_t bslot = (meta >> (8u + bpj)) & 1u, bxset = (meta >> (12u + 4u * bpj)) & 15u;
         const uint4 *bdeep = seed_sgprs(a.pt[bslot][strand ^ 1u].deep);
-        for (uint32_t bc0 = 0; bc0 < nlanes; bc0 += WAVE) {
-          const uint32_t idx = bc0 + lane, ri = idx >> 2, bx = idx & 3u;
-          bool act = idx < nlanes;
-          const uint2 rc = act ? rc_next : make_uint2(0u, 0u);
+        const uint32_t last_e = 31u - (uint32_t)__builtin_clz(bxset | 1u);
+        for (uint32_t bc0 = 0; bc0 < nrec; bc0 += WAVE) {
+          const uint32_t ri = bc0 + lane;
+          const bool act = ri < nrec;
+          const uint2 rc = rc_next; /* (lanes beyond the list hold zeros: they load nothing) */
           {
-            const uint32_t nidx = (bc0 + WAVE >= nlanes ? 0u : bc0 + WAVE) + lane;
+            const uint32_t nidx = (bc0 + WAVE >= nrec ? 0u : bc0 + WAVE) + lane;
             rc_next = make_uint2(0u, 0u);
-            if (nidx < nlanes) rc_next = recs[nidx >> 2];
+            if (nidx < nrec) rc_next = recs[nidx];
           }
           count_lines(c_rec, act, recs + ri);
           const uint32_t jb = rc.x & 7u, lo = (rc.x >> 3) & 7u;
           const uint32_t pidx = apply_recipe(rc, pidxg);
-          const uint4 *ep = bdeep + ((size_t)pidx << 2) + bx;
-          act = act && ((bxset >> bx) & 1u) != 0u;
-          uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-          if (act) ent = *ep;
-          count_lines(c_tab, act, ep);
-          const uint32_t ecnt = ent.y & 0x7FFFFFFFu, eflag = ent.y >> 31;
-          bool live = act && ecnt != 0u && !(a.dbg_skip & 2u);
-          if (!eflag) { /* fewer of the query's pairs left of the rows than the budget for X can break: no row can match */
-            const uint32_t intact = (uint32_t)__popc(ent.z & bsel_z) + (uint32_t)__popc(ent.w & bsel_w);
-            if (intact + (m - jb) < n_bpairs) live = false;
+          const uint4 *lp = bdeep + ((size_t)pidx << 2);
+          uint4 en0 = make_uint4(0u, 0u, 0u, 0u), en1 = en0, en2 = en0, en3 = en0;
+          if (bxset & 1u) {
+            if (act) en0 = lp[0];
           }
-          const uint32_t rem = (live && !(a.dbg_skip & 1u)) ? ecnt : 0u;
-          queue_step(rem, ent.x, (jb << 14) | (lo << DSC_LO) | (eflag << DSC_EXC), ri | (bx << 24) | (bpj << 26),
-                     bc0 + WAVE >= nlanes && bpj + 1u == npams);
+          if (bxset & 2u) {
+            if (act) en1 = lp[1];
+          }
+          if (bxset & 4u) {
+            if (act) en2 = lp[2];
+          }
+          if (bxset & 8u) {
+            if (act) en3 = lp[3];
+          }
+          count_lines(c_tab, act, lp);
+          /* fewer of the query's pairs left of an entry's rows than the budget for X can break: no row can match (an entry
+           * with exception rows skips the test).  Per entry what is kept: its first row, and rows | flag << 31 */
+          const uint32_t need = n_bpairs > m - jb ? n_bpairs - (m - jb) : 0u; /* intact pairs a live entry shows at least */
+          auto rows_of = [&](const uint4 en) __attribute__((always_inline)) -> uint32_t {
+            const uint32_t intact = (uint32_t)__popc(en.z & bsel_z) + (uint32_t)__popc(en.w & bsel_w);
+            return ((int32_t)en.y < 0 || intact >= need) ? en.y & keep : 0u;
+          };
+          const uint32_t y0 = rows_of(en0), y1 = rows_of(en1), y2 = rows_of(en2), y3 = rows_of(en3);
+          const uint32_t ym = (jb << 14) | (lo << DSC_LO), sid0 = ri | (bpj << 26);
+          const bool last_step = bc0 + WAVE >= nrec && bpj + 1u == npams;
+#pragma unroll 1
+          for (uint32_t e = 0; e < 4u; ++e) {
+            if (!((bxset >> e) & 1u)) continue;
+            const uint32_t y = e == 0u ? y0 : e == 1u ? y1 : e == 2u ? y2 : y3;
+            const uint32_t f = e == 0u ? en0.x : e == 1u ? en1.x : e == 2u ? en2.x : en3.x;
+            queue_step(y & 0x7FFFFFFFu, f, ym | ((y >> 31) << DSC_EXC), sid0 | (e << 24), last_step && e == last_e);
+            if (bailed) break;
+          }
           if (bailed) break;
         }
       }
@@ -672,7 +700,7 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
         for (uint32_t spos = 0; spos < nrec; spos += WAVE) {
           const uint32_t l = spos + lane;
           const bool act = l < nrec;
-          const uint2 rc = act ? rc_ahead : make_uint2(0u, 0u);
+          const uint2 rc = rc_ahead; /* (lanes beyond the list hold zeros: they load nothing) */
           {
             const uint32_t nl = (spos + WAVE >= nrec ? 0u : spos + WAVE) + lane; /* past the end: the next table's pass */
             rc_ahead = make_uint2(0u, 0u);
@@ -681,36 +709,35 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
           count_lines(c_rec, act, recs + l);
           const uint32_t kk = rc.x & 7u;
           const uint32_t pidx = apply_recipe(rc, pidx0);
-          size_t ei = pidx;
-          bool in_rot = false;
+          const uint2 *ep = atab8 + pidx;
           const uint32_t rs = (rc.x >> 7) & 31u;
-          if ((rc.x & 64u) != 0u && rs >= arot_first) {
-            /* the copy rotated at step rs: that step's symbol and everything after it swap places */
-            const uint32_t sh = 2u * (k - 1u - rs);
-            const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) | ((pidx >> sh) & 3u);
-            ei = ((size_t)(rs - arot_first) << (2u * k)) + ridx;
-            in_rot = true;
+          const bool rot = (rc.x & 64u) != 0u && rs >= arot_first;
+          if (__ballot(rot) != 0ull) {
+            if (rot) {
+              /* the copy rotated at step rs: that step's symbol and everything after it swap places */
+              const uint32_t sh = 2u * (k - 1u - rs);
+              const uint32_t ridx = ((pidx >> (sh + 2u)) << (sh + 2u)) | ((pidx & ((1u << sh) - 1u)) << 2) | ((pidx >> sh) & 3u);
+              ep = arot8 + (((size_t)(rs - arot_first) << (2u * k)) + ridx);
+            }
           }
-          const uint2 *ep = (in_rot ? arot8 : atab8) + ei;
           uint2 e8 = make_uint2(0u, 0u);
           if (act) e8 = *ep;
           count_lines(c_tab, act, ep);
           uint32_t first = e8.x, ecnt = e8.y & 63u;
           const uint32_t filt = e8.y >> 6, bl = m - kk;
-          bool hopeless = false;
-          if (ecnt == 1u) {
-            const uint32_t xf = (filt ^ qrem) & gmask13; /* the row's own context symbols */
-            hopeless = (uint32_t)__popc((xf | (xf >> 1)) & 0x55555555u) > bl;
-          } else if (ecnt > 1u) {
-            hopeless = (uint32_t)__popc(qhot & ~filt) > bl; /* a query symbol none of the rows shows there is a substitution in every row */
-            if (ecnt == GS_PT_BIG && !hopeless) { /* 63 rows and more: the count sits in a header slot in front of them */
+          /* one row: its own context symbols against the query's; several: a query symbol none of the rows shows at its
+           * position is a substitution in every row (an empty entry keeps nothing whatever this says) */
+          const uint32_t xf = (filt ^ qrem) & gmask13;
+          const uint32_t tw = ecnt == 1u ? ((xf | (xf >> 1)) & 0x55555555u) : (qhot & ~filt);
+          const bool hopeless = (uint32_t)__popc(tw) > bl;
+          if (__ballot(ecnt == GS_PT_BIG && !hopeless) != 0ull) { /* 63 rows and more: the count sits in a header slot in front of them */
+            if (ecnt == GS_PT_BIG && !hopeless) {
               ecnt = arow[first];
               first += 1u;
-              if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(true));
             }
+            if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(true));
           }
-          const bool live = act && ecnt != 0u && !hopeless && !(a.dbg_skip & 2u);
-          const uint32_t rem = (live && !(a.dbg_skip & 1u)) ? ecnt : 0u;
+          const uint32_t rem = hopeless ? 0u : ecnt & keep;
           queue_step(rem, first, kk << 14, l, spos + WAVE >= nrec);
           if (bailed) break;
         }
