@@ -142,10 +142,9 @@ struct gs_search_args {
   uint32_t sh_prof;
   uint32_t helper_only; /* a launch that has no items of its own: its waves run packages until the OTHER launch's n_waves have left their items */
   /* ---- the two-launch form of a batch whose every pattern has its PAM-pair + deep tables (gs_seed.hip) ----
-   * desc: one descriptor per guide (k_describe); sched_a / sched_b: the guides in the order each launch takes them (by
-   * their first / last symbols; nullptr: as given); xwork: eight work counters per launch, one per XCD, 128 bytes apart */
-  const struct gs_guide_desc *desc;
-  const uint32_t *sched_a, *sched_b;
+   * desc_a / desc_b: one descriptor per guide (k_describe) in the order each launch takes the guides (by their first / last
+   * symbols, or as given: one array); xwork: eight work counters per launch, one per XCD, 128 bytes apart */
+  const struct gs_guide_desc *desc_a, *desc_b;
   uint32_t *xwork;
   uint32_t seed_opt; /* bit 0: single-use reads non-temporal; bit 1: seeds without a substitution in X read the plain table */
 };
@@ -161,7 +160,7 @@ struct gs_guide_desc {
   uint32_t bsel_z, bsel_w; /* the bit of the guide's pair in each of a deep-table entry's four 16-bit masks */
   uint32_t qhot;       /* the nearest six remaining guide symbols as one-hot nibbles (PAM-pair table filters) */
   uint32_t key_a, key_b; /* scheduling keys: the first min(x_len, 8) symbols as the pair table indexes them; the last min(L - k, 8) as the deep table does */
-  uint32_t spare;
+  uint32_t guide;      /* whose descriptor this is (a launch reads them in its schedule's order) */
 };
 struct gs_describe_args {
   const gs_guide_rec *guides;

@@ -111,7 +111,7 @@ __global__ void k_describe(gs_describe_args a) {
   const uint32_t xa = sx < 8u ? sx : 8u, rb = (L - k) < 8u ? (L - k) : 8u;
   d.key_a = xa ? pidx0 >> (2u * (k - xa)) : 0u;
   d.key_b = (rb && rb <= nYb) ? pidxg >> (2u * (nYb - rb)) : 0u;
-  d.spare = 0;
+  d.guide = g;
   a.desc[g] = d;
   if (a.hist != nullptr) {
     atomicAdd(&a.hist[d.key_a], 1u);
@@ -140,12 +140,12 @@ __global__ void __launch_bounds__(1024) k_sched_scan(uint32_t *hist) {
     run += c;
   }
 }
-__global__ void k_sched_scatter(const gs_guide_desc *desc, uint32_t n, uint32_t *cursor, uint32_t *sched_a, uint32_t *sched_b) {
+__global__ void k_sched_scatter(const gs_guide_desc *desc, uint32_t n, uint32_t *cursor, gs_guide_desc *desc_a, gs_guide_desc *desc_b) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
-  const uint32_t ka = desc[g].key_a, kb = desc[g].key_b;
-  sched_a[atomicAdd(&cursor[ka], 1u)] = g;
-  sched_b[atomicAdd(&cursor[65536u + kb], 1u)] = g;
+  const gs_guide_desc d = desc[g];
+  desc_a[atomicAdd(&cursor[d.key_a], 1u)] = d;
+  desc_b[atomicAdd(&cursor[65536u + d.key_b], 1u)] = d;
 }
 
 /* ---- the seeding launches ------------------------------------------------------------------------------------------
@@ -166,7 +166,6 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
   const bool k_append = modeB ? a.append != 0u : true;
   const uint64_t *const k_slot_off = a.slot_off;
   const uint32_t k_cap = a.cap, n_items = a.n_items, ng = n_items >> 1;
-  const uint32_t *const sched = modeB ? a.sched_b : a.sched_a;
   uint32_t *const xwork = a.xwork + (modeB ? 0u : 256u);
   unsigned long long n_ovf = 0;
   uint32_t n_fail = 0, n_hpass = 0, n_two = 0;
@@ -188,20 +187,27 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-  /* items: each XCD draws from its own eighth of the schedule, then from the others' */
+  /* items: each XCD draws from its own eighth of the schedule, then from the others'.  The draw for the NEXT visit is issued
+   * when a visit's last item starts (the counter's answer comes from the memory side of the fabric: ~2 us that nothing waits for
+   * any more), and the descriptors lie in the schedule's order, so an item is its position and one scalar load */
+  const gs_guide_desc *const descs = modeB ? a.desc_b : a.desc_a;
   uint32_t cur = seed_xcc_id(), tried = 0;
-  uint32_t item_next = 0, item_end = 0, item_base = 0;
-  uint32_t gv = 0; /* lane i: the guide of item item_base + i */
+  uint32_t item_next = 0, item_end = 0;
+  uint32_t pend = 0xFFFFFFFFu; /* lane 0: the answer of the draw that is on its way */
+  bool pending = false;
   for (;;) {
     if (item_next == item_end) {
       bool none = false;
       for (;;) {
         const uint32_t lo = (uint32_t)(((uint64_t)cur * n_items) >> 3), hi = (uint32_t)(((uint64_t)(cur + 1u) * n_items) >> 3);
-        uint32_t base = 0xFFFFFFFFu;
-        /* (a piece that is not this wave's own is looked at before it is drawn from: at the end of a launch every wave visits
-         * every counter, and a load does not queue behind the others as an atomic does) */
-        if (lane == 0 && (tried == 0u || ld_agent(&xwork[32u * cur]) < hi - lo)) base = atomicAdd(&xwork[32u * cur], a.take);
-        base = __builtin_amdgcn_readfirstlane(base);
+        if (!pending) {
+          pend = 0xFFFFFFFFu;
+          /* (a piece that is not this wave's own is looked at before it is drawn from: at the end of a launch every wave visits
+           * every counter, and a load does not queue behind the others as an atomic does) */
+          if (lane == 0 && (tried == 0u || ld_agent(&xwork[32u * cur]) < hi - lo)) pend = atomicAdd(&xwork[32u * cur], a.take);
+        }
+        pending = false;
+        const uint32_t base = __builtin_amdgcn_readfirstlane(pend);
         if (base < hi - lo) {
           item_next = lo + base;
           item_end = (hi - lo) - base < a.take ? hi : item_next + a.take;
@@ -214,21 +220,19 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
         }
       }
       if (none) break; /* exit condition every wave reaches: all eight pieces are taken */
-      item_base = item_next;
-      const uint32_t pos = item_next + lane;
-      gv = 0u;
-      if (pos < item_end) {
-        const uint32_t j = pos >= ng ? pos - ng : pos;
-        gv = sched != nullptr ? sched[j] : j;
-      }
     }
     const uint32_t pos = item_next++;
+    if (item_next == item_end) { /* the visit's last item: the next draw goes out now */
+      pend = 0xFFFFFFFFu;
+      if (lane == 0) pend = atomicAdd(&xwork[32u * cur], a.take);
+      pending = true;
+    }
     const uint32_t strand = pos >= ng ? 1u : 0u;
-    const uint32_t guide = (uint32_t)__builtin_amdgcn_readlane((int)gv, (int)(pos - item_base));
-    const uint32_t slot = 2u * guide + strand;
     /* the descriptor: sixteen wave-uniform words, one scalar load */
     typedef uint32_t seed_u32x16 __attribute__((ext_vector_type(16)));
-    const seed_u32x16 dp = *(const seed_u32x16 __attribute__((address_space(4))) *)(uintptr_t)(a.desc + guide);
+    const seed_u32x16 dp = *(const seed_u32x16 __attribute__((address_space(4))) *)(uintptr_t)(descs + (pos - strand * ng));
+    const uint32_t guide = dp[15];
+    const uint32_t slot = 2u * guide + strand;
     const uint32_t gw0 = dp[0], gw1 = dp[1];
     const uint64_t gr_q = ((uint64_t)gw1 << 32) | gw0;
     const uint32_t gr_pam0 = dp[2], gr_pam1 = dp[3], gr_pam2 = dp[4], gr_pam3 = dp[5];
@@ -355,6 +359,51 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
     const uint32_t gmask = g >= 16u ? 0xFFFFFFFFu : ((1u << (2u * g)) - 1u);
     const uint32_t qrem = modeB ? dp[9] : ((uint32_t)(gr_q >> (2u * k)) & gmask);
 
+    /* ---- a row that passed both levels: its place in THIS strand's suffix array - through the other strand's SA and this
+     * strand's ISA, or a PAM-pair table's row numbers -, its seed's path from the recipe, its record.  (Parking the hits in
+     * LDS and resolving them 64 at a time, so that a pass does not wait for these dependent reads, changed nothing: 16.4 ms
+     * against 16.3, profiles/r06_ab_seed_variants.txt - the waves that wait are covered by the SIMD's other seven) ---- */
+    auto resolve = [&](const bool on, const uint32_t e_x, const uint32_t e_y, const uint32_t w, const uint32_t e_w) __attribute__((always_inline)) {
+      const uint32_t n = (uint32_t)__popcll(__ballot(on));
+      const uint4 e = make_uint4(e_x, e_y, w, e_w);
+      if constexpr (modeB) {
+        /* word symbol j is guide symbol g-1-j, complemented; the site's row on THIS strand through SA -> ISA */
+        uint64_t mmeta = 0;
+        uint32_t rowA = 0;
+        if (on) {
+          const uint32_t pB = sv.sa[e.x];
+          const uint64_t sp = seed_path(e.y);
+          rowA = sd.isa[(sd.n - 1u) - (pB - g) - (L + P)];
+          const uint64_t gpath = (uint64_t)seed_codes16(~w & gmask, ~qrem & gmask) << (52u + PB - 2u * g);
+          mmeta = ((uint64_t)e.w << KSH) | sp | gpath;
+        }
+        if constexpr (CNT) c_isa += 2u * n;
+        emit(on, rowA, mmeta, 0u);
+      } else {
+        uint32_t orow = 0;
+        uint64_t base_meta = 0;
+        if (on) {
+          orow = arow[e.x];
+          const uint64_t gpath = ((uint64_t)seed_rev16(seed_codes16(w & gmask, qrem)) << 32) >> (12u - PB + 2u * k);
+          base_meta = ((uint64_t)e.w << KSH) | seed_path(e.y) | gpath;
+        }
+        if constexpr (CNT) c_isa += n;
+        for (uint32_t pj = 0; pj < npams; ++pj) {
+          const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
+          bool ok = on;
+          uint64_t ppath = 0;
+          for (uint32_t u = 0; u < P; ++u) {
+            const uint32_t pc = (pw >> (3u * u)) & 7u;
+            const uint32_t tb = (w >> (2u * (g + u))) & 3u;
+            ok = ok && (pc == 4u || pc == tb);
+            ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (PSP - 2u * L - 3u * u);
+          }
+          if (!__ballot(ok)) continue;
+          emit(ok, orow, base_meta | ppath, 1u);
+        }
+      }
+    };
+
     /* ---- context verification of `take` queued seeds (k_search_body::verify, the plain form) ---- */
     auto verify = [&](const uint32_t take, uint4 *dsrc) __attribute__((always_inline)) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -470,42 +519,9 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
           const uint32_t xf = (w ^ qrem) & gmask;
           const uint32_t mmv = __popc((xf | (xf >> 1)) & 0x55555555u);
           const bool gok = has && !excbad && kv + mmv <= m && mmv >= ((dd.y >> DSC_LO) & 7u);
-          if (!__ballot(gok)) continue;
-          if constexpr (modeB) {
-            /* word symbol j is guide symbol g-1-j, complemented; the site's row on THIS strand through SA -> ISA */
-            uint64_t mmeta = 0;
-            uint32_t rowA = 0;
-            if (gok) {
-              const uint32_t pB = sv.sa[row];
-              rowA = sd.isa[(sd.n - 1u) - (pB - g) - (L + P)];
-              const uint64_t gpath = (uint64_t)seed_codes16(~w & gmask, ~qrem & gmask) << (52u + PB - 2u * g);
-              mmeta = ((uint64_t)(kv + mmv) << KSH) | seed_path(dd.z) | gpath;
-            }
-            if constexpr (CNT) c_isa += 2u * (uint32_t)__popcll(__ballot(gok));
-            emit(gok, rowA, mmeta, 0u);
-          } else {
-            uint32_t orow = row;
-            uint64_t base_meta = 0;
-            if (gok) {
-              orow = arow[row];
-              const uint64_t gpath = ((uint64_t)seed_rev16(seed_codes16(w & gmask, qrem)) << 32) >> (12u - PB + 2u * k);
-              base_meta = ((uint64_t)(kv + mmv) << KSH) | seed_path(dd.z) | gpath;
-            }
-            if constexpr (CNT) c_isa += (uint32_t)__popcll(__ballot(gok));
-            for (uint32_t pj = 0; pj < npams; ++pj) {
-              const uint32_t pw = pj == 0 ? gr_pam0 : pj == 1 ? gr_pam1 : pj == 2 ? gr_pam2 : gr_pam3;
-              bool ok = gok;
-              uint64_t ppath = 0;
-              for (uint32_t u = 0; u < P; ++u) {
-                const uint32_t pc = (pw >> (3u * u)) & 7u;
-                const uint32_t tb = (w >> (2u * (g + u))) & 3u;
-                ok = ok && (pc == 4u || pc == tb);
-                ppath |= (uint64_t)(tb < 3u ? tb : 4u) << (PSP - 2u * L - 3u * u);
-              }
-              if (!__ballot(ok)) continue;
-              emit(ok, orow, base_meta | ppath, 1u);
-            }
-          }
+          const uint64_t bh = __ballot(gok);
+          if (!bh) continue;
+          resolve(gok, row, dd.z, w, kv + mmv);
         }
       }
     };
@@ -620,63 +636,39 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
           }
         }
       }
-      /* ---- the other strand's seeds: per pattern one pass over the recipes, a lane per recipe reading the deep-table line of
-       * its (k-2)-mer - four entries, one per base under the N, their loads in flight together - and queueing, entry by entry,
-       * what survives the entry's pair masks (four lanes per recipe, one entry each, decoded every recipe four times: 11 steps
-       * per item where this form takes 3) ---- */
+      /* ---- the other strand's seeds: per pattern one pass over (recipe, base under the N), four lanes per recipe reading the
+       * four entries of one deep-table line ---- */
       const uint32_t pidxg = dp[8], bsel_z = dp[10], bsel_w = dp[11], n_bpairs = (meta >> 5) & 7u;
+      const uint32_t nlanes = 4u * nrec;
       fill_dtab();
       uint2 rc_next = make_uint2(0u, 0u);
-      if (lane < nrec) rc_next = recs[lane];
+      if (lane < nlanes) rc_next = recs[lane >> 2];
       for (uint32_t bpj = 0; bpj < npams && !bailed; ++bpj) {
         const uint32_t bslot = (meta >> (8u + bpj)) & 1u, bxset = (meta >> (12u + 4u * bpj)) & 15u;
         const uint4 *bdeep = seed_sgprs(a.pt[bslot][strand ^ 1u].deep);
-        const uint32_t last_e = 31u - (uint32_t)__builtin_clz(bxset | 1u);
-        for (uint32_t bc0 = 0; bc0 < nrec; bc0 += WAVE) {
-          const uint32_t ri = bc0 + lane;
-          const bool act = ri < nrec;
+        for (uint32_t bc0 = 0; bc0 < nlanes; bc0 += WAVE) {
+          const uint32_t idx = bc0 + lane, ri = idx >> 2, bx = idx & 3u;
+          const bool act = idx < nlanes && ((bxset >> bx) & 1u) != 0u;
           const uint2 rc = rc_next; /* (lanes beyond the list hold zeros: they load nothing) */
           {
-            const uint32_t nidx = (bc0 + WAVE >= nrec ? 0u : bc0 + WAVE) + lane;
+            const uint32_t nidx = (bc0 + WAVE >= nlanes ? 0u : bc0 + WAVE) + lane;
             rc_next = make_uint2(0u, 0u);
-            if (nidx < nrec) rc_next = recs[nidx];
+            if (nidx < nlanes) rc_next = recs[nidx >> 2];
           }
-          count_lines(c_rec, act, recs + ri);
+          count_lines(c_rec, idx < nlanes, recs + ri);
           const uint32_t jb = rc.x & 7u, lo = (rc.x >> 3) & 7u;
           const uint32_t pidx = apply_recipe(rc, pidxg);
-          const uint4 *lp = bdeep + ((size_t)pidx << 2);
-          uint4 en0 = make_uint4(0u, 0u, 0u, 0u), en1 = en0, en2 = en0, en3 = en0;
-          if (bxset & 1u) {
-            if (act) en0 = lp[0];
-          }
-          if (bxset & 2u) {
-            if (act) en1 = lp[1];
-          }
-          if (bxset & 4u) {
-            if (act) en2 = lp[2];
-          }
-          if (bxset & 8u) {
-            if (act) en3 = lp[3];
-          }
-          count_lines(c_tab, act, lp);
-          /* fewer of the query's pairs left of an entry's rows than the budget for X can break: no row can match (an entry
-           * with exception rows skips the test).  Per entry what is kept: its first row, and rows | flag << 31 */
-          const uint32_t need = n_bpairs > m - jb ? n_bpairs - (m - jb) : 0u; /* intact pairs a live entry shows at least */
-          auto rows_of = [&](const uint4 en) __attribute__((always_inline)) -> uint32_t {
-            const uint32_t intact = (uint32_t)__popc(en.z & bsel_z) + (uint32_t)__popc(en.w & bsel_w);
-            return ((int32_t)en.y < 0 || intact >= need) ? en.y & keep : 0u;
-          };
-          const uint32_t y0 = rows_of(en0), y1 = rows_of(en1), y2 = rows_of(en2), y3 = rows_of(en3);
-          const uint32_t ym = (jb << 14) | (lo << DSC_LO), sid0 = ri | (bpj << 26);
-          const bool last_step = bc0 + WAVE >= nrec && bpj + 1u == npams;
-#pragma unroll 1
-          for (uint32_t e = 0; e < 4u; ++e) {
-            if (!((bxset >> e) & 1u)) continue;
-            const uint32_t y = e == 0u ? y0 : e == 1u ? y1 : e == 2u ? y2 : y3;
-            const uint32_t f = e == 0u ? en0.x : e == 1u ? en1.x : e == 2u ? en2.x : en3.x;
-            queue_step(y & 0x7FFFFFFFu, f, ym | ((y >> 31) << DSC_EXC), sid0 | (e << 24), last_step && e == last_e);
-            if (bailed) break;
-          }
+          const uint4 *ep = bdeep + ((size_t)pidx << 2) + bx;
+          uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+          if (act) ent = *ep;
+          count_lines(c_tab, act, ep);
+          /* fewer of the query's pairs left of the rows than the budget for X can break: no row can match (an entry with
+           * exception rows skips the test) */
+          const uint32_t need = n_bpairs > m - jb ? n_bpairs - (m - jb) : 0u;
+          const uint32_t intact = (uint32_t)__popc(ent.z & bsel_z) + (uint32_t)__popc(ent.w & bsel_w);
+          const uint32_t y = ((int32_t)ent.y < 0 || intact >= need) ? ent.y & keep : 0u;
+          queue_step(y & 0x7FFFFFFFu, ent.x, (jb << 14) | (lo << DSC_LO) | ((y >> 31) << DSC_EXC), ri | (bx << 24) | (bpj << 26),
+                     bc0 + WAVE >= nlanes && bpj + 1u == npams);
           if (bailed) break;
         }
       }
@@ -788,14 +780,15 @@ GS_DEF_SEED(k_seed_count_a, true, 1)
 /* ---- host: the descriptor pre-pass + the schedules, then the two launches (run_search's SPEC form) ---- */
 gs_status gs_seed_describe(gs_index *ix, const gs_search_args &sa, uint32_t ng, bool sorted, hipStream_t st, gs_search_args *out) {
   gs_status rc;
-  if ((rc = gs_reserve(ix->w_desc, sizeof(gs_guide_desc) * ((size_t)ng + 1))) != GS_OK) return rc;
-  if ((rc = gs_reserve(ix->w_sched, 4 * (2 * (size_t)ng + 2 * 65536 + 512 + 16))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_desc, sizeof(gs_guide_desc) * ((size_t)ng + 1) * (sorted ? 3u : 1u))) != GS_OK) return rc;
+  if ((rc = gs_reserve(ix->w_sched, 4 * (2 * 65536 + 512 + 16))) != GS_OK) return rc;
   uint32_t *base = (uint32_t *)ix->w_sched.p;
-  uint32_t *xwork = base, *hist = base + 512, *sched_a = hist + 2 * 65536, *sched_b = sched_a + ng;
+  uint32_t *xwork = base, *hist = base + 512;
+  gs_guide_desc *desc = (gs_guide_desc *)ix->w_desc.p, *desc_a = desc + ng, *desc_b = desc_a + ng;
   gs_describe_args da;
   memset(&da, 0, sizeof(da));
   da.guides = sa.guides;
-  da.desc = (gs_guide_desc *)ix->w_desc.p;
+  da.desc = desc;
   da.n = ng;
   da.L = sa.L;
   da.P = sa.P;
@@ -809,12 +802,11 @@ gs_status gs_seed_describe(gs_index *ix, const gs_search_args &sa, uint32_t ng, 
   hipLaunchKernelGGL(k_describe, dim3((ng + 255) / 256), dim3(256), 0, st, da);
   if (sorted) {
     hipLaunchKernelGGL(k_sched_scan, dim3(2), dim3(1024), 0, st, hist);
-    hipLaunchKernelGGL(k_sched_scatter, dim3((ng + 255) / 256), dim3(256), 0, st, (const gs_guide_desc *)da.desc, ng, hist, sched_a, sched_b);
+    hipLaunchKernelGGL(k_sched_scatter, dim3((ng + 255) / 256), dim3(256), 0, st, (const gs_guide_desc *)desc, ng, hist, desc_a, desc_b);
   }
   *out = sa;
-  out->desc = da.desc;
-  out->sched_a = sorted ? sched_a : nullptr;
-  out->sched_b = sorted ? sched_b : nullptr;
+  out->desc_a = sorted ? desc_a : desc;
+  out->desc_b = sorted ? desc_b : desc;
   out->xwork = xwork;
   return GS_OK;
 }
