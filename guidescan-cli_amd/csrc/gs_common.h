@@ -180,6 +180,7 @@ struct gs_index {
        * descriptors, bucket space, chunk index, partitioned items, class starts, rank tables + flags */
       w_cls, w_desc, w_sched, /* gs_seed.hip: descriptors per guide; work counters, histograms, the two schedules */
       w_t_plan, w_t_tiles, w_t_buckets, w_t_chunkof, w_t_big, w_t_rel, w_t_tab, w_t_excl, w_t_spill, w_b_redo_pos2;
+  uint32_t share_backoff = 0; /* batches this handle still runs without sharing after a sharing launch was not resident as a whole */
   bool share_timed_out = false; /* a helping wave gave up waiting for a package (k_search_body): the call fails, gs_enumerate_device redoes the batch without sharing */
   uint32_t opt_share_min = 512, opt_share_max = 2048; /* groups of eight rows: a verification pass of share_min or more is handed out, in packages of at most share_max (0: items are never shared) */
   unsigned long long last_share[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* the last batch: shared items, packages reserved, queue capacity, tickets handed out; [4] guides beyond the tiles' reach, ordered device-wide alone */

@@ -66,7 +66,9 @@ extern "C" gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uin
                                          d_offsets, d_hits, stats);
     if (rc == GS_ERR_DEVICE && ix && ix->share_timed_out) { /* (run_search: the sharing's bounded wait ran out) */
       ix->share_timed_out = false;
-      ix->opt_share_min = 0; /* this handle shares no more: whatever kept the launch off the chip may still be there */
+      /* this handle shares nothing for a while - whatever kept the launch off the chip may still be there -, whatever the
+       * tuning switches say (GS_SHARE_MIN, GS_HEAVY, GS_SPLIT_SHARE): run_search looks at the back-off after it has read them */
+      ix->share_backoff = 64;
       if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] sharing timed out: batch redone with every item on its own wave\n");
       rc = enumerate_device_impl(ix, d_guides, n, L, d_guide_pams, P, alt_pams, n_alt, mismatches, flags, stream, d_offsets, d_hits, stats);
     }
@@ -672,7 +674,9 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
      * last batch of the same shape showed (gs_search_args::hpass): no heavy pass - plain; one per sixteen items, or any in a
      * batch of at most 64 items per wave slot - heavy (a repeat-rich batch: 9.3 ms per 20,000 guides against 9.7 split, 16.2
      * plain); fewer - split (1 M light guides + 8 of an Alu-like family, 650,000 hits each: 26.7 ms against 33.6 plain, 32.7 heavy). */
-    const bool share_ok = with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0;
+    /* (a handle whose sharing launch was not resident as a whole backs off for 64 batches, then tries again) */
+    if (with_arena && ix->share_backoff != 0) ix->share_backoff--;
+    const bool share_ok = with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0 && ix->share_backoff == 0;
     const bool seen = mismatches < 8 &&
                       ix->seen_key[mismatches] == (((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START)) &&
                       ix->seen_hpass[mismatches] != 0;
@@ -690,6 +694,17 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     const uint32_t weu = walk ? GS_WAVES_EU : heavy ? GS_WAVES_EU_HEAVY : spec ? GS_WAVES_EU_PD : GS_WAVES_EU_FAST;
     if (per_cu > weu) per_cu = weu; /* 4 SIMDs x weu waves = weu four-wave workgroups per CU */
+    /* The sharing forms need their whole grid on the chip at once (a helper waits for a package only a resident wave can
+     * write): never more workgroups than the runtime says the heavy kernel gets per CU - registers, LDS AND its scratch. */
+    uint32_t heavy_per_cu = std::min<uint32_t>((uint32_t)(160u * 1024u / lds_wg), GS_WAVES_EU_HEAVY);
+    if (heavy || split) {
+      int occ = 0;
+      hipError_t oe = spec ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_heavy_pd, WAVE * SEARCH_WAVES, dyn)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_search_heavy, WAVE * SEARCH_WAVES, dyn);
+      if (oe != hipSuccess) (void)hipGetLastError();
+      if (oe == hipSuccess && occ > 0 && (uint32_t)occ < heavy_per_cu) heavy_per_cu = (uint32_t)occ;
+      if (heavy && per_cu > heavy_per_cu) per_cu = heavy_per_cu;
+    }
     uint32_t grid = (uint32_t)cus * per_cu;
     const uint32_t need = (2 * ng + SEARCH_WAVES - 1) / SEARCH_WAVES;
     if (grid > need) grid = need;
@@ -759,7 +774,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         sh_args = sa;
         sh_args.helper_only = 1u;
         sh_args.work = d_work + 9; /* a counter that is past the items from the start */
-        sh_grid = (uint32_t)cus * std::min<uint32_t>((uint32_t)(160u * 1024u / lds_wg), GS_WAVES_EU_HEAVY);
+        sh_grid = (uint32_t)cus * heavy_per_cu;
         bool side = split == 2u;
         if (side && !ix->st_help) {
           int lo = 0, hi = 0;
@@ -808,6 +823,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         sb.take = gs_opt(ix, "GS_SEED_TAKE") ? (uint32_t)std::max(1l, atol(gs_opt(ix, "GS_SEED_TAKE"))) : 1u;
         if (r2 == GS_OK) r2 = gs_seed_launch(sb, seed_grid, count_req, st);
         if (r2 != GS_OK) return r2;
+        if (with_arena) ix->last_share[6] = 3u; /* (gs_index_last_sharing: the form of the main pass) */
       } else if (spec)
         hipLaunchKernelGGL(k_search_fast_pd, dim3(grid), dim3(WAVE * SEARCH_WAVES), dyn, st, sa);
       else if (count_req)
@@ -822,7 +838,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     if (d_shctl) GS_HIP(hipMemcpyAsync(h_ctl, d_shctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
     GS_HIP(hipStreamSynchronize(st));
     GS_HIP(hipGetLastError());
-    if (d_shctl && split && sh_grid != 0u && h_ctl[32] < h_ctl[0] && ((const uint32_t *)(h7 + 16))[5] == 0u) {
+    /* (packages reserved beyond the queue's size were run by their owners: what the helpers could draw is the smaller) */
+    if (d_shctl && split && sh_grid != 0u && h_ctl[32] < std::min(h_ctl[0], sa.shq_cap) && ((const uint32_t *)(h7 + 16))[5] == 0u) {
       /* packages nobody ran: the launch without items was on the chip before the one it serves and left (k_search_body's
        * first lines) - again, behind it */
       launch_helpers(st);
@@ -1753,7 +1770,28 @@ extern "C" gs_status gs_index_prepare(gs_index *ix, uint64_t n, uint32_t L, cons
   hipLaunchKernelGGL(k_prepare_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, d_g, d_p, n, L, P, pat);
   const void *off = nullptr, *hits = nullptr;
   gs_result_view v;
+  /* what the handle learns from its batches (slot sizing, the search's form, the queue of shared passes) must come from the
+   * caller's guides, not from this synthetic few-hit batch: saved and put back.  The call does overwrite the device
+   * buffers an earlier gs_enumerate_device left its results in (include/guidescan_amd.h says so). */
+  double s_mean[8], s_max[8];
+  uint64_t s_hp[8], s_it[8], s_key[8];
+  for (int i = 0; i < 8; i++) {
+    s_mean[i] = ix->seen_mean[i];
+    s_max[i] = ix->seen_max[i];
+    s_hp[i] = ix->seen_hpass[i];
+    s_it[i] = ix->seen_items[i];
+    s_key[i] = ix->seen_key[i];
+  }
+  const uint64_t s_pk = ix->shq_packages;
   const gs_status rc = gs_enumerate_device(ix, d_g, n, L, d_p, P, alt_pams, n_alt, mismatches, flags & ~GS_FLAG_COUNT_REQUESTS, nullptr, &off, &hits, &v);
+  for (int i = 0; i < 8; i++) {
+    ix->seen_mean[i] = s_mean[i];
+    ix->seen_max[i] = s_max[i];
+    ix->seen_hpass[i] = s_hp[i];
+    ix->seen_items[i] = s_it[i];
+    ix->seen_key[i] = s_key[i];
+  }
+  ix->shq_packages = s_pk;
   (void)hipDeviceSynchronize();
   (void)hipFree(d_g);
   (void)hipFree(d_p);

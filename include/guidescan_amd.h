@@ -227,7 +227,9 @@ gs_status gs_enumerate_device(gs_index *ix, const void *d_guides, uint64_t n, ui
  * of length L drawn from a generator (not from the genome: few hits), each with the pattern `pam` (P symbols), are enumerated
  * with these alt PAMs, budget and flags and the result is dropped.  Nothing in the reference corresponds (its index is ready
  * when loaded, src/guidescan.cxx:198-211); a service calls this after opening a handle so that a 2,500-guide job
- * (manual/manual.tex:472-475) is not all warm-up.  The batch's own workspace for hits still grows with the first real batch. */
+ * (manual/manual.tex:472-475) is not all warm-up.  The batch's own workspace for hits still grows with the first real batch.
+ * The call runs a batch on the handle: device results an earlier gs_enumerate_device left in HBM are no longer valid after
+ * it; what the handle has learned from the caller's batches (slot sizes, the form of the search) is kept as it was. */
 gs_status gs_index_prepare(gs_index *ix, uint64_t n, uint32_t L, const char *pam, uint32_t P, const char *alt_pams,
                            uint32_t n_alt, uint32_t mismatches, uint32_t flags);
 
