@@ -48,20 +48,37 @@ class ChunkDealer:
     a kmers file); every rank calls take() until it returns None.  With torch.distributed the counter
     lives in the process group's store (TCPStore.add is atomic); without it, in this process."""
 
+    # how many dealers this process has made per key: every rank makes them in the same order (one program, many ranks),
+    # so the count is the same number everywhere and a key used again - the same kmers file twice, a retry after a failure -
+    # gets a counter of its own in the store instead of finding the last job's, already past its chunks
+    _generation = {}
+
     def __init__(self, n_chunks: int, key: str, dist=None):
         self.n_chunks, self.key, self.dist = int(n_chunks), key, dist
         self._local = 0
+        self._taken = 0
         self.store = None
+        self.world = 1
+        gen = ChunkDealer._generation.get(key, 0)
+        ChunkDealer._generation[key] = gen + 1
+        self.store_key = f"gs_deal/{key}/{gen}"
         if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
             from torch.distributed import distributed_c10d
             self.store = distributed_c10d._get_default_store()
+            self.world = dist.get_world_size()
 
     def take(self):
         if self.store is not None:
-            c = int(self.store.add(f"gs_deal/{self.key}", 1)) - 1
+            c = int(self.store.add(self.store_key, 1)) - 1
+            # a rank's FIRST draw can be past the chunks only by the draws of the other ranks that found the job finished:
+            # anything beyond is a counter that was not this job's
+            if self._taken == 0 and self.n_chunks > 0 and c >= self.n_chunks + self.world:
+                raise RuntimeError(f"chunk counter {self.store_key!r} already stood at {c} before this rank's first draw "
+                                   f"({self.n_chunks} chunks, {self.world} ranks): it belongs to another job")
         else:
             c = self._local
             self._local += 1
+        self._taken += 1
         return c if c < self.n_chunks else None
 
 

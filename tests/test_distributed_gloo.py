@@ -90,6 +90,10 @@ def _skew_worker(rank, world, port, out_dir):
     dist.barrier()
     mine, busy = parallel.deal_chunks(work, n, chunk, "skew", dist=dist)
     dealt = parallel.gather_floats(busy, dist)
+    # the same key once more (the same kmers file enumerated twice, a retry): a job of its own, every chunk dealt again
+    again, _ = parallel.deal_chunks(lambda c, lo, hi: None, n, chunk, "skew", dist=dist)
+    n_again = parallel.gather_floats(float(len(again)), dist)
+    assert sum(n_again) == len(parallel.chunk_bounds(n, chunk)), n_again
     b = parallel.shard_bounds(n, world)
     static = parallel.gather_floats(float(cost[b[rank]:b[rank + 1]].sum()), dist)
     if rank == 0:
