@@ -17,6 +17,7 @@ import argparse
 import json
 import os
 import sys
+import subprocess
 import time
 from importlib import import_module
 from pathlib import Path
@@ -87,6 +88,8 @@ def main():
     ap.add_argument("--extra-rows", choices=["auto", "on", "off"], default="auto",
                     help="after the headline: the repeat-rich genome at <= 3 mismatches and <= 6 mismatches + CFD on this "
                          "genome, 20 k guides each (auto: with the default hg38 workload on one GPU)")
+    ap.add_argument("--e2e-guides", type=int, default=1_000_000,
+                    help="guides of the end-to-end row among the extra rows (the built `guidescan enumerate`, kmers CSV -> CSV; 0 = skip)")
     ap.add_argument("--n-gaps", type=int, default=0,
                     help="overwrite this many random stretches of the genome with N runs (a scaffold-level assembly: "
                          "three literal-N windows per run and strand for k_search to look through)")
@@ -347,7 +350,7 @@ def main():
                                + (", CFD + specificity in the step" if args.score else ""),
                    "guides_per_step_per_gpu": batch, "guides_per_step": batch_all, "mismatches": m,
                    "parallelism": f"replicated index, guide batch sharded x{world}"},
-        "roofline": {"bound": "hbm", "kernel": "k_search", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": search_kernel_name(gidx), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      # achieved / frac price the lines each load instruction asks for; on a repeat-rich batch
                      # neighbouring hits share lines that L2 serves, so the figure can pass the HBM peak -
                      # `traffic` (PMC) is then the measure of what HBM delivered
@@ -397,6 +400,8 @@ def main():
         "detail": {"executed_ext_per_guide": n_ext / (batch * K), "hits_per_guide": n_hits / (batch * K),
                    "prefix_table_k": os.environ.get("GS_PREFIX_K", "auto"),
                    "k_search_ms_per_step": per_step_ms,
+                   "k_search_ms_min_median_max": spread(per_step_ms),
+                   "clocks": gpu_clocks(),
                    "device_ms_total_per_step": ms_total / K, "index_build_s": t_index,
                    "genome_gen_s": t_gen, "index_bytes": gidx.device_bytes,
                    "items_two_sided": req["items_two_sided"], "items_one_sided": req["items_one_sided"],
@@ -445,7 +450,8 @@ def main():
         # the rows the headline does not show, under the same clock: the deep budget on this genome and the
         # repeat-rich genome (24 k hits per guide: what real hg38's repeat half looks like) - never part of `value`
         try:
-            out["detail"]["extra_rows"], gidx = extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P)
+            out["detail"]["extra_rows"], gidx = extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P,
+                                                           e2e_guides=args.e2e_guides)
         except Exception as e:
             print(f"[bench] extra rows failed: {e!r}", file=sys.stderr)
     if rank == 0:
@@ -454,6 +460,31 @@ def main():
         gidx.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def search_kernel_name(gidx):
+    """what ran between the library's search events in the last call: the one-launch k_search, or - a batch whose every
+    pattern has its PAM-pair + deep tables and that shares no item - k_describe + k_sched_* + k_seed_b + k_seed_a"""
+    form = gidx.last_sharing()["form"]
+    return {0: "k_search", 1: "k_search (heavy instantiation)", 2: "k_search (publishing) + k_search (helpers)",
+            3: "k_seed_b + k_seed_a (gs_seed.hip; + k_describe, k_sched_scan, k_sched_scatter: 0.3 ms)"}.get(form, "k_search")
+
+
+def spread(ms):
+    v = sorted(float(x) for x in ms)
+    return [v[0], v[len(v) // 2], v[-1]] if v else None
+
+
+def gpu_clocks():
+    """shader / memory clocks as rocm-smi reports them at the end of the run (a box's clocks move the launch time by
+    several per cent: profiles/r05_ab_headline_across_commits.txt); None where the tool is not to be had"""
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        card = j[sorted(j)[0]]
+        return {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower()}
+    except Exception:
+        return None
 
 
 def genome_file(workload):
@@ -579,6 +610,8 @@ def kernel_stamp():
     h = hashlib.sha256()
     src = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_search.hip").read_text()
     h.update(src[:src.index("/* ---- prepare: ASCII")].encode())
+    seed = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_seed.hip").read_text()   # the two-launch form of the table-seeded search
+    h.update(seed[:seed.index("/* ---- host: the descriptor pre-pass")].encode())
     h.update((ROOT / "guidescan-cli_amd" / "csrc" / "gs_kernels.h").read_bytes())
     com = (ROOT / "guidescan-cli_amd" / "csrc" / "gs_common.h").read_text()
     h.update(com[com.index("struct gs_pairtab_dev {"):com.index("struct gs_strand {")].encode())  # the device layout
@@ -747,8 +780,10 @@ def timed_row(torch, api, gidx, text, names, lengths, L, P, m, n_guides, steps, 
     t0 = time.perf_counter()
     hits = 0
     ms_search = ms_enum = t_score = 0.0
+    per_ms = []
     for i in range(2, steps + 2):
         st, t_sc = step(i)
+        per_ms.append(round(st["ms_search"], 2))
         hits += st["n_hits"]
         ms_search += st["ms_search"]
         ms_enum += st["ms_total"]
@@ -758,6 +793,14 @@ def timed_row(torch, api, gidx, text, names, lengths, L, P, m, n_guides, steps, 
     ctr = gidx.last_counters()
     sh = gidx.last_sharing()
     el_enum = el - t_score
+    # the lines THIS algorithm asks for on the last step's guides: one untimed pass through the counting instantiation
+    # (the headline's definition of the algorithmic bytes, bench.py main)
+    i = steps + 1
+    _, _, st_c = gidx.enumerate_device(d_s[i * n_guides:(i + 1) * n_guides].data_ptr(), n_guides, L,
+                                       d_p[i * n_guides:(i + 1) * n_guides].data_ptr(), P, mismatches=m, count_requests=True)
+    rq = gidx.last_counters()
+    lines = {k: rq[k] for k in ("table_lines", "ctx16_lines", "ctx_words", "sa_isa_gathers", "occ_lines")}
+    alg_bytes = 64.0 * sum(lines.values()) + 16.0 * st_c["n_matches"]
     return {"guides_per_step": n_guides, "mismatches": m, "steps": steps, "guides_per_s": n_guides * steps / el,
             "hits_per_s": hits / el, "hits_per_guide": hits / (n_guides * steps), "ms_per_step": el / steps * 1e3,
             "enumerate_ms_per_step": el_enum / steps * 1e3, "k_search_ms_per_step": ms_search / steps,
@@ -768,17 +811,32 @@ def timed_row(torch, api, gidx, text, names, lengths, L, P, m, n_guides, steps, 
             "guides_redone": ctr["guides_redone"], "matches_max_per_item": ctr["matches_max_per_item"], "warmup_steps_ms": warm,
             # heavy items handed to idle waves (k_search's heavy instantiation, picked by the handle after a batch with heavy passes)
             "heavy_instantiation": sh["queue_packages"] != 0, "shared_items": sh["shared_items"], "packages": sh["packages"],
-            "guides_ordered_device_wide_alone": sh["guides_ordered_device_wide_alone"]}
+            "guides_ordered_device_wide_alone": sh["guides_ordered_device_wide_alone"],
+            "search_form": sh["form"], "k_search_ms_min_median_max": spread(per_ms),
+            "alg_bytes_per_launch": alg_bytes, "requests_per_guide": {k: v / n_guides for k, v in lines.items()}}
 
 
-def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P):
+def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P, e2e_guides=1_000_000):
     """(rows, index still open or None).  Row 1 on the resident index: 20,000 guides at <= 6 mismatches with CFD
     (config 5's depth).  Row 2: the same index is closed, the repeat-rich genome of the same size is generated and
     indexed, 20,000 guides at <= 3 mismatches (bench.py --workload hg38rep)."""
     rows = {}
     rows["hg38_20k_m6_cfd"] = timed_row(torch, api, gidx, text, names, lengths, L, P, 6, 20000, 3, True, 4242)
     rows["hg38_20k_m6_cfd"]["roofline"] = row_roofline("hg38", 20000, 6, rows["hg38_20k_m6_cfd"])
+    prep = None
+    if e2e_guides:
+        try:
+            prep = e2e_prepare(torch, api, synth, gidx, text, names, lengths, L, P, e2e_guides)
+        except Exception as e:
+            print(f"[bench] end-to-end row (in-process half) failed: {e!r}", file=sys.stderr)
     gidx.close()
+    if prep is not None:
+        # the CLI builds its own index in its own process: the bench's is closed, the repeat-rich one not yet built
+        try:
+            rows[f"e2e_cli_{e2e_guides // 1000}k_m3"] = e2e_cli_row(prep, text, names, lengths, "csv")
+        except Exception as e:
+            print(f"[bench] end-to-end row (CLI) failed: {e!r}", file=sys.stderr)
+        prep = None
     # the repeat-rich genome, and the one whose SINE-like family is Alu-like (1.2e6 copies at 2-15 %)
     for wl, key, steps in (("hg38rep", "hg38rep_20k_m3", 3), ("hg38alu", "hg38alu_20k_m3", 2)):
         t0 = time.time()
@@ -798,23 +856,121 @@ def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P):
     return rows, None
 
 
+def e2e_prepare(torch, api, synth, gidx, text, names, lengths, L, P, n_guides, check_guides=100_000):
+    """The in-process half of the end-to-end row, on the resident index: rates (i) and (ii) of SURVEY 8d on the row's own
+    guide set, and the CSV text of its first `check_guides` guides from the in-process formatter (gs_score +
+    gs_format_guides_scored: the same encoder the CLI calls batch by batch) - what the CLI's file must begin with."""
+    import ctypes as C
+    import hashlib
+    seqs, pams, pos, strands = synth.sample_guides(text, n_guides, seed=7777)
+    d_s, d_p = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+    ms_dev = []
+    for _ in range(3):   # (i) inputs and results in HBM; the first call sizes the workspace
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gidx.enumerate_device(d_s.data_ptr(), n_guides, L, d_p.data_ptr(), P, mismatches=3)
+        torch.cuda.synchronize()
+        ms_dev.append((time.perf_counter() - t0) * 1e3)
+    L_ = api.lib()
+    best_h = None
+    for _ in range(2):   # (ii) host pointers in, host CSR out (PCIe both ways)
+        r = C.c_void_p()
+        t0 = time.perf_counter()
+        rc = L_.gs_enumerate(gidx._h, seqs.ctypes.data, n_guides, L, pams.ctypes.data, P, None, 0, 3, 0, C.byref(r))
+        dt = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError(L_.gs_status_string(rc).decode())
+        L_.gs_result_free(r)
+        best_h = dt if best_h is None else min(best_h, dt)
+    nc = min(check_guides, n_guides)
+    gs = api.make_genome_structure(names, lengths)
+    off, hits, _ = gidx.enumerate(seqs[:nc], pams[:nc], mismatches=3)
+    _, spec = gidx.score(gs, seqs[:nc], P, off, hits, want_cfd=False)
+    ids = [f"g{i}" for i in range(nc)]
+    body = api.format_guides(gs, ids, [seqs[i].tobytes().decode() for i in range(nc)], ["NGG"] * nc,
+                             [chr(strands[i]) == "+" for i in range(nc)], off, hits, spec, 3, sam=False, complete=True)
+    head = api.format_header(gs, sam=False, complete=True).encode()
+    expect = head + body
+    return {"seqs": seqs, "pos": pos, "strands": strands, "n": n_guides, "expect_prefix": expect,
+            "in_hbm_ms": min(ms_dev[1:]), "host_pointer_ms": best_h * 1e3, "check_guides": nc,
+            "expect_sha256": hashlib.sha256(expect).hexdigest()}
+
+
+def e2e_cli_row(prep, text, names, lengths, fmt="csv"):
+    """SURVEY 8d's rate (iii) under this run's clock: the built `guidescan enumerate` (the reference's command line,
+    src/guidescan.cxx:42-73,181-258) on the same genome and the row's guides, kmers CSV in -> database out, in a process
+    of its own that builds its own index.  The reference's timer starts after the index is loaded (src/guidescan.cxx:239)
+    and so does `Processed N kmers in S seconds`: guides/s = N / S; the index build is reported beside it."""
+    import hashlib
+    import shutil
+    import tempfile
+    base = os.environ.get("GS_E2E_DIR") or ("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+    d = Path(tempfile.mkdtemp(prefix="gs_e2e_", dir=base))
+    try:
+        np.asarray(text).tofile(d / "g.dna")
+        (d / "g.gs").write_text("".join(f"{a}\n{b}\n" for a, b in zip(names, lengths)))
+        n, seqs, pos, strands = prep["n"], prep["seqs"], prep["pos"], prep["strands"]
+        rows = ["id,sequence,pam,chromosome,position,sense\n"]
+        sq = [x.decode() for x in np.ascontiguousarray(seqs).view(f"S{seqs.shape[1]}").ravel()]
+        rows += [f"g{i},{sq[i]},NGG,chr1,{int(pos[i]) + 1},{chr(strands[i])}\n" for i in range(n)]
+        (d / "k.csv").write_text("".join(rows))
+        del rows, sq
+        cli = ROOT / "guidescan-cli_amd" / "bin" / "guidescan"
+        out_file = d / f"o.{fmt}"
+        t0 = time.perf_counter()
+        r = subprocess.run([str(cli), "enumerate", str(d / "g"), "-f", str(d / "k.csv"), "-o", str(out_file), "-m", "3",
+                            "--format", fmt, "--mode", "complete"], capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError(f"guidescan enumerate failed: {r.stderr[-400:]}")
+        import re
+        m_proc = re.search(r"Processed (\d+) kmers in ([0-9.eE+-]+) seconds", r.stdout)
+        m_build = re.search(r"index on .* in ([0-9.eE+-]+) s", r.stdout)
+        m_st = re.search(r"device ([0-9.eE+-]+) s, text formatting ([0-9.eE+-]+) s, file writes ([0-9.eE+-]+) s", r.stdout)
+        secs = float(m_proc.group(2))
+        size = out_file.stat().st_size
+        out = {"format": fmt, "guides": n, "mismatches": 3,
+               "i_results_in_hbm_ms": prep["in_hbm_ms"], "i_guides_per_s": n / (prep["in_hbm_ms"] * 1e-3),
+               "ii_host_pointers_ms": prep["host_pointer_ms"], "ii_guides_per_s": n / (prep["host_pointer_ms"] * 1e-3),
+               "iii_cli_seconds_after_index_load": secs, "iii_guides_per_s": n / secs,
+               "cli_index_build_s": float(m_build.group(1)) if m_build else None,
+               "cli_wall_s_incl_text_read_and_index_build": wall,
+               "cli_stage_seconds_overlapping": ({"device": float(m_st.group(1)), "text_formatting": float(m_st.group(2)),
+                                                  "file_writes": float(m_st.group(3))} if m_st else None),
+               "output_bytes": size, "writer_GB_per_s": size / secs / 1e9, "output_on": base}
+        if fmt == "csv":
+            exp = prep["expect_prefix"]
+            with open(out_file, "rb") as fh:
+                got = fh.read(len(exp))
+            out.update({"first_guides_checked": prep["check_guides"], "checked_bytes": len(exp),
+                        "first_bytes_equal_in_process_formatter": got == exp,
+                        "sha256_first_bytes_cli": hashlib.sha256(got).hexdigest(), "sha256_in_process": prep["expect_sha256"]})
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def row_roofline(workload, batch, m, row):
-    """the roofline of an extra row's dominant kernel (k_search): the memory side from the recorded PMC passes of
-    `bench.py --workload W --batch B --mismatches M` (tools/profile_round.sh, stamped with the kernel sources' hash),
-    priced on the launch time measured in this run; hits moved per second as the algorithmic side (16 bytes written per
-    match record, one context word and one row number gathered per record)"""
+    """the roofline of an extra row's search, by the headline's definition: achieved = the algorithm's own bytes (64 B per
+    distinct line its loads ask for, counted by the counting instantiation on the row's guides, + 16 B per match record)
+    over the launch time measured in this run, frac = achieved / 8 TB/s.  Beside it the memory side from the recorded PMC
+    passes of `bench.py --workload W --batch B --mismatches M` (tools/profile_round.sh, stamped with the kernel sources'
+    hash): corrected bytes and frac_hbm - a different quantity (what HBM delivered, not what the algorithm asked for)."""
     launch_ms = row["k_search_ms_per_step"]
     rec = recorded_memory_side(workload, batch, m)
     mem = memory_side_fields(rec, launch_ms)
-    hits = row["hits_per_guide"] * row["guides_per_step"]
-    alg = 16.0 * hits + 64.0 * (rec["read_requests"] if rec and rec.get("read_requests") else 0.0)
-    out = {"bound": "hbm", "kernel": "k_search" + (" (heavy instantiation)" if row.get("heavy_instantiation") else ""),
-           "avg_launch_ms": launch_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "achieved": (mem["traffic_bytes_corrected"] / (launch_ms * 1e-3) / 1e9) if mem.get("traffic_bytes_corrected") else None,
-           "frac": mem.get("frac_hbm"), "traffic": (rec["fetch_bytes"] + rec["write_bytes"]) if rec else None,
-           "alg_bytes_per_launch": alg if rec else None,
-           "alg_bytes_are": "16 B per match record written + 64 B per read request of the recorded pass (the requests ARE the "
-                            "algorithm's: every one is a table block, a context piece or a row gather it asks for)"}
+    alg = row.get("alg_bytes_per_launch")
+    achieved = alg / (launch_ms * 1e-3) / 1e9 if alg and launch_ms else None
+    form = row.get("search_form", 0)
+    out = {"bound": "hbm",
+           "kernel": {1: "k_search (heavy instantiation)", 2: "k_search (publishing) + k_search (helpers)",
+                      3: "k_seed_b + k_seed_a"}.get(form, "k_search"),
+           "avg_launch_ms": launch_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": achieved,
+           "frac": achieved / HBM_PEAK_GBS if achieved else None,
+           "traffic": (rec["fetch_bytes"] + rec["write_bytes"]) if rec else None,
+           "alg_bytes_per_launch": alg,
+           "alg_bytes_are": "64 B per distinct line the search's loads ask for (counting instantiation, this row's guides) + 16 B "
+                            "per match record: the headline's definition"}
     out.update(mem)
     return out
 

@@ -480,9 +480,12 @@ class GenomeIndex:
         return out
 
     def verify_sa(self, text, strand=0, samples=1 << 20, seed=1):
-        """self-check from the text alone -> dict of gs_sa_report (all counters but rows/sampled must be 0)"""
+        """self-check from the text alone -> dict of gs_sa_report (all counters but rows/sampled must be 0).
+        samples="all": every adjacent pair of rows by the linear-time rule (GS_VERIFY_ALL_ROWS) - a complete proof"""
         text = np.ascontiguousarray(text, dtype=np.uint8)
         rep = GsSaReport()
+        if samples == "all":
+            samples = (1 << 64) - 1
         _check(lib().gs_index_verify_sa(self._h, strand, text.ctypes.data, text.shape[0], samples, seed,
                                         C.byref(rep)))
         return {k: int(getattr(rep, k)) for k, _ in GsSaReport._fields_}
@@ -612,11 +615,14 @@ class GenomeIndex:
         return buf.value.decode() if rc == 0 else None
 
     def last_sharing(self):
-        """heavy items shared among waves in the last search launch (gs_index_last_sharing)"""
+        """heavy items shared among waves in the last search launch (gs_index_last_sharing); form: 0 one launch, every item
+        with its wave; 1 one launch that publishes heavy passes and helps; 2 two launches (publishing + helpers); 3 the two
+        seeding launches of gs_seed.hip (no sharing); guides_with_heavy_kmer: what the form was chosen from"""
         out = (C.c_uint64 * 8)()
         _check(lib().gs_index_last_sharing(self._h, out))
         return dict(shared_items=int(out[0]), packages=int(out[1]), queue_packages=int(out[2]), tickets=int(out[3]),
-                    guides_ordered_device_wide_alone=int(out[4]), launches_behind=int(out[5]), form=int(out[6]))
+                    guides_ordered_device_wide_alone=int(out[4]), launches_behind=int(out[5]), form=int(out[6]),
+                    guides_with_heavy_kmer=int(out[7]))
 
     def last_counters(self):
         """k_search's counters of the last enumerate_device call (see gs_index_last_counters)"""

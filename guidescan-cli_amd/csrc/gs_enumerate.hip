@@ -677,11 +677,24 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     /* (a handle whose sharing launch was not resident as a whole backs off for 64 batches, then tries again) */
     if (with_arena && ix->share_backoff != 0) ix->share_backoff--;
     const bool share_ok = with_arena && !walk && n_chunks == 1 && !count_req && share_min != 0 && ix->share_backoff == 0;
-    const bool seen = mismatches < 8 &&
-                      ix->seen_key[mismatches] == (((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START)) &&
-                      ix->seen_hpass[mismatches] != 0;
-    const bool dense = seen && (16.0 * (double)ix->seen_hpass[mismatches] >= (double)ix->seen_items[mismatches] ||
-                                2 * (uint64_t)ng <= 64ull * (uint64_t)cus * 32u);
+    /* which form: from THIS batch - the guides whose own k-mer heads an interval of 8 x share_min rows or more in a strand
+     * table sit in a repeat family, their items are the ones with heavy passes (k_estimate_heavy: one table read per guide
+     * and strand, 20 us) -, and from what the last batch of the same shape counted (a guide a substitution away from a
+     * family's consensus has heavy passes without a heavy k-mer of its own) */
+    uint32_t est_heavy = 0;
+    if (share_ok && with_arena && !gs_opt(ix, "GS_NO_FORM_ESTIMATE")) {
+      const gs_status er = gs_estimate_heavy(ix, guides, ng, 8u * share_min, d_work + 10, st, &est_heavy);
+      if (er != GS_OK) return er;
+    }
+    const bool seen_last = mismatches < 8 &&
+                           ix->seen_key[mismatches] == (((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START)) &&
+                           ix->seen_hpass[mismatches] != 0;
+    /* heavy items expected in this batch (each guide counts for two items; the last batch's count scaled to this batch's size) */
+    const double hp_last = seen_last && ix->seen_items[mismatches] ? (double)ix->seen_hpass[mismatches] * (2.0 * ng) / (double)ix->seen_items[mismatches] : 0.0;
+    const double hp = std::max(2.0 * (double)est_heavy, hp_last);
+    const bool seen = hp >= 1.0;
+    const bool dense = seen && (16.0 * hp >= 2.0 * (double)ng || 2 * (uint64_t)ng <= 64ull * (uint64_t)cus * 32u);
+    ix->last_share[7] = est_heavy; /* (gs_index_last_sharing: guides of the batch with a heavy k-mer of their own) */
     bool heavy = share_ok && dense;
     uint32_t split = share_ok && seen && !dense ? 2u : 0u; /* 1: the second launch behind the first; 3: before it (tests) */
     if (const char *e = gs_opt(ix, "GS_HEAVY")) {
@@ -741,7 +754,10 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     }
     /* the form of a batch whose every pattern has its tables and that shares no item: 0 - k_search_fast_pd (one launch, every item
      * sets itself up), 1 - two launches from descriptors (gs_seed.hip), 2 - ... with the guides scheduled by their symbols */
-    uint32_t seed_form = (spec && sa.shq == nullptr && !heavy && !split) ? 2u : 0u;
+    /* (budgets beyond four substitutions stay with the one launch: a hit is no longer rare there - 10^4 per guide at m <= 6 -
+     * and rebuilding every hit's path from its recipe costs what the descriptors save: 65.0 against 63.1 ms per 20,000
+     * guides at m <= 6, 2.6 against 2.6 at m <= 4, profiles/r06_seed_forms_m6.txt) */
+    uint32_t seed_form = (spec && sa.shq == nullptr && !heavy && !split && mismatches <= 4u) ? 2u : 0u;
     if (const char *e = gs_opt(ix, "GS_SEED_FORM")) seed_form = seed_form ? (uint32_t)std::min(2l, std::max(0l, atol(e))) : 0u;
     const uint32_t seed_sort_from = gs_opt(ix, "GS_SEED_SORT_FROM") ? (uint32_t)atol(gs_opt(ix, "GS_SEED_SORT_FROM")) : 4096u;
     uint32_t seed_grid = 0;

@@ -148,6 +148,37 @@ __global__ void k_sched_scatter(const gs_guide_desc *desc, uint32_t n, uint32_t 
   desc_b[atomicAdd(&cursor[65536u + d.key_b], 1u)] = d;
 }
 
+/* ---- which form of the search this batch needs, from the batch itself: guides whose own k-mer - the first k symbols
+ * they consume, unsubstituted - heads an interval of `thresh` rows or more in either strand's table.  Such a guide sits in
+ * a repeat family: its seeds verify 10^4 .. 10^6 rows, the passes the sharing forms hand to idle waves (run_search).  One
+ * table read per guide and strand; the handle used to learn this from the PREVIOUS batch's count of heavy passes, so the
+ * first batch of a shape - and any batch unlike its predecessor - met its giant items with one wave each. ---- */
+__global__ void k_estimate_heavy(const gs_guide_rec *guides, uint32_t n, const uint4 *ptab0, const uint4 *ptab1, uint32_t k,
+                                 uint32_t thresh, uint32_t *out) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  bool heavy = false;
+  if (g < n && guides[g].valid) {
+    const uint64_t q = guides[g].q;
+    uint32_t pidx = 0;
+    for (uint32_t t = 0; t < k; ++t) pidx |= ((uint32_t)(q >> (2u * t)) & 3u) << (2u * (k - 1u - t));
+    const uint32_t c0 = ptab0[pidx].y & 0x7FFFFFFFu, c1 = ptab1[pidx].y & 0x7FFFFFFFu;
+    heavy = c0 >= thresh || c1 >= thresh;
+  }
+  const uint64_t b = __ballot(heavy);
+  if (b && lane_id() == 0) atomicAdd(out, (uint32_t)__popcll(b));
+}
+gs_status gs_estimate_heavy(gs_index *ix, const gs_guide_rec *guides, uint32_t n, uint32_t thresh, uint32_t *d_out, hipStream_t st,
+                            uint32_t *n_heavy) {
+  *n_heavy = 0;
+  if (!ix->pt_k || !ix->strand[0].ptab || !ix->strand[1].ptab || !n) return GS_OK;
+  GS_HIP(hipMemsetAsync(d_out, 0, 4, st));
+  hipLaunchKernelGGL(k_estimate_heavy, dim3((n + 255) / 256), dim3(256), 0, st, guides, n, (const uint4 *)ix->strand[0].ptab,
+                     (const uint4 *)ix->strand[1].ptab, ix->pt_k, thresh, d_out);
+  GS_HIP(hipMemcpyAsync(n_heavy, d_out, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipStreamSynchronize(st));
+  return GS_OK;
+}
+
 /* ---- the seeding launches ------------------------------------------------------------------------------------------
  * SIDE 0: the other strand's seeds + the window list; SIDE 1: this strand's seeds, appending.  CNT: the request tally. */
 template <bool CNT, int SIDE>

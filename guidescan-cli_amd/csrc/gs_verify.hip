@@ -144,6 +144,51 @@ __global__ void k_v_order(gs_vorder_args a) {
   atomicAdd(&a.out[1], 1ull);
 }
 
+/* ---- every row (n_samples = GS_VERIFY_ALL_ROWS): the linear-time check of a suffix array against its text.  With SA a
+ * permutation of [0, n) (k_v_permutation) and ISA its inverse (isa[sa[r]] == r, checked here), SA is the suffix array iff
+ * for every r: text[sa[r]] < text[sa[r+1]], or the two symbols are equal and isa[sa[r]+1] < isa[sa[r+1]+1] - the order of
+ * two suffixes that start alike is the order of what follows them, which the array itself states (induction over the
+ * length of the common prefix; the sentinel is unique and smallest).  One streaming pass, five random reads per row;
+ * nothing undecided, no sampling.  What sdsl's own tests do for csa_wt on small texts (sdsl/test/csa_byte_test.cpp), and
+ * what csa_wt::operator[] (sdsl/include/sdsl/csa_wt.hpp:333-346) presumes. ---- */
+struct gs_vfull_args {
+  const uint8_t *text;
+  const uint32_t *sa, *isa;
+  const uint4 *blocks;
+  unsigned long long *out; /* [0] out of order, [2] BWT symbol differs, [3] isa is not the inverse */
+  uint64_t n;
+};
+__global__ void k_v_full(gs_vfull_args a) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= a.n) return;
+  const uint64_t pa = a.sa[r];
+  if (pa >= a.n) { /* (counted by k_v_permutation; not to be used as an offset) */
+    atomicAdd(&a.out[0], 1ull);
+    return;
+  }
+  if (a.isa[pa] != (uint32_t)r) atomicAdd(&a.out[3], 1ull);
+  {
+    const uint32_t *b = (const uint32_t *)(a.blocks + (r >> GS_BLOCK_SHIFT) * 4);
+    const uint32_t w = (uint32_t)(r & 127u) >> 5, j = (uint32_t)r & 31u;
+    const uint32_t lo = (b[4 + w] >> j) & 1u, hi = (b[8 + w] >> j) & 1u, ex = (b[12 + w] >> j) & 1u;
+    const uint8_t c = pa ? a.text[pa - 1] : a.text[a.n - 1];
+    const int cls = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1;
+    const bool ok = cls < 0 ? ex == 1u : (ex == 0u && (lo | (hi << 1)) == (uint32_t)cls);
+    if (!ok) atomicAdd(&a.out[2], 1ull);
+  }
+  if (r + 1 >= a.n) return;
+  const uint64_t pb = a.sa[r + 1];
+  if (pb >= a.n || pb == pa) {
+    atomicAdd(&a.out[0], 1ull);
+    return;
+  }
+  const uint8_t ca = a.text[pa], cb = a.text[pb];
+  bool bad = ca > cb;
+  if (ca == cb) /* (equal and not the sentinel: neither suffix is the last one, pa + 1 and pb + 1 are positions) */
+    bad = ca == 0 || pa + 1 >= a.n || pb + 1 >= a.n || !(a.isa[pa + 1] < a.isa[pb + 1]);
+  if (bad) atomicAdd(&a.out[0], 1ull);
+}
+
 extern "C" gs_status gs_index_verify_sa(gs_index *ix, int strand, const uint8_t *text, uint64_t len,
                                         uint64_t n_samples, uint64_t seed, gs_sa_report *rep) {
   GS_HANDLE_LOCK(ix);
@@ -195,6 +240,30 @@ extern "C" gs_status gs_index_verify_sa(gs_index *ix, int strand, const uint8_t 
   unsigned long long *out = (unsigned long long *)d_out.p;
   hipLaunchKernelGGL(k_v_permutation, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const uint32_t *)s.sa, n,
                      (uint32_t *)d_bitmap.p, out + 3);
+  if (n_samples == GS_VERIFY_ALL_ROWS) {
+    if (!s.isa) {
+      gs_set_error("gs_index_verify_sa: the check of every row reads the inverse suffix array, which this index was built without");
+      return GS_ERR_UNSUPPORTED;
+    }
+    gs_vfull_args a;
+    a.text = (const uint8_t *)d_text.p;
+    a.sa = (const uint32_t *)s.sa;
+    a.isa = (const uint32_t *)s.isa;
+    a.blocks = (const uint4 *)s.blocks;
+    a.out = out;
+    a.n = n;
+    hipLaunchKernelGGL(k_v_full, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, a);
+    n_samples = n - 1;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    GS_HIP(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+    GS_HIP(hipGetLastError());
+    rep->sampled = n_samples;
+    rep->out_of_order = h[0];
+    rep->undecided = 0;
+    rep->bwt_mismatch = h[2];
+    rep->not_permutation = h[3]; /* repeated / out-of-range values (the bitmap) + rows whose isa entry is not their own */
+    return GS_OK;
+  }
   if (n_samples > n - 1) n_samples = n - 1;
   if (n_samples) {
     gs_vorder_args a;

@@ -179,7 +179,9 @@ gs_status gs_index_last_counters(const gs_index *ix, uint64_t out[16]);
  * device-wide ordering - alone, the rest of the batch stays in tiles; [5] launches of the package-running form BEHIND the
  * search launch (the one beside it came too early and left); [6] the form the search ran in: 0 every item with its wave,
  * 1 one launch that publishes and helps, 2 two launches (the plain form publishes, the heavy form beside it runs the
- * packages); [7] zero. */
+ * packages), 3 the two seeding launches of a batch whose every pattern has its PAM-pair + deep tables and that shares no
+ * item (gs_seed.hip); [7] guides of the batch whose own k-mer heads an interval of 8 x share_min rows or more in a strand
+ * table: what the form is chosen from, together with the last batch's count of heavy passes. */
 gs_status gs_index_last_sharing(const gs_index *ix, uint64_t out[8]);
 /* Switches of a handle.  The library's tuning and test switches ("GS_NO_BIDIR", "GS_SHARE_MIN", "GS_DEBUG", ... -
  * DESIGN.md names each where it acts) are a per-handle table: filled from the process environment's GS_* variables
@@ -289,6 +291,12 @@ typedef struct {
 } gs_sa_report;
 gs_status gs_index_verify_sa(gs_index *ix, int strand, const uint8_t *text, uint64_t len,
                              uint64_t n_samples, uint64_t seed, gs_sa_report *report);
+/* n_samples = GS_VERIFY_ALL_ROWS: EVERY adjacent pair of rows, by the linear-time rule - text[SA[r]] < text[SA[r+1]], or equal
+ * symbols and ISA[SA[r]+1] < ISA[SA[r+1]+1] - with ISA checked to be SA's inverse (counted in not_permutation) and the BWT
+ * symbol of every row compared with the text: a complete proof that the resident array is the suffix array of `text`
+ * (what csa_wt::operator[] presumes, sdsl/include/sdsl/csa_wt.hpp:333-346), one streaming pass (0.4 s per strand at hg38
+ * size); `undecided` is 0 by construction.  Needs the inverse suffix array (GS_ERR_UNSUPPORTED on an index built without). */
+#define GS_VERIFY_ALL_ROWS (~0ull)
 
 /* ---- text encoders: the step right after the path (host side) ---------------------------- */
 

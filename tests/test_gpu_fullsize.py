@@ -151,6 +151,9 @@ def test_config2_chr1_sized_100k_guides_m3():
             rep = gidx.verify_sa(text, strand=s, samples=1 << 22, seed=5 + s)
             assert rep["rows"] == text.shape[0] + 1 and rep["sampled"] == 1 << 22
             assert rep["not_permutation"] == rep["out_of_order"] == rep["undecided"] == rep["bwt_mismatch"] == 0, rep
+            rep = gidx.verify_sa(text, strand=s, samples="all")   # ... and every adjacent pair by the linear-time rule
+            assert rep["sampled"] == text.shape[0], rep
+            assert rep["not_permutation"] == rep["out_of_order"] == rep["undecided"] == rep["bwt_mismatch"] == 0, rep
         n = 100_000
         seqs, pams, pos, strands = synth.sample_guides(text, n, seed=21)
         d_seqs, d_pams = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
@@ -262,6 +265,16 @@ class Hg38:
         t0 = time.time()
         self.gidx = api.GenomeIndex.build(self.text, device=0)
         self.t_build = time.time() - t0
+        # The reference's index files below are written from THIS suffix array, and the large oracle tests borrow it: it is
+        # proved first, from the text alone - every adjacent pair of rows by the linear-time rule (text[SA[r]] < text[SA[r+1]],
+        # or equal symbols and ISA[SA[r]+1] < ISA[SA[r+1]+1]), ISA the inverse of SA, every row's BWT symbol
+        # (gs_index_verify_sa with GS_VERIFY_ALL_ROWS; csa_wt::operator[] presumes exactly this, csa_wt.hpp:333-346)
+        t0 = time.time()
+        self.sa_reports = [self.gidx.verify_sa(self.text, strand=s, samples="all") for s in (0, 1)]
+        self.t_verify = time.time() - t0
+        for rep in self.sa_reports:
+            assert rep["rows"] == self.text.shape[0] + 1 and rep["sampled"] == self.text.shape[0], rep
+            assert rep["not_permutation"] == rep["out_of_order"] == rep["undecided"] == rep["bwt_mismatch"] == 0, rep
         self.gs = api.make_genome_structure(self.names, self.lengths)
         self.dir = tempfile.mkdtemp(prefix="gs_full_")
         self.ref_ok = ol.ref() is not None and SHIM.exists()
@@ -348,6 +361,7 @@ def test_hg38_suffix_arrays_against_the_text_alone(hg38):
     """n = 3.09e9 > 2^31: both suffix arrays are permutations, 2^24 (1.7e7) evenly spread adjacent
     row pairs per strand are in suffix order by direct text comparison, and the Occ blocks hold the
     BWT symbol text[SA[r]-1] on those rows"""
+    assert len(hg38.sa_reports) == 2   # (the fixture has checked EVERY pair of rows by the linear-time rule already)
     for s in (0, 1):
         rep = hg38.gidx.verify_sa(hg38.text, strand=s, samples=1 << 24, seed=11 + s)
         assert rep["rows"] == hg38.text.shape[0] + 1 and rep["sampled"] == 1 << 24

@@ -38,6 +38,28 @@ def toy_gpu(toy):
     oidx.close()
 
 
+def test_every_row_check_proves_a_suffix_array_and_catches_a_wrong_one(toy_gpu):
+    """gs_index_verify_sa with GS_VERIFY_ALL_ROWS: zero findings on the index's own arrays; an index built on a suffix array
+    with two neighbouring rows swapped - still a permutation, the sampled check would have to hit that very pair - is caught"""
+    toy, oidx, gidx = toy_gpu
+    text = toy["text"]
+    for s in (0, 1):
+        rep = gidx.verify_sa(text, strand=s, samples="all")
+        assert rep["sampled"] == text.shape[0]
+        assert rep["not_permutation"] == rep["out_of_order"] == rep["undecided"] == rep["bwt_mismatch"] == 0, rep
+    sa_f, sa_r = gidx.suffix_array(0).copy(), gidx.suffix_array(1).copy()
+    r = sa_f.shape[0] // 3
+    sa_f[r], sa_f[r + 1] = sa_f[r + 1], sa_f[r]
+    bad = api.GenomeIndex.build(text, device=0, sa_fwd=sa_f, sa_rev=sa_r)
+    try:
+        rep = bad.verify_sa(text, strand=0, samples="all")
+        assert rep["not_permutation"] == 0 and rep["out_of_order"] >= 1, rep
+        rep = bad.verify_sa(text, strand=1, samples="all")
+        assert rep["out_of_order"] == rep["bwt_mismatch"] == rep["not_permutation"] == 0, rep
+    finally:
+        bad.close()
+
+
 def test_suffix_array_matches_oracle(toy_gpu):
     toy, oidx, gidx = toy_gpu
     for s, which in ((0, "fwd"), (1, "rev")):
@@ -881,10 +903,21 @@ def test_a_heavy_item_is_run_by_many_waves():
         other, _, _, _ = synth.sample_guides(text[n_copies * unit:], 5, seed=9)
         seqs = np.concatenate([other[:2], np.array([list(site)], dtype=np.uint8), other[2:]])
         pams = np.tile(np.frombuffer(b"NGG", np.uint8), (seqs.shape[0], 1))
-        # a handle's first batch of a shape runs the plain instantiation, which counts the verification passes of 512 row
-        # groups and more; the second batch finds them in the count and takes the heavy instantiation by itself
+        # the form is chosen from the batch at hand: the repeat-derived guide's own k-mer heads an interval of thousands of rows
+        # (k_estimate_heavy), so already the handle's FIRST batch shares its heavy passes; without the estimate a first batch
+        # runs every item on its own wave and the second one learns from its count of heavy passes
+        gidx.set_option("GS_NO_FORM_ESTIMATE", "1")
         off0, hits0, _ = gidx.enumerate(seqs, pams, mismatches=3)
         assert gidx.last_sharing()["shared_items"] == 0
+        gidx.set_option("GS_NO_FORM_ESTIMATE", None)
+        fresh = api.GenomeIndex.build(text, device=0)
+        try:
+            off_f, hits_f, _ = fresh.enumerate(seqs, pams, mismatches=3)
+            shf = fresh.last_sharing()
+            assert shf["guides_with_heavy_kmer"] >= 1 and shf["shared_items"] >= 1 and shf["form"] == 1, shf
+            assert np.array_equal(off0, off_f) and hits0.tobytes() == hits_f.tobytes()
+        finally:
+            fresh.close()
         off1, hits1, _ = gidx.enumerate(seqs, pams, mismatches=3)
         sh, ctr = gidx.last_sharing(), gidx.last_counters()
         assert sh["shared_items"] >= 1 and sh["packages"] >= 8 and sh["tickets"] >= sh["packages"], sh
@@ -904,8 +937,11 @@ def test_a_heavy_item_is_run_by_many_waves():
         # batch is redone with every item on its own wave, and the handle shares no more
         gidx.set_options(GS_SHARE_MIN=None, GS_SHARE_MAX=None, GS_HEAVY="1", GS_DBG_SHARE_TIMEOUT="1")
         off5, hits5, _ = gidx.enumerate(seqs, pams, mismatches=3)
-        assert gidx.last_sharing()["shared_items"] == 0 and gidx.last_sharing()["form"] == 0
+        assert gidx.last_sharing()["shared_items"] == 0 and gidx.last_sharing()["form"] in (0, 3)
         assert np.array_equal(off0, off5) and hits0.tobytes() == hits5.tobytes()
+        off6, hits6, _ = gidx.enumerate(seqs, pams, mismatches=3)   # ... and keeps off it for a while (a back-off, not for good)
+        assert gidx.last_sharing()["shared_items"] == 0
+        assert np.array_equal(off0, off6) and hits0.tobytes() == hits6.tobytes()
         gidx.set_options(GS_HEAVY=None, GS_DBG_SHARE_TIMEOUT=None)
         gidx.close()
         gidx = api.GenomeIndex.build(text, device=0)      # (a fresh handle: this one has given sharing up)
@@ -936,7 +972,8 @@ def test_a_heavy_item_is_run_by_many_waves():
         big_s = np.concatenate([np.tile(other, (60_000, 1)), np.array([list(site)], dtype=np.uint8)])
         big_p = np.tile(np.frombuffer(b"NGG", np.uint8), (big_s.shape[0], 1))
         boff0, bhits0, _ = gidx.enumerate(big_s, big_p, mismatches=2)     # (another budget: a shape this handle has not seen)
-        assert gidx.last_sharing()["form"] == 0
+        shb0 = gidx.last_sharing()   # the FIRST batch of the shape: one guide of 300,001 has a heavy k-mer - two launches at once
+        assert shb0["guides_with_heavy_kmer"] >= 1 and shb0["form"] == 2 and shb0["shared_items"] >= 1, shb0
         boff1, bhits1, _ = gidx.enumerate(big_s, big_p, mismatches=2)
         shb = gidx.last_sharing()
         assert shb["form"] == 2 and shb["shared_items"] >= 1, shb

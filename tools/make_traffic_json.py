@@ -29,6 +29,15 @@ def main():
         heavy = sorted(d.get("k_search_heavy", []) + d.get("k_search_heavy_pd", []), key=lambda e: e["dispatch_id"])
         if heavy:
             return heavy[-1], "the last k_search_heavy dispatch"
+        if d.get("k_seed_b") and d.get("k_seed_a"):
+            # the two-launch form (gs_seed.hip): the first k_seed_b / k_seed_a pair after the counting pass, counters and
+            # durations added up (one search = the two launches)
+            after = max((e["dispatch_id"] for e in d.get("k_seed_count_a", []) + d.get("k_seed_count_b", [])), default=-1)
+            b = sorted([e for e in d["k_seed_b"] if e["dispatch_id"] > after], key=lambda e: e["dispatch_id"])[0]
+            a = sorted([e for e in d["k_seed_a"] if e["dispatch_id"] > b["dispatch_id"]], key=lambda e: e["dispatch_id"])[0]
+            row = {k: (a[k] + b[k]) if isinstance(a[k], (int, float)) and k not in ("dispatch_id", "vgpr", "lds") else a[k] for k in a}
+            row["per_launch"] = {"k_seed_b": b, "k_seed_a": a}
+            return row, "the first k_seed_b + k_seed_a pair after the counting pass (counters and durations added)"
         counting = d.get("k_search_count", []) + d.get("k_search_count_pd", [])
         after = max((e["dispatch_id"] for e in counting), default=-1)
         rows = sorted([e for e in d.get("k_search_fast", []) + d.get("k_search_fast_pd", []) if e["dispatch_id"] > after],

@@ -34,9 +34,9 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST
             "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
   name=$(echo $pass | cut -d' ' -f1 | tr 'A-Z' 'a-z')
-  rocprofv3 --pmc $pass -f csv --kernel-include-regex 'k_search|k_order|k_locate|k_big2|k_score|k_to_|k_share' -d $OUT/pmc_$name -- python3 bench.py $ARGS --steps $STEPS --warmup $WARM > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
+  rocprofv3 --pmc $pass -f csv --kernel-include-regex 'k_search|k_seed|k_order|k_locate|k_big2|k_score|k_to_|k_share' -d $OUT/pmc_$name -- python3 bench.py $ARGS --steps $STEPS --warmup $WARM > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err
   echo "pmc $name rc=$?"
-  python3 tools/pmc_summary.py $OUT/pmc_$name k_search k_order k_locate k_big2 k_score k_to_ k_share > $SUM/${NAME}_pmc_$name.json
+  python3 tools/pmc_summary.py $OUT/pmc_$name k_search k_seed k_order k_locate k_big2 k_score k_to_ k_share > $SUM/${NAME}_pmc_$name.json
 done
 B=$(python3 -c "import json;print(json.loads(open('$SUM/${NAME}_bench_under_rocprof.json').read().strip().splitlines()[-1])['config']['guides_per_step_per_gpu'])")
 python3 tools/make_traffic_json.py $NAME $WL $B $M $SUM/${NAME}_pmc_fetch_size.json $SUM/${NAME}_pmc_write_size.json $SUM/${NAME}_pmc_sq_wave_cycles.json \
