@@ -681,11 +681,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
      * table sit in a repeat family, their items are the ones with heavy passes (k_estimate_heavy: one table read per guide
      * and strand, 20 us) -, and from what the last batch of the same shape counted (a guide a substitution away from a
      * family's consensus has heavy passes without a heavy k-mer of its own) */
-    uint32_t est_heavy = 0;
+    uint32_t est[2] = {0, 0};
     if (share_ok && with_arena && !gs_opt(ix, "GS_NO_FORM_ESTIMATE")) {
-      const gs_status er = gs_estimate_heavy(ix, guides, ng, 8u * share_min, d_work + 10, st, &est_heavy);
+      const gs_status er = gs_estimate_heavy(ix, guides, ng, 8u * share_min, d_work + 10, st, est);
       if (er != GS_OK) return er;
+      if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] form estimate: %u guides with a heavy k-mer of their own, the largest interval %u rows\n", est[0], est[1]);
     }
+    const uint32_t est_heavy = est[0];
     const bool seen_last = mismatches < 8 &&
                            ix->seen_key[mismatches] == (((uint64_t)L << 32) | ((uint64_t)P << 16) | (n_alt << 8) | (flags & GS_FLAG_PAM_AT_START)) &&
                            ix->seen_hpass[mismatches] != 0;
@@ -696,7 +698,12 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     const bool dense = seen && (16.0 * hp >= 2.0 * (double)ng || 2 * (uint64_t)ng <= 64ull * (uint64_t)cus * 32u);
     ix->last_share[7] = est_heavy; /* (gs_index_last_sharing: guides of the batch with a heavy k-mer of their own) */
     bool heavy = share_ok && dense;
-    uint32_t split = share_ok && seen && !dense ? 2u : 0u; /* 1: the second launch behind the first; 3: before it (tests) */
+    /* few heavy items in a large batch: the two launches pay only when an item is too large to hide behind the rest of the
+     * batch on one wave - the publishing form runs k_search's one-launch kernel, a quarter slower than the two seeding launches
+     * on the light guides (1 M light guides + 8 guides of 650,000 hits, the largest k-mer interval 145,000 rows: every item
+     * with its wave 24.9 ms, two launches 29.4, profiles/r06_mixed_batch.txt).  From 2^19 rows under one k-mer on (GS_SPLIT_FROM) */
+    const uint32_t split_from = gs_opt(ix, "GS_SPLIT_FROM") ? (uint32_t)atol(gs_opt(ix, "GS_SPLIT_FROM")) : (1u << 19);
+    uint32_t split = share_ok && seen && !dense && est[1] >= split_from ? 2u : 0u; /* 1: the second launch behind the first; 3: before it (tests) */
     if (const char *e = gs_opt(ix, "GS_HEAVY")) {
       heavy = atol(e) != 0 && share_ok;
       split = 0u;

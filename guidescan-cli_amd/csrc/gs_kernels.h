@@ -392,9 +392,10 @@ __global__ void k_seed_count_a(gs_search_args a);
 /* descriptors (+ schedules when `sorted`) of the guides sa.guides[0 .. ng); *out = sa with desc / sched_* / xwork set */
 gs_status gs_seed_describe(gs_index *ix, const gs_search_args &sa, uint32_t ng, bool sorted, hipStream_t st, gs_search_args *out);
 gs_status gs_seed_launch(const gs_search_args &sa, uint32_t grid, bool count_req, hipStream_t st);
-/* guides of the batch whose own k-mer heads an interval of `thresh` rows or more in a strand table (d_out: 4 bytes of scratch) */
+/* n_heavy[0]: guides of the batch whose own k-mer heads an interval of `thresh` rows or more in a strand table, [1]: the
+ * largest such interval (d_out: 8 bytes of scratch) */
 gs_status gs_estimate_heavy(gs_index *ix, const gs_guide_rec *guides, uint32_t n, uint32_t thresh, uint32_t *d_out, hipStream_t st,
-                            uint32_t *n_heavy);
+                            uint32_t n_heavy[2]);
 
 /* ---- gs_recipes.hip (host) ---- */
 void gs_choose_astar(uint32_t m, uint32_t nX, uint32_t nO, uint32_t nR, double epam, uint32_t astar[8], double verify_a = 1.5,

@@ -157,24 +157,29 @@ __global__ void k_estimate_heavy(const gs_guide_rec *guides, uint32_t n, const u
                                  uint32_t thresh, uint32_t *out) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   bool heavy = false;
+  uint32_t most = 0;
   if (g < n && guides[g].valid) {
     const uint64_t q = guides[g].q;
     uint32_t pidx = 0;
     for (uint32_t t = 0; t < k; ++t) pidx |= ((uint32_t)(q >> (2u * t)) & 3u) << (2u * (k - 1u - t));
     const uint32_t c0 = ptab0[pidx].y & 0x7FFFFFFFu, c1 = ptab1[pidx].y & 0x7FFFFFFFu;
     heavy = c0 >= thresh || c1 >= thresh;
+    most = c0 > c1 ? c0 : c1;
   }
   const uint64_t b = __ballot(heavy);
-  if (b && lane_id() == 0) atomicAdd(out, (uint32_t)__popcll(b));
+  if (b) {
+    if (lane_id() == 0) atomicAdd(out, (uint32_t)__popcll(b));
+    if (heavy) atomicMax(out + 1, most); /* the largest interval a guide's own k-mer heads */
+  }
 }
 gs_status gs_estimate_heavy(gs_index *ix, const gs_guide_rec *guides, uint32_t n, uint32_t thresh, uint32_t *d_out, hipStream_t st,
-                            uint32_t *n_heavy) {
-  *n_heavy = 0;
+                            uint32_t n_heavy[2]) {
+  n_heavy[0] = n_heavy[1] = 0;
   if (!ix->pt_k || !ix->strand[0].ptab || !ix->strand[1].ptab || !n) return GS_OK;
-  GS_HIP(hipMemsetAsync(d_out, 0, 4, st));
+  GS_HIP(hipMemsetAsync(d_out, 0, 8, st));
   hipLaunchKernelGGL(k_estimate_heavy, dim3((n + 255) / 256), dim3(256), 0, st, guides, n, (const uint4 *)ix->strand[0].ptab,
                      (const uint4 *)ix->strand[1].ptab, ix->pt_k, thresh, d_out);
-  GS_HIP(hipMemcpyAsync(n_heavy, d_out, 4, hipMemcpyDeviceToHost, st));
+  GS_HIP(hipMemcpyAsync(n_heavy, d_out, 8, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   return GS_OK;
 }

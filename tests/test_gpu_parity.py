@@ -971,9 +971,16 @@ def test_a_heavy_item_is_run_by_many_waves():
         gidx.set_options(GS_SHARE_MIN=None, GS_SHARE_MAX=None)
         big_s = np.concatenate([np.tile(other, (60_000, 1)), np.array([list(site)], dtype=np.uint8)])
         big_p = np.tile(np.frombuffer(b"NGG", np.uint8), (big_s.shape[0], 1))
+        # ... when the heavy item is too large to hide behind the batch on one wave (from GS_SPLIT_FROM rows under its k-mer on:
+        # 2^19 by default; the planted family has thousands): below that every item stays with its wave in the seeding launches
+        boff9, bhits9, _ = gidx.enumerate(big_s, big_p, mismatches=2)
+        shb9 = gidx.last_sharing()
+        assert shb9["guides_with_heavy_kmer"] >= 1 and shb9["form"] == 3 and shb9["shared_items"] == 0, shb9
+        gidx.set_option("GS_SPLIT_FROM", "1000")
         boff0, bhits0, _ = gidx.enumerate(big_s, big_p, mismatches=2)     # (another budget: a shape this handle has not seen)
         shb0 = gidx.last_sharing()   # the FIRST batch of the shape: one guide of 300,001 has a heavy k-mer - two launches at once
         assert shb0["guides_with_heavy_kmer"] >= 1 and shb0["form"] == 2 and shb0["shared_items"] >= 1, shb0
+        assert np.array_equal(boff0, boff9) and bhits0.tobytes() == bhits9.tobytes()
         boff1, bhits1, _ = gidx.enumerate(big_s, big_p, mismatches=2)
         shb = gidx.last_sharing()
         assert shb["form"] == 2 and shb["shared_items"] >= 1, shb
