@@ -476,13 +476,22 @@ def spread(ms):
 
 
 def gpu_clocks():
-    """shader / memory clocks as rocm-smi reports them at the end of the run (a box's clocks move the launch time by
-    several per cent: profiles/r05_ab_headline_across_commits.txt); None where the tool is not to be had"""
+    """shader / memory / fabric clocks the driver reports at the end of the run (a box's clocks move the launch time by
+    several per cent: profiles/r05_ab_headline_across_commits.txt), read from sysfs - pp_dpm_sclk / _mclk / _fclk, the
+    level marked '*' - without starting a program (under rocprofv3 a child that execs is refused on this pool); None
+    where the files are not to be had"""
+    import glob
     try:
-        r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
-        j = json.loads(r.stdout)
-        card = j[sorted(j)[0]]
-        return {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower()}
+        out = {}
+        for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+            for name in ("sclk", "mclk", "fclk"):
+                f = os.path.join(card, f"pp_dpm_{name}")
+                if not os.path.exists(f):
+                    continue
+                cur = [ln.split(":")[1].strip().rstrip("*").strip() for ln in open(f).read().splitlines() if ln.strip().endswith("*")]
+                if cur:
+                    out.setdefault(os.path.basename(os.path.dirname(card)), {})[name] = cur[0]
+        return out or None
     except Exception:
         return None
 
