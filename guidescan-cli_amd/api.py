@@ -199,7 +199,7 @@ EXPORTS = ["gs_index_build", "gs_index_build_with_sa", "gs_index_open_sdsl", "gs
            "gs_format_guide_ex", "gs_score_device", "gs_score", "gs_kmers_generate", "gs_kmers_get",
            "gs_kmers_free", "gs_format_guide_scored", "gs_index_verify_sa", "gs_index_last_counters", "gs_enumerate_general",
            "gs_index_last_guide_flags", "gs_enumerate_general_pams", "gs_index_save_sa", "gs_index_open_sa", "gs_format_guides_scored", "gs_result_ex_raw_hits",
-           "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_debug_tile_plan", "gs_index_lock", "gs_index_unlock",
+           "gs_debug_seed_recipes", "gs_debug_choose_thresholds", "gs_debug_tile_plan", "gs_debug_guide_descriptor", "gs_index_lock", "gs_index_unlock",
            "gs_index_last_sharing", "gs_index_set_option", "gs_index_get_option", "gs_index_prepare"]
 
 
@@ -224,6 +224,21 @@ def seed_recipes(k, L, P, m, n_x, astar=None, deep=False):
     _check(L_.gs_debug_seed_recipes(k, L, P, m, n_x, a, 1 if deep else 0, out.ctypes.data, n, counts))
     c0, c1 = int(counts[0]), int(counts[1])
     return out[:c0], out[c0:c0 + c1], out[c0 + c1:]
+
+
+def guide_descriptor(q: int, pams, L: int, P: int, k: int, x_len: int, codes=(0, 0xFFFFFFFF), n_pt: int = 1, valid: bool = True):
+    """the sixteen words an item of the seeding launches starts from (gs_debug_guide_descriptor; host only)"""
+    L_ = lib()
+    L_.gs_debug_guide_descriptor.restype = C.c_int
+    L_.gs_debug_guide_descriptor.argtypes = [C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                             C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    pam = (C.c_uint32 * 4)(*(list(pams) + [0] * (4 - len(pams))))
+    code = (C.c_uint32 * 2)(*codes)
+    out = (C.c_uint32 * 16)()
+    _check(L_.gs_debug_guide_descriptor(q, pam, len(pams), 1 if valid else 0, L, P, k, x_len, n_pt, code, out))
+    names = ("q_lo", "q_hi", "pam0", "pam1", "pam2", "pam3", "meta", "pidx0", "pidxg", "qrem_b", "bsel_z", "bsel_w", "qhot",
+             "key_a", "key_b", "guide")
+    return dict(zip(names, (int(x) for x in out)))
 
 
 def choose_thresholds(m, n_x, n_o, n_r, pam_expansions=4.0, verify_a=1.5, verify_b=1.9):

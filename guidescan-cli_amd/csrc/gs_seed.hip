@@ -55,11 +55,14 @@ __device__ __forceinline__ uint32_t seed_rev16(const uint32_t x) {
   return ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
 }
 
-/* ---- per guide: the descriptor (process.hpp:51-63 gave the record; this is what k_search_body computed per item) ---- */
-__global__ void k_describe(gs_describe_args a) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= a.n) return;
-  const gs_guide_rec r = a.guides[g];
+/* ---- per guide: the descriptor (process.hpp:51-63 gave the record; this is what k_search_body computed per item) ----
+ * One function for the device (k_describe) and the host (gs_debug_guide_descriptor: tests pin every field against a
+ * restatement in numpy, tests/test_seed_descriptor.py). */
+struct gs_describe_shape {
+  uint32_t L, P, k, x_len, n_pt;
+  uint32_t code[2];
+};
+__host__ __device__ inline gs_guide_desc gs_describe_one(const gs_guide_rec &r, const gs_describe_shape &a, uint32_t g) {
   gs_guide_desc d;
   const uint64_t q = r.q;
   const uint32_t L = a.L, P = a.P, k = a.k, sx = a.x_len, nYb = L - sx;
@@ -112,11 +115,48 @@ __global__ void k_describe(gs_describe_args a) {
   d.key_a = xa ? pidx0 >> (2u * (k - xa)) : 0u;
   d.key_b = (rb && rb <= nYb) ? pidxg >> (2u * (nYb - rb)) : 0u;
   d.guide = g;
+  return d;
+}
+__global__ void k_describe(gs_describe_args a) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.n) return;
+  gs_describe_shape sh;
+  sh.L = a.L;
+  sh.P = a.P;
+  sh.k = a.k;
+  sh.x_len = a.x_len;
+  sh.n_pt = a.n_pt;
+  sh.code[0] = a.code[0];
+  sh.code[1] = a.code[1];
+  const gs_guide_desc d = gs_describe_one(a.guides[g], sh, g);
   a.desc[g] = d;
   if (a.hist != nullptr) {
     atomicAdd(&a.hist[d.key_a], 1u);
     atomicAdd(&a.hist[65536u + d.key_b], 1u);
   }
+}
+/* host only: the descriptor of one packed guide record for a batch shape (k = table depth, x_len = |X|, the pair codes of
+ * the table slots), as sixteen words */
+extern "C" gs_status gs_debug_guide_descriptor(uint64_t q, const uint32_t pam[4], uint32_t npams, uint32_t valid, uint32_t L, uint32_t P,
+                                               uint32_t k, uint32_t x_len, uint32_t n_pt, const uint32_t code[2], uint32_t out[16]) {
+  if (!pam || !code || !out || L < 1 || L > 31 || k < 4 || k > 16 || k > L || x_len < 1 || x_len >= L || P < 2 || P > 8) return GS_ERR_ARG;
+  gs_guide_rec r;
+  r.q = q;
+  for (int j = 0; j < 4; j++) r.pam[j] = pam[j];
+  r.npams = npams;
+  r.valid = valid;
+  gs_describe_shape sh;
+  sh.L = L;
+  sh.P = P;
+  sh.k = k;
+  sh.x_len = x_len;
+  sh.n_pt = n_pt;
+  sh.code[0] = code[0];
+  sh.code[1] = code[1];
+  const gs_guide_desc d = gs_describe_one(r, sh, 0u);
+  static_assert(sizeof(gs_guide_desc) == 64, "one descriptor is sixteen words");
+  memcpy(out, &d, 64);
+  return GS_OK;
 }
 /* exclusive scans of the two histograms (65,536 bins each): one workgroup per histogram */
 __global__ void __launch_bounds__(1024) k_sched_scan(uint32_t *hist) {

@@ -270,6 +270,12 @@ gs_status gs_debug_seed_recipes(uint32_t k, uint32_t L, uint32_t P, uint32_t m, 
                                 uint32_t deep, uint64_t *out, uint64_t cap, uint64_t counts[3]);
 void gs_debug_choose_thresholds(uint32_t m, uint32_t n_x, uint32_t n_o, uint32_t n_r, double pam_expansions,
                                 double verify_a, double verify_b, uint32_t astar[8]);
+/* What an item of the two seeding launches (gs_seed.hip) starts from: the 64-byte descriptor k_describe derives from a packed
+ * guide record - q (2-bit codes in consumption order), four PAM patterns (3 bits per symbol, 4 = N) - for a batch shape
+ * (table depth k, |X| = x_len, the PAM-pair codes of the table slots), as sixteen words: q lo, q hi, pam[4], meta, pidx0,
+ * pidxg, qrem_b, bsel_z, bsel_w, qhot, key_a, key_b, guide (host only; tests/test_seed_descriptor.py pins every field). */
+gs_status gs_debug_guide_descriptor(uint64_t q, const uint32_t pam[4], uint32_t npams, uint32_t valid, uint32_t L, uint32_t P,
+                                    uint32_t k, uint32_t x_len, uint32_t n_pt, const uint32_t code[2], uint32_t out[16]);
 /* The tile ordering's plan for one (guide, index) item of `records` match records, as data (host only; tests pin it):
  * out = {buckets the item is dealt into (0: the item is one tile), records a bucket's slot holds, sample words per
  * splitter, records one wave orders, buckets an item may have at most (more: the batch is ordered device-wide)}. */
