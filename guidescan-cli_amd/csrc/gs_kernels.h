@@ -153,7 +153,8 @@ struct gs_guide_desc {
   uint32_t q_lo, q_hi; /* gs_guide_rec::q */
   uint32_t pam[4];
   uint32_t meta;       /* [2:0] patterns (0: the guide is not valid), [4:3] PAM-pair table slots its patterns go through, [7:5] pairs the
-                          deep tables' masks test, [8 + j] the slot of pattern j's tables, [12 + 4 j +: 4] the bases pattern j's first symbol takes */
+                          deep tables' masks test, [8 + j] the slot of pattern j's tables, [12 + 4 j +: 4] the bases pattern j's first symbol takes,
+                          [28 + s] strand s has a literal-N window within the budget of the guide's symbols */
   uint32_t pidx0;      /* this strand's side: table index of the guide's exact k-mer */
   uint32_t pidxg;      /* the other strand's side: index of the complemented last L - x_len guide symbols */
   uint32_t qrem_b;     /* the complemented first x_len guide symbols, last first */
@@ -168,6 +169,12 @@ struct gs_describe_args {
   uint32_t *hist; /* [2][65536] or nullptr */
   uint32_t n, L, P, k, x_len, n_pt;
   uint32_t code[2];
+  /* the literal-N windows of the batch (gs_search_args::cand ...): a guide none of whose strand's windows lies within m
+   * substitutions of its symbols says so in its descriptor (meta bits 28, 29 clear), and its items skip the list */
+  const uint4 *cand[2];
+  const uint32_t *cand_off[2], *cand_ids[2];
+  uint32_t n_cand[2];
+  uint32_t m;
 };
 #define SHQ_PKG 72u /* uint4 per package: header + 64 descriptors, padded to nine 128-byte lines */
 #define SH_NONE 0xFFFFFFFFu

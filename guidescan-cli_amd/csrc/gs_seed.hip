@@ -128,7 +128,34 @@ __global__ void k_describe(gs_describe_args a) {
   sh.n_pt = a.n_pt;
   sh.code[0] = a.code[0];
   sh.code[1] = a.code[1];
-  const gs_guide_desc d = gs_describe_one(a.guides[g], sh, g);
+  gs_guide_desc d = gs_describe_one(a.guides[g], sh, g);
+  /* literal-N windows within reach (index.hpp:139-149; what k_seed_b reports straight from the list): does the strand have
+   * one at all for this guide?  Almost never - and then the item does not read the list (four dependent reads and 150
+   * vector instructions per item, 12 % of k_seed_b).  Through the 5-symbol buckets where the batch has them. */
+  if ((d.meta & 7u) != 0u) {
+    const uint64_t q = ((uint64_t)d.q_hi << 32) | d.q_lo, lmask = (1ull << (2u * a.L)) - 1ull;
+    for (uint32_t s = 0; s < 2u; ++s) {
+      bool any = false;
+      const uint32_t nc = a.n_cand[s];
+      if (a.cand_ids[s] != nullptr) {
+        for (uint32_t sg = 0; sg < 4u && !any; ++sg) {
+          const uint32_t *off = a.cand_off[s] + 1025u * sg + ((uint32_t)(q >> (10u * sg)) & 1023u);
+          for (uint32_t c = off[0]; c < off[1] && !any; ++c) {
+            const uint4 ce = a.cand[s][a.cand_ids[s][(size_t)sg * nc + c]];
+            const uint64_t x = ((((uint64_t)ce.y << 32) | ce.x) ^ q);
+            any = (uint32_t)__popcll((x | (x >> 1)) & 0x5555555555555555ull & lmask) <= a.m;
+          }
+        }
+      } else {
+        for (uint32_t c = 0; c < nc && !any; ++c) {
+          const uint4 ce = a.cand[s][c];
+          const uint64_t x = ((((uint64_t)ce.y << 32) | ce.x) ^ q);
+          any = (uint32_t)__popcll((x | (x >> 1)) & 0x5555555555555555ull & lmask) <= a.m;
+        }
+      }
+      if (any) d.meta |= 1u << (28u + s);
+    }
+  }
   a.desc[g] = d;
   if (a.hist != nullptr) {
     atomicAdd(&a.hist[d.key_a], 1u);
@@ -670,7 +697,8 @@ __device__ __forceinline__ void k_seed_body(const gs_search_args &a, uint4 *lds)
         const uint32_t ncand = a.n_cand[strand];
         const uint64_t lmask = (1ull << (2u * L)) - 1ull;
         const uint32_t *cids = a.cand_ids[strand];
-        const uint32_t nseg = (a.dbg_skip & 8u) ? 0u : cids != nullptr ? 4u : 1u; /* (8: timing experiments - no window scan) */
+        /* (k_describe has looked: the strand has a window within the budget of this guide's symbols, or the list is not read) */
+        const uint32_t nseg = !((meta >> (28u + strand)) & 1u) ? 0u : cids != nullptr ? 4u : 1u;
         for (uint32_t sg = 0; sg < nseg; ++sg) {
           uint32_t s0 = 0, s1 = ncand;
           if (cids != nullptr) {
@@ -874,6 +902,13 @@ gs_status gs_seed_describe(gs_index *ix, const gs_search_args &sa, uint32_t ng, 
   da.code[0] = sa.pt[0][0].code;
   da.code[1] = sa.n_pt > 1 ? sa.pt[1][0].code : 0xFFFFFFFFu;
   da.hist = sorted ? hist : nullptr;
+  da.m = sa.m;
+  for (uint32_t s = 0; s < 2; s++) {
+    da.cand[s] = sa.cand[s];
+    da.cand_off[s] = sa.cand_off[s];
+    da.cand_ids[s] = sa.cand_ids[s];
+    da.n_cand[s] = sa.n_cand[s];
+  }
   if (sorted) GS_HIP(hipMemsetAsync(hist, 0, 4 * 2 * 65536, st));
   hipLaunchKernelGGL(k_describe, dim3((ng + 255) / 256), dim3(256), 0, st, da);
   if (sorted) {
