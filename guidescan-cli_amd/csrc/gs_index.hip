@@ -461,8 +461,10 @@ __global__ void k_ptab_build(const uint8_t *text, const uint32_t *sa, uint64_t n
   if (!vn || cn != c) tab[c].y = (uint32_t)(r + 1); /* one past its last row */
 }
 
-static uint32_t choose_prefix_k(uint64_t n) {
-  if (const char *e = getenv("GS_PREFIX_K")) return (uint32_t)atoi(e);
+/* (the builder's choices are switches of the handle like every other: the environment's GS_* variables as they were when
+ * the handle was made, gs_opt() the only reader - no getenv on any path of the library) */
+static uint32_t choose_prefix_k(const gs_index *ix, uint64_t n) {
+  if (const char *e = gs_opt(ix, "GS_PREFIX_K")) return (uint32_t)atoi(e);
   /* deepest level at which k-mers still average 2+ rows; capped so the table stays <= 4 GiB.
    * (Until the two-level context check the rule was 8+ rows; a chr1-sized genome then got k = 12,
    * one short of what two-sided seeding needs for 20+3-mers, and ran 6 times slower than at 13:
@@ -544,7 +546,7 @@ __global__ void k_isa_build(const uint32_t *sa, uint64_t n, uint32_t *isa) {
   if (r < n) isa[sa[r]] = (uint32_t)r;
 }
 
-static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hipStream_t st) {
+static gs_status build_ptab(const gs_index *ix, const uint8_t *d_text, gs_strand *s, uint32_t k, hipStream_t st) {
   if (!k) return GS_OK;
   const uint64_t entries = 1ull << (2 * k);
   const size_t bytes = sizeof(uint4) * entries;
@@ -556,7 +558,7 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
   hipLaunchKernelGGL(k_ptab_finish, dim3(nblk(entries, 256)), dim3(256), 0, st, tab, entries);
   uint32_t *ctx = nullptr;
   uint16_t *ctx16 = nullptr;
-  if (!getenv("GS_NO_CTX")) {
+  if (!gs_opt(ix, "GS_NO_CTX")) {
     GS_HIP(hipMalloc(&ctx, 4 * s->n + 16));
     GS_HIP(hipMalloc(&ctx16, 2 * s->n + 32)); /* one row group of padding (k_search reads groups of eight) */
     /* pair positions of the context mask (gs_strand_dev::mask_off) */
@@ -564,7 +566,7 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
     if (off3 < 6) off3 = 6;
     if (off3 > 14) off3 = 14;
     uint32_t mask_off = 0u | (2u << 4) | (4u << 8) | (off3 << 12);
-    if (const char *e = getenv("GS_MASK_OFFSETS")) { /* experiments: "0,2,4,7" */
+    if (const char *e = gs_opt(ix, "GS_MASK_OFFSETS")) { /* experiments: "0,2,4,7" */
       mask_off = 0;
       for (uint32_t j = 0; j < 4 && *e; j++) {
         const unsigned long v = strtoul(e, (char **)&e, 10);
@@ -627,14 +629,14 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
    * (4n: what two-sided seeding needs).  GS_INDEX_BUDGET_GB caps the whole index (both strands):
    * the copies go first, then the inverse suffix array; an allocation that fails is skipped too. */
   double budget = 1e30;
-  if (const char *e = getenv("GS_INDEX_BUDGET_GB")) budget = atof(e) * 1e9 / 2.0; /* per strand */
+  if (const char *e = gs_opt(ix, "GS_INDEX_BUDGET_GB")) budget = atof(e) * 1e9 / 2.0; /* per strand */
   const double base_bytes = (double)s->bytes + (double)bytes; /* blocks, SA, context arrays, table */
   uint32_t rot_first = 3; /* see gs_strand_dev::rot_first */
-  if (const char *e = getenv("GS_ROT_FIRST")) rot_first = (uint32_t)atoi(e);
+  if (const char *e = gs_opt(ix, "GS_ROT_FIRST")) rot_first = (uint32_t)atoi(e);
   const uint32_t nrot = k >= 4 && rot_first + 1 < k ? k - 1 - rot_first : 0;
   const double rot_bytes = (double)bytes * nrot, isa_bytes = 4.0 * (double)s->n;
   uint32_t *isa = nullptr;
-  if (ctx && !getenv("GS_NO_BIDIR") && !getenv("GS_NO_ISA") && base_bytes + isa_bytes <= budget) {
+  if (ctx && !gs_opt(ix, "GS_NO_BIDIR") && !gs_opt(ix, "GS_NO_ISA") && base_bytes + isa_bytes <= budget) {
     if (hipMalloc(&isa, 4 * s->n) == hipSuccess) {
       hipLaunchKernelGGL(k_isa_build, dim3(nblk(s->n, 256)), dim3(256), 0, st, (const uint32_t *)s->sa, s->n, isa);
       s->bytes += 4 * s->n;
@@ -647,7 +649,7 @@ static gs_status build_ptab(const uint8_t *d_text, gs_strand *s, uint32_t k, hip
    * (gs_strand_rot_ensure) - a batch served by PAM-pair and deep tables never does, and their 86 GB at hg38
    * size are better left to those tables and to the workspace */
   s->rot_plan_first = rot_first;
-  s->rot_plan_n = (ctx && nrot && !getenv("GS_NO_ROT") && base_bytes + (isa ? isa_bytes : 0.0) + rot_bytes <= budget) ? nrot : 0;
+  s->rot_plan_n = (ctx && nrot && !gs_opt(ix, "GS_NO_ROT") && base_bytes + (isa ? isa_bytes : 0.0) + rot_bytes <= budget) ? nrot : 0;
   s->rot_k = k;
   GS_HIP(hipStreamSynchronize(st));
   s->isa = isa;
@@ -693,7 +695,7 @@ gs_status gs_strand_rot_ensure(gs_index *ix, hipStream_t st) {
     S.d.ptab_rot = rot;
     S.d.rot_first = S.rot_plan_first;
     S.bytes += bytes;
-    if (getenv("GS_DEBUG"))
+    if (gs_opt(ix, "GS_DEBUG"))
       fprintf(stderr, "[gs] strand %d: %u rotated table copies built (%.1f GB)\n", s, S.rot_plan_n, 1e-9 * (double)bytes);
   }
   return GS_OK;
@@ -773,7 +775,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
   hipLaunchKernelGGL(k_revcomp, dim3(nblk(len, 256)), dim3(256), 0, st, d_fwd, d_rev, len);
   GS_HIP(hipMemset(d_rev + len, 0, 1));
   gs_status rc = GS_OK;
-  const uint32_t pk = choose_prefix_k(n);
+  const uint32_t pk = choose_prefix_k(ix, n);
   for (int s = 0; s < 2 && rc == GS_OK; s++) {
     uint32_t *d_sa = nullptr;
     GS_HIP(hipMalloc(&d_sa, 4 * n));
@@ -796,7 +798,7 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
     }
     if (rc == GS_OK) rc = gs_strand_from_device(d_t, d_sa, n, &ix->strand[s], st);
     if (ix->strand[s].sa == d_sa) cleanup.sa = nullptr; /* the strand owns it now (also when it failed later) */
-    if (rc == GS_OK) rc = build_ptab(d_t, &ix->strand[s], pk, st);
+    if (rc == GS_OK) rc = build_ptab(ix, d_t, &ix->strand[s], pk, st);
   }
   if (rc == GS_OK) ix->pt_k = pk; /* depth of the prefix interval tables; the seed recipes are written per batch shape (gs_search.hip) */
   if (rc == GS_OK) scan_n_runs(text, len, ix->nruns_text);

@@ -198,19 +198,14 @@ def test_no_entry_point_reads_the_environment():
     """the library's switches are a per-handle table filled from the environment ONCE, when the handle is made
     (gs_opts_from_env, gs_host.hip), and changed through gs_index_set_option: no translation unit on a
     gs_enumerate* / gs_score* / gs_kmers* call path calls getenv (a multithreaded host may setenv at any time).
-    What remains: the table's own filling, and build-time choices of gs_index.hip's strand builder (table depth,
-    mask offsets, which optional arrays to build) - read while a handle is being made."""
+    Round 6: the index builder's choices (table depth, mask offsets, which optional arrays to build) read the table too -
+    no getenv call is left anywhere in the library but the table's own filling."""
     import re
     csrc = ol.ROOT / "guidescan-cli_amd" / "csrc"
     for p in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.h")):
         txt = p.read_text()
         n = len(re.findall(r"\bgetenv\s*\(", txt))
-        if p.name == "gs_index.hip":
-            # build-time only: every getenv sits above the handle's construction (gs_index_build_with_sa)
-            at = txt.index("new (std::nothrow) gs_index()")
-            assert not re.search(r"\bgetenv\s*\(", txt[at:]), p
-        else:
-            assert n == 0, (p, n)
+        assert n == 0, (p, n)
     host = (csrc / "gs_host.hip").read_text()
     assert "environ" in host and "gs_opts_from_env" in host
 
