@@ -975,7 +975,9 @@ def test_a_heavy_item_is_run_by_many_waves():
         # 2^19 by default; the planted family has thousands): below that every item stays with its wave in the seeding launches
         boff9, bhits9, _ = gidx.enumerate(big_s, big_p, mismatches=2)
         shb9 = gidx.last_sharing()
-        assert shb9["guides_with_heavy_kmer"] >= 1 and shb9["form"] == 3 and shb9["shared_items"] == 0, shb9
+        # (form 3 - the two seeding launches - where the batch's patterns have their deep tables; this small genome's table is too
+        # shallow for them: the one launch, form 0)
+        assert shb9["guides_with_heavy_kmer"] >= 1 and shb9["form"] in (0, 3) and shb9["shared_items"] == 0, shb9
         gidx.set_option("GS_SPLIT_FROM", "1000")
         boff0, bhits0, _ = gidx.enumerate(big_s, big_p, mismatches=2)     # (another budget: a shape this handle has not seen)
         shb0 = gidx.last_sharing()   # the FIRST batch of the shape: one guide of 300,001 has a heavy k-mer - two launches at once
