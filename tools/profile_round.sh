@@ -14,6 +14,7 @@ WARM=${6:-0}
 NAME=${TAG}_${WL}_m${M}
 OUT=/tmp/prof_$NAME   # raw rocprof output stays off gpurun_out/ (64 MiB limit)
 SUM=gpurun_out/prof_summary
+rm -rf $OUT   # (a box may be one an earlier call ran on: summaries must not pick up its files)
 mkdir -p $OUT $SUM
 export TMPDIR=/tmp
 ARGS="--workload $WL --mismatches $M --batch $BATCH --cpu-sample 0 --extra-rows off"
