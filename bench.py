@@ -491,6 +491,12 @@ def gpu_clocks():
                 cur = [ln.split(":")[1].strip().rstrip("*").strip() for ln in open(f).read().splitlines() if ln.strip().endswith("*")]
                 if cur:
                     out.setdefault(os.path.basename(os.path.dirname(card)), {})[name] = cur[0]
+            busy = os.path.join(card, "gpu_busy_percent")   # (a host holds eight cards: the busy one is this run's)
+            if os.path.exists(busy) and os.path.basename(os.path.dirname(card)) in out:
+                try:
+                    out[os.path.basename(os.path.dirname(card))]["busy_percent"] = int(open(busy).read().strip())
+                except ValueError:
+                    pass
         return out or None
     except Exception:
         return None
@@ -976,6 +982,10 @@ def row_roofline(workload, batch, m, row):
                       3: "k_seed_b + k_seed_a"}.get(form, "k_search"),
            "avg_launch_ms": launch_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": achieved,
            "frac": achieved / HBM_PEAK_GBS if achieved else None,
+           # the lines are counted per load instruction: on a repeat-rich batch neighbouring hits ask for the same lines and the
+           # L2s serve them, so the algorithm's bytes can pass what HBM delivers - frac_hbm is then the memory side's share
+           "frac_note": ("counted lines exceed what HBM delivered: many are served by L2 (see frac_hbm / traffic)"
+                         if achieved and achieved > HBM_PEAK_GBS * 0.8 else None),
            "traffic": (rec["fetch_bytes"] + rec["write_bytes"]) if rec else None,
            "alg_bytes_per_launch": alg,
            "alg_bytes_are": "64 B per distinct line the search's loads ask for (counting instantiation, this row's guides) + 16 B "
