@@ -1,0 +1,78 @@
+"""The forms of the table-seeded search return the same bytes: k_search's one launch (GS_SEED_FORM=0), the two seeding launches
+from per-guide descriptors in the order given (1) and scheduled by the guides' symbols with each XCD drawing from its own
+piece of the schedule (2) - on a chr1-sized genome (deep tables need a table depth of 13), over what decides their code paths:
+batch sizes from one guide (seven of the eight XCD pieces empty) to thousands, one and two PAM-pair tables, PAM lists longer
+than a guide record holds (appending passes), --start, budgets 1 .. 4, and the budget from which the one launch is kept.
+The search order these forms must reproduce: index.hpp:182-248 (recursion), process.hpp:51-63 (PAM list), 100-115 (expansion)."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+api = import_module("guidescan-cli_amd.api")
+synth = import_module("guidescan-cli_amd.synth")
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def chr1():
+    text, names, lengths = synth.make_genome([synth.CHR1_LENGTH], seed=1)
+    gidx = api.GenomeIndex.build(text, device=0)
+    yield text, gidx
+    gidx.close()
+
+
+def run(gidx, seqs, pams, form, **kw):
+    gidx.set_option("GS_SEED_FORM", str(form))
+    off, hits, _ = gidx.enumerate(seqs, pams, **kw)
+    return off, hits, gidx.last_sharing()["form"]
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 1000, 6000])
+def test_batch_sizes_and_schedules(chr1, n):
+    text, gidx = chr1
+    seqs, pams, _, _ = synth.sample_guides(text, n, seed=100 + n)
+    gidx.set_option("GS_SEED_SORT_FROM", "1")   # schedule even the smallest batch
+    try:
+        off0, hits0, f0 = run(gidx, seqs, pams, 0, mismatches=3)
+        assert f0 == 0
+        for form in (1, 2):
+            off, hits, f = run(gidx, seqs, pams, form, mismatches=3)
+            assert f == 3, f   # the two seeding launches ran
+            assert np.array_equal(off0, off) and hits0.tobytes() == hits.tobytes(), (n, form)
+        assert int(off0[-1]) >= n   # every sampled guide finds its own site
+    finally:
+        gidx.set_options(GS_SEED_SORT_FROM=None, GS_SEED_FORM=None)
+
+
+@pytest.mark.parametrize("m", [1, 2, 4, 5])
+def test_budgets(chr1, m):
+    text, gidx = chr1
+    seqs, pams, _, _ = synth.sample_guides(text, 600, seed=7 + m)
+    try:
+        off0, hits0, _ = run(gidx, seqs, pams, 0, mismatches=m)
+        off2, hits2, f = run(gidx, seqs, pams, 2, mismatches=m)
+        assert f == (3 if m <= 4 else 0), (m, f)   # budgets beyond four substitutions keep the one launch
+        assert np.array_equal(off0, off2) and hits0.tobytes() == hits2.tobytes(), m
+    finally:
+        gidx.set_option("GS_SEED_FORM", None)
+
+
+@pytest.mark.parametrize("alts,start", [(("NAG",), False), (("NAG", "NGA"), False), (("NAG", "CGG", "AGG", "TGG", "GGG"), False), ((), True)])
+def test_pam_lists_and_start(chr1, alts, start):
+    """two PAM-pair tables (NGG + NAG), a third pair (NGA: the batch no longer has a table per pattern - the general form
+    of k_search takes it, whatever GS_SEED_FORM says), a list of six patterns (two appending passes), PAM at the 5' end"""
+    text, gidx = chr1
+    seqs, pams, _, _ = synth.sample_guides(text, 800, seed=31)
+    if start:
+        pams = np.tile(np.frombuffer(b"TTN", np.uint8), (seqs.shape[0], 1))
+    try:
+        off0, hits0, _ = run(gidx, seqs, pams, 0, mismatches=3, alt_pams=alts, start=start)
+        for form in (1, 2):
+            off, hits, f = run(gidx, seqs, pams, form, mismatches=3, alt_pams=alts, start=start)
+            assert np.array_equal(off0, off) and hits0.tobytes() == hits.tobytes(), (alts, start, form)
+            if len({p[1:] for p in alts} | {"GG"}) <= 2 and not start:
+                assert f == 3, (alts, f)
+    finally:
+        gidx.set_option("GS_SEED_FORM", None)
