@@ -45,9 +45,21 @@ static uint32_t choose_cap(const gs_index *ix, uint32_t m, uint32_t L, uint32_t 
 }
 
 int gs_num_cus(int device) {
+  /* asked once per device: hipGetDeviceProperties fills a kilobyte-sized struct through the driver every time it is called,
+   * and every enumerate and score call wants this one number */
+  static std::atomic<int> cached[64];
+  if (device >= 0 && device < 64) {
+    const int c = cached[device].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
   hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, device) != hipSuccess) return 256;
-  return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  const int n = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  if (device >= 0 && device < 64) cached[device].store(n, std::memory_order_relaxed);
+  return n;
 }
 
 static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint64_t n, uint32_t L,

@@ -18,6 +18,7 @@
 
 #define WAVE 64
 #define SCORE_WAVES 4
+int gs_num_cus(int device); /* gs_enumerate.hip: asked of the driver once per device */
 
 struct gs_score_args {
   const uint8_t *guides;   /* n*L ASCII (A,C,G,T) */
@@ -29,6 +30,10 @@ struct gs_score_args {
   float *spec;             /* per guide */
   long long max_off;       /* -1 = none */
   uint32_t n, L, P, n_chr, start, sam;
+  /* k_score_sum's work counter hands out tickets: the first p0 tickets are one guide each (the order is heaviest first),
+   * every later one `take` guides - a counter bumped once per guide serves ~88 waves per microsecond chip-wide and held a
+   * batch of 10^6 light guides at 11 ms whatever their hits (19 ms per 1 M guides with 2 x 10^6 hits; now 2 ms) */
+  uint32_t p0, take;
 };
 
 __device__ __forceinline__ int sc_bidx(uint32_t c) {
@@ -243,12 +248,31 @@ __global__ __launch_bounds__(256) void k_score_classes(const uint64_t *offsets, 
 }
 __global__ __launch_bounds__(256) void k_score_place(const uint64_t *offsets, uint32_t n, const uint32_t *cls, uint32_t *cursor, uint32_t *order) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  const uint64_t c = offsets[g + 1u] - offsets[g];
-  const uint32_t k = 63u - (uint32_t)__builtin_clzll(c | 1ull);
+  const bool on = g < n;
+  uint32_t k = 0;
+  if (on) {
+    const uint64_t c = offsets[g + 1u] - offsets[g];
+    k = 63u - (uint32_t)__builtin_clzll(c | 1ull);
+  }
+  /* one atomic per wave and class: a batch of 10^6 guides with a handful of hits each is three or four classes - an atomic
+   * per guide on those few words took 6 of the 9 ms the scoring of such a batch took */
+  const uint32_t lane = threadIdx.x & (WAVE - 1u);
+  uint32_t pos = 0;
+  uint64_t todo = __ballot(on);
+  while (todo) {
+    const int l = __ffsll((long long)todo) - 1;
+    const uint32_t kk = (uint32_t)__shfl((int)k, l);
+    const uint64_t same = __ballot(on && k == kk);
+    uint32_t b0 = 0;
+    if ((int)lane == l) b0 = atomicAdd(&cursor[kk], (uint32_t)__popcll(same));
+    b0 = (uint32_t)__shfl((int)b0, l);
+    if (on && k == kk) pos = b0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if (!on) return;
   uint32_t base = 0;
   for (uint32_t j = 39u; j > k; --j) base += cls[j]; /* the classes of more hits go first */
-  order[base + atomicAdd(&cursor[k], 1u)] = g;
+  order[base + pos] = g;
 }
 /* --max-off-targets given: one wavefront per guide, 64 hits per round, the per-distance counters from ballots and the
  * additions as a chain of v_readlane / v_add pairs (the form every batch took until round 5) */
@@ -352,10 +376,16 @@ __global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a
   const uint32_t lane = threadIdx.x & (WAVE - 1u);
   float *buf = s_buf[threadIdx.x / WAVE];
   for (;;) {
-    uint32_t t = 0;
-    if (lane == 0) t = atomicAdd(next, 1u);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-    if (t >= a.n) break;
+    uint32_t tk = 0;
+    if (lane == 0) tk = atomicAdd(next, 1u);
+    tk = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+    /* (64-bit: tickets far beyond the last guide - every wave draws one more at the end - must not wrap) */
+    const uint64_t tb = tk < a.p0 ? (uint64_t)tk : (uint64_t)a.p0 + (uint64_t)(tk - a.p0) * a.take;
+    if (tb >= a.n) break;
+    const uint32_t t_lo = (uint32_t)tb;
+    const uint64_t te = tb + (tk < a.p0 ? 1u : a.take);
+    const uint32_t t_hi = te < a.n ? (uint32_t)te : a.n;
+    for (uint32_t t = t_lo; t < t_hi; ++t) {
     const uint32_t g = order[t];
     const uint64_t hb = a.offsets[g], len = a.offsets[g + 1u] - hb;
     const float *pc = cfm + hb + SC_PER * lane;
@@ -417,6 +447,7 @@ __global__ __launch_bounds__(WAVE *SCORE_WAVES) void k_score_sum(gs_score_args a
     float sp = 0.0f;
     if (sum > 0.0f) sp = __fdiv_rn(1.0f, sum);
     a.spec[g] = sp; /* all lanes, same address */
+    }
   }
 }
 
@@ -479,10 +510,7 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   a.n_chr = gs->n_chr;
   a.start = (flags & GS_FLAG_PAM_AT_START) ? 1u : 0u;
   a.sam = (flags & GS_TEXT_SAM) ? 1u : 0u;
-  hipDeviceProp_t prop;
-  int cus = 256;
-  if (hipGetDeviceProperties(&prop, ix->device) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  const int cus = gs_num_cus(ix->device);
   /* hits of the batch (the last offset), their CFDs (the caller's array or one of the handle's) and facts */
   uint64_t n_hits = 0;
   GS_HIP(hipMemcpyAsync(&n_hits, (const uint64_t *)d_offsets + n, 8, hipMemcpyDeviceToHost, st));
@@ -518,6 +546,12 @@ extern "C" gs_status gs_score_device(gs_index *ix, const void *d_guides, uint64_
   } else {
     uint32_t grid = (uint32_t)((n + SCORE_WAVES - 1) / SCORE_WAVES);
     if (grid > (uint32_t)cus * 8u) grid = (uint32_t)cus * 8u;
+    {
+      const uint64_t waves = (uint64_t)grid * SCORE_WAVES;
+      a.p0 = (uint32_t)std::min<uint64_t>(n, 4u * waves); /* the heaviest guides one at a time: they set the balance */
+      const uint64_t rest = n - a.p0;
+      a.take = (uint32_t)std::min<uint64_t>(64u, std::max<uint64_t>(1u, rest / (waves * 8u)));
+    }
     hipLaunchKernelGGL(k_score_sum, dim3(grid), dim3(WAVE * SCORE_WAVES), 0, st, a, (const float *)cfm, (const uint32_t *)d_perfect,
                        (const uint32_t *)d_order, d_next);
   }
