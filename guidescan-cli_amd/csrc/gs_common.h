@@ -297,4 +297,13 @@ gs_status gs_count_bad_sa_rows(const uint32_t *d_sa, uint64_t n, hipStream_t st,
 gs_status gs_sdsl_read(const char *path, std::vector<uint8_t> &bwt, std::vector<uint64_t> &sa_samples,
                        uint64_t C256[257]);
 
+/* k_order / k_locate (gs_order.hip): guides one wave takes at a time, a lane each for the ones that need no wave - as
+ * many as still leave every wave of the chip a group (the guides of a group that DO need the wave are served one after
+ * the other) */
+static inline __host__ __device__ uint32_t gs_lane_group(uint32_t n_guides) {
+  uint32_t g = 64;
+  while (g > 1 && (n_guides + g - 1) / g < 8192u) g >>= 1;
+  return g;
+}
+
 #endif

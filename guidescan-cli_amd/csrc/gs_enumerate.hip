@@ -986,7 +986,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
      * that many launched so the tail balances */
     const uint32_t ow = ORDER_WAVES;
     const size_t lds = sizeof(uint4) * (2 * (size_t)cap_ + ORDER_SMALL) * ow;
-    uint32_t grid = (ng + ow - 1) / ow;
+    const uint32_t gsz = gs_lane_group(ng); /* guides a wave takes at a time: a lane each where one record needs no order */
+    uint32_t grid = ((ng + gsz - 1) / gsz + ow - 1) / ow;
     const uint32_t gmax = (uint32_t)cus * 16u;
     if (grid > gmax) grid = gmax;
     if (grid == 0) grid = 1;
@@ -1008,7 +1009,8 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     la.cap = cap_;
     la.v_rem = v_rem;
     const size_t lds = sizeof(uint32_t) * (2 * (size_t)cap_ + 1);
-    hipLaunchKernelGGL(k_locate, dim3(ng), dim3(WAVE), lds, st, la);
+    const uint32_t gsz = gs_lane_group(ng);
+    hipLaunchKernelGGL(k_locate, dim3((ng + gsz - 1) / gsz), dim3(WAVE), lds, st, la);
   };
 
   /* ---- guides whose match count exceeds what k_order sorts in LDS: `n_set`
@@ -1380,7 +1382,7 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
   unsigned long long h_cstat[2] = {0, 0}; /* sum and maximum of this batch's exact per-item counts */
   {
     GS_HIP(hipMemsetAsync(d_stats + 14, 0, 16, st));
-    hipLaunchKernelGGL(k_count_stats, dim3(std::min<uint32_t>((2 * n32 + 255) / 256, 1024u)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_count_stats, dim3(std::min<uint32_t>((2 * n32 + 1023) / 1024, 256u)), dim3(256), 0, st,
                        (const uint32_t *)ix->w_counts.p, 2 * n32, d_stats + 14);
     if (cap > 128) { /* sizes k_order_wg's LDS; the small-slot path does not wait for it */
       GS_HIP(hipMemcpyAsync(h_cstat, d_stats + 14, 16, hipMemcpyDeviceToHost, st));

@@ -7,104 +7,211 @@
 
 /* ---- order: per guide canonical order + dedupe ----------------------------- */
 
-/* One wavefront per guide at a time, ORDER_WAVES wavefronts per workgroup, guides dealt to the
- * waves grid-stride (a launch of one single-wave workgroup per guide with one atomic each was
- * latency bound: 12 ms per 1 M guides).  Dynamic LDS per wave: 2*cap uint4 (records) + ORDER_SMALL
+/* k_order's guides of at most SEGW records, 64 / SEGW of them at a time: a lane per record - the rank sort's compares run
+ * over the segment's records in LDS (`srt`: 64 records in, 64 out), the std::set's dedupe over the segment's share of one
+ * ballot.  lc0, lc1: the lanes' own guides' counts (guide g0 + lane); todo: the lanes whose guides are served here.
+ * Returns the records kept (wave-uniform). */
+template <uint32_t SEGW>
+__device__ __forceinline__ uint32_t order_segments(const gs_order_args &a, uint32_t g0, uint32_t lc0, uint32_t lc1, uint64_t todo,
+                                                   uint4 *srt) {
+  const uint32_t lane = lane_id(), cap = a.cap;
+  const uint32_t seg = lane / SEGW, sub = lane % SEGW;
+  uint4 *qin = srt + seg * SEGW, *qout = srt + WAVE + seg * SEGW;
+  uint32_t total = 0;
+  while (todo) {
+    uint32_t tsel = WAVE;
+#pragma unroll
+    for (uint32_t s4 = 0; s4 < WAVE / SEGW; s4++) {
+      const uint32_t t = todo ? (uint32_t)__ffsll((unsigned long long)todo) - 1u : (uint32_t)WAVE;
+      todo &= todo - 1ull;
+      tsel = seg == s4 ? t : tsel;
+    }
+    const bool act = tsel < WAVE;
+    const uint32_t src = act ? tsel : lane;
+    const uint32_t c0 = (uint32_t)__shfl((int)lc0, (int)src), c1 = (uint32_t)__shfl((int)lc1, (int)src);
+    const uint32_t M = act ? c0 + c1 : 0u;
+    const uint32_t g = g0 + src;
+    uint4 *base = a.slots + (size_t)g * 2 * cap;
+    const bool has = sub < M;
+    uint4 me = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (has) me = sub < c0 ? base[sub] : base[cap + (sub - c0)];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    qin[sub] = me;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint64_t key = ((uint64_t)me.y << 32) | me.x;
+    uint32_t rank = 0; /* ascending (key, first row, original index) */
+    for (uint32_t j = 0; j < SEGW; j++) {
+      if (__ballot(j < M) == 0ull) break;
+      const uint4 o = qin[j];
+      const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
+      rank += (j < M && ((ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < sub))))) ? 1u : 0u;
+    }
+    if (has) qout[rank] = me;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    /* dedupe equal sequences (std::set keeps the first), compact, count hits */
+    bool keep = false;
+    uint4 sm = make_uint4(0, 0, 0, 0);
+    if (has) {
+      sm = qout[sub];
+      keep = true;
+      if (sub > 0) {
+        const uint4 pv = qout[sub - 1u];
+        keep = !(pv.x == sm.x && pv.y == sm.y && pv.z == sm.z); /* same sequence, same rows */
+      }
+    }
+    const uint64_t kb = __ballot(keep);
+    const uint32_t kseg = (uint32_t)(kb >> (seg * SEGW)) & (uint32_t)((1ull << SEGW) - 1ull);
+    const uint32_t cnt = keep ? (sm.w - sm.z + 1u) : 0u;
+    if (keep) base[__popc(kseg & (uint32_t)((1ull << sub) - 1ull))] = make_uint4(sm.x, sm.y, sm.z, cnt);
+    uint32_t hs = cnt;
+    for (int o = SEGW / 2; o > 0; o >>= 1) hs += __shfl_xor(hs, o);
+    if (act && sub == 0u) {
+      a.nmatch[g] = (uint32_t)__popc(kseg);
+      a.nhits[g] = hs;
+    }
+    total += (uint32_t)__popcll(kb);
+  }
+  return total;
+}
+
+/* A wavefront takes a GROUP of guides at a time (gs_lane_group: 64 on a batch of a million), ORDER_WAVES wavefronts per
+ * workgroup, groups dealt to the waves grid-stride (a launch of one single-wave workgroup per guide with one atomic each
+ * was latency bound: 12 ms per 1 M guides).  Round 6: a guide with at most ONE record - nearly every guide of an m <= 3
+ * batch on a genome without repeat families - needs no order: lane l of the wave serves guide l of the group by itself
+ * (64 count reads, 64 record reads and 64 stores in flight instead of one guide's chain of five dependent steps:
+ * what a batch of guides that occur once gains); guides of 2 .. 16 records - the headline's batch: 13 per guide - are
+ * served FOUR at a time, sixteen lanes each, those of 17 .. 32 two at a time (order_segments); the guides of the group
+ * with more records by the whole wave, one after the other, as before (0.33 -> 0.2 ms per 1 M guides).  Dynamic LDS per wave: 2*cap uint4 (records) + ORDER_SMALL
  * uint4 (rank-sort output).  Up to ORDER_SMALL records a guide is rank-sorted (M^2/64 compares per
  * lane: 11 at the 26 records of an m = 3 guide); larger guides go through a bitonic network in
  * place (log^2 N / 2 steps of N/128 compare-exchanges per lane: at the 1,440 records of an m = 5
- * guide 2.1 k per lane instead of 32 k).  The loop body has no lane-conditional blocks (DESIGN.md
+ * guide 2.1 k per lane instead of 32 k).  The wave's loop body has no lane-conditional blocks (DESIGN.md
  * 5b, compiler pitfall): per-guide results are stored by all lanes to the same address. */
 __global__ __launch_bounds__(WAVE *ORDER_WAVES) void k_order(gs_order_args a) {
   extern __shared__ uint4 s_mem[];
+  __shared__ uint32_t s_total;
   const uint32_t lane = lane_id();
   const uint32_t wave = threadIdx.x / WAVE, nw = blockDim.x / WAVE;
   const uint32_t cap = a.cap;
   uint4 *rec = s_mem + (size_t)wave * (2u * cap + ORDER_SMALL);
   uint4 *srt = rec + 2u * cap;
   uint32_t total_out = 0;
-  for (uint32_t g = blockIdx.x * nw + wave; g < a.n; g += gridDim.x * nw) {
-    const uint32_t c0 = a.counts[2 * g], c1 = a.counts[2 * g + 1];
-    if (c0 > cap || c1 > cap) {
-      /* more matches than slots: this guide is redone with larger slots (host side); the
-       * redo's totals are patched in before the scan */
-      a.nmatch[g] = 0;
-      a.nhits[g] = 0;
-      continue;
+  if (threadIdx.x == 0) s_total = 0;
+  __syncthreads();
+  const uint32_t gsz = gs_lane_group(a.n), n_groups = (a.n + gsz - 1) / gsz;
+  for (uint32_t G = blockIdx.x * nw + wave; G < n_groups; G += gridDim.x * nw) {
+    /* the lanes' own guides: none or one record, or more records than slots (redone with larger slots, host side; the
+     * redo's totals are patched in before the scan) */
+    const uint32_t gl = G * gsz + lane;
+    const bool mine = lane < gsz && gl < a.n;
+    uint32_t lc0 = 0, lc1 = 0;
+    if (mine) {
+      const uint2 c = ((const uint2 *)a.counts)[gl];
+      lc0 = c.x;
+      lc1 = c.y;
     }
-    const uint32_t M = c0 + c1;
-    uint4 *base = a.slots + (size_t)g * 2 * cap;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (uint32_t i = lane; i < M; i += WAVE) rec[i] = i < c0 ? base[i] : base[cap + (i - c0)];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint4 *sorted = srt;
-    if (M <= ORDER_SMALL) {
-      /* rank sort: ascending (key, first row, original index) */
-      for (uint32_t i = lane; i < M; i += WAVE) {
-        const uint4 me = rec[i];
-        const uint64_t key = ((uint64_t)me.y << 32) | me.x;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < M; j++) {
-          const uint4 o = rec[j];
-          const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
-          rank += (ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < i)));
-        }
-        srt[rank] = me;
+    const bool ovf = lc0 > cap || lc1 > cap;
+    const bool one = mine && !ovf && lc0 + lc1 == 1u;
+    if (mine && (ovf || lc0 + lc1 <= 1u)) {
+      uint32_t h = 0;
+      if (one) {
+        uint4 *b = a.slots + (size_t)gl * 2 * cap;
+        const uint4 me = b[lc0 ? 0u : cap];
+        h = me.w - me.z + 1u;
+        b[0] = make_uint4(me.x, me.y, me.z, h);
       }
-    } else {
-      /* bitonic network over N = the next power of two, padded with records that sort last */
-      uint32_t N = 2u * ORDER_SMALL;
-      while (N < M) N <<= 1;
-      for (uint32_t i = M + lane; i < N; i += WAVE) rec[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+      a.nmatch[gl] = one ? 1u : 0u;
+      a.nhits[gl] = h;
+    }
+    total_out += (uint32_t)__popcll(__ballot(one));
+    /* guides of 2 .. 16 records FOUR at a time, sixteen lanes each; of 17 .. 32 two at a time */
+    total_out += order_segments<16>(a, G * gsz, lc0, lc1, __ballot(mine && !ovf && lc0 + lc1 > 1u && lc0 + lc1 <= 16u), srt);
+    total_out += order_segments<32>(a, G * gsz, lc0, lc1, __ballot(mine && !ovf && lc0 + lc1 > 16u && lc0 + lc1 <= 32u), srt);
+    uint64_t todo = __ballot(mine && !ovf && lc0 + lc1 > 32u);
+    while (todo) {
+      const uint32_t tl = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+      todo &= todo - 1ull;
+      const uint32_t g = G * gsz + tl;
+      const uint32_t c0 = (uint32_t)__shfl((int)lc0, (int)tl), c1 = (uint32_t)__shfl((int)lc1, (int)tl);
+      const uint32_t M = c0 + c1;
+      uint4 *base = a.slots + (size_t)g * 2 * cap;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (uint32_t i = lane; i < M; i += WAVE) rec[i] = i < c0 ? base[i] : base[cap + (i - c0)];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      for (uint32_t kk = 2; kk <= N; kk <<= 1)
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          for (uint32_t t = lane; t < (N >> 1); t += WAVE) {
-            const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), hi = lo | j;
-            const uint4 A = rec[lo], B = rec[hi];
-            const uint64_t ka = ((uint64_t)A.y << 32) | A.x, kb = ((uint64_t)B.y << 32) | B.x;
-            const bool gt = ka > kb || (ka == kb && A.z > B.z);
-            if (gt == ((lo & kk) == 0u)) {
-              rec[lo] = B;
-              rec[hi] = A;
-            }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint4 *sorted = srt;
+      if (M <= ORDER_SMALL) {
+        /* rank sort: ascending (key, first row, original index) */
+        for (uint32_t i = lane; i < M; i += WAVE) {
+          const uint4 me = rec[i];
+          const uint64_t key = ((uint64_t)me.y << 32) | me.x;
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < M; j++) {
+            const uint4 o = rec[j];
+            const uint64_t ok = ((uint64_t)o.y << 32) | o.x;
+            rank += (ok < key) || (ok == key && (o.z < me.z || (o.z == me.z && j < i)));
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          srt[rank] = me;
         }
-      sorted = rec;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    /* dedupe equal sequences (std::set keeps the first), compact, count hits */
-    uint32_t n_out = 0, hits = 0;
-    for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
-      const uint32_t i = i0 + lane;
-      bool keep = false;
-      uint4 me = make_uint4(0, 0, 0, 0);
-      if (i < M) {
-        me = sorted[i];
-        keep = true;
-        if (i > 0) {
-          const uint4 pv = sorted[i - 1];
-          keep = !(pv.x == me.x && pv.y == me.y && pv.z == me.z); /* same sequence, same rows */
-        }
+      } else {
+        /* bitonic network over N = the next power of two, padded with records that sort last */
+        uint32_t N = 2u * ORDER_SMALL;
+        while (N < M) N <<= 1;
+        for (uint32_t i = M + lane; i < N; i += WAVE) rec[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (uint32_t kk = 2; kk <= N; kk <<= 1)
+          for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t t = lane; t < (N >> 1); t += WAVE) {
+              const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), hi = lo | j;
+              const uint4 A = rec[lo], B = rec[hi];
+              const uint64_t ka = ((uint64_t)A.y << 32) | A.x, kb = ((uint64_t)B.y << 32) | B.x;
+              const bool gt = ka > kb || (ka == kb && A.z > B.z);
+              if (gt == ((lo & kk) == 0u)) {
+                rec[lo] = B;
+                rec[hi] = A;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          }
+        sorted = rec;
       }
-      const uint64_t kb = __ballot(keep);
-      const uint32_t cnt = keep ? (me.w - me.z + 1u) : 0u;
-      if (keep) base[n_out + lanes_below(kb)] = make_uint4(me.x, me.y, me.z, cnt);
-      n_out += __popcll(kb);
-      /* wave sum of cnt */
-      uint32_t s = cnt;
-      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      hits += s;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      /* dedupe equal sequences (std::set keeps the first), compact, count hits */
+      uint32_t n_out = 0, hits = 0;
+      for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
+        const uint32_t i = i0 + lane;
+        bool keep = false;
+        uint4 me = make_uint4(0, 0, 0, 0);
+        if (i < M) {
+          me = sorted[i];
+          keep = true;
+          if (i > 0) {
+            const uint4 pv = sorted[i - 1];
+            keep = !(pv.x == me.x && pv.y == me.y && pv.z == me.z); /* same sequence, same rows */
+          }
+        }
+        const uint64_t kb = __ballot(keep);
+        const uint32_t cnt = keep ? (me.w - me.z + 1u) : 0u;
+        if (keep) base[n_out + lanes_below(kb)] = make_uint4(me.x, me.y, me.z, cnt);
+        n_out += __popcll(kb);
+        /* wave sum of cnt */
+        uint32_t s = cnt;
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        hits += s;
+      }
+      a.nmatch[g] = n_out;
+      a.nhits[g] = hits;
+      total_out += n_out;
     }
-    a.nmatch[g] = n_out;
-    a.nhits[g] = hits;
-    total_out += n_out;
   }
-  if (lane == 0 && total_out) atomicAdd(&a.stats[2], (unsigned long long)total_out);
+  /* one atomic per workgroup (one per wave was 16,000 on one word of memory: 0.18 ms behind the last guide) */
+  if (lane == 0 && total_out) atomicAdd(&s_total, total_out);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_total) atomicAdd(&a.stats[2], (unsigned long long)s_total);
 }
 
 /* The same for guides with hundreds to thousands of matches (cap > 128): one 256-thread workgroup
@@ -253,52 +360,111 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_final(const uint32_t *in, c
 
 /* ---- locate: SA gather + coordinate rule ----------------------------------- */
 
-/* one wavefront per guide; dynamic LDS: (2*cap + 1) uint32 exclusive prefix of match sizes */
+/* One wavefront per GROUP of guides (gs_lane_group: 64 on a batch of a million; one single-wave workgroup per group);
+ * dynamic LDS: (2*cap + 1) uint32 exclusive prefix of match sizes.  Round 6: the guides whose every record is ONE row
+ * (hits == records: nearly every guide of a genome without repeat families) are located TOGETHER, a lane per hit of the
+ * group - lane -> (guide, record) through the prefix of the guides' hit counts in LDS - so 64 suffix array gathers are in
+ * flight whatever a guide holds (a workgroup per guide had 13 of 64 lanes at work on the headline's batch, and a million
+ * workgroups to dispatch: 0.36 ms per 1 M guides); the other guides of the group are served by the whole wave one after
+ * the other, as before. */
 __global__ __launch_bounds__(WAVE) void k_locate(gs_locate_args a) {
   extern __shared__ uint32_t s_pre[];
-  const uint32_t g = blockIdx.x;
+  __shared__ uint32_t s_fl[WAVE + 1];
+  __shared__ uint64_t s_off[WAVE];
   const uint32_t lane = lane_id();
-  if (g >= a.n) return;
-  const uint32_t M = a.nmatch[g];
-  if (M == 0) return;
-  const uint4 *mt = a.matches + (size_t)g * 2 * a.cap;
-  uint32_t run = 0;
-  for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
-    const uint32_t i = i0 + lane;
-    const uint32_t c = i < M ? mt[i].w : 0;
+  const uint32_t gsz = gs_lane_group(a.n);
+  const uint32_t gl = blockIdx.x * gsz + lane;
+  const bool mine = lane < gsz && gl < a.n;
+  const uint32_t lM = mine ? a.nmatch[gl] : 0u;
+  uint64_t off = 0;
+  uint32_t lH = 0;
+  if (lM != 0u) {
+    const uint32_t oi = a.gmap ? a.gmap[gl] : gl;
+    off = a.offsets[oi];
+    lH = (uint32_t)(a.offsets[oi + 1] - off);
+  }
+  const bool flat = lM != 0u && lH == lM; /* one row per record */
+  {
+    const uint32_t c = flat ? lM : 0u;
     uint32_t inc = c; /* inclusive wave scan */
     for (int o = 1; o < WAVE; o <<= 1) {
       const uint32_t up = __shfl_up(inc, o);
       if ((int)lane >= o) inc += up;
     }
-    if (i < M) s_pre[i] = run + inc - c;
-    run += __shfl(inc, WAVE - 1);
-  }
-  if (lane == 0) s_pre[M] = run;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  const uint32_t H = run;
-  gs_hit *out = a.hits + a.offsets[a.gmap ? a.gmap[g] : g];
-  for (uint32_t h = lane; h < H; h += WAVE) {
-    /* last match j with s_pre[j] <= h */
-    uint32_t lo = 0, hi = M;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (s_pre[mid] <= h)
-        lo = mid;
-      else
-        hi = mid;
+    s_fl[lane] = inc - c;
+    s_off[lane] = off;
+    if (lane == WAVE - 1) s_fl[WAVE] = inc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t T = s_fl[WAVE];
+    for (uint32_t f = lane; f < T; f += WAVE) {
+      uint32_t lo = 0, hi = WAVE; /* the last guide j of the group with s_fl[j] <= f: the one that has hit f */
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_fl[mid] <= f)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      const uint32_t r = f - s_fl[lo];
+      const uint4 m = a.matches[(size_t)(blockIdx.x * gsz + lo) * 2 * a.cap + r];
+      const uint64_t key = ((uint64_t)m.y << 32) | m.x;
+      const uint32_t strand = (uint32_t)(key >> 60) & 1u;
+      const uint64_t sa = (uint64_t)a.sd[strand].sa[m.z] - ((key & 1ull) ? a.v_rem : 0u);
+      gs_hit o;
+      /* process.hpp:104 / :111 */
+      o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
+      o.key = key & ~1ull;
+      a.hits[s_off[lo] + r] = o;
     }
-    const uint4 m = mt[lo];
-    const uint64_t key = ((uint64_t)m.y << 32) | m.x;
-    const uint32_t strand = (uint32_t)(key >> 60) & 1u;
-    const uint32_t row = m.z + (h - s_pre[lo]);
-    const uint64_t sa = (uint64_t)a.sd[strand].sa[row] - ((key & 1ull) ? a.v_rem : 0u);
-    gs_hit o;
-    /* process.hpp:104 / :111 */
-    o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
-    o.key = key & ~1ull;
-    out[h] = o;
+  }
+  uint64_t todo = __ballot(lM != 0u && !flat);
+  while (todo) {
+    const uint32_t tl = (uint32_t)__ffsll((unsigned long long)todo) - 1u;
+    todo &= todo - 1ull;
+    const uint32_t g = blockIdx.x * gsz + tl;
+    const uint32_t M = (uint32_t)__shfl((int)lM, (int)tl);
+    const uint4 *mt = a.matches + (size_t)g * 2 * a.cap;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); /* the guide before this one has read its prefix */
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t run = 0;
+    for (uint32_t i0 = 0; i0 < M; i0 += WAVE) {
+      const uint32_t i = i0 + lane;
+      const uint32_t c = i < M ? mt[i].w : 0;
+      uint32_t inc = c; /* inclusive wave scan */
+      for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o);
+        if ((int)lane >= o) inc += up;
+      }
+      if (i < M) s_pre[i] = run + inc - c;
+      run += __shfl(inc, WAVE - 1);
+    }
+    if (lane == 0) s_pre[M] = run;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t H = run;
+    gs_hit *out = a.hits + a.offsets[a.gmap ? a.gmap[g] : g];
+    for (uint32_t h = lane; h < H; h += WAVE) {
+      /* last match j with s_pre[j] <= h */
+      uint32_t lo = 0, hi = M;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pre[mid] <= h)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      const uint4 m = mt[lo];
+      const uint64_t key = ((uint64_t)m.y << 32) | m.x;
+      const uint32_t strand = (uint32_t)(key >> 60) & 1u;
+      const uint32_t row = m.z + (h - s_pre[lo]);
+      const uint64_t sa = (uint64_t)a.sd[strand].sa[row] - ((key & 1ull) ? a.v_rem : 0u);
+      gs_hit o;
+      /* process.hpp:104 / :111 */
+      o.pos = strand == 0 ? -(int64_t)sa : (int64_t)(a.genome_length - (sa + 1ull));
+      o.key = key & ~1ull;
+      out[h] = o;
+    }
   }
 }
 
@@ -575,11 +741,20 @@ __global__ __launch_bounds__(256) void k_raw_counts(const uint4 *slots, const ui
 }
 /* sum and maximum of the per-item match counts (slot sizing of the next batch) */
 __global__ void k_count_stats(const uint32_t *counts, uint32_t n_items, unsigned long long *out) {
-  /* a grid-stride loop: one pair of atomics per wave of a grid of at most 1,024 workgroups (one per 64 items
-   * was 62 k atomics on two words at 2 M items: 0.65 ms of a 23 ms step) */
+  /* a grid-stride loop over 16-byte words of four counts, ONE pair of atomics per workgroup of a grid of at most 256:
+   * two words of memory take ~90 atomics per microsecond, so the count of them is what this kernel costs (one pair per
+   * 64 items was 0.65 ms of a 23 ms step at 2 M items; one per wave of 1,024 workgroups still 0.1 ms; now 0.01) */
+  __shared__ unsigned long long s_v[16], s_m[16];
   unsigned long long v = 0, mx = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += (uint64_t)gridDim.x * blockDim.x) {
-    const unsigned long long c = counts[i];
+  const uint32_t n4 = n_items >> 2;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 c = ((const uint4 *)counts)[i];
+    v += (unsigned long long)c.x + c.y + c.z + c.w;
+    const uint32_t m01 = c.x > c.y ? c.x : c.y, m23 = c.z > c.w ? c.z : c.w, m4 = m01 > m23 ? m01 : m23;
+    mx = m4 > mx ? m4 : mx;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n_items & 3u)) {
+    const unsigned long long c = counts[4u * n4 + threadIdx.x];
     v += c;
     mx = c > mx ? c : mx;
   }
@@ -589,8 +764,17 @@ __global__ void k_count_stats(const uint32_t *counts, uint32_t n_items, unsigned
     mx = x > mx ? x : mx;
   }
   if (lane_id() == 0) {
+    s_v[threadIdx.x / WAVE] = v;
+    s_m[threadIdx.x / WAVE] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (uint32_t w = 1; w < blockDim.x / WAVE; w++) {
+      v += s_v[w];
+      mx = s_m[w] > mx ? s_m[w] : mx;
+    }
     if (v) atomicAdd(&out[0], v);
-    atomicMax(&out[1], mx);
+    if (mx) atomicMax(&out[1], mx);
   }
 }
 /* arena chunks the items' records beyond their slots take (the exact counts are known even when the arena ran out) */

@@ -1638,8 +1638,12 @@ __device__ __forceinline__ int base_code(uint8_t c) {
 
 
 __global__ void k_prepare(gs_prep_args a) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= a.n) return;
+  __shared__ uint32_t s_pair[17];
+  if (threadIdx.x < 17u) s_pair[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t g0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool inside = g0 < a.n;
+  const uint32_t g = inside ? g0 : a.n - 1u; /* (the lanes beyond the batch redo its last guide and store nothing) */
   gs_guide_rec r;
   r.q = 0;
   r.valid = a.force_invalid ? 0u : 1u;
@@ -1685,10 +1689,19 @@ __global__ void k_prepare(gs_prep_args a) {
   } else {
     r.npams = 1;
   }
+  if (inside) {
+    if (a.chunk == 0) {
+      if (!r.valid) atomicAdd(a.n_invalid, 1u);
+      if (a.flags) a.flags[g] = r.valid ? 0u : 1u;
+    }
+    a.out[g] = r;
+  }
   if (a.pair_hist != nullptr && a.P >= 2u) {
-    /* which PAM-pair tables would serve this batch: one atomic per wave and distinct pair */
+    /* which PAM-pair tables would serve this batch: one LDS atomic per wave and distinct pair, then one atomic per
+     * WORKGROUP and pair to memory - a batch's patterns end in one or two pairs, and one word of memory takes ~90
+     * atomics per microsecond: one per wave of 64 guides was 0.18 of this kernel's 0.19 ms at a million guides */
     for (uint32_t j = 0; j < 4u; j++) {
-      const bool has = r.valid && j < r.npams;
+      const bool has = inside && r.valid && j < r.npams;
       const uint32_t c0 = (r.pam[j] >> (3u * (a.P - 2u))) & 7u, c1 = (r.pam[j] >> (3u * (a.P - 1u))) & 7u;
       const uint32_t code = (c0 > 3u || c1 > 3u) ? 16u : (c0 | (c1 << 2));
       uint64_t todo = __ballot(has);
@@ -1696,18 +1709,15 @@ __global__ void k_prepare(gs_prep_args a) {
         const int l = __ffsll((long long)todo) - 1;
         const uint32_t c = (uint32_t)__shfl((int)code, l);
         const uint64_t same = __ballot(has && code == c);
-        if ((int)lane_id() == l) atomicAdd(&a.pair_hist[c], (uint32_t)__popcll(same));
+        if ((int)lane_id() == l) atomicAdd(&s_pair[c], (uint32_t)__popcll(same));
         todo &= ~same;
       }
     }
+    __syncthreads();
+    if (threadIdx.x < 17u && s_pair[threadIdx.x]) atomicAdd(&a.pair_hist[threadIdx.x], s_pair[threadIdx.x]);
   }
-  if (a.chunk == 0) {
-    if (!r.valid) atomicAdd(a.n_invalid, 1u);
-    if (a.flags) a.flags[g] = r.valid ? 0u : 1u;
-  }
-  a.out[g] = r;
 }
 
 void gs_launch_prepare(const gs_prep_args &pa, hipStream_t st) {
-  hipLaunchKernelGGL(k_prepare, dim3((pa.n + 255) / 256), dim3(256), 0, st, pa);
+  hipLaunchKernelGGL(k_prepare, dim3((pa.n + 1023) / 1024), dim3(1024), 0, st, pa);
 }
