@@ -85,9 +85,9 @@ def main():
     ap.add_argument("--cpu-threads", default="32,64,128,256",
                     help="thread counts the reference CPU baseline is timed at (the best is reported)")
     ap.add_argument("--hwpopcnt", action="store_true", help="also time the reference built with hardware POPCNT")
-    ap.add_argument("--extra-rows", choices=["auto", "on", "off"], default="auto",
+    ap.add_argument("--extra-rows", choices=["auto", "on", "off", "e2e"], default="auto",
                     help="after the headline: the repeat-rich genome at <= 3 mismatches and <= 6 mismatches + CFD on this "
-                         "genome, 20 k guides each (auto: with the default hg38 workload on one GPU)")
+                         "genome, 20 k guides each (auto: with the default hg38 workload on one GPU; e2e: the end-to-end row alone)")
     ap.add_argument("--e2e-guides", type=int, default=1_000_000,
                     help="guides of the end-to-end row among the extra rows (the built `guidescan enumerate`, kmers CSV -> CSV; 0 = skip)")
     ap.add_argument("--n-gaps", type=int, default=0,
@@ -444,14 +444,14 @@ def main():
                 kind = "port"
         if kind == "port":
             out["cpu_baseline"] = cpu_baseline(text, gidx, seqs, pams, m, args.cpu_sample)
-    want_rows = args.extra_rows == "on" or (args.extra_rows == "auto" and args.workload == "hg38" and m == 3 and world == 1
+    want_rows = args.extra_rows in ("on", "e2e") or (args.extra_rows == "auto" and args.workload == "hg38" and m == 3 and world == 1
                                             and not args.batch and not args.stream and args.cpu_sample != 0)
     if rank == 0 and world == 1 and want_rows:
         # the rows the headline does not show, under the same clock: the deep budget on this genome and the
         # repeat-rich genome (24 k hits per guide: what real hg38's repeat half looks like) - never part of `value`
         try:
             out["detail"]["extra_rows"], gidx = extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P,
-                                                           e2e_guides=args.e2e_guides)
+                                                           e2e_guides=args.e2e_guides, only_e2e=args.extra_rows == "e2e")
         except Exception as e:
             print(f"[bench] extra rows failed: {e!r}", file=sys.stderr)
     if rank == 0:
@@ -833,13 +833,14 @@ def timed_row(torch, api, gidx, text, names, lengths, L, P, m, n_guides, steps, 
             "alg_bytes_per_launch": alg_bytes, "requests_per_guide": {k: v / n_guides for k, v in lines.items()}}
 
 
-def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P, e2e_guides=1_000_000):
+def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P, e2e_guides=1_000_000, only_e2e=False):
     """(rows, index still open or None).  Row 1 on the resident index: 20,000 guides at <= 6 mismatches with CFD
     (config 5's depth).  Row 2: the same index is closed, the repeat-rich genome of the same size is generated and
     indexed, 20,000 guides at <= 3 mismatches (bench.py --workload hg38rep)."""
     rows = {}
-    rows["hg38_20k_m6_cfd"] = timed_row(torch, api, gidx, text, names, lengths, L, P, 6, 20000, 3, True, 4242)
-    rows["hg38_20k_m6_cfd"]["roofline"] = row_roofline("hg38", 20000, 6, rows["hg38_20k_m6_cfd"])
+    if not only_e2e:
+        rows["hg38_20k_m6_cfd"] = timed_row(torch, api, gidx, text, names, lengths, L, P, 6, 20000, 3, True, 4242)
+        rows["hg38_20k_m6_cfd"]["roofline"] = row_roofline("hg38", 20000, 6, rows["hg38_20k_m6_cfd"])
     prep = None
     if e2e_guides:
         try:
@@ -855,7 +856,7 @@ def extra_rows(torch, api, synth, gidx, text, names, lengths, probs, L, P, e2e_g
             print(f"[bench] end-to-end row (CLI) failed: {e!r}", file=sys.stderr)
         prep = None
     # the repeat-rich genome, and the one whose SINE-like family is Alu-like (1.2e6 copies at 2-15 %)
-    for wl, key, steps in (("hg38rep", "hg38rep_20k_m3", 3), ("hg38alu", "hg38alu_20k_m3", 2)):
+    for wl, key, steps in (() if only_e2e else (("hg38rep", "hg38rep_20k_m3", 3), ("hg38alu", "hg38alu_20k_m3", 2))):
         t0 = time.time()
         text2, names2, lengths2 = make_workload_genome(synth, wl, lengths, probs)
         t_gen = time.time() - t0

@@ -632,7 +632,13 @@ int do_enumerate(int argc, char **argv) {
   /* batches of equal (L, P) in input order: the device call takes fixed-width rows.  The hit lists
    * of a batch live in HBM and on the host until it is written: ~13 hits per guide at <= 3
    * mismatches, ~1.4e3 at 5, ~1.1e4 at 6 on a human-sized genome, so deeper searches take smaller batches */
-  if (!batch_size) batch_size = mismatches <= 3 ? (1u << 20) : mismatches == 4 ? (1u << 18) : mismatches == 5 ? (1u << 16) : (1u << 13);
+  /* At <= 3 mismatches a batch of 2^17 guides: the search is 3 ms of device time per batch at hg38 size (a million guides in
+   * one batch: 17.5 ms, in eight: 24), but its 1.1 GB of text took 0.22 s to format and 0.19 s to write BEHIND the search when
+   * the set was one batch - three stages that overlap only from batch to batch (bench.py's e2e_cli row: 0.60 -> 0.4 s). */
+  if (!batch_size) batch_size = mismatches <= 3 ? (1u << 17) : mismatches == 4 ? (1u << 18) : mismatches == 5 ? (1u << 16) : (1u << 13);
+  /* searched, being formatted, being written: three batches in flight per device where a batch's hit lists and text are
+   * small (m <= 4: ~0.2 GB), two where they are gigabytes */
+  if (mismatches <= 4) job.max_in_flight = 3 * (size_t)gpus;
   for (size_t done = 0; done < job.kmers.size();) {
     const size_t L = job.kmers[done].sequence.size(), P = job.kmers[done].pam.size();
     batch b;
