@@ -76,3 +76,26 @@ def test_pam_lists_and_start(chr1, alts, start):
                 assert f == 3, (alts, f)
     finally:
         gidx.set_option("GS_SEED_FORM", None)
+
+
+@pytest.mark.parametrize("n,alts,m", [(20_000, (), 3), (70_000, ("NAG",), 4), (300_000, (), 4)])
+def test_groups_of_guides_in_the_ordering_and_locate_kernels(chr1, n, alts, m):
+    """k_order and k_locate take GROUPS of guides per wave (gs_lane_group: 1 below 16,384 guides, 2 at 20,000, 8 at 70,000,
+    32 at 300,000) - a lane per guide of one record, sixteen or thirty-two lanes per guide of a few, a lane per hit of the
+    group: a batch's bytes are those of its pieces of 4,000 guides (group size 1) put together.  <= 3 mismatches on this
+    genome: one to a few hits per guide; <= 4: a dozen, some guides beyond 16 and beyond 32
+    (order: process.hpp:21-23, 100-115)"""
+    text, gidx = chr1
+    seqs, pams, _, _ = synth.sample_guides(text, n, seed=77)
+    off, hits, _ = gidx.enumerate(seqs, pams, mismatches=m, alt_pams=alts)
+    per = np.diff(off)
+    assert (per == 0).sum() == 0 and (per <= 2).any()                # the lanes' guides ...
+    assert m < 4 or ((per > 16).any() and (per > 32).any()), per.max()   # ... the segments' and the wave's
+    pos = 0
+    for lo in range(0, n, 4000):
+        hi = min(n, lo + 4000)
+        o, h, _ = gidx.enumerate(seqs[lo:hi], pams[lo:hi], mismatches=m, alt_pams=alts)
+        assert np.array_equal(o, off[lo:hi + 1] - off[lo]), (n, lo)
+        assert h.tobytes() == hits[pos:pos + int(o[-1])].tobytes(), (n, lo)
+        pos += int(o[-1])
+    assert pos == int(off[-1])
