@@ -297,6 +297,9 @@ gs_status gs_count_bad_sa_rows(const uint32_t *d_sa, uint64_t n, hipStream_t st,
 gs_status gs_sdsl_read(const char *path, std::vector<uint8_t> &bwt, std::vector<uint64_t> &sa_samples,
                        uint64_t C256[257]);
 
+/* gs_suffix.hip: the same suffix array by doubling over the rows whose groups still have company only */
+gs_status gs_device_suffix_array_discarding(const uint8_t *d_text, uint64_t n, uint32_t *d_sa, hipStream_t st, bool debug);
+
 /* k_order / k_locate (gs_order.hip): guides one wave takes at a time, a lane each for the ones that need no wave - as
  * many as still leave every wave of the chip a group (the guides of a group that DO need the wave are served one after
  * the other) */

@@ -794,7 +794,9 @@ static gs_status build_common(const uint8_t *text, uint64_t len, const uint32_t 
       }
       if (rc != GS_OK) continue;
     } else {
-      rc = gs_device_suffix_array(d_t, n, d_sa, st);
+      /* (gs_suffix.hip: doubling that leaves sorted suffixes alone; GS_SA_PLAIN: the first builder, every row every round) */
+      rc = gs_opt(ix, "GS_SA_PLAIN") ? gs_device_suffix_array(d_t, n, d_sa, st)
+                                     : gs_device_suffix_array_discarding(d_t, n, d_sa, st, gs_opt(ix, "GS_DEBUG") != nullptr);
     }
     if (rc == GS_OK) rc = gs_strand_from_device(d_t, d_sa, n, &ix->strand[s], st);
     if (ix->strand[s].sa == d_sa) cleanup.sa = nullptr; /* the strand owns it now (also when it failed later) */
