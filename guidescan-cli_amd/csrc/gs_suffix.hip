@@ -145,7 +145,7 @@ gs_status gs_device_suffix_array_discarding(const uint8_t *d_text, uint64_t n, u
 
   uint8_t *d_dense = nullptr;
   uint64_t *keys_a = nullptr, *keys_b = nullptr;
-  uint32_t *idx_a = nullptr, *rank = nullptr, *head = nullptr, *d_last = nullptr;
+  uint32_t *idx_a = nullptr, *rank = nullptr, *head = nullptr;
   GS_HIP(B.get(&d_dense, 256));
   GS_HIP(hipMemcpy(d_dense, dense, 256, hipMemcpyHostToDevice));
   GS_HIP(B.get(&keys_a, 8 * n));
@@ -153,7 +153,6 @@ gs_status gs_device_suffix_array_discarding(const uint8_t *d_text, uint64_t n, u
   GS_HIP(B.get(&idx_a, 4 * n));
   GS_HIP(B.get(&rank, 4 * n));
   GS_HIP(B.get(&head, 4 * n));
-  GS_HIP(B.get(&d_last, 16));
   const unsigned g = sx_blk(n, 256);
   hipLaunchKernelGGL(k_sx_init_keys, dim3(g), dim3(256), 0, st, d_text, n, d_dense, bits, k0, keys_a, idx_a);
   size_t sort_bytes = 0, scan_bytes = 0, xscan_bytes = 0;
