@@ -4,9 +4,9 @@
  * What it replaces: sdsl::construct's suffix sort behind `guidescan index` (src/guidescan.cxx:109-179: divsufsort on
  * the host, about an hour at hg38 size), and - since round 6 - this library's own first builder (gs_index.hip:
  * gs_device_suffix_array), which doubled over ALL n rows every round: 18 rounds of 0.47 s per strand at hg38 size,
- * although after the first sort (21 symbols per key at six distinct bytes) nineteen rows in twenty are alone in their
+ * although after the first sort (21 symbols per key at six distinct bytes) 98.7 % of the rows are alone in their
  * group and will never move again - what keeps the rounds coming are the rows inside runs of N (a run of 2^22 N needs
- * 18 doublings), 5 % of a human assembly.
+ * 18 doublings): 1.2 % of bench.py's hg38-sized text, 5 % of the real assembly.
  *
  * The rule (Larsson & Sadakane's discarding, in its sort-everything-that-is-left form): a suffix whose group has one
  * member has its final row.  After each round only the rows of groups with two or more members stay in play
@@ -16,7 +16,7 @@
  * still have company.  rank[] of a suffix out of play is its row, which is what a later comparison needs.
  *
  * The result is THE suffix array of the text (there is only one): gs_index_verify_sa proves it row by row from the
- * text alone in the full-size tests, and tests/test_gpu_parity.py compares it with the first builder's.
+ * text alone in the full-size tests, and tests/test_gpu_suffix_array.py compares it with the first builder's.
  * GS_SA_PLAIN=1 on the handle takes the first builder.  Offline step, not on the enumerate hot path; rocPRIM for the
  * plain sorts and scans.
  */
