@@ -203,7 +203,10 @@ struct gs_index {
   uint32_t pt_k = 0; /* depth of the prefix interval tables (0: none) */
   unsigned long long last_counters[16] = {0}; /* k_search's stats array of the last gs_enumerate_device call */
   std::vector<gs_nrun> nruns_text; /* 'N' runs of the forward text */
-  gs_buffer w_cand;                /* per-batch literal-N candidate windows (device) */
+  gs_buffer w_cand;                /* literal-N candidate windows (device): kept from batch to batch of one shape */
+  uint64_t cand_key = ~0ull;       /* (L, P, bucketed or not) w_cand was made for; ~0: nothing kept */
+  uint32_t cand_n[2] = {0, 0};     /* windows per strand */
+  size_t cand_bidx[2] = {0, 0};    /* words of each strand's bucket index behind them */
   /* seed recipes of the last two (budget, geometry, thresholds) - the CLI's --threshold pass alternates two
    * budgets on one handle: full | a | b per set; rec_cur = the set the last call used */
   gs_recipe_set rec[2];

@@ -432,10 +432,20 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
      * PAM), so its share of them is reported from this list.  Window of strand s, left to right:
      * P PAM symbols (last consumed first), then the guide symbols L-1 .. 0.  Entry = {q lo, q hi,
      * PAM symbols in consumption order (3 bits each, 4 = N), position of the site in the strand's text}. */
+    /* The list depends on the text's N runs and on (L, P, whether it is bucketed) only - not on the batch's guides or
+     * patterns: the handle keeps the last one it uploaded (a batch of the same shape finds it in place: the host's
+     * pass over the runs and three blocking copies were 0.1 ms of every 17 ms step). */
+    uint32_t cand_from = 256;
+    if (const char *e = gs_opt(ix, "GS_CAND_BUCKETS_FROM")) cand_from = (uint32_t)atol(e);
+    const bool cand_buckets_ok = !(mismatches > 3 || L < 20 || gs_opt(ix, "GS_NO_CAND_BUCKETS"));
+    const uint64_t cand_key = (uint64_t)L | ((uint64_t)P << 8) | ((uint64_t)(cand_buckets_ok ? 1u : 0u) << 16) | ((uint64_t)cand_from << 32);
+    const bool cand_hit = ix->cand_key == cand_key && ix->w_cand.p != nullptr;
     std::vector<uint4> cand[2];
+    std::vector<uint32_t> bidx[2];
     const uint32_t W = L + P;
     const uint64_t len = ix->genome_length;
     auto code = [](uint8_t c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
+    if (!cand_hit)
     for (const gs_nrun &r : ix->nruns_text) {
       auto at = [&](int64_t pos) -> uint8_t { /* forward text around the run */
         if (pos < 0 || (uint64_t)pos >= len) return 0;
@@ -487,15 +497,18 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
         if (ok) cand[1].push_back(make_uint4((uint32_t)q, (uint32_t)(q >> 32), pc, (uint32_t)(len - ((uint64_t)j + W))));
       }
     }
-    n_cand[0] = (uint32_t)cand[0].size();
-    n_cand[1] = (uint32_t)cand[1].size();
-    if (n_cand[0] + n_cand[1]) {
+    size_t n_bidx[2] = {0, 0};
+    if (cand_hit) {
+      n_cand[0] = ix->cand_n[0];
+      n_cand[1] = ix->cand_n[1];
+      n_bidx[0] = ix->cand_bidx[0];
+      n_bidx[1] = ix->cand_bidx[1];
+    } else {
+      n_cand[0] = (uint32_t)cand[0].size();
+      n_cand[1] = (uint32_t)cand[1].size();
       /* behind the windows: per strand with many of them, the bucket index (4 x 1025 offsets, 4 x n places) */
-      std::vector<uint32_t> bidx[2];
       for (uint32_t s = 0; s < 2; s++) {
-        uint32_t from = 256;
-        if (const char *e = gs_opt(ix, "GS_CAND_BUCKETS_FROM")) from = (uint32_t)atol(e);
-        if (n_cand[s] <= from || mismatches > 3 || L < 20 || gs_opt(ix, "GS_NO_CAND_BUCKETS")) continue;
+        if (n_cand[s] <= cand_from || !cand_buckets_ok) continue;
         const uint32_t nc = n_cand[s];
         bidx[s].assign(4u * 1025u + 4u * (size_t)nc, 0u);
         for (uint32_t c = 0; c < 4; c++) {
@@ -506,22 +519,35 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
           std::vector<uint32_t> cur(off, off + 1024);
           for (uint32_t i = 0; i < nc; i++) ids[cur[val(i)]++] = i;
         }
+        n_bidx[s] = bidx[s].size();
       }
+      ix->cand_key = ~0ull; /* (valid again once everything below is in place) */
+    }
+    if (n_cand[0] + n_cand[1]) {
       const size_t b_w = 16 * (size_t)(n_cand[0] + n_cand[1]);
-      if ((rc = gs_reserve(ix->w_cand, b_w + 4 * (bidx[0].size() + bidx[1].size()) + 16)) != GS_OK) return rc;
+      if (!cand_hit && (rc = gs_reserve(ix->w_cand, b_w + 4 * (n_bidx[0] + n_bidx[1]) + 16)) != GS_OK) return rc;
       uint4 *dc = (uint4 *)ix->w_cand.p;
-      if (n_cand[0]) GS_HIP(hipMemcpy(dc, cand[0].data(), 16 * (size_t)n_cand[0], hipMemcpyHostToDevice));
-      if (n_cand[1]) GS_HIP(hipMemcpy(dc + n_cand[0], cand[1].data(), 16 * (size_t)n_cand[1], hipMemcpyHostToDevice));
+      if (!cand_hit) {
+        if (n_cand[0]) GS_HIP(hipMemcpy(dc, cand[0].data(), 16 * (size_t)n_cand[0], hipMemcpyHostToDevice));
+        if (n_cand[1]) GS_HIP(hipMemcpy(dc + n_cand[0], cand[1].data(), 16 * (size_t)n_cand[1], hipMemcpyHostToDevice));
+      }
       d_cand[0] = dc;
       d_cand[1] = dc + n_cand[0];
       uint32_t *di = (uint32_t *)((char *)ix->w_cand.p + b_w);
       for (uint32_t s = 0; s < 2; s++) {
-        if (bidx[s].empty()) continue;
-        GS_HIP(hipMemcpy(di, bidx[s].data(), 4 * bidx[s].size(), hipMemcpyHostToDevice));
+        if (n_bidx[s] == 0) continue;
+        if (!cand_hit) GS_HIP(hipMemcpy(di, bidx[s].data(), 4 * n_bidx[s], hipMemcpyHostToDevice));
         d_cand_off[s] = di;
         d_cand_ids[s] = di + 4u * 1025u; /* chunk c's places: from c * n_cand[s] on */
-        di += bidx[s].size();
+        di += n_bidx[s];
       }
+    }
+    if (!cand_hit) {
+      ix->cand_n[0] = n_cand[0];
+      ix->cand_n[1] = n_cand[1];
+      ix->cand_bidx[0] = n_bidx[0];
+      ix->cand_bidx[1] = n_bidx[1];
+      ix->cand_key = n_cand[0] + n_cand[1] ? cand_key : ~0ull; /* (no windows: nothing to keep, nothing to upload) */
     }
     if (gs_opt(ix, "GS_DEBUG"))
       fprintf(stderr, "[gs] two-sided seeding: astar %u,%u,%u,%u,%u,%u,%u,%u over |X|=%u |O|=%u |R|=%u, "
