@@ -5,6 +5,10 @@
  */
 #include "gs_kernels.h"
 
+/* gs_seed.hip (launched here behind k_prepare; gs_estimate_heavy is its stand-alone form) */
+__global__ void k_estimate_heavy(const gs_guide_rec *guides, uint32_t n, const uint4 *ptab0, const uint4 *ptab1, uint32_t k,
+                                 uint32_t thresh, uint32_t *out);
+
 #include <rocprim/rocprim.hpp>
 
 #include <cmath>
@@ -220,12 +224,26 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     pa.chunk = c;
     pa.force_invalid = force_general ? 1u : 0u;
     pa.pair_hist = (uint32_t *)((char *)ix->w_misc.p + 256);
-    hipLaunchKernelGGL(k_prepare, dim3((n32 + 255) / 256), dim3(256), 0, st, pa);
+    gs_launch_prepare(pa, st); /* (workgroups of 1,024: one atomic per workgroup and PAM pair) */
+  }
+  /* run_search's form estimate (k_estimate_heavy, gs_seed.hip: the guides whose own k-mer heads a giant interval) is
+   * launched here, behind the records it reads, so that its two words come back with this stage's readback instead of
+   * costing the step a host round trip of their own (25-70 us on this pool's hosts) */
+  uint32_t pre_est[2] = {0, 0}, pre_est_thresh = 0;
+  {
+    uint32_t smin = ix->opt_share_min;
+    if (const char *e = gs_opt(ix, "GS_SHARE_MIN")) smin = (uint32_t)std::max(0l, atol(e));
+    if (n_chunks == 1 && smin != 0 && smin < (1u << 28) && ix->pt_k && ix->strand[0].ptab && ix->strand[1].ptab && !gs_opt(ix, "GS_NO_FORM_ESTIMATE")) {
+      pre_est_thresh = 8u * smin;
+      hipLaunchKernelGGL(k_estimate_heavy, dim3((n32 + 255) / 256), dim3(256), 0, st, (const gs_guide_rec *)ix->w_grec.p, n32,
+                         (const uint4 *)ix->strand[0].ptab, (const uint4 *)ix->strand[1].ptab, ix->pt_k, pre_est_thresh, d_work + 10);
+    }
   }
   /* guides the fast path does not encode get empty hit lists and a flag; the batch goes on */
   uint32_t h_invalid = 0, h_pairs[17] = {0};
   GS_HIP(hipMemcpyAsync(&h_invalid, d_invalid, 4, hipMemcpyDeviceToHost, st));
   GS_HIP(hipMemcpyAsync(h_pairs, (char *)ix->w_misc.p + 256, sizeof(h_pairs), hipMemcpyDeviceToHost, st));
+  if (pre_est_thresh) GS_HIP(hipMemcpyAsync(pre_est, d_work + 10, 8, hipMemcpyDeviceToHost, st));
   GS_HIP(hipStreamSynchronize(st));
   ix->last_unsupported = h_invalid;
   const uint32_t n_alt_given = n_alt;
@@ -721,8 +739,13 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
      * family's consensus has heavy passes without a heavy k-mer of its own) */
     uint32_t est[2] = {0, 0};
     if (share_ok && with_arena && !gs_opt(ix, "GS_NO_FORM_ESTIMATE")) {
-      const gs_status er = gs_estimate_heavy(ix, guides, ng, 8u * share_min, d_work + 10, st, est);
-      if (er != GS_OK) return er;
+      if (pre_est_thresh == 8u * share_min && guides == (const gs_guide_rec *)ix->w_grec.p && ng == n32) {
+        est[0] = pre_est[0]; /* (the main pass: estimated behind k_prepare) */
+        est[1] = pre_est[1];
+      } else {
+        const gs_status er = gs_estimate_heavy(ix, guides, ng, 8u * share_min, d_work + 10, st, est);
+        if (er != GS_OK) return er;
+      }
       if (gs_opt(ix, "GS_DEBUG")) fprintf(stderr, "[gs] form estimate: %u guides with a heavy k-mer of their own, the largest interval %u rows\n", est[0], est[1]);
     }
     const uint32_t est_heavy = est[0];
