@@ -956,6 +956,8 @@ def e2e_cli_row(prep, text, names, lengths, fmt="csv"):
                "cli_stage_seconds_overlapping": ({"device": float(m_st.group(1)), "text_formatting": float(m_st.group(2)),
                                                   "file_writes": float(m_st.group(3))} if m_st else None),
                "output_bytes": size, "writer_GB_per_s": size / secs / 1e9, "output_on": base}
+        if os.environ.get("GS_DEBUG"):   # the library's own account of the CLI's batches (forms, tables, arena)
+            out["cli_stderr_tail"] = r.stderr[-6000:]
         if fmt == "csv":
             exp = prep["expect_prefix"]
             with open(out_file, "rb") as fh:

@@ -602,11 +602,15 @@ int do_enumerate(int argc, char **argv) {
   for (size_t i = 0; i < job.gs.names.size(); i++) job.refid[job.gs.names[i]] = (int32_t)i;
   job.sflags = start ? GS_FLAG_PAM_AT_START : 0u;
   {
-    /* the PAM-pair tables cost ~0.3 s per device at hg38 size and save ~15 ms per million guides: short
-     * jobs go without (the library's default is to build them) */
+    /* the PAM-pair and deep tables cost ~0.23 s per device at hg38 size (the strand tables' rotated copies, which a
+     * job without them builds instead: ~0.1 s) and - since the seeding launches read them (gs_seed.hip) - save ~85 ms
+     * per million guides in batches of 2^17 (3.5 against 14 ms per batch): jobs below ~1.9 M guides per device at
+     * that size go without (the library's default is to build them).  Measured with bench.py's e2e row, 1 M guides:
+     * 0.35 s without the tables, 0.45 s with them - the first batch's build also keeps the writer waiting.  (Until
+     * round 6 the saving was 15 ms per million and the bar stood at 15 M guides.) */
     uint64_t glen = 0;
     for (uint64_t l : job.gs.lengths) glen += l;
-    if ((double)job.kmers.size() / (double)gpus < 5e-3 * (double)glen) job.sflags |= GS_FLAG_NO_NEW_TABLES;
+    if ((double)job.kmers.size() / (double)gpus < 6e-4 * (double)glen) job.sflags |= GS_FLAG_NO_NEW_TABLES;
   }
   job.mismatches = (uint32_t)mismatches;
   job.rna = (uint32_t)rna;
