@@ -105,6 +105,8 @@ struct sx_buffers { /* everything the builder allocates: released on every way o
   template <typename T>
   hipError_t get(T **out, size_t bytes) {
     void *q = nullptr;
+    *out = nullptr;
+    if (n >= 16) return hipErrorOutOfMemory; /* (the list is sized for what the builder allocates: 13 at most) */
     const hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
     if (e == hipSuccess) p[n++] = q;
     *out = (T *)q;
