@@ -650,6 +650,49 @@ def test_config4_two_chromosomes_and_config5_stream_checksums(hg38):
     assert len(got) == len(want) and got == want
 
 
+CONFIG4_WHOLE_GENOME = {"candidates": 269_049_665, "hits": 3_485_210_395, "checksum": "08fc836fc587650b"}
+
+
+def test_config4_every_candidate_of_the_genome_on_one_gpu(hg38):
+    """BASELINE config 4 AT ITS SIZE on one GPU (15 s of wall time in all since the index builds in 8): every NGG candidate
+    of all 24 chromosomes scanned on the device (gs_kmers_generate), enumerated from HBM at <= 3 mismatches in batches of
+    2^20 and scored (CFD + specificity) - 2.69 x 10^8 guides, 3.49 x 10^9 hits.  Candidates and hits equal what
+    tools/genomewide_enumerate.py has printed since round 4 (profiles/r0*_hg38_genomewide.json.log); the checksum over every
+    offset, hit record and specificity is this path's own first run - a tripwire at the stated size, not a second opinion:
+    correctness at size rests on the lines compared with the compiled reference above (4,096 + 128 candidates, 512 + 64
+    guides at depth 6) and on the properties checked here: every candidate finds its own site, hits per guide >= 1."""
+    import torch
+    hip = _hip()
+    text = hg38.text
+    csum, total_hits, n_cand = 0, 0, 0
+    spec_sum = 0.0
+    t0 = time.time()
+    for c in range(len(hg38.lengths)):
+        c_off = int(sum(hg38.lengths[:c]))
+        d_chr = torch.from_numpy(np.ascontiguousarray(text[c_off:c_off + hg38.lengths[c]])).cuda()
+        km = api.generate_kmers(None, "NGG", 20, device=0, chrm_device_ptr=d_chr.data_ptr(), chrm_len=hg38.lengths[c])
+        try:
+            n_cand += km.n
+            for b0 in range(0, km.n, 1 << 20):
+                nb = min(1 << 20, km.n - b0)
+                d_off, d_hits, st = hg38.gidx.enumerate_device(km.seqs_ptr + b0 * 20, nb, 20, km.pams_ptr + b0 * 3, 3, mismatches=3)
+                assert st["n_hits"] >= nb
+                d_spec = torch.empty(nb, dtype=torch.float32, device="cuda")
+                hg38.gidx.score_device(hg38.gs, km.seqs_ptr + b0 * 20, nb, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
+                csum = fold_batch(torch, hip, csum, d_off, d_hits, nb, st["n_hits"], d_spec)
+                spec_sum += float(d_spec.double().sum().item())
+                assert float(d_spec.min().item()) > 0.0 and float(d_spec.max().item()) <= 1.0
+                total_hits += st["n_hits"]
+                del d_spec
+        finally:
+            km.close()
+        del d_chr
+    got = {"candidates": n_cand, "hits": total_hits, "checksum": f"{csum:016x}"}
+    print("config 4, the whole genome:", got, f"mean specificity {spec_sum / n_cand:.10f}, {time.time() - t0:.1f} s")
+    assert abs(spec_sum / n_cand - 0.3665231549) < 1e-6   # (tools/genomewide_enumerate.py --score, rounds 4 and 6)
+    assert got == CONFIG4_WHOLE_GENOME, got
+
+
 def test_hg38_reference_index_files_open_through_the_importer(hg38):
     """SURVEY 8a row a12 at the size users download it: the <prefix>.forward / .reverse files the reference leg reads
     (csa_wt<wt_huff<>,64,8192>::serialize, sdsl/include/sdsl/csa_wt.hpp:372-391; 1.48 GB per strand, n > 2^31, 32-bit-wide
