@@ -693,6 +693,36 @@ def test_config4_every_candidate_of_the_genome_on_one_gpu(hg38):
     assert got == CONFIG4_WHOLE_GENOME, got
 
 
+CONFIG5_ONE_MILLION = {"hits": 10_806_215_010, "checksum": "6817fb7783584b19"}
+
+
+def test_config5_one_million_guides_at_depth_6_with_cfd(hg38):
+    """BASELINE config 5 AT ITS SIZE on one GPU: 1,000,000 sampled guides at <= 6 mismatches with CFD + specificity, as a
+    stream of batches of 20,000 whose hit lists (2 x 10^8 hits = 3.5 GB each) stay in HBM - 1.08 x 10^10 hits in ~4 s.  The hit
+    total equals what tools/config5_stream.py has printed (profiles/r06_hg38_config5_stream.json.log, same seed); the checksum
+    over every offset, hit record and specificity is this path's own first run - a tripwire at the stated size: correctness
+    at depth 6 rests on the 512 + 64 guides compared with the compiled reference above and on the properties checked here."""
+    import torch
+    hip = _hip()
+    n, batch = 1_000_000, 20_000
+    seqs, pams, _, _ = synth.sample_guides(hg38.text, n, seed=1000)
+    d_s, d_p = torch.from_numpy(seqs).cuda(), torch.from_numpy(pams).cuda()
+    csum, hits = 0, 0
+    t0 = time.time()
+    for lo in range(0, n, batch):
+        d_off, d_hits, st = hg38.gidx.enumerate_device(d_s.data_ptr() + lo * 20, batch, 20, d_p.data_ptr() + lo * 3, 3, mismatches=6)
+        assert st["n_hits"] >= batch   # every sampled guide finds its own site
+        d_spec = torch.empty(batch, dtype=torch.float32, device="cuda")
+        hg38.gidx.score_device(hg38.gs, d_s.data_ptr() + lo * 20, batch, 20, 3, d_off, d_hits, None, d_spec.data_ptr())
+        assert float(d_spec.min().item()) > 0.0 and float(d_spec.max().item()) <= 1.0
+        csum = fold_batch(torch, hip, csum, d_off, d_hits, batch, st["n_hits"], d_spec)
+        hits += st["n_hits"]
+        del d_spec
+    got = {"hits": hits, "checksum": f"{csum:016x}"}
+    print("config 5, one million guides:", got, f"{time.time() - t0:.1f} s")
+    assert got == CONFIG5_ONE_MILLION, got
+
+
 def test_hg38_reference_index_files_open_through_the_importer(hg38):
     """SURVEY 8a row a12 at the size users download it: the <prefix>.forward / .reverse files the reference leg reads
     (csa_wt<wt_huff<>,64,8192>::serialize, sdsl/include/sdsl/csa_wt.hpp:372-391; 1.48 GB per strand, n > 2^31, 32-bit-wide
