@@ -464,57 +464,57 @@ static gs_status enumerate_device_impl(gs_index *ix, const void *d_guides, uint6
     const uint64_t len = ix->genome_length;
     auto code = [](uint8_t c) -> int { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; };
     if (!cand_hit)
-    for (const gs_nrun &r : ix->nruns_text) {
-      auto at = [&](int64_t pos) -> uint8_t { /* forward text around the run */
-        if (pos < 0 || (uint64_t)pos >= len) return 0;
-        if ((uint64_t)pos < r.start) return r.start - pos <= GS_NRUN_FLANK ? r.left[GS_NRUN_FLANK - (r.start - pos)] : 0;
-        if ((uint64_t)pos < r.start + r.len) return 'N';
-        const uint64_t o = pos - (r.start + r.len);
-        return o < GS_NRUN_FLANK ? r.right[o] : 0;
-      };
-      const int64_t s0 = (int64_t)r.start, e0 = (int64_t)(r.start + r.len);
-      /* forward strand: the run's tail under the window's first P symbols; text offset o < P holds
-       * the PAM symbol of consumption step P-1-o */
-      for (int64_t i = e0 - (int64_t)P; i < e0; i++) {
-        if (i < 0 || (uint64_t)i + W > len) continue;
-        bool ok = true;
-        uint64_t q = 0;
-        uint32_t pc = 0;
-        for (uint32_t o = 0; o < W && ok; o++) {
-          const uint8_t c = at(i + o);
-          if (o < P) {
-            ok = c == 'N' || code(c) >= 0;
-            if (ok) pc |= (uint32_t)(c == 'N' ? 4 : code(c)) << (3u * (P - 1u - o));
-          } else {
-            const int cc = code(c);
-            ok = cc >= 0;
-            if (ok) q |= (uint64_t)cc << (2u * (L - 1u - (o - P)));
+      for (const gs_nrun &r : ix->nruns_text) {
+        auto at = [&](int64_t pos) -> uint8_t { /* forward text around the run */
+          if (pos < 0 || (uint64_t)pos >= len) return 0;
+          if ((uint64_t)pos < r.start) return r.start - pos <= GS_NRUN_FLANK ? r.left[GS_NRUN_FLANK - (r.start - pos)] : 0;
+          if ((uint64_t)pos < r.start + r.len) return 'N';
+          const uint64_t o = pos - (r.start + r.len);
+          return o < GS_NRUN_FLANK ? r.right[o] : 0;
+        };
+        const int64_t s0 = (int64_t)r.start, e0 = (int64_t)(r.start + r.len);
+        /* forward strand: the run's tail under the window's first P symbols; text offset o < P holds
+         * the PAM symbol of consumption step P-1-o */
+        for (int64_t i = e0 - (int64_t)P; i < e0; i++) {
+          if (i < 0 || (uint64_t)i + W > len) continue;
+          bool ok = true;
+          uint64_t q = 0;
+          uint32_t pc = 0;
+          for (uint32_t o = 0; o < W && ok; o++) {
+            const uint8_t c = at(i + o);
+            if (o < P) {
+              ok = c == 'N' || code(c) >= 0;
+              if (ok) pc |= (uint32_t)(c == 'N' ? 4 : code(c)) << (3u * (P - 1u - o));
+            } else {
+              const int cc = code(c);
+              ok = cc >= 0;
+              if (ok) q |= (uint64_t)cc << (2u * (L - 1u - (o - P)));
+            }
           }
+          if (ok) cand[0].push_back(make_uint4((uint32_t)q, (uint32_t)(q >> 32), pc, (uint32_t)i));
         }
-        if (ok) cand[0].push_back(make_uint4((uint32_t)q, (uint32_t)(q >> 32), pc, (uint32_t)i));
-      }
-      /* reverse strand: its window is the forward window read backwards and complemented, so the
-       * run's head lies under the forward window's last P symbols; guide symbol t sits at forward
-       * offset t, complemented; PAM step u at forward offset L+u, complemented */
-      for (int64_t j = s0 + 1 - (int64_t)W; j <= s0 + (int64_t)P - (int64_t)W; j++) {
-        if (j < 0 || (uint64_t)j + W > len) continue;
-        bool ok = true;
-        uint64_t q = 0;
-        uint32_t pc = 0;
-        for (uint32_t o = 0; o < W && ok; o++) {
-          const uint8_t c = at(j + o);
-          if (o >= L) {
-            ok = c == 'N' || code(c) >= 0;
-            if (ok) pc |= (uint32_t)(c == 'N' ? 4 : 3 - code(c)) << (3u * (o - L));
-          } else {
-            const int cc = code(c);
-            ok = cc >= 0;
-            if (ok) q |= (uint64_t)(3 - cc) << (2u * o);
+        /* reverse strand: its window is the forward window read backwards and complemented, so the
+         * run's head lies under the forward window's last P symbols; guide symbol t sits at forward
+         * offset t, complemented; PAM step u at forward offset L+u, complemented */
+        for (int64_t j = s0 + 1 - (int64_t)W; j <= s0 + (int64_t)P - (int64_t)W; j++) {
+          if (j < 0 || (uint64_t)j + W > len) continue;
+          bool ok = true;
+          uint64_t q = 0;
+          uint32_t pc = 0;
+          for (uint32_t o = 0; o < W && ok; o++) {
+            const uint8_t c = at(j + o);
+            if (o >= L) {
+              ok = c == 'N' || code(c) >= 0;
+              if (ok) pc |= (uint32_t)(c == 'N' ? 4 : 3 - code(c)) << (3u * (o - L));
+            } else {
+              const int cc = code(c);
+              ok = cc >= 0;
+              if (ok) q |= (uint64_t)(3 - cc) << (2u * o);
+            }
           }
+          if (ok) cand[1].push_back(make_uint4((uint32_t)q, (uint32_t)(q >> 32), pc, (uint32_t)(len - ((uint64_t)j + W))));
         }
-        if (ok) cand[1].push_back(make_uint4((uint32_t)q, (uint32_t)(q >> 32), pc, (uint32_t)(len - ((uint64_t)j + W))));
       }
-    }
     size_t n_bidx[2] = {0, 0};
     if (cand_hit) {
       n_cand[0] = ix->cand_n[0];
